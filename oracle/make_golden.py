@@ -1,0 +1,266 @@
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference/code) on CPU.
+
+Build-container tool only (the GPU box has no /root/reference).  Nothing here is imported by the
+product; tests only read the .npz files this script writes.  The reference is imported unmodified
+with three arithmetic-neutral shims:
+  1. stub modules for packages that are not installed (cv2, imageio, torchvision.*);
+     torchvision.transforms.functional.resize / resized_crop are provided as bilinear interpolate
+     (identity at equal size) and slice-then-resize;
+  2. torch.Tensor.cuda = identity (the step hard-codes .cuda(), code/train.py:88,184,199,202,300,322);
+  3. F.grid_sample promotes both arguments to fp32 (what CUDA autocast's fp32 policy does).
+
+Run:  python oracle/make_golden.py            (writes tests/golden/, ~1-2 min single-threaded)
+"""
+import argparse
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference/code"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+import tecogan_oracle as orc  # noqa: E402
+
+
+def install_shims():
+    for name in ("cv2", "imageio"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional")
+    tvu = types.ModuleType("torchvision.utils")
+
+    def resize(img, size, *a, **k):
+        if list(img.shape[-2:]) == list(size):
+            return img
+        return F.interpolate(img, size=list(size), mode="bilinear", align_corners=False)
+
+    def resized_crop(img, top, left, height, width, size, *a, **k):
+        return resize(img[..., top:top + height, left:left + width], size)
+
+    tvf.resize = resize
+    tvf.resized_crop = resized_crop
+    for cls in ("RandomResizedCrop", "Compose", "Resize", "ToTensor"):
+        setattr(tvt, cls, type(cls, (), {"__init__": lambda self, *a, **k: None}))
+    tvt.functional = tvf
+    tv.transforms = tvt
+    tv.utils = tvu
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt,
+                        "torchvision.transforms.functional": tvf, "torchvision.utils": tvu})
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    orig = F.grid_sample
+    F.grid_sample = lambda inp, grid, *a, **k: orig(inp.float(), grid.float(), *a, **k)
+
+
+def synth(B, T, cs, seed):
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.random((B, T, 3, cs, cs), dtype=np.float32))
+    y = torch.from_numpy(rng.random((B, T, 3, 4 * cs, 4 * cs), dtype=np.float32))
+    return x, y
+
+
+SAMPLE_IDX_SEED = 1234
+
+
+def sample_idx(n, k=256):
+    return np.random.default_rng(SAMPLE_IDX_SEED).integers(0, n, size=k)
+
+
+def t2n(t):
+    return t.detach().cpu().float().numpy()
+
+
+class GradTap:
+    """Duck-typed optimizer: records gradients then delegates to the real Adam."""
+
+    def __init__(self, real, named):
+        self.real, self.named, self.grads = real, named, None
+
+    def zero_grad(self):
+        self.real.zero_grad()
+
+    def step(self):
+        self.grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in self.named.items()}
+        self.real.step()
+
+    # GradScaler (disabled on CPU) calls optimizer.step() directly
+    @property
+    def param_groups(self):
+        return self.real.param_groups
+
+
+def run_reference_steps(models, train, B, seed, n_steps, **arg_over):
+    args = orc.default_args(**arg_over)
+    x, y = synth(B, int(args.RNN_N), args.crop_size, seed)
+    G = models.generator(3, args)
+    D = models.discriminator(args)
+    gp = orc.init_params(orc.generator_param_shapes(args.num_resblock), seed + 100)
+    dp = orc.init_params(orc.discriminator_param_shapes(args.discrim_resblocks, args.discrim_channels), seed + 200)
+    G.load_state_dict(gp, strict=True)
+    D.load_state_dict(dp, strict=False)  # BN buffers keep their defaults
+    assert [k for k, _ in G.named_parameters()] == list(gp.keys())
+    assert [k for k, _ in D.named_parameters()] == list(dp.keys()), "oracle param order != reference registration order"
+    og = GradTap(torch.optim.Adam(G.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps),
+                 dict(G.named_parameters()))
+    od = GradTap(torch.optim.Adam(D.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps),
+                 dict(D.named_parameters()))
+    rec = {}
+    for s in range(n_steps):
+        out = train.FRVSR_Train(x, y, args, D, G, s, 0.0, 0.0, og, od)
+        pre = f"s{s}_"
+        rec[pre + "update_list"] = np.array([float(v) for v in out.update_list], dtype=np.float64)
+        rec[pre + "update_list_avg"] = np.array([float(v) for v in out.update_list_avg], dtype=np.float64)
+        rec[pre + "names"] = np.array(out.update_list_name)
+        rec[pre + "gen_loss"] = np.float64(float(out.gen_loss))
+        rec[pre + "fnet_loss"] = np.float64(float(out.fnet_loss))
+        rec[pre + "d_loss"] = np.float64(float(out.d_loss))
+        rec[pre + "tb"] = np.float64(float(out.tb))
+        rec[pre + "global_step"] = np.int64(out.global_step)
+        go = out.gen_output.detach()
+        rec[pre + "gen_sum"] = np.float64(go.double().sum())
+        rec[pre + "gen_sumsq"] = np.float64((go.double() ** 2).sum())
+        rec[pre + "gen_sample"] = t2n(go.reshape(-1)[sample_idx(go.numel())])
+        rec[pre + "target_sum"] = np.float64(out.target.double().sum())
+        rec[pre + "target_sample"] = t2n(out.target.reshape(-1)[sample_idx(out.target.numel())])
+        rec[pre + "g_grad_norms"] = np.array([float(og.grads[k].double().norm()) for k in gp.keys()])
+        rec[pre + "d_grad_norms"] = np.array([float(od.grads[k].double().norm()) for k in dp.keys()])
+        if s == 0:
+            rec["gen_frames_f16"] = go[0, [0, 1, int(args.RNN_N) - 1]].half().numpy()
+            rec["g_grad_output_weight"] = t2n(og.grads["output.weight"])
+            rec["g_grad_conv0_weight_sample"] = t2n(og.grads["conv.0.weight"].reshape(-1)[sample_idx(64 * 51 * 9)])
+            rec["d_grad_fc_weight"] = t2n(od.grads["fc.weight"])
+            rec["d_grad_block5_weight"] = t2n(od.grads["block5.0.weight"])
+            rec["d_grad_block1_bn_weight"] = t2n(od.grads["block1.1.weight"])
+        sdG, sdD = G.state_dict(), D.state_dict()
+        rec[pre + "post_output_weight"] = t2n(sdG["output.weight"])
+        rec[pre + "post_fc_weight"] = t2n(sdD["fc.weight"])
+        rec[pre + "post_block5_weight"] = t2n(sdD["block5.0.weight"])
+        for bn in ("block1.1", f"resids3.{int(args.discrim_resblocks) - 1}.1"):
+            rec[pre + bn + ".running_mean"] = t2n(sdD[bn + ".running_mean"])
+            rec[pre + bn + ".running_var"] = t2n(sdD[bn + ".running_var"])
+            rec[pre + bn + ".nbt"] = np.int64(sdD[bn + ".num_batches_tracked"])
+    return rec
+
+
+def unit_fixtures(ops, models):
+    rec = {}
+    # bilinear x4 on an 8x8 ramp (code/ops.py:98-100)
+    ramp = (torch.arange(64, dtype=torch.float32).reshape(1, 1, 8, 8) * 0.25 - 3.0)
+    rec["up4_in"] = t2n(ramp)
+    rec["up4_out"] = t2n(ops.upscale_four(ramp))
+    # warp on a hand-built grid with on-boundary / out-of-range coordinates (F.grid_sample defaults)
+    rng = np.random.default_rng(7)
+    img = torch.from_numpy(rng.random((2, 3, 8, 8), dtype=np.float32))
+    g = rng.uniform(-1.3, 1.3, size=(2, 8, 8, 2)).astype(np.float32)
+    specials = [-1.0, 1.0, 0.0, -0.875, 0.875, -1.125, 1.125, 1.0 - 1.0 / 8, -1.0 + 1.0 / 8, 4.0, -4.0, 0.5]
+    g[0, 0, :, 0] = specials[:8]
+    g[0, 1, :, 1] = specials[4:12]
+    g[1, 0, :4, :] = np.array([[-1, -1], [1, 1], [-1, 1], [1, -1]], dtype=np.float32)
+    grid = torch.from_numpy(g)
+    rec["warp_img"] = t2n(img)
+    rec["warp_grid"] = g
+    rec["warp_out_f32grid"] = t2n(F.grid_sample(img, grid))
+    rec["warp_out_f16grid"] = t2n(F.grid_sample(img, grid.half()))
+    # pixel-unshuffle equivalence of the recurrent packing (code/train.py:102-106)
+    z = torch.from_numpy(rng.random((2, 3, 16, 16), dtype=np.float32))
+    zz = z.view(2, 3, 4, 4, 4, 4).permute(0, 1, 3, 5, 2, 4)
+    rec["pack_in"] = t2n(z)
+    rec["pack_out"] = t2n(torch.reshape(zz, (2, 48, 4, 4)))
+    # module forwards on small inputs
+    args = orc.default_args()
+    G = models.generator(3, args)
+    gp = orc.init_params(orc.generator_param_shapes(16), 11)
+    G.load_state_dict(gp)
+    xin = torch.from_numpy(rng.random((2, 51, 8, 8), dtype=np.float32))
+    rec["g_in"] = t2n(xin)
+    with torch.no_grad():
+        rec["g_out"] = t2n(G(xin))
+    D = models.discriminator(args)
+    dp = orc.init_params(orc.discriminator_param_shapes(4, 128), 12)
+    D.load_state_dict(dp, strict=False)
+    din = torch.from_numpy(np.random.default_rng(77).random((3, 27, 128, 128), dtype=np.float32))  # tests regenerate it
+    with torch.no_grad():
+        prob, layers = D(din)
+    rec["d_prob"] = t2n(prob)
+    for i, l in enumerate(layers):
+        rec[f"d_layer{i}_sum"] = np.float64(l.double().sum())
+        rec[f"d_layer{i}_abs"] = np.float64(l.double().abs().sum())
+        rec[f"d_layer{i}_sample"] = t2n(l.reshape(-1)[sample_idx(l.numel())])
+    sd = D.state_dict()
+    rec["d_block1_rm"] = t2n(sd["block1.1.running_mean"])
+    rec["d_block1_rv"] = t2n(sd["block1.1.running_var"])
+    Fn = models.f_net()
+    fp = orc.init_params(orc.fnet_param_shapes(), 13)
+    Fn.load_state_dict(fp)
+    fin = torch.from_numpy(rng.random((2, 3, 32, 32), dtype=np.float32))
+    rec["f_in"] = t2n(fin)
+    with torch.no_grad():
+        rec["f_out"] = t2n(Fn(fin))
+    # compute_psnr (code/ops.py:130-139)
+    a = torch.from_numpy(rng.random((2, 3, 8, 8), dtype=np.float32)) * 255
+    b = torch.from_numpy(rng.random((2, 3, 8, 8), dtype=np.float32)) * 255
+    rec["psnr_a"], rec["psnr_b"] = t2n(a), t2n(b)
+    rec["psnr"] = np.float64(ops.compute_psnr(a, b))
+    return rec
+
+
+def expected_failures(models, train):
+    """Documented divergences: configurations the reference cannot execute (SURVEY finding 4)."""
+    res = {}
+    for tag, over in (("RNN_N=16", dict(RNN_N=16)), ("RNN_N=7", dict(RNN_N=7)), ("crop_size=64", dict(crop_size=64)),
+                      ("Dt_mergeDs=False", dict(Dt_mergeDs=False)), ("vgg_scaling>0", dict(vgg_scaling=0.2))):
+        try:
+            run_reference_steps(models, train, 1, 3, 1, **over)
+            res[tag] = "ran"
+        except Exception as e:  # noqa: BLE001
+            res[tag] = type(e).__name__
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-failures", action="store_true")
+    a = ap.parse_args()
+    warnings.filterwarnings("ignore")
+    torch.set_num_threads(1)
+    install_shims()
+    sys.path.insert(1, REF)
+    import ops  # noqa: E402  (reference)
+    import models  # noqa: E402  (reference)
+    import train  # noqa: E402  (reference)
+    os.makedirs(OUT, exist_ok=True)
+
+    np.savez_compressed(os.path.join(OUT, "units.npz"), **unit_fixtures(ops, models))
+    print("units done")
+    np.savez_compressed(os.path.join(OUT, "step_b1.npz"), **run_reference_steps(models, train, 1, 1, 3))
+    print("step_b1 done")
+    np.savez_compressed(os.path.join(OUT, "step_b2.npz"), **run_reference_steps(models, train, 2, 2, 2))
+    print("step_b2 done")
+    np.savez_compressed(os.path.join(OUT, "step_b1_pingpang.npz"),
+                        **run_reference_steps(models, train, 1, 3, 1, pingpang=True))
+    np.savez_compressed(os.path.join(OUT, "step_b1_nolayerloss.npz"),
+                        **run_reference_steps(models, train, 1, 4, 1, D_LAYERLOSS=False))
+    np.savez_compressed(os.path.join(OUT, "step_b1_cropdt1.npz"),
+                        **run_reference_steps(models, train, 1, 5, 1, crop_dt=1.0))
+    np.savez_compressed(os.path.join(OUT, "step_b1_rb2.npz"),
+                        **run_reference_steps(models, train, 1, 6, 1, num_resblock=2, discrim_resblocks=1))
+    print("variants done")
+    if not a.skip_failures:
+        fails = expected_failures(models, train)
+        with open(os.path.join(OUT, "expected_failures.txt"), "w") as f:
+            for k, v in fails.items():
+                f.write(f"{k}: {v}\n")
+        print(fails)
+
+
+if __name__ == "__main__":
+    main()
