@@ -1,0 +1,189 @@
+/*
+ * tecogan_hip.h - C ABI of libtecogan_hip.so (gfx950 / MI355X).
+ *
+ * The reference (dwight-foster/Pytorch-TecoGAN) has no FFI: its hot path is Python calling ATen ops.
+ * Every entry point below therefore replaces an ATen call site of the reference; the citation after each
+ * declaration names that call site (file:line are into the reference tree).  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions:
+ *   - arguments are raw device pointers, int32 dims, a dtype enum and a hipStream_t (passed as void*);
+ *   - the caller owns every buffer including workspaces; functions only enqueue work on `stream`
+ *     (no allocation, no synchronisation, no global state beyond one-time function-attribute setup);
+ *   - return value: 0 ok, <0 invalid argument / unsupported shape (TG_E_*), >0 a hipError_t;
+ *   - nothing throws across the ABI; distinct streams may be used from distinct threads.
+ *
+ * Device tensor layout: activations are NHWC with the channel count padded to a multiple of 32
+ * ("Cp"); element type is TG_F32 or TG_BF16.  Weights are consumed in a packed, fragment-ordered
+ * layout produced by tg_pack_conv_weights from the PyTorch-layout fp32 master copy.
+ */
+#ifndef TECOGAN_HIP_H
+#define TECOGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_ABI_VERSION 1
+
+enum { TG_F32 = 0, TG_BF16 = 1 };
+
+enum {
+  TG_OK = 0,
+  TG_E_BADARG = -1,      /* null pointer / non-positive dim / bad enum */
+  TG_E_UNSUPPORTED = -2, /* shape outside what the kernels are instantiated for */
+  TG_E_ALIGN = -3        /* channel count not a multiple of 32, pointer not 16-byte aligned */
+};
+
+enum { TG_ACT_NONE = 0, TG_ACT_RELU = 1, TG_ACT_LRELU = 2, TG_ACT_SIGMOID = 3 };
+enum { TG_MASK_NONE = 0, TG_MASK_RELU = 1, TG_MASK_LRELU = 2 };
+enum { TG_OUT_NHWC = 0, TG_OUT_NCHW_F32 = 1 };
+
+#define TG_MAX_TAPS 16
+#define TG_MAX_CLASSES 4
+
+/* One output sub-lattice ("class") of a gather convolution.  For every class-grid pixel (cy,cx) the kernel
+ * computes   acc[co] = sum_t sum_ci in[n, cy*S + dy[t], cx*S + dx[t], ci] * W[widx[t]][co][ci]
+ * (out-of-range input pixels read as zero) and stores it at out[n, cy*OS + ooy, cx*OS + oox, co]. */
+typedef struct {
+  int32_t ooy, oox;
+  int32_t ntaps;
+  int8_t dy[TG_MAX_TAPS];
+  int8_t dx[TG_MAX_TAPS];
+  int16_t widx[TG_MAX_TAPS];
+} tg_conv_class;
+
+typedef struct {
+  int32_t dtype;                /* TG_F32 / TG_BF16: element type of in/out/res/mask and of the packed weights */
+  int32_t N, IH, IW, Cin;       /* input  [N][IH][IW][Cin]   (Cin multiple of 32) */
+  int32_t OH, OW, Cout;         /* output [N][OH][OW][Cout]  (Cout multiple of 32) */
+  int32_t S, OS;                /* input step per class-grid pixel; output step */
+  int32_t ncls;
+  tg_conv_class cls[TG_MAX_CLASSES];
+  /* epilogue, applied in this order: +bias, +res, act, *mask, store, per-channel stats */
+  int32_t act;                  /* TG_ACT_* */
+  int32_t mask_mode;            /* TG_MASK_*: multiply by act'(mask) where mask is the saved activation */
+  int32_t stats_mode;           /* 0 none, 1 per-channel sum, 2 sum and sum of squares */
+  int32_t stats_groups;         /* batch is split into this many equal groups with separate statistics */
+  int32_t out_mode;             /* TG_OUT_* */
+  int32_t c_real;               /* TG_OUT_NCHW_F32: number of real channels stored (<=4) */
+  int64_t out_n_stride;         /* TG_OUT_NCHW_F32: element stride between samples of `out` */
+  int32_t tile_cfg;             /* 0 auto; otherwise a TG_TILE_* id (tuning / tests) */
+} tg_conv_desc;
+
+enum { TG_TILE_AUTO = 0, TG_TILE_64x256 = 1, TG_TILE_64x64 = 2, TG_TILE_128x128 = 3, TG_TILE_32x128 = 4 };
+
+int tg_abi_version(void);
+const char* tg_error_string(int code);
+
+/* Bytes needed for the packed weights of a conv with `nslots` weight slots (taps). */
+int64_t tg_packed_weight_bytes(int dtype, int nslots, int cout_p, int cin_p);
+
+/* fp32 PyTorch-layout weights -> packed fragment-ordered weights of element type `dtype`.
+ *   packed[slot][chunk][row][kc]  with  value = w[co*s_co + ci*s_ci + slot_off[slot]]  (0 where co/ci are padding)
+ * slot_off gives, per packed slot, the element offset of that tap inside one (co,ci) kernel (e.g. kh*KW+kw), so the
+ * same routine packs forward weights (s_co = Cin*KH*KW, s_ci = KH*KW), transposed-conv weights and the
+ * role-swapped copies that the dgrad launches use.  Replaces the implicit weight handling inside
+ * aten::conv2d / conv_transpose2d (code/ops.py:45-63). */
+int tg_pack_conv_weights(int dtype, const float* w, void* packed, int cout, int cin, int cout_p, int cin_p,
+                         int64_t s_co, int64_t s_ci, int nslots, const int32_t* slot_off_dev, void* stream);
+
+/* Gather convolution on MFMA: conv3x3 (code/models.py:54-58,68,73-76,102 via code/ops.py:57-63), conv4x4 stride 2
+ * (code/models.py:90-94), conv-transpose k3 s2 p1 op1 as four sub-pixel classes (code/ops.py:45-54;
+ * code/models.py:72,74) and the input-gradient of each (aten::convolution_backward, code/train.py:336,340). */
+int tg_conv(const tg_conv_desc* d, const void* in, const void* w_packed, const float* bias, const void* res,
+            const void* mask, void* out, float* stats, void* stream);
+
+/* Weight gradient: slab[split][t][a][b] = sum over the split's pixels of X[n, y*S+dy[t], x*S+dx[t]][a] * Y[n,y,x][b].
+ * (aten::convolution_backward weight path, code/train.py:336,340.) */
+typedef struct {
+  int32_t dtype;
+  int32_t N, XH, XW, Cx;        /* X [N][XH][XW][Cx] */
+  int32_t YH, YW, Cy;           /* Y [N][YH][YW][Cy] */
+  int32_t S;
+  int32_t ntaps;                /* 9 or 16 */
+  int8_t dy[TG_MAX_TAPS];
+  int8_t dx[TG_MAX_TAPS];
+  int32_t nsplit;               /* number of pixel-range splits (= slabs) */
+} tg_wgrad_desc;
+
+int64_t tg_wgrad_slab_floats(const tg_wgrad_desc* d);
+int tg_wgrad(const tg_wgrad_desc* d, const void* x, const void* y, float* slab, void* stream);
+/* grad[a*s_a + b*s_b + slot_off[t]] (+)= sum_split slab[split][t][a][b]  for a<ca, b<cb.  Writes the PyTorch layout. */
+int tg_wgrad_finalize(const float* slab, int nsplit, int ntaps, int ca_p, int cb_p, int ca, int cb, float* grad,
+                      int64_t s_a, int64_t s_b, const int32_t* slot_off_dev, int accumulate, void* stream);
+
+/* ---- layout converters ------------------------------------------------------------------------------- */
+/* NCHW fp32 (strided samples) -> NHWC `dtype` with zero channel padding. */
+int tg_nchw_to_nhwc(int dtype, const float* src, int64_t src_n_stride, void* dst, int N, int C, int Cp, int H, int W,
+                    void* stream);
+int tg_nhwc_to_nchw(int dtype, const void* src, float* dst, int64_t dst_n_stride, int N, int C, int Cp, int H, int W,
+                    void* stream);
+
+/* ---- flow / warp / packing (code/train.py:71-111,138-198; code/ops.py:98-100) -------------------------- */
+/* dst_plane[i] = post_a * bilinear_x4(pre * src_plane[i]) + post_b ; planes are h*w (src) and 4h*4w (dst) fp32,
+ * addressed by element offsets (nn.Upsample(scale_factor=4, bilinear, align_corners=False)). */
+int tg_up4_planes(const float* src, const int64_t* src_off_dev, float* dst, const int64_t* dst_off_dev, int nplanes,
+                  int h, int w, float pre, float post_a, float post_b, void* stream);
+/* F.grid_sample(bilinear, zeros, align_corners=False) on NCHW fp32 images with a grid that is a REINTERPRETED
+ * contiguous (2,H,W) block per sample (code/train.py:84,96,157).  grid_off/img_off are per-sample element offsets.
+ * fp16_grid!=0 rounds grid values to fp16 first (code/train.py:98,187).  out may be null; corner_idx (int32
+ * [N][H][W][2] = x0,y0) may be null; if sq_ref is non-null accumulates sum((sq_ref - warp)^2) into loss_acc[0]. */
+int tg_warp_nchw(const float* img, const int64_t* img_off_dev, const float* grid, const int64_t* grid_off_dev,
+                 float* out, int32_t* corner_idx, const float* sq_ref, const int64_t* sq_off_dev, float* loss_acc,
+                 int N, int C, int IH, int IW, int GH, int GW, int fp16_grid, void* stream);
+/* Generator input [B][h][w][64] (NHWC dtype): ch0-2 = lr frame, ch3-50 = pixel_unshuffle4((warp(prev,grid)+1)/2),
+ * rest 0.  prev==null gives the first-frame input (zeros).  (code/train.py:86-88,95-107; main.py:191-213) */
+int tg_gen_input(int dtype, const float* lr, int64_t lr_n_stride, const float* prev, int64_t prev_n_stride,
+                 const float* grid, int64_t grid_n_stride, void* dst, int B, int h, int w, void* stream);
+/* Discriminator input [2*tb][H][H][32]: real rows then fake rows (code/train.py:160-198). */
+int tg_d_assemble(int dtype, const float* x, const float* y, const float* gen, const float* tvel, void* dst, int B,
+                  int T, int K, int h, int border, void* stream);
+/* dst[dst_off[i] + e] = src_off[i] < 0 ? 0 : src[src_off[i] + e], e < len: assembles T_vel (code/train.py:147-158)
+ * from the pseudo-flow blocks, zero blocks and (with tg_up4_planes) the "back" flow planes. */
+int tg_copy_blocks(const float* src, const int64_t* src_off_dev, float* dst, const int64_t* dst_off_dev, int nblocks,
+                   int64_t len, void* stream);
+
+/* ---- batch norm, training mode, eps/momentum as code/ops.py:75-77 -------------------------------------- */
+/* y = act(gamma*(z-mean)*invstd+beta) (+skip).  stats = [groups][2][C] sums from the producing conv.  Block 0 also
+ * updates running_mean/var (group after group) and writes mean/invstd to save[groups][2][C]. */
+int tg_bn_apply(int dtype, const void* z, const float* stats, const float* gamma, const float* beta, const void* skip,
+                void* y, float* running_mean, float* running_var, float* save, int N, int HW, int C, int groups,
+                int act, float eps, float momentum, void* stream);
+/* red[groups][2][C] += (sum dyp, sum dyp*xhat) where dyp = dy * act'(yact). */
+int tg_bn_bwd_reduce(int dtype, const void* dy, const void* yact, const void* z, const float* save, float* red, int N,
+                     int HW, int C, int groups, int act, void* stream);
+/* dz = gamma*invstd*(dyp - mean(dyp) - xhat*mean(dyp*xhat)); block 0 accumulates dgamma/dbeta. */
+int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, const void* z, const float* save, const float* red,
+                    const float* gamma, void* dz, float* dgamma, float* dbeta, int N, int HW, int C, int groups,
+                    int act, void* stream);
+
+/* ---- heads and losses (code/models.py:143-145; code/train.py:205-333) ----------------------------------- */
+int tg_fc_head_fwd(int dtype, const void* feat, const float* w, const float* b, float* prob, int N, int HW, int C,
+                   int Cp, void* stream);
+int tg_fc_head_bwd(int dtype, const void* feat, const float* w, const float* dlogit, void* dfeat, float* dw,
+                   float* db, int N, int HW, int C, int Cp, void* stream);
+/* acc[0] += sum |a-b| over real channels (layer loss, code/train.py:219-220). */
+int tg_absdiff_sum(int dtype, const void* a, const void* b, float* acc, int64_t npix, int C, int Cp, void* stream);
+/* acc[0] += sum |a[a_off[k]+e] - b[b_off[k]+e]| (ping-pong loss, code/train.py:275-279). */
+int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const float* b, const int64_t* b_off_dev, float* acc,
+                    int nblocks, int64_t len, void* stream);
+/* content loss partial sum and d(pre-sigmoid) for the generator output (code/train.py:239-241):
+ * acc[0] += sum (gen-y)^2 ; dpre[nhwc] = gscale * 2*(gen-y) * gen*(1-gen).  gen/y are NCHW fp32 (B,T,3,H,W);
+ * dpre is NHWC [T*B][H][W][32] in (t,b) order. */
+int tg_content_loss(int dtype, const float* gen, const float* y, void* dpre, float* acc, int B, int T, int H, int W,
+                    float gscale, void* stream);
+/* All step scalars on device + d(logit) for the discriminator loss (code/train.py:287-333). */
+int tg_loss_finalize(const float* prob, const float* acc, float* scalars, float* dlogit, int tb, const float* cfg,
+                     void* stream);
+
+/* ---- optimiser (torch.optim.Adam as built at main.py:239-243) ------------------------------------------- */
+int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+            float bc1, float bc2, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,97 @@
+"""ctypes binding of libtecogan_hip.so (include/tecogan_hip.h).  No fallback: if the library is missing the
+product path raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtecogan_hip.so")
+
+TG_F32, TG_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
+MASK_NONE, MASK_RELU, MASK_LRELU = 0, 1, 2
+OUT_NHWC, OUT_NCHW_F32 = 0, 1
+TILE_AUTO, TILE_64x256, TILE_64x64, TILE_128x128, TILE_32x128 = 0, 1, 2, 3, 4
+MAX_TAPS, MAX_CLASSES = 16, 4
+
+
+class ConvClass(C.Structure):
+    _fields_ = [("ooy", C.c_int32), ("oox", C.c_int32), ("ntaps", C.c_int32), ("dy", C.c_int8 * MAX_TAPS),
+                ("dx", C.c_int8 * MAX_TAPS), ("widx", C.c_int16 * MAX_TAPS)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("N", C.c_int32), ("IH", C.c_int32), ("IW", C.c_int32), ("Cin", C.c_int32),
+                ("OH", C.c_int32), ("OW", C.c_int32), ("Cout", C.c_int32), ("S", C.c_int32), ("OS", C.c_int32),
+                ("ncls", C.c_int32), ("cls", ConvClass * MAX_CLASSES), ("act", C.c_int32), ("mask_mode", C.c_int32),
+                ("stats_mode", C.c_int32), ("stats_groups", C.c_int32), ("out_mode", C.c_int32),
+                ("c_real", C.c_int32), ("out_n_stride", C.c_int64), ("tile_cfg", C.c_int32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("N", C.c_int32), ("XH", C.c_int32), ("XW", C.c_int32), ("Cx", C.c_int32),
+                ("YH", C.c_int32), ("YW", C.c_int32), ("Cy", C.c_int32), ("S", C.c_int32), ("ntaps", C.c_int32),
+                ("dy", C.c_int8 * MAX_TAPS), ("dx", C.c_int8 * MAX_TAPS), ("nsplit", C.c_int32)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+_PROTOS = {
+    "tg_abi_version": (C.c_int, []),
+    "tg_error_string": (C.c_char_p, [_I]),
+    "tg_packed_weight_bytes": (_L, [_I, _I, _I, _I]),
+    "tg_pack_conv_weights": (_I, [_I, _P, _P, _I, _I, _I, _I, _L, _L, _I, _P, _P]),
+    "tg_conv": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "tg_wgrad_slab_floats": (_L, [C.POINTER(WgradDesc)]),
+    "tg_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P]),
+    "tg_wgrad_finalize": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _L, _L, _P, _I, _P]),
+    "tg_nchw_to_nhwc": (_I, [_I, _P, _L, _P, _I, _I, _I, _I, _I, _P]),
+    "tg_nhwc_to_nchw": (_I, [_I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "tg_up4_planes": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P]),
+    "tg_copy_blocks": (_I, [_P, _P, _P, _P, _I, _L, _P]),
+    "tg_warp_nchw": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "tg_gen_input": (_I, [_I, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _P]),
+    "tg_d_assemble": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "tg_bn_apply": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "tg_bn_bwd_reduce": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "tg_bn_bwd_apply": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "tg_fc_head_fwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "tg_fc_head_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "tg_absdiff_sum": (_I, [_I, _P, _P, _P, _L, _I, _I, _P]),
+    "tg_absdiff_nchw": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
+    "tg_content_loss": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "tg_loss_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P]),
+    "tg_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P]),
+}
+
+EXPORTED = tuple(_PROTOS.keys())
+_lib = None
+
+
+class TecoganHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the C-ABI library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TecoganHipError(
+            f"{LIB_PATH} is missing: build it with pytorch-tecogan_amd/csrc/build.sh (or __graft_entry__.build()). "
+            "There is no CPU fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError here means header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tg_abi_version() != 1:
+        raise TecoganHipError("libtecogan_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().tg_error_string(int(code)).decode()
+        raise TecoganHipError(f"{what}: {msg} (status {code})")

@@ -1,0 +1,102 @@
+// Shared device/host helpers for libtecogan_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/tecogan_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+struct BF16 {};  // tag types: element type is a template tag, never a runtime branch inside kernels
+struct F32 {};
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<F32> {
+  static constexpr int kBytes = 4;
+  static constexpr int kChunk = 16;  // channels per 64-byte K chunk
+  static constexpr int kVec = 4;     // elements per 16-byte vector
+};
+template <> struct ElemTraits<BF16> {
+  static constexpr int kBytes = 2;
+  static constexpr int kChunk = 32;
+  static constexpr int kVec = 8;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+  return __builtin_bit_cast(unsigned short, h);
+}
+
+// Load/store `kVec` consecutive elements (16 bytes) as floats.
+template <typename T> struct Vec;
+template <> struct Vec<F32> {
+  static constexpr int N = 4;
+  __device__ __forceinline__ static void load(const void* p, float* v) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  __device__ __forceinline__ static void store(void* p, const float* v) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  }
+};
+template <> struct Vec<BF16> {
+  static constexpr int N = 8;
+  __device__ __forceinline__ static void load(const void* p, float* v) {
+    u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(t[i] << 16);
+      v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
+    }
+  }
+  __device__ __forceinline__ static void store(void* p, const float* v) {
+    u32x4 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      t[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+    *reinterpret_cast<u32x4*>(p) = t;
+  }
+};
+
+template <typename T> __device__ __forceinline__ float load_elem(const void* base, int64_t i);
+template <> __device__ __forceinline__ float load_elem<F32>(const void* base, int64_t i) {
+  return reinterpret_cast<const float*>(base)[i];
+}
+template <> __device__ __forceinline__ float load_elem<BF16>(const void* base, int64_t i) {
+  return bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(base)[i]);
+}
+template <typename T> __device__ __forceinline__ void store_elem(void* base, int64_t i, float v);
+template <> __device__ __forceinline__ void store_elem<F32>(void* base, int64_t i, float v) {
+  reinterpret_cast<float*>(base)[i] = v;
+}
+template <> __device__ __forceinline__ void store_elem<BF16>(void* base, int64_t i, float v) {
+  reinterpret_cast<unsigned short*>(base)[i] = f32_to_bf16_bits(v);
+}
+
+// Packed-weight row order.  Row R of the packed matrix holds output channel row_to_channel(R): for bf16 two
+// adjacent 16-row MFMA tiles are interleaved so that one lane's 2x4 accumulator rows are 8 consecutive
+// channels (one 16-byte store); for f32 the 4 accumulator rows of a lane already are 16 bytes.
+template <typename T> __host__ __device__ __forceinline__ int row_to_channel(int R);
+template <> __host__ __device__ __forceinline__ int row_to_channel<F32>(int R) { return R; }
+template <> __host__ __device__ __forceinline__ int row_to_channel<BF16>(int R) {
+  int tile = R >> 4, r = R & 15, q = r >> 2, j = r & 3;
+  return 32 * (tile >> 1) + 8 * q + 4 * (tile & 1) + j;
+}
+
+#define TG_CHECK_HIP(expr)                 \
+  do {                                     \
+    hipError_t _e = (expr);                \
+    if (_e != hipSuccess) return (int)_e;  \
+  } while (0)
+
+static inline int tg_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? TG_OK : (int)e;
+}
+
+static inline bool tg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

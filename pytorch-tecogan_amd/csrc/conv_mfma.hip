@@ -1,0 +1,432 @@
+// Gather convolution on the CDNA4 matrix cores (implicit GEMM, no im2col buffer).
+//
+//   D[co][px] += W[co][k] * X[k][px]      k = (tap, input channel)
+//
+// The MFMA "A" operand is the weight tile (rows = output channels) and the "B" operand the activation tile
+// (columns = 16 consecutive output pixels of one image row), so that one lane's accumulator registers are
+// consecutive CHANNELS of one pixel: the NHWC epilogue store is one 16-byte store per lane per tile (pair).
+//
+// Work decomposition: one 256-thread workgroup (4 waves) owns CO_TILE output channels x (TH rows x 16 px) of
+// one output sub-lattice ("class") of one image.  K is walked in 64-byte channel chunks (32 bf16 / 16 f32
+// channels): per chunk the activation halo patch is staged ONCE into LDS and reused by every tap; the packed
+// weight rows of a group of taps are staged next to it.  Both element types share this code; only the MFMA
+// issue (1 x 16x16x32 bf16 vs 4 x 16x16x4 f32 per 16-byte fragment) and the accumulator->channel map differ.
+//
+// Replaces aten::conv2d / conv_transpose2d / convolution_backward(input) call sites of the reference:
+// code/models.py:54-58,68,72-76,90-94,102 (via code/ops.py:45-63) and the autograd of code/train.py:336,340.
+#include "common.h"
+
+namespace {
+
+constexpr int kRowBytes = 80;  // 64 data bytes + 16 pad: keeps ds_read_b128 fragment reads at most 2-way conflicted
+
+struct ConvClassK {
+  int ooy, oox, ntaps, dymin, dxmin, ih, iw;
+  int8_t dy[TG_MAX_TAPS];
+  int8_t dx[TG_MAX_TAPS];
+  int16_t widx[TG_MAX_TAPS];
+};
+
+struct ConvK {
+  const char* in;
+  const char* w;
+  const float* bias;
+  const char* res;
+  const char* mask;
+  char* out;
+  float* stats;
+  int N, IH, IW, Cin, OH, OW, Cout, S, OS;
+  int tiles_x, tiles_y, nchunks, tg;
+  int act, mask_mode, stats_mode, stats_groups, out_mode, c_real;
+  long long out_n_stride;
+  int a_rows_max;
+  ConvClassK cls[TG_MAX_CLASSES];
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<BF16> {
+  using Frag = bf16x8;
+  __device__ __forceinline__ static f32x4 run(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<F32> {
+  using Frag = f32x4;
+  __device__ __forceinline__ static f32x4 run(Frag a, Frag b, f32x4 c) {
+    // k index of (lane group g, element i) is channel 4g+i for BOTH operands, so any consistent order is a valid GEMM
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], c, 0, 0, 0);
+    return c;
+  }
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == TG_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == TG_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+  if (act == TG_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+  return v;
+}
+
+template <typename T, int CT, int PT, int WC, int WP>
+__global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
+  using TR = ElemTraits<T>;
+  using Frag = typename Mma<T>::Frag;
+  constexpr int CO_TILE = 16 * CT * WC;
+  constexpr int TH = PT * WP;
+  constexpr int E = TR::kVec;                              // channels per 16-byte epilogue vector
+  constexpr int NG = (TR::kBytes == 2) ? CT / 2 : CT;      // epilogue vectors per px-tile per lane
+  static_assert(WC * WP == 4, "4 waves per workgroup");
+  static_assert(TR::kBytes == 4 || CT % 2 == 0, "bf16 pairs co-tiles");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_a = smem;
+  char* lds_w = smem + (size_t)p.a_rows_max * kRowBytes;
+
+  const ConvClassK& cl = p.cls[blockIdx.z];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wc = wid % WC, wp = wid / WC;
+  const int idx = lane & 15, g = lane >> 4;
+
+  int bx = blockIdx.x;
+  const int txb = bx % p.tiles_x;
+  bx /= p.tiles_x;
+  const int tyb = bx % p.tiles_y;
+  const int n = bx / p.tiles_y;
+  const int co_base = blockIdx.y * CO_TILE;
+
+  const int OHc = (p.OH - cl.ooy + p.OS - 1) / p.OS;
+  const int OWc = (p.OW - cl.oox + p.OS - 1) / p.OS;
+  const int ty0 = tyb * TH, tx0 = txb * 16;
+  if (ty0 >= OHc || tx0 >= OWc) return;  // whole tile outside this class's grid (uniform per workgroup)
+
+  const int iy0 = ty0 * p.S + cl.dymin, ix0 = tx0 * p.S + cl.dxmin;
+  const int prow_n = cl.ih * cl.iw;
+  const int ntaps = cl.ntaps;
+
+  f32x4 acc[CT][PT];
+#pragma unroll
+  for (int a = 0; a < CT; ++a)
+#pragma unroll
+    for (int b = 0; b < PT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const size_t in_pix_bytes = (size_t)p.Cin * TR::kBytes;
+  const char* in_n = p.in + (size_t)n * p.IH * p.IW * in_pix_bytes;
+
+  for (int c = 0; c < p.nchunks; ++c) {
+    for (int t0 = 0; t0 < ntaps; t0 += p.tg) {
+      const int tn = min(p.tg, ntaps - t0);
+      __syncthreads();  // previous fragment reads are done before LDS is overwritten
+      if (t0 == 0) {
+        for (int i = tid; i < prow_n * 4; i += 256) {
+          const int prow = i >> 2, s = i & 3;
+          const int py = prow / cl.iw, px = prow - py * cl.iw;
+          const int iy = iy0 + py, ix = ix0 + px;
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
+            v = *reinterpret_cast<const u32x4*>(in_n + ((size_t)iy * p.IW + ix) * in_pix_bytes + (size_t)c * 64 + s * 16);
+          *reinterpret_cast<u32x4*>(lds_a + prow * kRowBytes + s * 16) = v;
+        }
+      }
+      for (int i = tid; i < tn * CO_TILE * 4; i += 256) {
+        const int r = i >> 2, s = i & 3;
+        const int tt = r / CO_TILE, row = r - tt * CO_TILE;
+        const int slot = cl.widx[t0 + tt];
+        const char* src = p.w + (((size_t)slot * p.nchunks + c) * p.Cout + co_base + row) * 64 + s * 16;
+        *reinterpret_cast<u32x4*>(lds_w + r * kRowBytes + s * 16) = *reinterpret_cast<const u32x4*>(src);
+      }
+      __syncthreads();
+
+      for (int tt = 0; tt < tn; ++tt) {
+        const int dy = cl.dy[t0 + tt] - cl.dymin, dx = cl.dx[t0 + tt] - cl.dxmin;
+        Frag wf[CT];
+#pragma unroll
+        for (int a = 0; a < CT; ++a)
+          wf[a] = *reinterpret_cast<const Frag*>(lds_w + (tt * CO_TILE + (wc * CT + a) * 16 + idx) * kRowBytes + g * 16);
+#pragma unroll
+        for (int b = 0; b < PT; ++b) {
+          const int ty = wp * PT + b;
+          const int prow = (ty * p.S + dy) * cl.iw + idx * p.S + dx;
+          const Frag xf = *reinterpret_cast<const Frag*>(lds_a + prow * kRowBytes + g * 16);
+#pragma unroll
+          for (int a = 0; a < CT; ++a) acc[a][b] = Mma<T>::run(wf[a], xf, acc[a][b]);
+        }
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  const int q = g;  // accumulator rows 4q..4q+3 of each 16-row tile live in this lane
+  float s1[NG][E], s2[NG][E];
+#pragma unroll
+  for (int a = 0; a < NG; ++a)
+#pragma unroll
+    for (int e = 0; e < E; ++e) s1[a][e] = s2[a][e] = 0.f;
+
+#pragma unroll
+  for (int b = 0; b < PT; ++b) {
+    const int cy = ty0 + wp * PT + b, cx = tx0 + idx;
+    const bool valid = (cy < OHc) && (cx < OWc);
+    const int oy = cy * p.OS + cl.ooy, ox = cx * p.OS + cl.oox;
+    const size_t pix = ((size_t)n * p.OH + oy) * p.OW + ox;
+#pragma unroll
+    for (int a = 0; a < NG; ++a) {
+      float v[E];
+      int ch0;
+      if constexpr (TR::kBytes == 2) {
+        ch0 = co_base + (wc * CT + 2 * a) * 16 + 8 * q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[2 * a][b][j];
+          v[4 + j] = acc[2 * a + 1][b][j];
+        }
+      } else {
+        ch0 = co_base + (wc * CT + a) * 16 + 4 * q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j];
+      }
+      if (valid) {
+        if (p.bias) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) v[e] += p.bias[ch0 + e];
+        }
+        const size_t eoff = (pix * p.Cout + ch0) * TR::kBytes;
+        if (p.res) {
+          float r[E];
+          Vec<T>::load(p.res + eoff, r);
+#pragma unroll
+          for (int e = 0; e < E; ++e) v[e] += r[e];
+        }
+        if (p.act != TG_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) v[e] = apply_act(v[e], p.act);
+        }
+        if (p.mask_mode != TG_MASK_NONE) {
+          float m[E];
+          Vec<T>::load(p.mask + eoff, m);
+          const float neg = p.mask_mode == TG_MASK_LRELU ? 0.2f : 0.f;
+#pragma unroll
+          for (int e = 0; e < E; ++e) v[e] *= (m[e] > 0.f ? 1.f : neg);
+        }
+        if (p.out_mode == TG_OUT_NHWC) {
+          Vec<T>::store(p.out + eoff, v);
+        } else if (ch0 == 0) {
+          float* o = reinterpret_cast<float*>(p.out) + (size_t)n * p.out_n_stride + (size_t)oy * p.OW + ox;
+          for (int e = 0; e < p.c_real; ++e) o[(size_t)e * p.OH * p.OW] = v[e];
+        }
+        if (p.stats_mode) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            s1[a][e] += v[e];
+            s2[a][e] += v[e] * v[e];
+          }
+        }
+      }
+    }
+  }
+
+  if (p.stats_mode) {  // uniform branch
+#pragma unroll
+    for (int a = 0; a < NG; ++a)
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          s1[a][e] += __shfl_xor(s1[a][e], m);
+          s2[a][e] += __shfl_xor(s2[a][e], m);
+        }
+      }
+    __syncthreads();  // all fragment reads finished: LDS becomes the cross-wave reduction scratch
+    float* red = reinterpret_cast<float*>(smem);  // [WP][2][CO_TILE]
+    if (idx == 0) {
+#pragma unroll
+      for (int a = 0; a < NG; ++a) {
+        const int cl0 = (TR::kBytes == 2) ? (wc * CT + 2 * a) * 16 + 8 * q : (wc * CT + a) * 16 + 4 * q;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          red[(wp * 2 + 0) * CO_TILE + cl0 + e] = s1[a][e];
+          red[(wp * 2 + 1) * CO_TILE + cl0 + e] = s2[a][e];
+        }
+      }
+    }
+    __syncthreads();
+    const int grp = n / (p.N / p.stats_groups);
+    for (int i = tid; i < p.stats_mode * CO_TILE; i += 256) {
+      const int which = i / CO_TILE, chn = i - which * CO_TILE;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WP; ++w) s += red[(w * 2 + which) * CO_TILE + chn];
+      atomicAdd(p.stats + ((size_t)grp * 2 + which) * p.Cout + co_base + chn, s);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ packing
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, char* __restrict__ packed, int cout, int cin,
+                                    int cout_p, int cin_p, long long s_co, long long s_ci, int nslots,
+                                    const int* __restrict__ slot_off) {
+  using TR = ElemTraits<T>;
+  const int nchunks = cin_p / TR::kChunk;
+  const long long total = (long long)nslots * nchunks * cout_p * TR::kChunk;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int kc = (int)(i % TR::kChunk);
+    long long r = i / TR::kChunk;
+    const int row = (int)(r % cout_p);
+    r /= cout_p;
+    const int c = (int)(r % nchunks);
+    const int slot = (int)(r / nchunks);
+    const int co = row_to_channel<T>(row);
+    const int ci = c * TR::kChunk + kc;
+    float v = 0.f;
+    if (co < cout && ci < cin) v = w[co * s_co + ci * s_ci + slot_off[slot]];
+    store_elem<T>(packed, i, v);
+  }
+}
+
+struct TileCfg {
+  int co_tile, th;
+};
+
+template <typename T, int CT, int PT, int WC, int WP>
+int launch_conv(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+  auto fn = conv_gather_kernel<T, CT, PT, WC, WP>;
+  static bool attr_done = false;  // one-time function attribute (benign race: idempotent)
+  if (!attr_done) {
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k);
+  return tg_launch_status();
+}
+
+template <typename T>
+int dispatch_conv(int cfg, const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+  switch (cfg) {
+    case TG_TILE_64x256: return launch_conv<T, 4, 4, 1, 4>(k, grid, lds, st);
+    case TG_TILE_64x64: return launch_conv<T, 2, 2, 2, 2>(k, grid, lds, st);
+    case TG_TILE_128x128: return launch_conv<T, 4, 4, 2, 2>(k, grid, lds, st);
+    case TG_TILE_32x128: return launch_conv<T, 2, 2, 1, 4>(k, grid, lds, st);
+  }
+  return TG_E_UNSUPPORTED;
+}
+
+TileCfg tile_cfg(int cfg) {
+  switch (cfg) {
+    case TG_TILE_64x256: return {64, 16};
+    case TG_TILE_64x64: return {64, 4};
+    case TG_TILE_128x128: return {128, 8};
+    case TG_TILE_32x128: return {32, 8};
+  }
+  return {0, 0};
+}
+
+}  // namespace
+
+extern "C" int64_t tg_packed_weight_bytes(int dtype, int nslots, int cout_p, int cin_p) {
+  if (nslots <= 0 || cout_p <= 0 || cin_p <= 0) return TG_E_BADARG;
+  return (int64_t)nslots * cout_p * cin_p * (dtype == TG_BF16 ? 2 : 4);
+}
+
+extern "C" int tg_pack_conv_weights(int dtype, const float* w, void* packed, int cout, int cin, int cout_p, int cin_p,
+                                    int64_t s_co, int64_t s_ci, int nslots, const int32_t* slot_off_dev,
+                                    void* stream) {
+  if (!w || !packed || !slot_off_dev || cout <= 0 || cin <= 0 || nslots <= 0) return TG_E_BADARG;
+  if (cout_p % 32 || cin_p % 32 || cout > cout_p || cin > cin_p) return TG_E_ALIGN;
+  if (dtype != TG_F32 && dtype != TG_BF16) return TG_E_BADARG;
+  const long long total = (long long)nslots * cout_p * cin_p;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TG_BF16)
+    hipLaunchKernelGGL(pack_weights_kernel<BF16>, dim3(blocks), dim3(256), 0, st, w, (char*)packed, cout, cin, cout_p,
+                       cin_p, (long long)s_co, (long long)s_ci, nslots, slot_off_dev);
+  else
+    hipLaunchKernelGGL(pack_weights_kernel<F32>, dim3(blocks), dim3(256), 0, st, w, (char*)packed, cout, cin, cout_p,
+                       cin_p, (long long)s_co, (long long)s_ci, nslots, slot_off_dev);
+  return tg_launch_status();
+}
+
+extern "C" int tg_conv(const tg_conv_desc* d, const void* in, const void* w_packed, const float* bias, const void* res,
+                       const void* mask, void* out, float* stats, void* stream) {
+  if (!d || !in || !w_packed || !out) return TG_E_BADARG;
+  if (d->dtype != TG_F32 && d->dtype != TG_BF16) return TG_E_BADARG;
+  if (d->N <= 0 || d->IH <= 0 || d->IW <= 0 || d->OH <= 0 || d->OW <= 0 || d->S <= 0 || d->OS <= 0) return TG_E_BADARG;
+  if (d->ncls <= 0 || d->ncls > TG_MAX_CLASSES) return TG_E_BADARG;
+  if (d->Cin <= 0 || d->Cout <= 0 || d->Cin % 32 || d->Cout % 32) return TG_E_ALIGN;
+  if (!tg_aligned16(in) || !tg_aligned16(w_packed) || !tg_aligned16(out) || (res && !tg_aligned16(res)) ||
+      (mask && !tg_aligned16(mask)))
+    return TG_E_ALIGN;
+  if (d->mask_mode != TG_MASK_NONE && !mask) return TG_E_BADARG;
+  if (d->stats_mode < 0 || d->stats_mode > 2) return TG_E_BADARG;
+  if (d->stats_mode && (!stats || d->stats_groups <= 0 || d->N % d->stats_groups)) return TG_E_BADARG;
+  if (d->out_mode == TG_OUT_NCHW_F32 && (d->c_real <= 0 || d->c_real > 4 || d->out_n_stride <= 0)) return TG_E_BADARG;
+  if (d->out_mode != TG_OUT_NHWC && d->out_mode != TG_OUT_NCHW_F32) return TG_E_BADARG;
+  if (d->out_mode == TG_OUT_NCHW_F32 && (res || d->mask_mode)) return TG_E_UNSUPPORTED;
+
+  int cfg = d->tile_cfg;
+  if (cfg == TG_TILE_AUTO) {
+    long long px = 0;
+    for (int c = 0; c < d->ncls; ++c) {
+      const long long ohc = (d->OH - d->cls[c].ooy + d->OS - 1) / d->OS, owc = (d->OW - d->cls[c].oox + d->OS - 1) / d->OS;
+      px += (long long)d->N * ohc * owc;
+    }
+    if (d->Cout % 64) cfg = TG_TILE_32x128;
+    else if (d->S > 1) cfg = (d->Cout % 128 == 0) ? TG_TILE_128x128 : TG_TILE_64x64;
+    else if (px < 64 * 1024) cfg = TG_TILE_64x64;
+    else if (d->Cout % 128 == 0) cfg = TG_TILE_128x128;
+    else cfg = TG_TILE_64x256;
+  }
+  const TileCfg tc = tile_cfg(cfg);
+  if (!tc.co_tile || d->Cout % tc.co_tile) return TG_E_UNSUPPORTED;
+
+  ConvK k;
+  k.in = (const char*)in; k.w = (const char*)w_packed; k.bias = bias; k.res = (const char*)res;
+  k.mask = (const char*)mask; k.out = (char*)out; k.stats = stats;
+  k.N = d->N; k.IH = d->IH; k.IW = d->IW; k.Cin = d->Cin; k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout;
+  k.S = d->S; k.OS = d->OS;
+  k.act = d->act; k.mask_mode = d->mask_mode; k.stats_mode = d->stats_mode; k.stats_groups = d->stats_groups;
+  k.out_mode = d->out_mode; k.c_real = d->c_real; k.out_n_stride = d->out_n_stride;
+  const int chunk = d->dtype == TG_BF16 ? 32 : 16;
+  k.nchunks = d->Cin / chunk;
+
+  int max_ohc = 0, max_owc = 0, max_rows = 0, max_taps = 0;
+  for (int c = 0; c < d->ncls; ++c) {
+    const tg_conv_class& s = d->cls[c];
+    if (s.ntaps <= 0 || s.ntaps > TG_MAX_TAPS || s.ooy < 0 || s.oox < 0 || s.ooy >= d->OS || s.oox >= d->OS)
+      return TG_E_BADARG;
+    ConvClassK& o = k.cls[c];
+    o.ooy = s.ooy; o.oox = s.oox; o.ntaps = s.ntaps;
+    int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
+    for (int t = 0; t < s.ntaps; ++t) {
+      o.dy[t] = s.dy[t]; o.dx[t] = s.dx[t]; o.widx[t] = s.widx[t];
+      if (s.widx[t] < 0) return TG_E_BADARG;
+      dymin = std::min<int>(dymin, s.dy[t]); dymax = std::max<int>(dymax, s.dy[t]);
+      dxmin = std::min<int>(dxmin, s.dx[t]); dxmax = std::max<int>(dxmax, s.dx[t]);
+    }
+    o.dymin = dymin; o.dxmin = dxmin;
+    o.ih = (tc.th - 1) * d->S + (dymax - dymin) + 1;
+    o.iw = 15 * d->S + (dxmax - dxmin) + 1;
+    max_rows = std::max(max_rows, o.ih * o.iw);
+    max_taps = std::max(max_taps, s.ntaps);
+    max_ohc = std::max(max_ohc, (d->OH - s.ooy + d->OS - 1) / d->OS);
+    max_owc = std::max(max_owc, (d->OW - s.oox + d->OS - 1) / d->OS);
+  }
+  k.a_rows_max = max_rows;
+  const size_t a_bytes = (size_t)max_rows * kRowBytes;
+  const size_t w_tap = (size_t)tc.co_tile * kRowBytes;
+  const size_t budget = 72 * 1024;  // two workgroups per CU
+  int tg = max_taps;
+  while (tg > 1 && a_bytes + tg * w_tap > budget) --tg;
+  size_t lds = a_bytes + tg * w_tap;
+  if (lds > 160 * 1024) return TG_E_UNSUPPORTED;
+  lds = std::max<size_t>(lds, 4 * 2 * tc.co_tile * sizeof(float));  // stats scratch
+  k.tg = tg;
+  k.tiles_x = (max_owc + 15) / 16;
+  k.tiles_y = (max_ohc + tc.th - 1) / tc.th;
+  const long long gx = (long long)k.tiles_x * k.tiles_y * d->N;
+  if (gx > 0x7fffffffLL) return TG_E_UNSUPPORTED;
+  dim3 grid((unsigned)gx, (unsigned)(d->Cout / tc.co_tile), (unsigned)d->ncls);
+  hipStream_t st = (hipStream_t)stream;
+  return d->dtype == TG_BF16 ? dispatch_conv<BF16>(cfg, k, grid, lds, st) : dispatch_conv<F32>(cfg, k, grid, lds, st);
+}

@@ -1,0 +1,481 @@
+// HBM-bound NHWC kernels: training-mode batch norm (code/ops.py:75-77, eps 1e-3, momentum 0.1) forward/backward,
+// the fc head (code/models.py:143-145), loss reductions (code/train.py:205-333) and fused Adam (main.py:239-243).
+// All kernels move 16 bytes per lane per access; per-channel quantities are kept in registers because a thread's
+// channel vector is fixed for its whole grid-stride loop.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+// Threads are arranged [rows = 256/VPP][VPP] where VPP = C / kVec vectors per pixel (a power of two <= 32).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ z, const float* __restrict__ stats,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const char* __restrict__ skip, char* __restrict__ y,
+                                                      float* __restrict__ rmean, float* __restrict__ rvar,
+                                                      float* __restrict__ save, int N, int HW, int C, int groups,
+                                                      int act, float eps, float momentum) {
+  using TR = ElemTraits<T>;
+  constexpr int E = TR::kVec;
+  const int vpp = C / E;
+  const int vec = threadIdx.x % vpp, prow = threadIdx.x / vpp, rows = 256 / vpp;
+  const int grp = blockIdx.y;
+  const long long npix = (long long)(N / groups) * HW;
+  const float cnt = (float)npix;
+  float scale[E], shift[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int c = vec * E + e;
+    const float mean = stats[(grp * 2 + 0) * C + c] / cnt;
+    float var = stats[(grp * 2 + 1) * C + c] / cnt - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    const float invstd = rsqrtf(var + eps);
+    scale[e] = gamma[c] * invstd;
+    shift[e] = beta[c] - mean * scale[e];
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < C) {  // single writer for running stats and saved mean/invstd
+    const int c = threadIdx.x;
+    float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
+    for (int g2 = 0; g2 < groups; ++g2) {  // sequential updates, one per forward call of the reference
+      const float mean = stats[(g2 * 2 + 0) * C + c] / cnt;
+      float var = stats[(g2 * 2 + 1) * C + c] / cnt - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      save[(g2 * 2 + 0) * C + c] = mean;
+      save[(g2 * 2 + 1) * C + c] = rsqrtf(var + eps);
+      rm = (1.f - momentum) * rm + momentum * mean;
+      rv = (1.f - momentum) * rv + momentum * var * (cnt / (cnt - 1.f));
+    }
+    if (rmean) rmean[c] = rm;
+    if (rvar) rvar[c] = rv;
+  }
+  const long long base = (long long)grp * npix;
+  for (long long p = (long long)blockIdx.x * rows + prow; p < npix; p += (long long)gridDim.x * rows) {
+    const long long off = ((base + p) * C + vec * E) * TR::kBytes;
+    float v[E];
+    Vec<T>::load(z + off, v);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      v[e] = v[e] * scale[e] + shift[e];
+      if (act == TG_ACT_LRELU) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+      else if (act == TG_ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    }
+    if (skip) {
+      float s[E];
+      Vec<T>::load(skip + off, s);
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] += s[e];
+    }
+    Vec<T>::store(y + off, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* __restrict__ dy, const char* __restrict__ yact,
+                                                           const char* __restrict__ z, const float* __restrict__ save,
+                                                           float* __restrict__ red, int N, int HW, int C, int groups,
+                                                           int act) {
+  using TR = ElemTraits<T>;
+  constexpr int E = TR::kVec;
+  __shared__ float sh[256 * 2 * E];
+  const int vpp = C / E;
+  const int vec = threadIdx.x % vpp, prow = threadIdx.x / vpp, rows = 256 / vpp;
+  const int grp = blockIdx.y;
+  const long long npix = (long long)(N / groups) * HW;
+  float mean[E], invstd[E], s1[E], s2[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    mean[e] = save[(grp * 2 + 0) * C + vec * E + e];
+    invstd[e] = save[(grp * 2 + 1) * C + vec * E + e];
+    s1[e] = s2[e] = 0.f;
+  }
+  const long long base = (long long)grp * npix;
+  for (long long p = (long long)blockIdx.x * rows + prow; p < npix; p += (long long)gridDim.x * rows) {
+    const long long off = ((base + p) * C + vec * E) * TR::kBytes;
+    float d[E], zz[E];
+    Vec<T>::load(dy + off, d);
+    Vec<T>::load(z + off, zz);
+    if (act == TG_ACT_LRELU) {
+      float a[E];
+      Vec<T>::load(yact + off, a);
+#pragma unroll
+      for (int e = 0; e < E; ++e) d[e] *= (a[e] > 0.f ? 1.f : 0.2f);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      s1[e] += d[e];
+      s2[e] += d[e] * (zz[e] - mean[e]) * invstd[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    sh[(threadIdx.x * 2 + 0) * E + e] = s1[e];
+    sh[(threadIdx.x * 2 + 1) * E + e] = s2[e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, c = i % C;
+    const int v = c / E, e = c % E;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += sh[((r * vpp + v) * 2 + which) * E + e];
+    atomicAdd(red + (grp * 2 + which) * C + c, s);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restrict__ dy, const char* __restrict__ yact,
+                                                          const char* __restrict__ z, const float* __restrict__ save,
+                                                          const float* __restrict__ red, const float* __restrict__ gamma,
+                                                          char* __restrict__ dz, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int N, int HW, int C, int groups,
+                                                          int act) {
+  using TR = ElemTraits<T>;
+  constexpr int E = TR::kVec;
+  const int vpp = C / E;
+  const int vec = threadIdx.x % vpp, prow = threadIdx.x / vpp, rows = 256 / vpp;
+  const int grp = blockIdx.y;
+  const long long npix = (long long)(N / groups) * HW;
+  const float inv_cnt = 1.f / (float)npix;
+  float mean[E], invstd[E], k0[E], m1[E], m2[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int c = vec * E + e;
+    mean[e] = save[(grp * 2 + 0) * C + c];
+    invstd[e] = save[(grp * 2 + 1) * C + c];
+    k0[e] = gamma[c] * invstd[e];
+    m1[e] = red[(grp * 2 + 0) * C + c] * inv_cnt;
+    m2[e] = red[(grp * 2 + 1) * C + c] * inv_cnt;
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < C) {
+    const int c = threadIdx.x;
+    float dg = 0.f, db = 0.f;
+    for (int g2 = 0; g2 < groups; ++g2) {
+      db += red[(g2 * 2 + 0) * C + c];
+      dg += red[(g2 * 2 + 1) * C + c];
+    }
+    dgamma[c] += dg;
+    dbeta[c] += db;
+  }
+  const long long base = (long long)grp * npix;
+  for (long long p = (long long)blockIdx.x * rows + prow; p < npix; p += (long long)gridDim.x * rows) {
+    const long long off = ((base + p) * C + vec * E) * TR::kBytes;
+    float d[E], zz[E];
+    Vec<T>::load(dy + off, d);
+    Vec<T>::load(z + off, zz);
+    if (act == TG_ACT_LRELU) {
+      float a[E];
+      Vec<T>::load(yact + off, a);
+#pragma unroll
+      for (int e = 0; e < E; ++e) d[e] *= (a[e] > 0.f ? 1.f : 0.2f);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float xh = (zz[e] - mean[e]) * invstd[e];
+      d[e] = k0[e] * (d[e] - m1[e] - xh * m2[e]);
+    }
+    Vec<T>::store(dz + off, d);
+  }
+}
+
+template <typename T>
+__global__ void fc_head_fwd_kernel(const char* __restrict__ feat, const float* __restrict__ w,
+                                   const float* __restrict__ b, float* __restrict__ prob, int N, int HW, int C, int Cp) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = b[0];
+  for (int c = 0; c < C; ++c)
+    for (int p = 0; p < HW; ++p) s += w[c * HW + p] * load_elem<T>(feat, ((long long)n * HW + p) * Cp + c);
+  prob[n] = 1.f / (1.f + __expf(-s));
+}
+
+template <typename T>
+__global__ void fc_head_bwd_kernel(const char* __restrict__ feat, const float* __restrict__ w,
+                                   const float* __restrict__ dlogit, char* __restrict__ dfeat, float* __restrict__ dw,
+                                   float* __restrict__ db, int N, int HW, int C, int Cp) {
+  // single block; feature gradient for every (n, p, c) including zeroed padding channels
+  for (int i = threadIdx.x; i < N * HW * Cp; i += blockDim.x) {
+    const int c = i % Cp, p = (i / Cp) % HW, n = i / (Cp * HW);
+    store_elem<T>(dfeat, i, c < C ? dlogit[n] * w[c * HW + p] : 0.f);
+  }
+  for (int i = threadIdx.x; i < C * HW; i += blockDim.x) {
+    const int c = i / HW, p = i % HW;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dlogit[n] * load_elem<T>(feat, ((long long)n * HW + p) * Cp + c);
+    dw[i] += s;
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dlogit[n];
+    db[0] += s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void absdiff_sum_kernel(const char* __restrict__ a, const char* __restrict__ b,
+                                                         float* __restrict__ acc, long long npix, int C, int Cp) {
+  using TR = ElemTraits<T>;
+  constexpr int E = TR::kVec;
+  __shared__ float sh[4];
+  const int vpp = Cp / E;
+  const long long total = npix * vpp;
+  float s = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += 256LL * gridDim.x) {
+    const int vec = (int)(i % vpp);
+    float x[E], y[E];
+    Vec<T>::load(a + i * 16, x);
+    Vec<T>::load(b + i * 16, y);
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (vec * E + e < C) s += fabsf(x[e] - y[e]);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void content_loss_kernel(const float* __restrict__ gen, const float* __restrict__ y,
+                                                          char* __restrict__ dpre, float* __restrict__ acc, int B,
+                                                          int T_, int H, int W, float gscale) {
+  using TR = ElemTraits<T>;
+  __shared__ float sh[4];
+  const long long HW = (long long)H * W;
+  const long long total = (long long)B * T_ * HW;
+  float s = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += 256LL * gridDim.x) {
+    const long long pos = i % HW;
+    const long long r = i / HW;
+    const int b = (int)(r % B);
+    const int t = (int)(r / B);  // destination order is (t, b): the batched backward sees frame-major samples
+    const long long src = ((long long)b * T_ + t) * 3 * HW + pos;
+    float v[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) v[c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float g = gen[src + c * HW], d = g - y[src + c * HW];
+      s += d * d;
+      v[c] = gscale * 2.f * d * g * (1.f - g);
+    }
+    if (dpre) {
+      char* o = dpre + i * 32 * TR::kBytes;
+#pragma unroll
+      for (int k = 0; k < 32 / TR::kVec; ++k) Vec<T>::store(o + k * 16, v + k * TR::kVec);
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+__global__ void absdiff_nchw_kernel(const float* __restrict__ a, const long long* __restrict__ a_off,
+                                    const float* __restrict__ b, const long long* __restrict__ b_off,
+                                    float* __restrict__ acc, int nblocks, long long len) {
+  __shared__ float sh[4];
+  const long long total = (long long)nblocks * len;
+  float s = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += 256LL * gridDim.x) {
+    const int k = (int)(i / len);
+    const long long e = i - (long long)k * len;
+    s += fabsf(a[a_off[k] + e] - b[b_off[k] + e]);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// cfg layout (floats): 0 content_div, 1 warp_div, 2..5 layer_div, 6 EPS, 7 ratio, 8 dt_ratio, 9 use_layerloss,
+//                      10 pp_div (0 = no pingpang), 11 pp_scaling, 12..15 layer_norm
+// acc layout: 0 content sumsq, 1 warp sumsq, 2..5 layer absdiff sums, 6 pingpang abs sum
+// scalars out: 0..3 layer losses, 4 layer_sum, 5 gen_loss total (aliased tensor), 6 warp loss, 7 t_adv, 8 d_loss,
+//              9 mean p_real, 10 mean p_fake, 11 content, 12 t_balance, 13 pingpang
+__global__ void loss_finalize_kernel(const float* __restrict__ prob, const float* __restrict__ acc,
+                                     float* __restrict__ sc, float* __restrict__ dlogit, int tb,
+                                     const float* __restrict__ cfg) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float eps = cfg[6];
+  float layer_sum = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    const float l = cfg[9] != 0.f ? acc[2 + i] / cfg[2 + i] : 0.f;
+    sc[i] = l;
+    layer_sum += 0.02f * l / cfg[12 + i];
+  }
+  sc[4] = layer_sum;
+  const float content = acc[0] / cfg[0];
+  sc[11] = content;
+  sc[6] = acc[1] / cfg[1];
+  float t_adv = 0.f, d_loss = 0.f, mr = 0.f, mf = 0.f, real_l = 0.f;
+  const float inv = 1.f / (float)tb;
+  for (int n = 0; n < tb; ++n) {
+    const float pr = prob[n], pf = prob[tb + n];
+    t_adv += -logf(pf + eps);
+    const float lr_ = logf(pr + eps), lf_ = logf(1.f - pf + eps);
+    d_loss += -(lf_ + lr_);
+    real_l += lr_;
+    mr += pr;
+    mf += pf;
+    dlogit[n] = -inv * (1.f / (pr + eps)) * pr * (1.f - pr);
+    dlogit[tb + n] = inv * (1.f / (1.f - pf + eps)) * pf * (1.f - pf);
+  }
+  t_adv *= inv; d_loss *= inv; mr *= inv; mf *= inv; real_l *= inv;
+  float total = content;
+  float pp = 0.f;
+  if (cfg[10] != 0.f) {
+    pp = acc[6] / cfg[10];
+    if (cfg[11] > 0.f) total += 2.f * pp * cfg[11];
+  }
+  sc[13] = pp;
+  total += 2.f * cfg[7] * t_adv;
+  if (cfg[9] != 0.f) total += layer_sum * cfg[8];
+  sc[5] = total; sc[7] = t_adv; sc[8] = d_loss; sc[9] = mr; sc[10] = mf;
+  sc[12] = real_l + t_adv;
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2, float gscale) {
+  const float step = lr / bc1, rs = rsqrtf(bc2);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);        // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;       // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step * (mi / (sqrtf(vi) * rs + eps));
+  }
+}
+
+inline int grid_for(long long total, int per_block, int cap) {
+  return (int)std::max<long long>(1, std::min<long long>((total + per_block - 1) / per_block, cap));
+}
+
+inline bool bn_shape_ok(int dtype, int C) {
+  const int e = dtype == TG_BF16 ? 8 : 4;
+  const int vpp = C / e;
+  return C % 32 == 0 && vpp <= 256 && (256 % vpp) == 0 && C <= 256;
+}
+
+}  // namespace
+
+#define TG_DISPATCH(dtype, KERNEL, grid, block, st, ...)                                         \
+  do {                                                                                           \
+    if ((dtype) == TG_BF16) hipLaunchKernelGGL(KERNEL<BF16>, grid, block, 0, st, __VA_ARGS__);   \
+    else if ((dtype) == TG_F32) hipLaunchKernelGGL(KERNEL<F32>, grid, block, 0, st, __VA_ARGS__); \
+    else return TG_E_BADARG;                                                                     \
+  } while (0)
+
+extern "C" int tg_bn_apply(int dtype, const void* z, const float* stats, const float* gamma, const float* beta,
+                           const void* skip, void* y, float* running_mean, float* running_var, float* save, int N,
+                           int HW, int C, int groups, int act, float eps, float momentum, void* stream) {
+  if (!z || !stats || !gamma || !beta || !y || !save || N <= 0 || HW <= 0 || groups <= 0 || N % groups) return TG_E_BADARG;
+  if (!bn_shape_ok(dtype, C)) return TG_E_UNSUPPORTED;
+  const int rows = 256 / (C / (dtype == TG_BF16 ? 8 : 4));
+  dim3 grid(grid_for((long long)(N / groups) * HW, rows * 4, 1024), groups);
+  TG_DISPATCH(dtype, bn_apply_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)z, stats, gamma, beta,
+              (const char*)skip, (char*)y, running_mean, running_var, save, N, HW, C, groups, act, eps, momentum);
+  return tg_launch_status();
+}
+
+extern "C" int tg_bn_bwd_reduce(int dtype, const void* dy, const void* yact, const void* z, const float* save,
+                                float* red, int N, int HW, int C, int groups, int act, void* stream) {
+  if (!dy || !z || !save || !red || N <= 0 || HW <= 0 || groups <= 0 || N % groups) return TG_E_BADARG;
+  if (act == TG_ACT_LRELU && !yact) return TG_E_BADARG;
+  if (!bn_shape_ok(dtype, C)) return TG_E_UNSUPPORTED;
+  const int rows = 256 / (C / (dtype == TG_BF16 ? 8 : 4));
+  dim3 grid(grid_for((long long)(N / groups) * HW, rows * 16, 256), groups);
+  TG_DISPATCH(dtype, bn_bwd_reduce_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)dy, (const char*)yact,
+              (const char*)z, save, red, N, HW, C, groups, act);
+  return tg_launch_status();
+}
+
+extern "C" int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, const void* z, const float* save,
+                               const float* red, const float* gamma, void* dz, float* dgamma, float* dbeta, int N,
+                               int HW, int C, int groups, int act, void* stream) {
+  if (!dy || !z || !save || !red || !gamma || !dz || !dgamma || !dbeta || N <= 0 || HW <= 0 || groups <= 0 || N % groups)
+    return TG_E_BADARG;
+  if (act == TG_ACT_LRELU && !yact) return TG_E_BADARG;
+  if (!bn_shape_ok(dtype, C)) return TG_E_UNSUPPORTED;
+  const int rows = 256 / (C / (dtype == TG_BF16 ? 8 : 4));
+  dim3 grid(grid_for((long long)(N / groups) * HW, rows * 4, 1024), groups);
+  TG_DISPATCH(dtype, bn_bwd_apply_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)dy, (const char*)yact,
+              (const char*)z, save, red, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act);
+  return tg_launch_status();
+}
+
+extern "C" int tg_fc_head_fwd(int dtype, const void* feat, const float* w, const float* b, float* prob, int N, int HW,
+                              int C, int Cp, void* stream) {
+  if (!feat || !w || !b || !prob || N <= 0 || HW <= 0 || C <= 0 || C > Cp) return TG_E_BADARG;
+  TG_DISPATCH(dtype, fc_head_fwd_kernel, dim3((N + 63) / 64), dim3(64), (hipStream_t)stream, (const char*)feat, w, b,
+              prob, N, HW, C, Cp);
+  return tg_launch_status();
+}
+
+extern "C" int tg_fc_head_bwd(int dtype, const void* feat, const float* w, const float* dlogit, void* dfeat, float* dw,
+                              float* db, int N, int HW, int C, int Cp, void* stream) {
+  if (!feat || !w || !dlogit || !dfeat || !dw || !db || N <= 0 || HW <= 0 || C <= 0 || C > Cp) return TG_E_BADARG;
+  TG_DISPATCH(dtype, fc_head_bwd_kernel, dim3(1), dim3(256), (hipStream_t)stream, (const char*)feat, w, dlogit,
+              (char*)dfeat, dw, db, N, HW, C, Cp);
+  return tg_launch_status();
+}
+
+extern "C" int tg_absdiff_sum(int dtype, const void* a, const void* b, float* acc, int64_t npix, int C, int Cp,
+                              void* stream) {
+  if (!a || !b || !acc || npix <= 0 || C <= 0 || C > Cp || Cp % 32) return TG_E_BADARG;
+  const long long total = npix * (Cp / (dtype == TG_BF16 ? 8 : 4));
+  TG_DISPATCH(dtype, absdiff_sum_kernel, dim3(grid_for(total, 1024, 512)), dim3(256), (hipStream_t)stream,
+              (const char*)a, (const char*)b, acc, (long long)npix, C, Cp);
+  return tg_launch_status();
+}
+
+extern "C" int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const float* b, const int64_t* b_off_dev,
+                               float* acc, int nblocks, int64_t len, void* stream) {
+  if (!a || !b || !a_off_dev || !b_off_dev || !acc || nblocks <= 0 || len <= 0) return TG_E_BADARG;
+  hipLaunchKernelGGL(absdiff_nchw_kernel, dim3(grid_for((long long)nblocks * len, 1024, 512)), dim3(256), 0,
+                     (hipStream_t)stream, a, (const long long*)a_off_dev, b, (const long long*)b_off_dev, acc, nblocks,
+                     (long long)len);
+  return tg_launch_status();
+}
+
+extern "C" int tg_content_loss(int dtype, const float* gen, const float* y, void* dpre, float* acc, int B, int T,
+                               int H, int W, float gscale, void* stream) {
+  if (!gen || !y || !acc || B <= 0 || T <= 0 || H <= 0 || W <= 0) return TG_E_BADARG;
+  const long long total = (long long)B * T * H * W;
+  TG_DISPATCH(dtype, content_loss_kernel, dim3(grid_for(total, 512, 1024)), dim3(256), (hipStream_t)stream, gen, y,
+              (char*)dpre, acc, B, T, H, W, gscale);
+  return tg_launch_status();
+}
+
+extern "C" int tg_loss_finalize(const float* prob, const float* acc, float* scalars, float* dlogit, int tb,
+                                const float* cfg, void* stream) {
+  if (!prob || !acc || !scalars || !dlogit || !cfg || tb <= 0) return TG_E_BADARG;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, prob, acc, scalars, dlogit, tb,
+                     cfg);
+  return tg_launch_status();
+}
+
+extern "C" int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float bc1, float bc2, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || n <= 0) return TG_E_BADARG;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (long long)n, lr, beta1, beta2, eps, bc1, bc2, grad_scale);
+  return tg_launch_status();
+}
+
+extern "C" int tg_abi_version(void) { return TG_ABI_VERSION; }
+
+extern "C" const char* tg_error_string(int code) {
+  switch (code) {
+    case TG_OK: return "ok";
+    case TG_E_BADARG: return "invalid argument";
+    case TG_E_UNSUPPORTED: return "unsupported shape";
+    case TG_E_ALIGN: return "misaligned pointer or channel count not a multiple of 32";
+  }
+  return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+}

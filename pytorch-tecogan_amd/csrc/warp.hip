@@ -1,0 +1,365 @@
+// Flow / warp / packing kernels (HBM-bound).  fp32 coordinate math written with explicit non-contracted
+// mul/add so that corner indices are bit-identical to the reference CPU arithmetic:
+//   bilinear x4      code/ops.py:98-100 (nn.Upsample scale 4, align_corners=False)
+//   grid_sample      code/train.py:81-84,98,165,187 ; main.py:203 (bilinear, zeros, align_corners=False)
+//   generator input  code/train.py:86-88,95-107 ; main.py:191-213
+//   D input          code/train.py:160-198
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+namespace {
+
+__device__ __forceinline__ float fp16_round(float v) { return __half2float(__float2half_rn(v)); }
+
+// source index/weight of nn.Upsample(scale_factor=4, bilinear, align_corners=False): src = 0.25*(dst+0.5)-0.5, clamped at 0
+__device__ __forceinline__ void up4_coord(int d, int in_size, int& i0, int& i1, float& l1) {
+  float s = __fsub_rn(__fmul_rn(0.25f, __fadd_rn((float)d, 0.5f)), 0.5f);
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = __fsub_rn(s, (float)i0);
+}
+
+__device__ __forceinline__ float up4_sample(const float* __restrict__ pl, int w, int y0, int y1, float ly, int x0,
+                                             int x1, float lx, float pre) {
+  const float hx = __fsub_rn(1.f, lx), hy = __fsub_rn(1.f, ly);
+  const float a = __fmul_rn(pl[y0 * w + x0], pre), b = __fmul_rn(pl[y0 * w + x1], pre);
+  const float c = __fmul_rn(pl[y1 * w + x0], pre), d = __fmul_rn(pl[y1 * w + x1], pre);
+  const float top = __fadd_rn(__fmul_rn(hx, a), __fmul_rn(lx, b));
+  const float bot = __fadd_rn(__fmul_rn(hx, c), __fmul_rn(lx, d));
+  return __fadd_rn(__fmul_rn(hy, top), __fmul_rn(ly, bot));
+}
+
+__global__ void up4_planes_kernel(const float* __restrict__ src, const long long* __restrict__ src_off,
+                                  float* __restrict__ dst, const long long* __restrict__ dst_off, int nplanes, int h,
+                                  int w, float pre, float post_a, float post_b) {
+  const int H = 4 * h, W = 4 * w;
+  const long long total = (long long)nplanes * H * W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % W);
+    const long long r = i / W;
+    const int Y = (int)(r % H);
+    const int pl = (int)(r / H);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    up4_coord(Y, h, y0, y1, ly);
+    up4_coord(X, w, x0, x1, lx);
+    const float v = up4_sample(src + src_off[pl], w, y0, y1, ly, x0, x1, lx, pre);
+    dst[dst_off[pl] + (long long)Y * W + X] = __fadd_rn(__fmul_rn(post_a, v), post_b);
+  }
+}
+
+__global__ void copy_blocks_kernel(const float* __restrict__ src, const long long* __restrict__ src_off,
+                                   float* __restrict__ dst, const long long* __restrict__ dst_off, int nblocks,
+                                   long long len) {
+  const long long total = (long long)nblocks * len;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / len);
+    const long long e = i - (long long)b * len;
+    const long long so = src_off[b];
+    dst[dst_off[b] + e] = so < 0 ? 0.f : src[so + e];
+  }
+}
+
+struct Bilin {
+  int x0, y0;
+  float nw, ne, sw, se;
+  bool vx0, vx1, vy0, vy1;
+};
+
+// grid_sampler_unnormalize (align_corners=False): ((g+1)*size-1)/2, then floor and the four corner weights
+__device__ __forceinline__ Bilin bilin_setup(float gx, float gy, int IW, int IH) {
+  Bilin b;
+  const float ix = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), (float)IW), 1.f), 0.5f);
+  const float iy = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), (float)IH), 1.f), 0.5f);
+  const float fx = floorf(ix), fy = floorf(iy);
+  // clamp before the int conversion: far out-of-range coordinates must stay "invalid", not wrap
+  b.x0 = (int)fminf(fmaxf(fx, -2.f), (float)IW + 1.f);
+  b.y0 = (int)fminf(fmaxf(fy, -2.f), (float)IH + 1.f);
+  const float w = __fsub_rn(ix, fx), e = __fsub_rn(1.f, w);
+  const float n = __fsub_rn(iy, fy), s = __fsub_rn(1.f, n);
+  b.nw = __fmul_rn(e, s); b.ne = __fmul_rn(w, s); b.sw = __fmul_rn(e, n); b.se = __fmul_rn(w, n);
+  b.vx0 = b.x0 >= 0 && b.x0 < IW; b.vx1 = b.x0 + 1 >= 0 && b.x0 + 1 < IW;
+  b.vy0 = b.y0 >= 0 && b.y0 < IH; b.vy1 = b.y0 + 1 >= 0 && b.y0 + 1 < IH;
+  if (!(ix == ix) || !(iy == iy)) b.vx0 = b.vx1 = b.vy0 = b.vy1 = false;  // NaN grid -> zeros
+  return b;
+}
+
+__device__ __forceinline__ float bilin_sample(const Bilin& b, const float* __restrict__ pl, int IW) {
+  float v = 0.f;
+  if (b.vy0 && b.vx0) v = __fadd_rn(v, __fmul_rn(pl[b.y0 * IW + b.x0], b.nw));
+  if (b.vy0 && b.vx1) v = __fadd_rn(v, __fmul_rn(pl[b.y0 * IW + b.x0 + 1], b.ne));
+  if (b.vy1 && b.vx0) v = __fadd_rn(v, __fmul_rn(pl[(b.y0 + 1) * IW + b.x0], b.sw));
+  if (b.vy1 && b.vx1) v = __fadd_rn(v, __fmul_rn(pl[(b.y0 + 1) * IW + b.x0 + 1], b.se));
+  return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) sh[wid] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+  return t;  // valid in thread 0
+}
+
+__global__ void warp_nchw_kernel(const float* __restrict__ img, const long long* __restrict__ img_off,
+                                 const float* __restrict__ grid, const long long* __restrict__ grid_off,
+                                 float* __restrict__ out, int* __restrict__ corner, const float* __restrict__ sq_ref,
+                                 const long long* __restrict__ sq_off, float* __restrict__ loss_acc, int N, int C,
+                                 int IH, int IW, int GH, int GW, int fp16_grid) {
+  __shared__ float sh[8];
+  const long long total = (long long)N * GH * GW;
+  float lsum = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pos = i % ((long long)GH * GW);
+    const int n = (int)(i / ((long long)GH * GW));
+    const float* gb = grid + grid_off[n] + 2 * pos;  // (2,GH,GW) block reinterpreted as (GH,GW,2)
+    float gx = gb[0], gy = gb[1];
+    if (fp16_grid) { gx = fp16_round(gx); gy = fp16_round(gy); }
+    const Bilin b = bilin_setup(gx, gy, IW, IH);
+    if (corner) { corner[2 * i] = b.x0; corner[2 * i + 1] = b.y0; }
+    for (int c = 0; c < C; ++c) {
+      const float v = bilin_sample(b, img + img_off[n] + (long long)c * IH * IW, IW);
+      if (out) out[((long long)n * C + c) * GH * GW + pos] = v;
+      if (sq_ref) {
+        const float d = sq_ref[sq_off[n] + (long long)c * GH * GW + pos] - v;
+        lsum += d * d;
+      }
+    }
+  }
+  if (sq_ref) {  // uniform
+    const float t = block_sum(lsum, sh);
+    if (threadIdx.x == 0) atomicAdd(loss_acc, t);
+  }
+}
+
+template <typename T>
+__global__ void gen_input_kernel(const float* __restrict__ lr, long long lr_n_stride, const float* __restrict__ prev,
+                                 long long prev_n_stride, const float* __restrict__ grid, long long grid_n_stride,
+                                 char* __restrict__ dst, int B, int h, int w) {
+  using TR = ElemTraits<T>;
+  const int H = 4 * h, W = 4 * w;
+  const long long total = (long long)B * h * w;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w);
+    const long long r = i / w;
+    const int y = (int)(r % h);
+    const int b = (int)(r / h);
+    float v[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) v[c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = lr[b * lr_n_stride + ((long long)c * h + y) * w + x];
+    if (prev) {
+      const float* gb = grid + b * grid_n_stride;
+      const float* pb = prev + b * prev_n_stride;
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const long long pos = (long long)(4 * y + ii) * W + 4 * x + jj;
+          const Bilin bl = bilin_setup(fp16_round(gb[2 * pos]), fp16_round(gb[2 * pos + 1]), W, H);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float s = bilin_sample(bl, pb + (long long)c * H * W, W);
+            v[3 + c * 16 + ii * 4 + jj] = __fmul_rn(__fadd_rn(s, 1.f), 0.5f);  // deprocess: (w+1)/2
+          }
+        }
+    }
+    char* o = dst + i * 64 * TR::kBytes;
+#pragma unroll
+    for (int k = 0; k < 64 / TR::kVec; ++k) Vec<T>::store(o + k * 16, v + k * TR::kVec);
+  }
+}
+
+template <typename T>
+__global__ void d_assemble_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                  const float* __restrict__ gen, const float* __restrict__ tvel, char* __restrict__ dst,
+                                  int B, int T_, int K, int h, int border) {
+  using TR = ElemTraits<T>;
+  const int H = 4 * h;
+  const int tb = B * K;
+  const long long HH = (long long)H * H;
+  const long long total = 2LL * tb * HH;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % H);
+    long long r = i / H;
+    const int Y = (int)(r % H);
+    r /= H;
+    const int m = (int)(r % tb);
+    const int fake = (int)(r / tb);
+    const int b = m / K, j = m % K;
+    const long long pos = (long long)Y * H + X;
+    const bool inside = Y >= border && Y < H - border && X >= border && X < H - border;
+    float v[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) v[c] = 0.f;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    up4_coord(Y, h, y0, y1, ly);
+    up4_coord(X, h, x0, x1, lx);
+    const float* src = fake ? gen : y;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+      const int f = 3 * j + rr;
+      const long long hr_frame = ((long long)b * T_ + f) * 3 * HH;
+      const long long lr_frame = ((long long)b * T_ + f) * 3 * h * h;
+      Bilin bl;
+      if (inside) {
+        const float* gb = tvel + ((long long)b * 3 * K + f) * 2 * HH + 2 * pos;
+        float gx = gb[0], gy = gb[1];
+        if (fake) { gx = fp16_round(gx); gy = fp16_round(gy); }
+        bl = bilin_setup(gx, gy, H, H);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        v[rr * 3 + c] = y[hr_frame + c * HH + pos];
+        if (inside) v[9 + rr * 3 + c] = bilin_sample(bl, src + hr_frame + c * HH, H);
+        v[18 + rr * 3 + c] = up4_sample(x + lr_frame + (long long)c * h * h, h, y0, y1, ly, x0, x1, lx, 1.f);
+      }
+    }
+    char* o = dst + i * 32 * TR::kBytes;
+#pragma unroll
+    for (int k = 0; k < 32 / TR::kVec; ++k) Vec<T>::store(o + k * 16, v + k * TR::kVec);
+  }
+}
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, long long src_n_stride, char* __restrict__ dst,
+                                    int N, int C, int Cp, int H, int W) {
+  using TR = ElemTraits<T>;
+  const int nvec = Cp / TR::kVec;
+  const long long HW = (long long)H * W;
+  const long long total = (long long)N * nvec * HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pos = i % HW;
+    const long long r = i / HW;
+    const int vc = (int)(r % nvec);
+    const int n = (int)(r / nvec);
+    float v[TR::kVec];
+#pragma unroll
+    for (int e = 0; e < TR::kVec; ++e) {
+      const int c = vc * TR::kVec + e;
+      v[e] = c < C ? src[n * src_n_stride + c * HW + pos] : 0.f;
+    }
+    Vec<T>::store(dst + (((long long)n * HW + pos) * Cp + vc * TR::kVec) * TR::kBytes, v);
+  }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const char* __restrict__ src, float* __restrict__ dst, long long dst_n_stride,
+                                    int N, int C, int Cp, int H, int W) {
+  const long long HW = (long long)H * W;
+  const long long total = (long long)N * C * HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pos = i % HW;
+    const long long r = i / HW;
+    const int c = (int)(r % C);
+    const int n = (int)(r / C);
+    dst[n * dst_n_stride + c * HW + pos] = load_elem<T>(src, ((long long)n * HW + pos) * Cp + c);
+  }
+}
+
+inline int grid_for(long long total, int block = 256, int cap = 4096) {
+  return (int)std::max<long long>(1, std::min<long long>((total + block - 1) / block, cap));
+}
+
+}  // namespace
+
+extern "C" int tg_up4_planes(const float* src, const int64_t* src_off_dev, float* dst, const int64_t* dst_off_dev,
+                             int nplanes, int h, int w, float pre, float post_a, float post_b, void* stream) {
+  if (!src || !dst || !src_off_dev || !dst_off_dev || nplanes <= 0 || h <= 0 || w <= 0) return TG_E_BADARG;
+  const long long total = (long long)nplanes * 16 * h * w;
+  hipLaunchKernelGGL(up4_planes_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
+                     (const long long*)src_off_dev, dst, (const long long*)dst_off_dev, nplanes, h, w, pre, post_a,
+                     post_b);
+  return tg_launch_status();
+}
+
+extern "C" int tg_copy_blocks(const float* src, const int64_t* src_off_dev, float* dst, const int64_t* dst_off_dev,
+                              int nblocks, int64_t len, void* stream) {
+  if (!src || !dst || !src_off_dev || !dst_off_dev || nblocks <= 0 || len <= 0) return TG_E_BADARG;
+  hipLaunchKernelGGL(copy_blocks_kernel, dim3(grid_for((long long)nblocks * len)), dim3(256), 0, (hipStream_t)stream,
+                     src, (const long long*)src_off_dev, dst, (const long long*)dst_off_dev, nblocks, (long long)len);
+  return tg_launch_status();
+}
+
+extern "C" int tg_warp_nchw(const float* img, const int64_t* img_off_dev, const float* grid,
+                            const int64_t* grid_off_dev, float* out, int32_t* corner_idx, const float* sq_ref,
+                            const int64_t* sq_off_dev, float* loss_acc, int N, int C, int IH, int IW, int GH, int GW,
+                            int fp16_grid, void* stream) {
+  if (!img || !img_off_dev || !grid || !grid_off_dev || N <= 0 || C <= 0 || IH <= 0 || IW <= 0 || GH <= 0 || GW <= 0)
+    return TG_E_BADARG;
+  if (sq_ref && (!sq_off_dev || !loss_acc)) return TG_E_BADARG;
+  hipLaunchKernelGGL(warp_nchw_kernel, dim3(grid_for((long long)N * GH * GW, 256, 1024)), dim3(256), 0,
+                     (hipStream_t)stream, img, (const long long*)img_off_dev, grid, (const long long*)grid_off_dev, out,
+                     corner_idx, sq_ref, (const long long*)sq_off_dev, loss_acc, N, C, IH, IW, GH, GW, fp16_grid);
+  return tg_launch_status();
+}
+
+extern "C" int tg_gen_input(int dtype, const float* lr, int64_t lr_n_stride, const float* prev, int64_t prev_n_stride,
+                            const float* grid, int64_t grid_n_stride, void* dst, int B, int h, int w, void* stream) {
+  if (!lr || !dst || B <= 0 || h <= 0 || w <= 0 || (prev && !grid)) return TG_E_BADARG;
+  if (!tg_aligned16(dst)) return TG_E_ALIGN;
+  const int g = grid_for((long long)B * h * w, 64);
+  if (dtype == TG_BF16)
+    hipLaunchKernelGGL(gen_input_kernel<BF16>, dim3(g), dim3(64), 0, (hipStream_t)stream, lr, (long long)lr_n_stride,
+                       prev, (long long)prev_n_stride, grid, (long long)grid_n_stride, (char*)dst, B, h, w);
+  else if (dtype == TG_F32)
+    hipLaunchKernelGGL(gen_input_kernel<F32>, dim3(g), dim3(64), 0, (hipStream_t)stream, lr, (long long)lr_n_stride,
+                       prev, (long long)prev_n_stride, grid, (long long)grid_n_stride, (char*)dst, B, h, w);
+  else
+    return TG_E_BADARG;
+  return tg_launch_status();
+}
+
+extern "C" int tg_d_assemble(int dtype, const float* x, const float* y, const float* gen, const float* tvel, void* dst,
+                             int B, int T, int K, int h, int border, void* stream) {
+  if (!x || !y || !gen || !tvel || !dst || B <= 0 || T < 3 * K || K <= 0 || h <= 0 || border < 0) return TG_E_BADARG;
+  if (!tg_aligned16(dst)) return TG_E_ALIGN;
+  const long long total = 2LL * B * K * 16 * h * h;
+  if (dtype == TG_BF16)
+    hipLaunchKernelGGL(d_assemble_kernel<BF16>, dim3(grid_for(total, 128)), dim3(128), 0, (hipStream_t)stream, x, y,
+                       gen, tvel, (char*)dst, B, T, K, h, border);
+  else if (dtype == TG_F32)
+    hipLaunchKernelGGL(d_assemble_kernel<F32>, dim3(grid_for(total, 128)), dim3(128), 0, (hipStream_t)stream, x, y,
+                       gen, tvel, (char*)dst, B, T, K, h, border);
+  else
+    return TG_E_BADARG;
+  return tg_launch_status();
+}
+
+extern "C" int tg_nchw_to_nhwc(int dtype, const float* src, int64_t src_n_stride, void* dst, int N, int C, int Cp,
+                               int H, int W, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || C > Cp) return TG_E_BADARG;
+  if (Cp % 32 || !tg_aligned16(dst)) return TG_E_ALIGN;
+  const long long total = (long long)N * H * W * (Cp / (dtype == TG_BF16 ? 8 : 4));
+  if (dtype == TG_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
+                       (long long)src_n_stride, (char*)dst, N, C, Cp, H, W);
+  else if (dtype == TG_F32)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<F32>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
+                       (long long)src_n_stride, (char*)dst, N, C, Cp, H, W);
+  else
+    return TG_E_BADARG;
+  return tg_launch_status();
+}
+
+extern "C" int tg_nhwc_to_nchw(int dtype, const void* src, float* dst, int64_t dst_n_stride, int N, int C, int Cp,
+                               int H, int W, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || C > Cp) return TG_E_BADARG;
+  const long long total = (long long)N * C * H * W;
+  if (dtype == TG_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const char*)src, dst, (long long)dst_n_stride, N, C, Cp, H, W);
+  else if (dtype == TG_F32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<F32>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const char*)src, dst, (long long)dst_n_stride, N, C, Cp, H, W);
+  else
+    return TG_E_BADARG;
+  return tg_launch_status();
+}

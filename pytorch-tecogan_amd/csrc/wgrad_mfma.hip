@@ -1,0 +1,296 @@
+// Weight gradient of a gather convolution on the matrix cores:
+//
+//   dW[t][a][b] = sum over (n, y, x) of  X[n, y*S + dy[t], x*S + dx[t]][a] * Y[n, y, x][b]
+//
+// The reduction dimension is the PIXEL index, but both operands are NHWC (channel-contiguous), so each MFMA
+// operand is a transposed read of a [pixel][channel] LDS image: ds_read_b64_tr_b16 for bf16 (4 pixels x 16
+// channels per 16-lane group, row addresses supplied per lane, which also makes tap shifts and stride-2
+// gathers free), plain ds_read_b32 for f32 (v_mfma_f32_16x16x4_f32 takes one value per lane).
+//
+// One workgroup owns a (16*AW)-channel slice of X times a (16*BT*BW)-channel slice of Y for ALL taps and
+// walks its share of the pixel tiles (split-K over pixels) with the partial dW kept in accumulators; it
+// writes one fp32 slab, and tg_wgrad_finalize sums the slabs into the PyTorch-layout gradient.
+//
+// Replaces aten::convolution_backward (weight path) behind code/train.py:336,340.
+#include "common.h"
+
+namespace {
+
+struct WgradK {
+  const char* x;
+  const char* y;
+  float* slab;
+  int N, XH, XW, Cx, YH, YW, Cy, S;
+  int ntaps;
+  int8_t dy[TG_MAX_TAPS];
+  int8_t dx[TG_MAX_TAPS];
+  int dymin, dxmin, ih, iw;
+  int tw_log2, th;
+  int tiles_x, tiles_y, tiles_total, nsplit;
+  int b_blocks;
+};
+
+template <typename T, int NTAPS, int AW, int BT>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
+  using TR = ElemTraits<T>;
+  constexpr int BW = 4 / AW;
+  constexpr int A_BLK = 16 * AW, B_BLK = 16 * BT * BW;
+  constexpr int XROW = A_BLK * TR::kBytes + 16, YROW = B_BLK * TR::kBytes + 16;
+  constexpr int XV = A_BLK * TR::kBytes / 16, YV = B_BLK * TR::kBytes / 16;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tw = 1 << p.tw_log2;
+  const int ypix = tw * p.th;
+  char* lds_y = smem;
+  char* lds_x = smem + (size_t)ypix * YROW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wa = wid % AW, wb = wid / AW;
+  const int idx = lane & 15, g = lane >> 4;
+  const int a_blk = blockIdx.y / p.b_blocks, b_blk = blockIdx.y % p.b_blocks;
+  const int a0 = a_blk * A_BLK, b0 = b_blk * B_BLK;
+
+  f32x4 acc[NTAPS][BT];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int b = 0; b < BT; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const size_t xpix_bytes = (size_t)p.Cx * TR::kBytes, ypix_bytes = (size_t)p.Cy * TR::kBytes;
+  const int prow_n = p.ih * p.iw;
+
+  for (int tile = blockIdx.x; tile < p.tiles_total; tile += p.nsplit) {
+    int r = tile;
+    const int txb = r % p.tiles_x;
+    r /= p.tiles_x;
+    const int tyb = r % p.tiles_y;
+    const int n = r / p.tiles_y;
+    const int ty0 = tyb * p.th, tx0 = txb * tw;
+    const int iy0 = ty0 * p.S + p.dymin, ix0 = tx0 * p.S + p.dxmin;
+
+    __syncthreads();
+    const char* xn = p.x + (size_t)n * p.XH * p.XW * xpix_bytes + (size_t)a0 * TR::kBytes;
+    for (int i = tid; i < prow_n * XV; i += 256) {
+      const int prow = i / XV, s = i - prow * XV;
+      const int py = prow / p.iw, px = prow - py * p.iw;
+      const int iy = iy0 + py, ix = ix0 + px;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (iy >= 0 && iy < p.XH && ix >= 0 && ix < p.XW)
+        v = *reinterpret_cast<const u32x4*>(xn + ((size_t)iy * p.XW + ix) * xpix_bytes + s * 16);
+      *reinterpret_cast<u32x4*>(lds_x + prow * XROW + s * 16) = v;
+    }
+    const char* yn = p.y + (size_t)n * p.YH * p.YW * ypix_bytes + (size_t)b0 * TR::kBytes;
+    for (int i = tid; i < ypix * YV; i += 256) {
+      const int prow = i / YV, s = i - prow * YV;
+      const int yy = ty0 + (prow >> p.tw_log2), xx = tx0 + (prow & (tw - 1));
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (yy < p.YH && xx < p.YW)
+        v = *reinterpret_cast<const u32x4*>(yn + ((size_t)yy * p.YW + xx) * ypix_bytes + s * 16);
+      *reinterpret_cast<u32x4*>(lds_y + prow * YROW + s * 16) = v;
+    }
+    __syncthreads();
+
+    for (int k0 = 0; k0 < ypix; k0 += 32) {
+      if constexpr (TR::kBytes == 2) {
+        // lane (q,pp) of each 16-lane group supplies row q, columns 4pp..4pp+3 of a 4-pixel x 16-channel block
+        const int q = idx >> 2, pp = idx & 3;
+        const int k_lo = k0 + 8 * g + q, k_hi = k_lo + 4;
+        bf16x8 bf[BT];
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+          const int ch = ((wb * BT + b) * 16 + 4 * pp) * 2;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(lds_y + k_lo * YROW + ch));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(lds_y + k_hi * YROW + ch));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 cat = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          bf[b] = __builtin_bit_cast(bf16x8, cat);
+        }
+        const int ty_lo = k_lo >> p.tw_log2, tx_lo = k_lo & (tw - 1);
+        const int ty_hi = k_hi >> p.tw_log2, tx_hi = k_hi & (tw - 1);
+        const int cha = (wa * 16 + 4 * pp) * 2;
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+          const int oy = p.dy[t] - p.dymin, ox = p.dx[t] - p.dxmin;
+          const int r_lo = (ty_lo * p.S + oy) * p.iw + tx_lo * p.S + ox;
+          const int r_hi = (ty_hi * p.S + oy) * p.iw + tx_hi * p.S + ox;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(lds_x + r_lo * XROW + cha));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(lds_x + r_hi * XROW + cha));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 cat = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const bf16x8 af = __builtin_bit_cast(bf16x8, cat);
+#pragma unroll
+          for (int b = 0; b < BT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[b], acc[t][b], 0, 0, 0);
+        }
+      } else {
+#pragma unroll 2
+        for (int sub = 0; sub < 8; ++sub) {
+          const int k = k0 + 4 * sub + g;  // lane group g carries pixel k of this 4-pixel MFMA
+          float bv[BT];
+#pragma unroll
+          for (int b = 0; b < BT; ++b)
+            bv[b] = *reinterpret_cast<const float*>(lds_y + k * YROW + ((wb * BT + b) * 16 + idx) * 4);
+          const int ty = k >> p.tw_log2, tx = k & (tw - 1);
+#pragma unroll
+          for (int t = 0; t < NTAPS; ++t) {
+            const int rr = (ty * p.S + p.dy[t] - p.dymin) * p.iw + tx * p.S + p.dx[t] - p.dxmin;
+            const float av = *reinterpret_cast<const float*>(lds_x + rr * XROW + (wa * 16 + idx) * 4);
+#pragma unroll
+            for (int b = 0; b < BT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[b], acc[t][b], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // slab[split][t][a][b]; accumulator rows 4g+j are the X channel, column idx the Y channel
+  float* slab = p.slab + (size_t)blockIdx.x * NTAPS * p.Cx * p.Cy;
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      const int bch = b0 + (wb * BT + b) * 16 + idx;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ach = a0 + wa * 16 + 4 * g + j;
+        slab[((size_t)t * p.Cx + ach) * p.Cy + bch] = acc[t][b][j];
+      }
+    }
+}
+
+__global__ void wgrad_finalize_kernel(const float* __restrict__ slab, int nsplit, int ntaps, int ca_p, int cb_p, int ca,
+                                      int cb, float* __restrict__ grad, long long s_a, long long s_b,
+                                      const int* __restrict__ slot_off, int accumulate) {
+  const long long total = (long long)ntaps * ca * cb;
+  const size_t slab_sz = (size_t)ntaps * ca_p * cb_p;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i % cb);
+    const long long r = i / cb;
+    const int a = (int)(r % ca);
+    const int t = (int)(r / ca);
+    const size_t off = ((size_t)t * ca_p + a) * cb_p + b;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[k * slab_sz + off];
+    float* dst = grad + a * s_a + b * s_b + slot_off[t];
+    *dst = accumulate ? *dst + s : s;
+  }
+}
+
+struct WgCfg {
+  int a_blk, b_blk;
+};
+
+template <typename T, int NTAPS, int AW, int BT>
+int launch_wgrad(const WgradK& k, dim3 grid, size_t lds, hipStream_t st) {
+  auto fn = wgrad_kernel<T, NTAPS, AW, BT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k);
+  return tg_launch_status();
+}
+
+int pick_cfg(const tg_wgrad_desc* d, WgCfg* c) {  // returns config id
+  if (d->ntaps == 16) {
+    if (d->Cx % 64 || d->Cy % 32) return -1;
+    *c = {64, 32};
+    return 3;
+  }
+  if (d->ntaps != 9) return -1;
+  if (d->Cx % 64) {
+    if (d->Cx % 32 || d->Cy % 64) return -1;
+    *c = {32, 64};
+    return 1;
+  }
+  if (d->Cy % 64) {
+    if (d->Cy % 32) return -1;
+    *c = {64, 32};
+    return 2;
+  }
+  *c = {64, 64};
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t tg_wgrad_slab_floats(const tg_wgrad_desc* d) {
+  if (!d || d->nsplit <= 0 || d->ntaps <= 0) return TG_E_BADARG;
+  return (int64_t)d->nsplit * d->ntaps * d->Cx * d->Cy;
+}
+
+extern "C" int tg_wgrad(const tg_wgrad_desc* d, const void* x, const void* y, float* slab, void* stream) {
+  if (!d || !x || !y || !slab) return TG_E_BADARG;
+  if (d->dtype != TG_F32 && d->dtype != TG_BF16) return TG_E_BADARG;
+  if (d->N <= 0 || d->XH <= 0 || d->XW <= 0 || d->YH <= 0 || d->YW <= 0 || d->S <= 0 || d->S > 2 || d->nsplit <= 0)
+    return TG_E_BADARG;
+  if (d->Cx % 32 || d->Cy % 32 || d->Cx <= 0 || d->Cy <= 0) return TG_E_ALIGN;
+  if (!tg_aligned16(x) || !tg_aligned16(y) || !tg_aligned16(slab)) return TG_E_ALIGN;
+  WgCfg c;
+  const int cfg = pick_cfg(d, &c);
+  if (cfg < 0) return TG_E_UNSUPPORTED;
+
+  WgradK k;
+  k.x = (const char*)x; k.y = (const char*)y; k.slab = slab;
+  k.N = d->N; k.XH = d->XH; k.XW = d->XW; k.Cx = d->Cx; k.YH = d->YH; k.YW = d->YW; k.Cy = d->Cy; k.S = d->S;
+  k.ntaps = d->ntaps;
+  int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
+  for (int t = 0; t < d->ntaps; ++t) {
+    k.dy[t] = d->dy[t]; k.dx[t] = d->dx[t];
+    dymin = std::min<int>(dymin, d->dy[t]); dymax = std::max<int>(dymax, d->dy[t]);
+    dxmin = std::min<int>(dxmin, d->dx[t]); dxmax = std::max<int>(dxmax, d->dx[t]);
+  }
+  k.dymin = dymin; k.dxmin = dxmin;
+  int tw, th;
+  if (d->S == 2) { tw = 16; th = 4; }
+  else if (d->YW > 16) { tw = 32; th = 4; }
+  else { tw = 16; th = 8; }
+  k.tw_log2 = tw == 32 ? 5 : 4; k.th = th;
+  k.ih = (th - 1) * d->S + (dymax - dymin) + 1;
+  k.iw = (tw - 1) * d->S + (dxmax - dxmin) + 1;
+  k.tiles_x = (d->YW + tw - 1) / tw;
+  k.tiles_y = (d->YH + th - 1) / th;
+  const long long tt = (long long)k.tiles_x * k.tiles_y * d->N;
+  if (tt > 0x7fffffffLL) return TG_E_UNSUPPORTED;
+  k.tiles_total = (int)tt;
+  k.nsplit = d->nsplit;
+  k.b_blocks = d->Cy / c.b_blk;
+  const int eb = d->dtype == TG_BF16 ? 2 : 4;
+  const size_t lds = (size_t)tw * th * (c.b_blk * eb + 16) + (size_t)k.ih * k.iw * (c.a_blk * eb + 16);
+  if (lds > 160 * 1024) return TG_E_UNSUPPORTED;
+  dim3 grid((unsigned)d->nsplit, (unsigned)((d->Cx / c.a_blk) * k.b_blocks));
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == TG_BF16) {
+    switch (cfg) {
+      case 0: return launch_wgrad<BF16, 9, 4, 4>(k, grid, lds, st);
+      case 1: return launch_wgrad<BF16, 9, 2, 2>(k, grid, lds, st);
+      case 2: return launch_wgrad<BF16, 9, 4, 2>(k, grid, lds, st);
+      case 3: return launch_wgrad<BF16, 16, 4, 2>(k, grid, lds, st);
+    }
+  } else {
+    switch (cfg) {
+      case 0: return launch_wgrad<F32, 9, 4, 4>(k, grid, lds, st);
+      case 1: return launch_wgrad<F32, 9, 2, 2>(k, grid, lds, st);
+      case 2: return launch_wgrad<F32, 9, 4, 2>(k, grid, lds, st);
+      case 3: return launch_wgrad<F32, 16, 4, 2>(k, grid, lds, st);
+    }
+  }
+  return TG_E_UNSUPPORTED;
+}
+
+extern "C" int tg_wgrad_finalize(const float* slab, int nsplit, int ntaps, int ca_p, int cb_p, int ca, int cb,
+                                 float* grad, int64_t s_a, int64_t s_b, const int32_t* slot_off_dev, int accumulate,
+                                 void* stream) {
+  if (!slab || !grad || !slot_off_dev || nsplit <= 0 || ntaps <= 0 || ca <= 0 || cb <= 0 || ca > ca_p || cb > cb_p)
+    return TG_E_BADARG;
+  const long long total = (long long)ntaps * ca * cb;
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 1024);
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slab, nsplit, ntaps, ca_p,
+                     cb_p, ca, cb, grad, (long long)s_a, (long long)s_b, slot_off_dev, accumulate);
+  return tg_launch_status();
+}

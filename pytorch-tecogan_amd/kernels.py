@@ -1,0 +1,303 @@
+"""Torch-tensor facing wrappers over the C ABI (include/tecogan_hip.h).  PyTorch is used for device memory and
+streams only; every function enqueues HIP kernels on torch's current stream (so they are graph-capturable)."""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+def pad32(c):
+    return (c + 31) // 32 * 32
+
+
+def tg_dtype(dt):
+    if dt == torch.bfloat16:
+        return L.TG_BF16
+    if dt == torch.float32:
+        return L.TG_F32
+    raise L.TecoganHipError(f"unsupported element type {dt}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.TecoganHipError("HIP kernels need device tensors (no CPU fallback)")
+    if not t.is_contiguous():
+        raise L.TecoganHipError("HIP kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# geometry of the reference's three conv flavours (code/ops.py:45-63) and of their gradients
+# ---------------------------------------------------------------------------------------------------------
+@dataclass
+class Geom:
+    S: int
+    OS: int
+    classes: List[Tuple[int, int, List[Tuple[int, int, int]]]]  # (ooy, oox, [(dy, dx, widx)])
+    out_scale: Tuple[int, int] = (1, 1)  # OH = IH * num // den
+
+
+@dataclass
+class ConvSpec:
+    kind: str  # "c3" conv3x3 s1 p1 | "c4s2" conv4x4 s2 p1 | "ct" conv-transpose k3 s2 p1 op1
+    cin: int
+    cout: int
+    k: int = field(init=False)
+
+    def __post_init__(self):
+        self.k = 4 if self.kind == "c4s2" else 3
+
+    @property
+    def nslots(self):
+        return self.k * self.k
+
+    @property
+    def weight_shape(self):
+        return (self.cin, self.cout, 3, 3) if self.kind == "ct" else (self.cout, self.cin, self.k, self.k)
+
+    def out_hw(self, h, w):
+        if self.kind == "c3":
+            return h, w
+        if self.kind == "c4s2":
+            return h // 2, w // 2
+        return 2 * h, 2 * w
+
+    # ---- forward: rows = cout, K = cin
+    def fwd_geom(self):
+        k = self.k
+        if self.kind in ("c3", "c4s2"):
+            taps = [(kh - 1, kw - 1, kh * k + kw) for kh in range(k) for kw in range(k)]
+            return Geom(S=1 if self.kind == "c3" else 2, OS=1, classes=[(0, 0, taps)],
+                        out_scale=(1, 1) if self.kind == "c3" else (1, 2))
+        cls = []
+        for a in (0, 1):
+            for b in (0, 1):
+                ys = [(1, 0)] if a == 0 else [(0, 1), (2, 0)]  # (kh, dy): oy = 2*iy - 1 + kh
+                xs = [(1, 0)] if b == 0 else [(0, 1), (2, 0)]
+                cls.append((a, b, [(dy, dx, kh * 3 + kw) for kh, dy in ys for kw, dx in xs]))
+        return Geom(S=1, OS=2, classes=cls, out_scale=(2, 1))
+
+    def fwd_pack(self):
+        """(rows, K, s_row, s_k): packed[slot][row][k] = w[row*s_row + k*s_k + slot]"""
+        kk = self.nslots
+        if self.kind == "ct":
+            return self.cout, self.cin, kk, self.cout * kk
+        return self.cout, self.cin, self.cin * kk, kk
+
+    # ---- input gradient: rows = cin, K = cout
+    def dgrad_geom(self):
+        k = self.k
+        if self.kind == "c3":
+            return Geom(S=1, OS=1, classes=[(0, 0, [(-(kh - 1), -(kw - 1), kh * 3 + kw) for kh in range(3)
+                                                     for kw in range(3)])])
+        if self.kind == "c4s2":
+            cls = []
+            for a in (0, 1):
+                for b in (0, 1):
+                    ys = [(1, 0), (3, -1)] if a == 0 else [(0, 1), (2, 0)]  # (kh, dy on the dout grid)
+                    xs = [(1, 0), (3, -1)] if b == 0 else [(0, 1), (2, 0)]
+                    cls.append((a, b, [(dy, dx, kh * 4 + kw) for kh, dy in ys for kw, dx in xs]))
+            return Geom(S=1, OS=2, classes=cls, out_scale=(2, 1))
+        taps = [(kh - 1, kw - 1, kh * 3 + kw) for kh in range(3) for kw in range(3)]
+        return Geom(S=2, OS=1, classes=[(0, 0, taps)], out_scale=(1, 2))
+
+    def dgrad_pack(self):
+        kk = self.nslots
+        if self.kind == "ct":
+            return self.cin, self.cout, self.cout * kk, kk
+        return self.cin, self.cout, kk, self.cin * kk
+
+    # ---- weight gradient: dWt[t][a][b] = sum X[p*S + d_t][a] * Y[p][b]
+    def wgrad_info(self):
+        """returns (x_is_input, S, taps, ca, cb, s_a, s_b)"""
+        k, kk = self.k, self.nslots
+        taps = [(kh - 1, kw - 1) for kh in range(k) for kw in range(k)]
+        if self.kind == "c3":
+            return True, 1, taps, self.cin, self.cout, kk, self.cin * kk
+        if self.kind == "c4s2":
+            return True, 2, taps, self.cin, self.cout, kk, self.cin * kk
+        return False, 2, taps, self.cout, self.cin, kk, self.cout * kk  # X = dout (2h grid), Y = in
+
+
+def make_conv_desc(geom: Geom, dtype, N, IH, IW, cin_p, OH, OW, cout_p, act=L.ACT_NONE, mask_mode=L.MASK_NONE,
+                   stats_mode=0, stats_groups=1, out_mode=L.OUT_NHWC, c_real=0, out_n_stride=0, tile_cfg=L.TILE_AUTO):
+    d = L.ConvDesc()
+    d.dtype = dtype
+    d.N, d.IH, d.IW, d.Cin, d.OH, d.OW, d.Cout = N, IH, IW, cin_p, OH, OW, cout_p
+    d.S, d.OS, d.ncls = geom.S, geom.OS, len(geom.classes)
+    for i, (ooy, oox, taps) in enumerate(geom.classes):
+        c = d.cls[i]
+        c.ooy, c.oox, c.ntaps = ooy, oox, len(taps)
+        for t, (dy, dx, w) in enumerate(taps):
+            c.dy[t], c.dx[t], c.widx[t] = dy, dx, w
+    d.act, d.mask_mode, d.stats_mode, d.stats_groups = act, mask_mode, stats_mode, stats_groups
+    d.out_mode, d.c_real, d.out_n_stride, d.tile_cfg = out_mode, c_real, out_n_stride, tile_cfg
+    return d
+
+
+def conv(desc, x, w_packed, out, bias=None, res=None, mask=None, stats=None):
+    L.check(L.load().tg_conv(C.byref(desc), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(res), _ptr(mask), _ptr(out),
+                             _ptr(stats), _stream()), "tg_conv")
+
+
+def slot_table(n, device):
+    return torch.arange(n, dtype=torch.int32, device=device)
+
+
+def pack_weights(dtype_t, w, rows, K, s_row, s_k, nslots, slots, out=None):
+    """w: fp32 PyTorch-layout weight tensor on device.  Returns packed tensor [nslots][K_p/chunk][rows_p][chunk]."""
+    rows_p, K_p = pad32(rows), pad32(K)
+    if out is None:
+        out = torch.empty(nslots * rows_p * K_p, dtype=dtype_t, device=w.device)
+    L.check(L.load().tg_pack_conv_weights(tg_dtype(dtype_t), _ptr(w), _ptr(out), rows, K, rows_p, K_p, s_row, s_k,
+                                          nslots, _ptr(slots), _stream()), "tg_pack_conv_weights")
+    return out
+
+
+def make_wgrad_desc(dtype, N, XH, XW, cx_p, YH, YW, cy_p, S, taps, nsplit):
+    d = L.WgradDesc()
+    d.dtype, d.N, d.XH, d.XW, d.Cx, d.YH, d.YW, d.Cy, d.S = dtype, N, XH, XW, cx_p, YH, YW, cy_p, S
+    d.ntaps, d.nsplit = len(taps), nsplit
+    for t, (dy, dx) in enumerate(taps):
+        d.dy[t], d.dx[t] = dy, dx
+    return d
+
+
+def wgrad(desc, x, y, slab):
+    L.check(L.load().tg_wgrad(C.byref(desc), _ptr(x), _ptr(y), _ptr(slab), _stream()), "tg_wgrad")
+
+
+def wgrad_finalize(slab, nsplit, ntaps, ca_p, cb_p, ca, cb, grad, s_a, s_b, slots, accumulate):
+    L.check(L.load().tg_wgrad_finalize(_ptr(slab), nsplit, ntaps, ca_p, cb_p, ca, cb, _ptr(grad), s_a, s_b,
+                                       _ptr(slots), int(accumulate), _stream()), "tg_wgrad_finalize")
+
+
+def wgrad_nsplit(N, YH, YW, S):
+    """Number of pixel splits: enough workgroups to fill the chip without drowning the layer in slab traffic."""
+    tw, th = (16, 4) if S == 2 else ((32, 4) if YW > 16 else (16, 8))
+    tiles = N * ((YW + tw - 1) // tw) * ((YH + th - 1) // th)
+    return max(1, min(256, tiles // 4, tiles))
+
+
+# ---------------------------------------------------------------------------------------------------------
+def nchw_to_nhwc(src, n_stride, dst, N, C_, H, W):
+    Cp = dst.shape[-1]
+    L.check(L.load().tg_nchw_to_nhwc(tg_dtype(dst.dtype), _ptr(src), n_stride, _ptr(dst), N, C_, Cp, H, W, _stream()),
+            "tg_nchw_to_nhwc")
+
+
+def nhwc_to_nchw(src, dst, n_stride, N, C_, H, W):
+    Cp = src.shape[-1]
+    L.check(L.load().tg_nhwc_to_nchw(tg_dtype(src.dtype), _ptr(src), _ptr(dst), n_stride, N, C_, Cp, H, W, _stream()),
+            "tg_nhwc_to_nchw")
+
+
+def to_nhwc(x, dtype_t):
+    """[N,C,H,W] fp32 device tensor -> [N,H,W,pad32(C)] of dtype_t."""
+    N, C_, H, W = x.shape
+    x = x.contiguous().float()
+    out = torch.empty(N, H, W, pad32(C_), dtype=dtype_t, device=x.device)
+    nchw_to_nhwc(x, C_ * H * W, out, N, C_, H, W)
+    return out
+
+
+def to_nchw(x, C_):
+    N, H, W, _ = x.shape
+    out = torch.empty(N, C_, H, W, dtype=torch.float32, device=x.device)
+    nhwc_to_nchw(x, out, C_ * H * W, N, C_, H, W)
+    return out
+
+
+def up4_planes(src, src_off, dst, dst_off, nplanes, h, w, pre=1.0, post_a=1.0, post_b=0.0):
+    L.check(L.load().tg_up4_planes(_ptr(src), _ptr(src_off), _ptr(dst), _ptr(dst_off), nplanes, h, w, pre, post_a,
+                                   post_b, _stream()), "tg_up4_planes")
+
+
+def copy_blocks(src, src_off, dst, dst_off, nblocks, length):
+    L.check(L.load().tg_copy_blocks(_ptr(src), _ptr(src_off), _ptr(dst), _ptr(dst_off), nblocks, length, _stream()),
+            "tg_copy_blocks")
+
+
+def warp_nchw(img, img_off, grid, grid_off, N, C_, IH, IW, GH, GW, fp16_grid, out=None, corner=None, sq_ref=None,
+              sq_off=None, loss_acc=None):
+    L.check(L.load().tg_warp_nchw(_ptr(img), _ptr(img_off), _ptr(grid), _ptr(grid_off), _ptr(out), _ptr(corner),
+                                  _ptr(sq_ref), _ptr(sq_off), _ptr(loss_acc), N, C_, IH, IW, GH, GW, int(fp16_grid),
+                                  _stream()), "tg_warp_nchw")
+
+
+def _sub_ptr(t, elem_off):
+    return C.c_void_p(t.data_ptr() + elem_off * t.element_size())
+
+
+def gen_input(lr, lr_off, lr_n_stride, prev, prev_off, prev_n_stride, grid, grid_off, grid_n_stride, dst, B, h, w):
+    """lr/prev/grid are fp32 device buffers addressed by element offset + per-sample stride."""
+    lib = L.load()
+    L.check(lib.tg_gen_input(tg_dtype(dst.dtype), _sub_ptr(lr, lr_off), lr_n_stride,
+                             None if prev is None else _sub_ptr(prev, prev_off), prev_n_stride,
+                             None if grid is None else _sub_ptr(grid, grid_off), grid_n_stride, _ptr(dst), B, h, w,
+                             _stream()), "tg_gen_input")
+
+
+def d_assemble(x, y, gen, tvel, dst, B, T, K, h, border):
+    L.check(L.load().tg_d_assemble(tg_dtype(dst.dtype), _ptr(x), _ptr(y), _ptr(gen), _ptr(tvel), _ptr(dst), B, T, K, h,
+                                   border, _stream()), "tg_d_assemble")
+
+
+def bn_apply(z, stats, gamma, beta, y, save, N, HW, C_, groups, act, skip=None, running_mean=None, running_var=None,
+             eps=1e-3, momentum=0.1):
+    L.check(L.load().tg_bn_apply(tg_dtype(z.dtype), _ptr(z), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(skip), _ptr(y),
+                                 _ptr(running_mean), _ptr(running_var), _ptr(save), N, HW, C_, groups, act, eps,
+                                 momentum, _stream()), "tg_bn_apply")
+
+
+def bn_bwd_reduce(dy, yact, z, save, red, N, HW, C_, groups, act):
+    L.check(L.load().tg_bn_bwd_reduce(tg_dtype(z.dtype), _ptr(dy), _ptr(yact), _ptr(z), _ptr(save), _ptr(red), N, HW,
+                                      C_, groups, act, _stream()), "tg_bn_bwd_reduce")
+
+
+def bn_bwd_apply(dy, yact, z, save, red, gamma, dz, dgamma, dbeta, N, HW, C_, groups, act):
+    L.check(L.load().tg_bn_bwd_apply(tg_dtype(z.dtype), _ptr(dy), _ptr(yact), _ptr(z), _ptr(save), _ptr(red),
+                                     _ptr(gamma), _ptr(dz), _ptr(dgamma), _ptr(dbeta), N, HW, C_, groups, act,
+                                     _stream()), "tg_bn_bwd_apply")
+
+
+def fc_head_fwd(feat, w, b, prob, N, HW, C_, Cp):
+    L.check(L.load().tg_fc_head_fwd(tg_dtype(feat.dtype), _ptr(feat), _ptr(w), _ptr(b), _ptr(prob), N, HW, C_, Cp,
+                                    _stream()), "tg_fc_head_fwd")
+
+
+def fc_head_bwd(feat, w, dlogit, dfeat, dw, db, N, HW, C_, Cp):
+    L.check(L.load().tg_fc_head_bwd(tg_dtype(feat.dtype), _ptr(feat), _ptr(w), _ptr(dlogit), _ptr(dfeat), _ptr(dw),
+                                    _ptr(db), N, HW, C_, Cp, _stream()), "tg_fc_head_bwd")
+
+
+def absdiff_sum(a, b, acc, acc_idx, npix, C_, Cp):
+    L.check(L.load().tg_absdiff_sum(tg_dtype(a.dtype), _ptr(a), _ptr(b), _sub_ptr(acc, acc_idx), npix, C_, Cp,
+                                    _stream()), "tg_absdiff_sum")
+
+
+def content_loss(gen, y, dpre, acc, B, T, H, W, gscale):
+    dt = tg_dtype(dpre.dtype) if dpre is not None else L.TG_F32
+    L.check(L.load().tg_content_loss(dt, _ptr(gen), _ptr(y), _ptr(dpre), _ptr(acc), B, T, H, W, gscale, _stream()),
+            "tg_content_loss")
+
+
+def loss_finalize(prob, acc, scalars, dlogit, tb, cfg):
+    L.check(L.load().tg_loss_finalize(_ptr(prob), _ptr(acc), _ptr(scalars), _ptr(dlogit), tb, _ptr(cfg), _stream()),
+            "tg_loss_finalize")
+
+
+def adam(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    L.check(L.load().tg_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, bc1, bc2,
+                             grad_scale, _stream()), "tg_adam")

@@ -1,0 +1,423 @@
+"""GPU parity tests of every HIP kernel, called through the C ABI, against plain PyTorch fp32 CPU ops / the oracle.
+fp32 mode must meet the 1e-3 relative gate of BASELINE.json (it lands around 1e-5); bf16 mode is compared against the
+same fp32 reference evaluated on bf16-rounded operands with a tolerance that covers bf16 output rounding (2^-8)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import pytorch_tecogan_amd  # noqa: E402,F401
+from pytorch_tecogan_amd import _lib as L  # noqa: E402
+from pytorch_tecogan_amd import kernels as K  # noqa: E402
+import tecogan_oracle as orc  # noqa: E402
+
+DEV = "cuda:0"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    return torch.from_numpy(np.random.default_rng(seed).uniform(lo, hi, size=shape).astype(np.float32))
+
+
+def q(t, dt):
+    """round to the element type the kernel will see"""
+    return t.to(dt).float()
+
+
+def tol(dt):
+    return dict(rtol=1e-3, atol=1e-4) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def ref_conv(spec, x, w, b):
+    if spec.kind == "c3":
+        return F.conv2d(x, w, b, 1, 1)
+    if spec.kind == "c4s2":
+        return F.conv2d(x, w, b, 2, 1)
+    return F.conv_transpose2d(x, w, b, 2, 1, 1)
+
+
+def hip_conv_fwd(spec, x, w, dt, bias=None, act=L.ACT_NONE, res=None, stats_groups=0, tile=L.TILE_AUTO):
+    N, _, H, W = x.shape
+    OH, OW = spec.out_hw(H, W)
+    xd = K.to_nhwc(x.to(DEV), dt)
+    wd = w.to(DEV).contiguous()
+    rows, Kd, s_row, s_k = spec.fwd_pack()
+    wp = K.pack_weights(dt, wd, rows, Kd, s_row, s_k, spec.nslots, K.slot_table(spec.nslots, DEV))
+    out = torch.empty(N, OH, OW, K.pad32(spec.cout), dtype=dt, device=DEV)
+    stats = torch.zeros(max(stats_groups, 1), 2, K.pad32(spec.cout), device=DEV) if stats_groups else None
+    d = K.make_conv_desc(spec.fwd_geom(), K.tg_dtype(dt), N, H, W, K.pad32(spec.cin), OH, OW, K.pad32(spec.cout), act=act,
+                         stats_mode=2 if stats_groups else 0, stats_groups=max(stats_groups, 1), tile_cfg=tile)
+    bd = None
+    if bias is not None:
+        bd = torch.zeros(K.pad32(spec.cout), device=DEV)
+        bd[:spec.cout] = bias.to(DEV)
+    rd = K.to_nhwc(res.to(DEV), dt) if res is not None else None
+    K.conv(d, xd, wp, out, bias=bd, res=rd, stats=stats)
+    torch.cuda.synchronize()
+    return K.to_nchw(out, spec.cout).cpu(), (stats.cpu() if stats is not None else None), out
+
+
+CONV_CASES = [
+    # kind, cin, cout, N, H, W
+    ("c3", 64, 64, 2, 32, 32),
+    ("c3", 51, 64, 1, 32, 32),
+    ("c3", 27, 64, 1, 24, 40),
+    ("c3", 64, 128, 2, 16, 16),
+    ("c3", 128, 128, 1, 20, 12),
+    ("c3", 128, 64, 1, 64, 64),
+    ("c3", 64, 3, 2, 32, 48),
+    ("c4s2", 64, 64, 2, 32, 32),
+    ("c4s2", 64, 128, 1, 16, 16),
+    ("c4s2", 128, 128, 2, 8, 8),
+    ("c4s2", 128, 64, 3, 16, 16),
+    ("c4s2", 64, 3, 2, 8, 8),
+    ("ct", 64, 64, 2, 16, 16),
+    ("ct", 128, 128, 1, 12, 20),
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("kind,cin,cout,N,H,W", CONV_CASES)
+def test_conv_forward(kind, cin, cout, N, H, W, dt):
+    spec = K.ConvSpec(kind, cin, cout)
+    x = q(rnd((N, cin, H, W), 1), dt)
+    w = q(rnd(spec.weight_shape, 2, -0.1, 0.1), dt)
+    b = rnd((cout,), 3)
+    ref = F.relu(ref_conv(spec, x, w, b))
+    out, _, _ = hip_conv_fwd(spec, x, w, dt, bias=b, act=L.ACT_RELU)
+    torch.testing.assert_close(out, ref, **tol(dt))
+    if dt == torch.float32:
+        assert rel_err(out, ref) < 1e-4
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("tile", [L.TILE_64x256, L.TILE_64x64, L.TILE_128x128, L.TILE_32x128])
+def test_conv_tile_configs(tile, dt):
+    cout = 128 if tile == L.TILE_128x128 else (32 if tile == L.TILE_32x128 else 64)
+    spec = K.ConvSpec("c3", 64, cout)
+    x = q(rnd((2, 64, 40, 24), 4), dt)
+    w = q(rnd(spec.weight_shape, 5, -0.1, 0.1), dt)
+    ref = ref_conv(spec, x, w, None)
+    out, _, _ = hip_conv_fwd(spec, x, w, dt, tile=tile)
+    torch.testing.assert_close(out, ref, **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv_epilogue_residual_stats_groups(dt):
+    spec = K.ConvSpec("c3", 64, 64)
+    x = q(rnd((4, 64, 16, 16), 6), dt)
+    w = q(rnd(spec.weight_shape, 7, -0.1, 0.1), dt)
+    res = q(rnd((4, 64, 16, 16), 8), dt)
+    ref = ref_conv(spec, x, w, None) + res
+    out, stats, _ = hip_conv_fwd(spec, x, w, dt, res=res, stats_groups=2)
+    torch.testing.assert_close(out, ref, **tol(dt))
+    for g in range(2):
+        r = ref[2 * g:2 * g + 2]
+        torch.testing.assert_close(stats[g, 0, :64], r.sum(dim=(0, 2, 3)), rtol=2e-2 if dt != torch.float32 else 1e-4,
+                                   atol=0.5 if dt != torch.float32 else 1e-3)
+        torch.testing.assert_close(stats[g, 1, :64], (r * r).sum(dim=(0, 2, 3)),
+                                   rtol=2e-2 if dt != torch.float32 else 1e-4, atol=0.5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv_sigmoid_nchw_output(dt):
+    """generator output layer: conv64->3 + sigmoid written straight into a strided NCHW fp32 (B,T,3,H,W) slot."""
+    spec = K.ConvSpec("c3", 64, 3)
+    B, T, t, H, W = 2, 3, 1, 32, 32
+    x = q(rnd((B, 64, H, W), 9), dt)
+    w = q(rnd(spec.weight_shape, 10, -0.1, 0.1), dt)
+    b = rnd((3,), 11)
+    ref = torch.sigmoid(ref_conv(spec, x, w, b))
+    xd = K.to_nhwc(x.to(DEV), dt)
+    rows, Kd, s_row, s_k = spec.fwd_pack()
+    wp = K.pack_weights(dt, w.to(DEV), rows, Kd, s_row, s_k, 9, K.slot_table(9, DEV))
+    gen = torch.zeros(B, T, 3, H, W, device=DEV)
+    bd = torch.zeros(32, device=DEV)
+    bd[:3] = b.to(DEV)
+    d = K.make_conv_desc(spec.fwd_geom(), K.tg_dtype(dt), B, H, W, 64, H, W, 32, act=L.ACT_SIGMOID,
+                         out_mode=L.OUT_NCHW_F32, c_real=3, out_n_stride=T * 3 * H * W)
+    L.check(L.load().tg_conv(__import__("ctypes").byref(d), xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), None, None,
+                             gen.data_ptr() + t * 3 * H * W * 4, None, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    g = gen.cpu()
+    torch.testing.assert_close(g[:, t], ref, rtol=1e-3, atol=1e-5 if dt == torch.float32 else 5e-3)
+    assert float(g[:, 0].abs().max()) == 0.0 and float(g[:, 2].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("kind,cin,cout,N,H,W", [
+    ("c3", 64, 64, 2, 32, 32), ("c3", 64, 128, 1, 16, 24), ("c3", 128, 64, 1, 16, 16), ("c3", 64, 3, 1, 32, 32),
+    ("c4s2", 64, 64, 2, 32, 32), ("c4s2", 64, 128, 1, 16, 16), ("c4s2", 128, 64, 2, 8, 8), ("c4s2", 64, 3, 2, 8, 8),
+    ("ct", 64, 64, 2, 16, 16), ("ct", 128, 128, 1, 8, 12),
+])
+def test_conv_dgrad_with_mask_and_residual(kind, cin, cout, N, H, W, dt):
+    spec = K.ConvSpec(kind, cin, cout)
+    OH, OW = spec.out_hw(H, W)
+    x = q(rnd((N, cin, H, W), 12), dt)
+    w = q(rnd(spec.weight_shape, 13, -0.1, 0.1), dt)
+    dout = q(rnd((N, cout, OH, OW), 14), dt)
+    res = q(rnd((N, cin, H, W), 15), dt)
+    xr = x.clone().requires_grad_(True)
+    ref_conv(spec, xr, w, None).backward(dout)
+    ref = (xr.grad + res) * (x > 0).float()  # epilogue order: +res, then *relu'(mask)
+    dd = K.to_nhwc(dout.to(DEV), dt)
+    rows, Kd, s_row, s_k = spec.dgrad_pack()
+    wp = K.pack_weights(dt, w.to(DEV), rows, Kd, s_row, s_k, spec.nslots, K.slot_table(spec.nslots, DEV))
+    out = torch.empty(N, H, W, K.pad32(cin), dtype=dt, device=DEV)
+    stats = torch.zeros(1, 2, K.pad32(cin), device=DEV)
+    d = K.make_conv_desc(spec.dgrad_geom(), K.tg_dtype(dt), N, OH, OW, K.pad32(cout), H, W, K.pad32(cin),
+                         mask_mode=L.MASK_RELU, stats_mode=1, stats_groups=1)
+    K.conv(d, dd, wp, out, res=K.to_nhwc(res.to(DEV), dt), mask=K.to_nhwc(x.to(DEV), dt), stats=stats)
+    torch.cuda.synchronize()
+    got = K.to_nchw(out, cin).cpu()
+    torch.testing.assert_close(got, ref, **tol(dt))
+    torch.testing.assert_close(stats[0, 0, :cin].cpu(), ref.sum(dim=(0, 2, 3)), rtol=2e-2, atol=0.5 if dt != torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("kind,cin,cout,N,H,W", [
+    ("c3", 64, 64, 3, 32, 32), ("c3", 51, 64, 2, 32, 32), ("c3", 27, 64, 1, 40, 24), ("c3", 128, 128, 2, 16, 16),
+    ("c3", 64, 3, 2, 32, 32), ("c3", 128, 64, 1, 64, 64),
+    ("c4s2", 64, 64, 2, 32, 32), ("c4s2", 64, 128, 2, 16, 16), ("c4s2", 128, 64, 2, 8, 8), ("c4s2", 64, 3, 3, 8, 8),
+    ("ct", 64, 64, 2, 16, 16), ("ct", 128, 128, 1, 8, 12),
+])
+def test_conv_wgrad(kind, cin, cout, N, H, W, dt):
+    spec = K.ConvSpec(kind, cin, cout)
+    OH, OW = spec.out_hw(H, W)
+    x = q(rnd((N, cin, H, W), 16), dt)
+    w = rnd(spec.weight_shape, 17, -0.1, 0.1).requires_grad_(True)
+    dout = q(rnd((N, cout, OH, OW), 18), dt)
+    ref_conv(spec, x, w, None).backward(dout)
+    ref = w.grad
+    x_is_in, S, taps, ca, cb, s_a, s_b = spec.wgrad_info()
+    xd, dd = K.to_nhwc(x.to(DEV), dt), K.to_nhwc(dout.to(DEV), dt)
+    X, Y = (xd, dd) if x_is_in else (dd, xd)
+    nsplit = 5
+    desc = K.make_wgrad_desc(K.tg_dtype(dt), N, X.shape[1], X.shape[2], X.shape[3], Y.shape[1], Y.shape[2], Y.shape[3],
+                             S, taps, nsplit)
+    slab = torch.empty(L.load().tg_wgrad_slab_floats(__import__("ctypes").byref(desc)), device=DEV)
+    K.wgrad(desc, X, Y, slab)
+    grad = torch.full(spec.weight_shape, 7.0, device=DEV)
+    K.wgrad_finalize(slab, nsplit, len(taps), X.shape[3], Y.shape[3], ca, cb, grad, s_a, s_b,
+                     K.slot_table(len(taps), DEV), False)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    torch.testing.assert_close(grad.cpu(), ref, rtol=1e-3 if dt == torch.float32 else 2e-2,
+                               atol=scale * (1e-5 if dt == torch.float32 else 1e-2))
+    # accumulate=1 adds on top
+    K.wgrad_finalize(slab, nsplit, len(taps), X.shape[3], Y.shape[3], ca, cb, grad, s_a, s_b,
+                     K.slot_table(len(taps), DEV), True)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(grad.cpu(), 2 * ref, rtol=1e-3 if dt == torch.float32 else 2e-2,
+                               atol=2 * scale * (1e-5 if dt == torch.float32 else 1e-2))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C_,act,skip", [(64, L.ACT_NONE, True), (128, L.ACT_LRELU, False), (32, L.ACT_LRELU, False)])
+def test_batchnorm_train_fwd_bwd(C_, act, skip, dt):
+    N, H, W, G = 4, 8, 8, 2
+    z = q(rnd((N, C_, H, W), 19, -2, 2), dt)
+    sk = q(rnd((N, C_, H, W), 20), dt)
+    gamma, beta = rnd((C_,), 21, 0.5, 1.5), rnd((C_,), 22, -0.2, 0.2)
+    dy = q(rnd((N, C_, H, W), 23), dt)
+    rm, rv = torch.zeros(C_), torch.ones(C_)
+    outs, dzs = [], []
+    gam = gamma.clone().requires_grad_(True)
+    bet = beta.clone().requires_grad_(True)
+    for g in range(G):  # the reference calls D twice: separate batch statistics, running stats updated twice
+        zz = z[2 * g:2 * g + 2].clone().requires_grad_(True)
+        yy = F.batch_norm(zz, rm, rv, gam, bet, True, 0.1, 1e-3)
+        if act == L.ACT_LRELU:
+            yy = F.leaky_relu(yy, 0.2)
+        if skip:
+            yy = yy + sk[2 * g:2 * g + 2]
+        yy.backward(dy[2 * g:2 * g + 2])
+        outs.append(yy.detach())
+        dzs.append(zz.grad)
+    ref_y, ref_dz = torch.cat(outs), torch.cat(dzs)
+
+    zd = K.to_nhwc(z.to(DEV), dt)
+    stats = torch.zeros(G, 2, C_, device=DEV)
+    for g in range(G):
+        zz = zd[2 * g:2 * g + 2].float()
+        stats[g, 0] = zz.sum(dim=(0, 1, 2))
+        stats[g, 1] = (zz * zz).sum(dim=(0, 1, 2))
+    y = torch.empty_like(zd)
+    save = torch.empty(G, 2, C_, device=DEV)
+    rmd, rvd = torch.zeros(C_, device=DEV), torch.ones(C_, device=DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    K.bn_apply(zd, stats, gd, bd, y, save, N, H * W, C_, G, act, skip=K.to_nhwc(sk.to(DEV), dt) if skip else None,
+               running_mean=rmd, running_var=rvd)
+    t = tol(dt)
+    torch.testing.assert_close(K.to_nchw(y, C_).cpu(), ref_y, **t)
+    torch.testing.assert_close(rmd.cpu(), rm, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rvd.cpu(), rv, rtol=1e-4, atol=1e-5)
+    dyd = K.to_nhwc(dy.to(DEV), dt)
+    red = torch.zeros(G, 2, C_, device=DEV)
+    K.bn_bwd_reduce(dyd, y, zd, save, red, N, H * W, C_, G, act)
+    dz = torch.empty_like(zd)
+    dgam, dbet = torch.zeros(C_, device=DEV), torch.zeros(C_, device=DEV)
+    K.bn_bwd_apply(dyd, y, zd, save, red, gd, dz, dgam, dbet, N, H * W, C_, G, act)
+    torch.cuda.synchronize()
+    if skip and act == L.ACT_NONE or dt == torch.float32:
+        torch.testing.assert_close(K.to_nchw(dz, C_).cpu(), ref_dz, **t)
+        torch.testing.assert_close(dgam.cpu(), gam.grad, rtol=1e-2, atol=1e-2 if dt != torch.float32 else 1e-4)
+        torch.testing.assert_close(dbet.cpu(), bet.grad, rtol=1e-2, atol=1e-2 if dt != torch.float32 else 1e-4)
+
+
+def test_up4_matches_golden_and_torch(golden_dir):
+    u = np.load(os.path.join(golden_dir, "units.npz"))
+    src = torch.from_numpy(u["up4_in"]).to(DEV)
+    dst = torch.empty(1, 1, 32, 32, device=DEV)
+    off = torch.zeros(1, dtype=torch.int64, device=DEV)
+    K.up4_planes(src, off, dst, off, 1, 8, 8)
+    assert np.array_equal(dst.cpu().numpy(), u["up4_out"])
+    x = rnd((6, 32, 32), 24, 0, 1)
+    ref = orc.up4(x[None] * 4.0)[0]
+    xd = x.to(DEV)
+    out = torch.empty(6, 128, 128, device=DEV)
+    so = (torch.arange(6, dtype=torch.int64) * 1024).to(DEV)
+    do = (torch.arange(6, dtype=torch.int64) * 128 * 128).to(DEV)
+    K.up4_planes(xd, so, out, do, 6, 32, 32, pre=4.0)
+    assert np.array_equal(out.cpu().numpy(), ref.numpy()), "bilinear x4 must be bit-exact (weights are multiples of 1/8)"
+
+
+def test_warp_golden_boundary_and_corner_indices(golden_dir):
+    u = np.load(os.path.join(golden_dir, "units.npz"))
+    img = torch.from_numpy(u["warp_img"]).to(DEV)  # (2,3,8,8)
+    grid = torch.from_numpy(u["warp_grid"]).to(DEV)  # (2,8,8,2) == reinterpretation of a (2,2,8,8) block
+    io = (torch.arange(2, dtype=torch.int64) * 3 * 64).to(DEV)
+    go = (torch.arange(2, dtype=torch.int64) * 2 * 64).to(DEV)
+    for fp16, key in ((0, "warp_out_f32grid"), (1, "warp_out_f16grid")):
+        out = torch.empty(2, 3, 8, 8, device=DEV)
+        corner = torch.empty(2, 8, 8, 2, dtype=torch.int32, device=DEV)
+        K.warp_nchw(img, io, grid, go, 2, 3, 8, 8, 8, 8, fp16, out=out, corner=corner)
+        np.testing.assert_allclose(out.cpu().numpy(), u[key], rtol=0, atol=2e-7)
+        g = torch.from_numpy(u["warp_grid"])
+        if fp16:
+            g = g.half().float()
+        ix = ((g[..., 0] + 1) * 8 - 1) / 2
+        iy = ((g[..., 1] + 1) * 8 - 1) / 2
+        exp = torch.stack([torch.floor(ix).clamp(-2, 9), torch.floor(iy).clamp(-2, 9)], dim=-1).int()
+        assert torch.equal(corner.cpu(), exp), "warp corner indices must be bit-exact"
+
+
+def test_warp_random_vs_oracle_hr():
+    B, H = 3, 128
+    img = rnd((B, 3, H, H), 25, 0, 1)
+    blk = rnd((B, 2, H, H), 26, 0, 4)
+    ref = orc.warp(img, orc.fp16_round(orc.as_grid(blk)))
+    out = torch.empty(B, 3, H, H, device=DEV)
+    corner = torch.empty(B, H, H, 2, dtype=torch.int32, device=DEV)
+    io = (torch.arange(B, dtype=torch.int64) * 3 * H * H).to(DEV)
+    go = (torch.arange(B, dtype=torch.int64) * 2 * H * H).to(DEV)
+    K.warp_nchw(img.to(DEV), io, blk.to(DEV), go, B, 3, H, H, H, H, 1, out=out, corner=corner)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=3e-7)
+    g = orc.fp16_round(orc.as_grid(blk))
+    ix = ((g[..., 0] + 1) * H - 1) / 2
+    iy = ((g[..., 1] + 1) * H - 1) / 2
+    exp = torch.stack([torch.floor(ix).clamp(-2, H + 1), torch.floor(iy).clamp(-2, H + 1)], dim=-1).int()
+    assert torch.equal(corner.cpu(), exp)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gen_input_pack(dt):
+    B, T, h = 2, 3, 16
+    H = 4 * h
+    x = rnd((B, T, 3, h, h), 27, 0, 1)
+    prev = rnd((B, T, 3, H, H), 28, 0, 1)
+    flow = orc.pseudo_flow(x)  # (B,T-1,2,H,H)
+    i = 1
+    w = orc.warp(prev[:, i], orc.fp16_round(orc.as_grid(flow[:, i])))
+    ref = torch.cat((x[:, i + 1], orc.pixel_unshuffle4((w + 1) / 2)), dim=1)
+    dst = torch.empty(B, h, h, 64, dtype=dt, device=DEV)
+    xd, pd, fd = x.to(DEV), prev.to(DEV), flow.to(DEV).contiguous()
+    K.gen_input(xd, (i + 1) * 3 * h * h, T * 3 * h * h, pd, i * 3 * H * H, T * 3 * H * H, fd, i * 2 * H * H,
+                (T - 1) * 2 * H * H, dst, B, h, h)
+    got = K.to_nchw(dst, 51).cpu()
+    torch.testing.assert_close(got, ref, rtol=0, atol=1e-6 if dt == torch.float32 else 4e-3)
+    assert float(dst[..., 51:].abs().max()) == 0.0
+    K.gen_input(xd, 0, T * 3 * h * h, None, 0, 0, None, 0, 0, dst, B, h, h)
+    got = K.to_nchw(dst, 51).cpu()
+    torch.testing.assert_close(got[:, :3], q(x[:, 0], dt), rtol=0, atol=0)
+    assert float(got[:, 3:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_d_assemble_vs_oracle(dt):
+    B, T, h = 2, 10, 8
+    H = 4 * h
+    x = rnd((B, T, 3, h, h), 29, 0, 1)
+    y = rnd((B, T, 3, H, H), 30, 0, 1)
+    gen = rnd((B, T, 3, H, H), 31, 0, 1)
+    flow = orc.pseudo_flow(x)
+    tvel = orc.t_velocity(x, flow, 9)
+    real_in, fake_in = orc.d_inputs(x, y, gen, tvel, 9, 0.75)
+    ref = torch.cat((real_in, fake_in), dim=0)
+    dst = torch.empty(2 * B * 3, H, H, 32, dtype=dt, device=DEV)
+    o = (H - int(H * 0.75)) // 2
+    K.d_assemble(x.to(DEV), y.to(DEV), gen.to(DEV), tvel.contiguous().to(DEV), dst, B, T, 3, h, o)
+    got = K.to_nchw(dst, 27).cpu()
+    torch.testing.assert_close(got, ref, rtol=0, atol=1e-6 if dt == torch.float32 else 4e-3)
+    assert float(dst[..., 27:].abs().max()) == 0.0
+
+
+def test_fc_head_losses_adam():
+    N, HW, C_, Cp = 6, 16, 3, 32
+    feat = rnd((N, C_, 4, 4), 32)
+    w, b = rnd((1, 48), 33), rnd((1,), 34)
+    fd = K.to_nhwc(feat.to(DEV), torch.float32)
+    prob = torch.empty(N, device=DEV)
+    K.fc_head_fwd(fd, w.to(DEV), b.to(DEV), prob, N, HW, C_, Cp)
+    wr, br, fr = w.clone().requires_grad_(True), b.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    logit = F.linear(fr.reshape(N, -1), wr, br)
+    ref_p = torch.sigmoid(logit)
+    torch.testing.assert_close(prob.cpu(), ref_p[:, 0].detach(), rtol=1e-5, atol=1e-6)
+    dl = rnd((N,), 35)
+    logit.backward(dl[:, None])
+    dfeat = torch.empty_like(fd)
+    dw, db = torch.zeros(48, device=DEV), torch.zeros(1, device=DEV)
+    K.fc_head_bwd(fd, w.to(DEV), dl.to(DEV), dfeat, dw, db, N, HW, C_, Cp)
+    torch.testing.assert_close(K.to_nchw(dfeat, 3).cpu(), fr.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dw.cpu(), wr.grad[0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-5, atol=1e-6)
+    # adam == torch.optim.Adam for 3 steps
+    p0, g = rnd((1000,), 36), rnd((3, 1000), 37)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], 1e-2, betas=(0.9, 0.999), eps=1e-8)
+    pd, m, v = p0.to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for s in range(3):
+        pt.grad = g[s].clone()
+        opt.step()
+        K.adam(pd, g[s].to(DEV), m, v, 1e-2, 0.9, 0.999, 1e-8, s + 1)
+    torch.testing.assert_close(pd.cpu(), pt.detach(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_content_loss_and_absdiff(dt):
+    B, T, H = 2, 3, 16
+    gen = rnd((B, T, 3, H, H), 38, 0.05, 0.95)
+    y = rnd((B, T, 3, H, H), 39, 0, 1)
+    gr = gen.clone().requires_grad_(True)
+    pre = torch.log(gr / (1 - gr))  # gen = sigmoid(pre)
+    loss = torch.mean(torch.sum(torch.square(torch.sigmoid(pre) - y).reshape(B * T, 3, H, H), dim=[3]))
+    gscale = 1.0 / (B * T * 3 * H)
+    ref_dpre = (2 * (gen - y) * gen * (1 - gen) * gscale)
+    acc = torch.zeros(8, device=DEV)
+    dpre = torch.empty(T * B, H, H, 32, dtype=dt, device=DEV)
+    K.content_loss(gen.to(DEV), y.to(DEV), dpre, acc, B, T, H, H, gscale)
+    torch.testing.assert_close(acc[0].cpu() * gscale, loss.detach(), rtol=1e-5, atol=1e-6)
+    got = K.to_nchw(dpre, 3).cpu().reshape(T, B, 3, H, H).transpose(0, 1)
+    torch.testing.assert_close(got, ref_dpre, rtol=1e-2 if dt != torch.float32 else 1e-5, atol=1e-6)
+    a, b2 = q(rnd((4, 64, 8, 8), 40), dt), q(rnd((4, 64, 8, 8), 41), dt)
+    K.absdiff_sum(K.to_nhwc(a.to(DEV), dt), K.to_nhwc(b2.to(DEV), dt), acc, 3, 4 * 64, 64, 64)
+    torch.testing.assert_close(acc[3].cpu(), (a - b2).abs().sum(), rtol=1e-5, atol=1e-3)
