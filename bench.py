@@ -1,0 +1,250 @@
+"""Throughput bench of the TecoGAN training step (BASELINE.json config 2: B=4 sequences per GPU, T=10, 32x32 -> 128x128,
+bf16 compute / fp32 master weights, full G + pseudo-flow/warp + D + losses + two Adam updates per step).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched once per rank by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline      the dominant kernel family, timed live with events around every one of its launches in one eager step
+  cpu_baseline  the CPU oracle (PyTorch-CPU fp32 restatement of the reference) timed on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+STEP_GFLOP_PER_SEQ = 380.0  # 10 G frames * 25.884 + 6 D samples * 20.196 GFLOP (T=10, cs=32)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="sequences per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def default_args(dtype):
+    return argparse.Namespace(RNN_N=10, crop_size=32, num_resblock=16, discrim_resblocks=4, discrim_channels=128,
+                              pingpang=False, pp_scaling=1.0, vgg_scaling=-0.002, crop_dt=0.75, Dt_mergeDs=True,
+                              D_LAYERLOSS=True, EPS=1e-12, ratio=0.01, Dt_ratio_0=1.0, Dt_ratio_add=0.0, Dt_ratio_max=1.0,
+                              learning_rate=1e-4, beta=0.9, adameps=1e-8, tg_dtype=dtype)
+
+
+def synth(B, T, cs, seed):
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.random((B, T, 3, cs, cs), dtype=np.float32))
+    y = torch.from_numpy(rng.random((B, T, 3, 4 * cs, 4 * cs), dtype=np.float32))
+    return x, y
+
+
+def conv_flops(spec, N, H, W):
+    """algorithmic FLOPs (2*MAC on REAL channels) of one forward/dgrad/wgrad launch of `spec` on an [N,*,H,W] input."""
+    if spec.kind == "c3":
+        return 2.0 * N * H * W * 9 * spec.cin * spec.cout
+    if spec.kind == "c4s2":
+        return 2.0 * N * (H // 2) * (W // 2) * 16 * spec.cin * spec.cout
+    return 2.0 * N * H * W * 9 * spec.cin * spec.cout  # conv-transpose: every input pixel meets all 9 taps
+
+
+def tile_label(K, L, spec_rows_p, S, px):
+    if spec_rows_p % 64:
+        return "32x128"
+    if S > 1:
+        return "128x128" if spec_rows_p % 128 == 0 else "64x64"
+    if px < 64 * 1024:
+        return "64x64"
+    return "128x128" if spec_rows_p % 128 == 0 else "64x256"
+
+
+def roofline_pass(st, dtype):
+    """One eager step with a start/stop event pair around every MFMA launch; returns the per-family table."""
+    from pytorch_tecogan_amd import engine as E
+    from pytorch_tecogan_amd import kernels as K
+    recs = []
+    orig_fwd, orig_dgrad, orig_wgrad = E.Conv.fwd, E.Conv.dgrad, E.Conv.wgrad
+
+    def timed(label_fn, flops_fn, fn):
+        def wrapper(self, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(self, *a, **kw)
+            e1.record()
+            recs.append((label_fn(self, *a), flops_fn(self, *a), e0, e1))
+            return r
+        return wrapper
+
+    def in_shape_fwd(self, x, *a):
+        return x.shape[0], x.shape[1], x.shape[2]
+
+    def lab_fwd(self, x, *a):
+        N, H, W = in_shape_fwd(self, x)
+        OH, OW = self.spec.out_hw(H, W)
+        g = self.spec.fwd_geom()
+        return f"conv_gather<{dtype},{tile_label(K, None, self.cout_p, g.S, N * OH * OW)}>"
+
+    def lab_dgrad(self, dout, out, *a):
+        g = self.spec.dgrad_geom()
+        N, H, W = out.shape[0], out.shape[1], out.shape[2]
+        return f"conv_gather<{dtype},{tile_label(K, None, self.cin_p, g.S, N * H * W)}>"
+
+    def fl_fwd(self, x, *a):
+        return conv_flops(self.spec, *in_shape_fwd(self, x))
+
+    def fl_dgrad(self, dout, out, *a):
+        return conv_flops(self.spec, out.shape[0], out.shape[1], out.shape[2])
+
+    def fl_wgrad(self, x_in, dout):
+        return conv_flops(self.spec, x_in.shape[0], x_in.shape[1], x_in.shape[2])
+
+    E.Conv.fwd = timed(lab_fwd, fl_fwd, orig_fwd)
+    E.Conv.dgrad = timed(lab_dgrad, fl_dgrad, orig_dgrad)
+    E.Conv.wgrad = timed(lambda self, *a: f"wgrad<{dtype},{self.spec.nslots}taps>(+finalize)", fl_wgrad, orig_wgrad)
+    try:
+        st._forward_and_g_backward()
+        st._d_backward()
+        torch.cuda.synchronize()
+    finally:
+        E.Conv.fwd, E.Conv.dgrad, E.Conv.wgrad = orig_fwd, orig_dgrad, orig_wgrad
+    fam = {}
+    for label, fl, e0, e1 in recs:
+        d = fam.setdefault(label, dict(launches=0, flops=0.0, ms=0.0))
+        d["launches"] += 1
+        d["flops"] += fl
+        d["ms"] += e0.elapsed_time(e1)
+    return fam
+
+
+def cpu_baseline(B, n_steps):
+    """the oracle (CPU restatement of the reference step) on this box's host cores; same synthetic workload shape."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import tecogan_oracle as orc
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    args = orc.default_args()
+    x, y = synth(B, 10, 32, 1)
+    gp = orc.init_params(orc.generator_param_shapes(16), 101)
+    dp = orc.init_params(orc.discriminator_param_shapes(4, 128), 201)
+    bufs = orc.init_bn_buffers(dp)
+    og = orc.AdamState(gp, 1e-4)
+    od = orc.AdamState(dp, 1e-4)
+    orc.tecogan_step(gp, dp, bufs, og, od, x, y, args, 0)  # warm-up
+    t0 = time.perf_counter()
+    for s in range(n_steps):
+        orc.tecogan_step(gp, dp, bufs, og, od, x, y, args, s + 1)
+    dt = (time.perf_counter() - t0) / n_steps
+    return dict(value=round(B * 10 / dt, 3), unit="HR-frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n_steps} full train steps (B={B}, T=10, 32->128, fp32) after 1 warm-up, {dt:.2f} s/step, "
+                       f"os.cpu_count()={os.cpu_count()}")
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    os.environ["TECOGAN_GRAPH"] = "0" if a.no_graph else "1"
+
+    import pytorch_tecogan_amd  # noqa: F401
+    from pytorch_tecogan_amd import models as M
+    from pytorch_tecogan_amd import train as TR
+
+    args = default_args(a.dtype)
+    torch.manual_seed(1)
+    G, D = M.generator(3, args).to(dev), M.discriminator(args).to(dev)
+    og = torch.optim.Adam(G.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
+    od = torch.optim.Adam(D.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
+    B, T = a.batch, 10
+    x, y = synth(B, T, 32, 1 + rank)  # every rank owns different sequences (weak scaling)
+    x, y = x.to(dev), y.to(dev)       # inputs resident in HBM before the timed region
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    log(f"models built ({a.dtype}, B={B}/gpu, world={world}); warm-up {a.warmup} steps (step 0 eager, then capture)")
+    for s in range(a.warmup):
+        TR.FRVSR_Train(x, y, args, D, G, s, 0.0, 0.0, og, od)
+        torch.cuda.synchronize()
+        log(f"warm-up step {s} done")
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        out = TR.FRVSR_Train(x, y, args, D, G, a.warmup + s, 0.0, 0.0, og, od)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    log(f"timed region done: {dt / a.steps * 1e3:.3f} ms/step")
+    gen_loss, d_loss = float(out.gen_loss), float(out.d_loss)
+    if not (np.isfinite(gen_loss) and np.isfinite(d_loss)):
+        raise SystemExit(f"non-finite losses after the timed steps: {gen_loss} {d_loss}")
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = world * B * T * a.steps / dt
+        res = {"metric": "HR frames/sec per train step, 4x 32->128 seq-10", "value": round(value, 2),
+               "unit": "HR-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": "configs[1]: full G+pseudo-flow/warp+D+losses+2xAdam train step, "
+                                      f"B={B} sequences/GPU, T=10, 32x32->128x128", "global_batch": world * B,
+                          "seq_len": T, "parallelism": f"dp{world}", "hipgraph": not a.no_graph},
+               "step_tflops": round(world * B * STEP_GFLOP_PER_SEQ / 1e3 / (dt / a.steps), 2),
+               "step_mfma_frac": round(B * STEP_GFLOP_PER_SEQ / 1e3 / (dt / a.steps) / MFMA_PEAK_TFLOPS[a.dtype], 5),
+               "final_losses": {"gen_loss": round(gen_loss, 5), "d_loss": round(d_loss, 5)}}
+        if not a.no_roofline:
+            st = next(iter(TR._STEPS.values()))
+            log("roofline pass (events around every MFMA launch of one eager step)")
+            fam = roofline_pass(st, a.dtype)
+            dom = max(fam, key=lambda k: fam[k]["ms"])
+            d = fam[dom]
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
+                               "peak": MFMA_PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
+                               "frac": round(ach / MFMA_PEAK_TFLOPS[a.dtype], 5), "traffic": None,
+                               "launches_per_step": d["launches"],
+                               "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+                               "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3),
+                               "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                                            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}}
+        if not a.no_cpu_baseline:
+            log(f"cpu baseline: oracle, {a.cpu_steps}+1 steps on {os.cpu_count()} host cores")
+            res["cpu_baseline"] = cpu_baseline(B, a.cpu_steps)
+        print(json.dumps(res), flush=True)
+    barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -171,7 +171,7 @@ int tg_absdiff_sum(int dtype, const void* a, const void* b, float* acc, int64_t 
 int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const float* b, const int64_t* b_off_dev, float* acc,
                     int nblocks, int64_t len, void* stream);
 /* content loss partial sum and d(pre-sigmoid) for the generator output (code/train.py:239-241):
- * acc[0] += sum (gen-y)^2 ; dpre[nhwc] = gscale * 2*(gen-y) * gen*(1-gen).  gen/y are NCHW fp32 (B,T,3,H,W);
+ * acc[0] += sum (gen-y)^2 ; dpre[nhwc] = gscale * 2*(gen-y) * gen*(1-gen) ; acc[8+c] += sum dpre[c] (output bias grad).  gen/y are NCHW fp32 (B,T,3,H,W);
  * dpre is NHWC [T*B][H][W][32] in (t,b) order. */
 int tg_content_loss(int dtype, const float* gen, const float* y, void* dpre, float* acc, int B, int T, int H, int W,
                     float gscale, void* stream);
@@ -180,8 +180,9 @@ int tg_loss_finalize(const float* prob, const float* acc, float* scalars, float*
                      void* stream);
 
 /* ---- optimiser (torch.optim.Adam as built at main.py:239-243) ------------------------------------------- */
-int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-            float bc1, float bc2, float grad_scale, void* stream);
+/* hyper_dev (device floats): lr, beta1, beta2, eps, 1-beta1^t, 1-beta2^t, grad_scale - in memory so that a captured
+ * hipGraph picks up each step's values. */
+int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -519,3 +519,37 @@ def tecogan_step(gp, dp, dbufs, opt_g, opt_d, x, y, args, global_step, counter1=
     if return_grads:
         return net, gg, dg, f
     return net
+
+
+def generator_content_grads(gp, x, y, dtype=torch.float64, num_resblock=16):
+    """Content-loss gradient of the generator (== the whole G gradient, SURVEY finding 3) evaluated in `dtype`.
+    Used by the tests as an fp64 yardstick: some trunk gradients are ~1e-7 in magnitude and cancel heavily, so the
+    fp32 PyTorch-CPU reference itself is only good to ~1.5e-3 relative on them (measured: fp32 8-thread vs fp64 1.6e-3,
+    8-thread vs 1-thread 1.2e-3 on resids.4.0.weight)."""
+    global warp
+    p = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in gp.items()}
+    xx, yy = x.to(dtype), y.to(dtype)
+    saved = warp
+    warp = lambda img, grid: F.grid_sample(img, grid.to(img.dtype), mode="bilinear", padding_mode="zeros",  # noqa: E731
+                                           align_corners=False)
+    try:
+        gen = recurrent_generator(p, xx, pseudo_flow(xx), num_resblock)
+    finally:
+        warp = saved
+    B, T = x.shape[:2]
+    H = y.shape[-1]
+    loss = torch.mean(torch.sum(torch.square(gen.reshape(B * T, 3, H, H) - yy.reshape(B * T, 3, H, H)), dim=[3]))
+    g = torch.autograd.grad(loss, list(p.values()))
+    return dict(zip(p.keys(), g)), gen.detach()
+
+
+def discriminator_loss_grads(dp, real_in, fake_in, eps=1e-12, dtype=torch.float64, resblocks=4):
+    """Gradient of t_discrim_loss (code/train.py:304-307) w.r.t. every D parameter, evaluated in `dtype` on fixed D inputs.
+    fp64 yardstick for the tests: with BN batches of 3 samples the fp32 PyTorch-CPU reference is itself ~1e-2 relative
+    from the fp64 value on several BN/bias gradients (measured, deterministic across thread counts)."""
+    p = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in dp.items()}
+    b = {k: (v.to(dtype) if v.dtype.is_floating_point else v.clone()) for k, v in init_bn_buffers(dp, resblocks).items()}
+    pr, _ = discriminator_forward(p, b, real_in.detach().to(dtype), resblocks)
+    pf, _ = discriminator_forward(p, b, fake_in.detach().to(dtype), resblocks)
+    loss = torch.mean(-(torch.log(1 - pf + eps) + torch.log(pr + eps)))
+    return dict(zip(p.keys(), torch.autograd.grad(loss, list(p.values()))))

@@ -3,6 +3,11 @@ product path raises."""
 import ctypes as C
 import os
 
+# torch must be imported (and its bundled HIP runtime mapped) BEFORE libtecogan_hip.so is dlopen'ed: the library's
+# libamdhip64 dependency then resolves to the runtime torch already loaded.  Loading in the other order maps a second
+# HIP runtime and every launch fails with hipErrorNoDevice against torch-allocated memory.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtecogan_hip.so")
 
@@ -60,7 +65,7 @@ _PROTOS = {
     "tg_absdiff_nchw": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
     "tg_content_loss": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "tg_loss_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P]),
-    "tg_adam": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "tg_adam": (_I, [_P, _P, _P, _P, _L, _P, _P]),
 }
 
 EXPORTED = tuple(_PROTOS.keys())

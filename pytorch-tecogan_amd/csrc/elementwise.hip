@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void content_loss_kernel(const float* __restri
   __shared__ float sh[4];
   const long long HW = (long long)H * W;
   const long long total = (long long)B * T_ * HW;
-  float s = 0.f;
+  float s = 0.f, cs[3] = {0.f, 0.f, 0.f};
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += 256LL * gridDim.x) {
     const long long pos = i % HW;
     const long long r = i / HW;
@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256) void content_loss_kernel(const float* __restri
       const float g = gen[src + c * HW], d = g - y[src + c * HW];
       s += d * d;
       v[c] = gscale * 2.f * d * g * (1.f - g);
+      cs[c] += v[c];
     }
     if (dpre) {
       char* o = dpre + i * 32 * TR::kBytes;
@@ -269,7 +270,13 @@ __global__ __launch_bounds__(256) void content_loss_kernel(const float* __restri
     }
   }
   s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) cs[c] = wave_sum(cs[c]);
+  if ((threadIdx.x & 63) == 0) {
+    sh[threadIdx.x >> 6] = s;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) atomicAdd(acc + 8 + c, cs[c]);  // output-layer bias gradient
+  }
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
 }
@@ -338,17 +345,20 @@ __global__ void loss_finalize_kernel(const float* __restrict__ prob, const float
   sc[12] = real_l + t_adv;
 }
 
+// hyper (device): 0 lr, 1 beta1, 2 beta2, 3 eps, 4 1-beta1^t, 5 1-beta2^t, 6 grad scale (1/world for data parallel).
+// Read from memory, not kernel arguments, so that a captured hipGraph replays with the current step's values.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float bc1,
-                            float bc2, float gscale) {
-  const float step = lr / bc1, rs = rsqrtf(bc2);
+                            float* __restrict__ v, long long n, const float* __restrict__ hyper) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], bc2 = hyper[5],
+              gscale = hyper[6];
+  const float step = lr / bc1, sq2 = sqrtf(bc2);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
     const float mi = m[i] + (gi - m[i]) * (1.f - b1);        // exp_avg.lerp_(grad, 1-beta1)
     const float vi = v[i] * b2 + (1.f - b2) * gi * gi;       // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
     m[i] = mi;
     v[i] = vi;
-    p[i] -= step * (mi / (sqrtf(vi) * rs + eps));
+    p[i] -= step * (mi / (sqrtf(vi) / sq2 + eps));              // denom = sqrt(v)/sqrt(bc2) + eps
   }
 }
 
@@ -460,11 +470,10 @@ extern "C" int tg_loss_finalize(const float* prob, const float* acc, float* scal
   return tg_launch_status();
 }
 
-extern "C" int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                       float eps, float bc1, float bc2, float grad_scale, void* stream) {
-  if (!p || !g || !m || !v || n <= 0) return TG_E_BADARG;
+extern "C" int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, void* stream) {
+  if (!p || !g || !m || !v || !hyper_dev || n <= 0) return TG_E_BADARG;
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     (long long)n, lr, beta1, beta2, eps, bc1, bc2, grad_scale);
+                     (long long)n, hyper_dev);
   return tg_launch_status();
 }
 

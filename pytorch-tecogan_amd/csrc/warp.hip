@@ -25,9 +25,11 @@ __device__ __forceinline__ float up4_sample(const float* __restrict__ pl, int w,
   const float hx = __fsub_rn(1.f, lx), hy = __fsub_rn(1.f, ly);
   const float a = __fmul_rn(pl[y0 * w + x0], pre), b = __fmul_rn(pl[y0 * w + x1], pre);
   const float c = __fmul_rn(pl[y1 * w + x0], pre), d = __fmul_rn(pl[y1 * w + x1], pre);
-  const float top = __fadd_rn(__fmul_rn(hx, a), __fmul_rn(lx, b));
-  const float bot = __fadd_rn(__fmul_rn(hx, c), __fmul_rn(lx, d));
-  return __fadd_rn(__fmul_rn(hy, top), __fmul_rn(ly, bot));
+  // ATen's CPU kernel evaluates each lerp as fma(w0, v0, w1*v1) (measured bit-exact in the build container); the
+  // flow is later rounded to fp16 for the warp grid, so the last bit matters here.
+  const float top = __fmaf_rn(hx, a, __fmul_rn(lx, b));
+  const float bot = __fmaf_rn(hx, c, __fmul_rn(lx, d));
+  return __fmaf_rn(hy, top, __fmul_rn(ly, bot));
 }
 
 __global__ void up4_planes_kernel(const float* __restrict__ src, const long long* __restrict__ src_off,

@@ -1,0 +1,477 @@
+"""Layer graphs of the generator and discriminator on the HIP kernels, forward and hand-derived backward.
+
+Nothing here uses torch autograd or torch math: torch supplies device buffers, streams and (optionally) hipGraph
+capture.  All activations are NHWC with channels padded to 32; parameters live in one flat fp32 buffer per network
+(PyTorch layouts, so state_dict keys/shapes are those of the reference: SURVEY.md 8b), with matching flat buffers
+for gradients and the Adam moments - one all-reduce and one Adam launch per network.
+
+Reference behaviour reproduced (file:line into the reference):
+  generator.forward        code/models.py:78-86      discriminator.forward   code/models.py:125-146
+  detach structure         code/train.py:90,108,199  (no gradient through warp / recurrence / from D into G), hence the
+                           T generator passes are independent in backward and are run as ONE batch of T*B samples.
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import _lib as L
+from . import kernels as K
+from .kernels import ConvSpec, pad32
+
+
+def _align32(n):
+    return (n + 31) // 32 * 32
+
+
+class FlatParams:
+    """One contiguous fp32 buffer (plus grad / exp_avg / exp_avg_sq twins) holding every parameter of a network.
+    Each tensor's slot is padded to 32 floats so that kernels can read channel-padded bias / BN vectors in place."""
+
+    def __init__(self, shapes, device):
+        self.shapes = OrderedDict(shapes)
+        self.offsets = OrderedDict()
+        off = 0
+        for name, shp in self.shapes.items():
+            n = 1
+            for s in shp:
+                n *= s
+            self.offsets[name] = (off, n)
+            off += _align32(n)
+        self.total = off
+        self.device = device
+        self.p = torch.zeros(off, dtype=torch.float32, device=device)
+        self.g = torch.zeros_like(self.p)
+        self.m = torch.zeros_like(self.p)
+        self.v = torch.zeros_like(self.p)
+
+    def view(self, buf, name):
+        off, n = self.offsets[name]
+        return buf[off:off + n].view(self.shapes[name])
+
+    def padded(self, buf, name):
+        off, n = self.offsets[name]
+        return buf[off:off + _align32(n)]
+
+    def load(self, tensors):
+        for name in self.shapes:
+            self.view(self.p, name).copy_(tensors[name].to(self.device, torch.float32))
+
+    def named_views(self, buf):
+        return OrderedDict((n, self.view(buf, n)) for n in self.shapes)
+
+
+class Workspace:
+    """Grow-only scratch (weight-gradient slabs) and a zero-initialised arena for per-step accumulators."""
+
+    def __init__(self, device):
+        self.device = device
+        self.slab = torch.empty(0, dtype=torch.float32, device=device)
+        self.frozen = False
+
+    def get_slab(self, nfloats):
+        if self.slab.numel() < nfloats:
+            if self.frozen:
+                raise L.TecoganHipError("workspace grew after graph capture")
+            self.slab = torch.empty(nfloats, dtype=torch.float32, device=self.device)
+        return self.slab
+
+
+class Conv:
+    """One conv / conv-transpose layer of the reference: packed weights + forward / dgrad / wgrad launches."""
+
+    def __init__(self, flat, wname, bname, spec, dtype_t, ws, need_dgrad=True, tile=L.TILE_AUTO):
+        self.flat, self.spec, self.dt, self.ws = flat, spec, dtype_t, ws
+        self.tg = K.tg_dtype(dtype_t)
+        self.w = flat.view(flat.p, wname)
+        self.gw = flat.view(flat.g, wname)
+        self.bias = flat.padded(flat.p, bname) if bname else None
+        self.gbias = flat.padded(flat.g, bname) if bname else None
+        dev = flat.device
+        self.slots = K.slot_table(spec.nslots, dev)
+        self.cin_p, self.cout_p = pad32(spec.cin), pad32(spec.cout)
+        if self.bias is not None and self.bias.numel() < self.cout_p:
+            raise L.TecoganHipError("bias slot smaller than padded channel count")
+        self.wf = torch.empty(spec.nslots * self.cin_p * self.cout_p, dtype=dtype_t, device=dev)
+        self.wb = torch.empty_like(self.wf) if need_dgrad else None
+        self.tile = tile
+        self._desc = {}
+
+    def repack(self):
+        s = self.spec
+        rows, Kd, s_row, s_k = s.fwd_pack()
+        K.pack_weights(self.dt, self.w, rows, Kd, s_row, s_k, s.nslots, self.slots, out=self.wf)
+        if self.wb is not None:
+            rows, Kd, s_row, s_k = s.dgrad_pack()
+            K.pack_weights(self.dt, self.w, rows, Kd, s_row, s_k, s.nslots, self.slots, out=self.wb)
+
+    def fwd(self, x, out, act=L.ACT_NONE, res=None, stats=None, groups=1, nchw=None):
+        """x [N,H,W,cin_p] -> out [N,OH,OW,cout_p]; nchw=(buffer, elem_offset, n_stride, c_real) for the fp32 NCHW store."""
+        N, H, W, _ = x.shape
+        OH, OW = self.spec.out_hw(H, W)
+        key = ("f", N, H, W, act, res is not None, stats is not None, groups, nchw is not None and nchw[2:])
+        d = self._desc.get(key)
+        if d is None:
+            d = K.make_conv_desc(self.spec.fwd_geom(), self.tg, N, H, W, self.cin_p, OH, OW, self.cout_p, act=act,
+                                 stats_mode=2 if stats is not None else 0, stats_groups=groups,
+                                 out_mode=L.OUT_NCHW_F32 if nchw else L.OUT_NHWC, c_real=nchw[3] if nchw else 0,
+                                 out_n_stride=nchw[2] if nchw else 0, tile_cfg=self.tile)
+            self._desc[key] = d
+        if nchw:
+            import ctypes
+            buf, off = nchw[0], nchw[1]
+            L.check(L.load().tg_conv(ctypes.byref(d), x.data_ptr(), self.wf.data_ptr(), self.bias.data_ptr(), None, None,
+                                     buf.data_ptr() + off * 4, None, torch.cuda.current_stream().cuda_stream), "tg_conv")
+        else:
+            K.conv(d, x, self.wf, out, bias=self.bias, res=res, stats=stats)
+
+    def dgrad(self, dout, out, mask=None, mask_mode=L.MASK_NONE, res=None, bias_grad_of=None):
+        """dout [N,OH,OW,cout_p] -> out [N,H,W,cin_p] = (dgrad + res) * act'(mask); bias_grad_of: Conv whose bias
+        gradient is the per-channel sum of `out` (accumulated straight into its grad slot)."""
+        N, OH, OW, _ = dout.shape
+        _, H, W, _ = out.shape
+        st = bias_grad_of.gbias if bias_grad_of is not None else None
+        key = ("d", N, OH, OW, mask_mode, res is not None, st is not None)
+        d = self._desc.get(key)
+        if d is None:
+            d = K.make_conv_desc(self.spec.dgrad_geom(), self.tg, N, OH, OW, self.cout_p, H, W, self.cin_p,
+                                 mask_mode=mask_mode, stats_mode=1 if st is not None else 0, stats_groups=1)
+            self._desc[key] = d
+        K.conv(d, dout, self.wb, out, res=res, mask=mask, stats=st)
+
+    def wgrad(self, x_in, dout):
+        """accumulates dW into the flat gradient buffer (which the step zeroes first)."""
+        x_is_in, S, taps, ca, cb, s_a, s_b = self.spec.wgrad_info()
+        X, Y = (x_in, dout) if x_is_in else (dout, x_in)
+        N, XH, XW, cx = X.shape
+        _, YH, YW, cy = Y.shape
+        key = ("w", N, XH, XW, YH, YW)
+        ent = self._desc.get(key)
+        if ent is None:
+            nsplit = K.wgrad_nsplit(N, YH, YW, S)
+            ent = (K.make_wgrad_desc(self.tg, N, XH, XW, cx, YH, YW, cy, S, taps, nsplit), nsplit)
+            self._desc[key] = ent
+        d, nsplit = ent
+        slab = self.ws.get_slab(nsplit * len(taps) * cx * cy)
+        K.wgrad(d, X, Y, slab)
+        K.wgrad_finalize(slab, nsplit, len(taps), cx, cy, ca, cb, self.gw, s_a, s_b, self.slots, True)
+
+
+class BatchNorm:
+    def __init__(self, flat, prefix, C_, bufs, dtype_t, arena):
+        self.C, self.Cp = C_, pad32(C_)
+        self.gamma, self.beta = flat.padded(flat.p, prefix + ".weight"), flat.padded(flat.p, prefix + ".bias")
+        self.dgamma, self.dbeta = flat.padded(flat.g, prefix + ".weight"), flat.padded(flat.g, prefix + ".bias")
+        self.rm, self.rv, self.nbt = bufs[prefix + ".running_mean"], bufs[prefix + ".running_var"], bufs[
+            prefix + ".num_batches_tracked"]
+        self.stats = arena.take(2 * 2 * self.Cp).view(2, 2, self.Cp)
+        self.red = arena.take(2 * 2 * self.Cp).view(2, 2, self.Cp)
+        self.save = torch.empty(2, 2, self.Cp, device=flat.device)
+
+    def apply(self, z, y, act, groups, skip=None, update=True):
+        N, H, W, C_ = z.shape
+        K.bn_apply(z, self.stats, self.gamma, self.beta, y, self.save, N, H * W, C_, groups, act, skip=skip,
+                   running_mean=self.rm if update else None, running_var=self.rv if update else None)
+        if update:
+            self.nbt += groups
+
+    def backward(self, dy, yact, z, dz, act, groups):
+        N, H, W, C_ = z.shape
+        K.bn_bwd_reduce(dy, yact, z, self.save, self.red, N, H * W, C_, groups, act)
+        K.bn_bwd_apply(dy, yact, z, self.save, self.red, self.gamma, dz, self.dgamma, self.dbeta, N, H * W, C_, groups,
+                       act)
+
+
+class Arena:
+    def __init__(self, nfloats, device):
+        self.buf = torch.zeros(nfloats, dtype=torch.float32, device=device)
+        self.used = 0
+
+    def take(self, n):
+        n = _align32(n)
+        if self.used + n > self.buf.numel():
+            raise L.TecoganHipError("accumulator arena too small")
+        v = self.buf[self.used:self.used + n]
+        self.used += n
+        return v
+
+    def zero(self):
+        self.buf.zero_()
+
+
+# =============================================================================================================
+def generator_shapes(num_resblock=16, out_ch=3):
+    s = OrderedDict()
+    s["conv.0.weight"], s["conv.0.bias"] = (64, 51, 3, 3), (64,)
+    for i in range(num_resblock):
+        s[f"resids.{i}.0.weight"], s[f"resids.{i}.0.bias"] = (64, 64, 3, 3), (64,)
+        s[f"resids.{i}.2.weight"] = (64, 64, 3, 3)
+    s["conv_trans.0.weight"], s["conv_trans.0.bias"] = (64, 64, 3, 3), (64,)
+    s["conv_trans.2.0.weight"], s["conv_trans.2.0.bias"] = (64, 64, 3, 3), (64,)
+    s["conv_trans.2.2.weight"] = (64, 64, 3, 3)
+    s["conv_trans.3.0.weight"], s["conv_trans.3.0.bias"] = (128, 64, 3, 3), (128,)
+    s["conv_trans.3.2.weight"] = (128, 128, 3, 3)
+    s["conv_trans.4.weight"], s["conv_trans.4.bias"] = (128, 128, 3, 3), (128,)
+    s["conv_trans.6.weight"], s["conv_trans.6.bias"] = (64, 128, 3, 3), (64,)
+    s["output.weight"], s["output.bias"] = (out_ch, 64, 3, 3), (out_ch,)
+    return s
+
+
+class GeneratorEngine:
+    """code/models.py:61-86 on HIP kernels.  `slots` activations sets are kept (T*B samples) for the batched backward."""
+
+    def __init__(self, flat, dtype_t, num_resblock=16, out_ch=3):
+        self.flat, self.dt, self.nrb, self.out_ch = flat, dtype_t, num_resblock, out_ch
+        self.ws = Workspace(flat.device)
+        mk = lambda w, b, kind, ci, co, dg=True: Conv(flat, w, b, ConvSpec(kind, ci, co), dtype_t, self.ws, need_dgrad=dg)
+        self.conv0 = mk("conv.0.weight", "conv.0.bias", "c3", 51, 64, dg=False)
+        self.rb = [(mk(f"resids.{i}.0.weight", f"resids.{i}.0.bias", "c3", 64, 64),
+                    mk(f"resids.{i}.2.weight", None, "c3", 64, 64)) for i in range(num_resblock)]
+        self.ct0 = mk("conv_trans.0.weight", "conv_trans.0.bias", "ct", 64, 64)
+        self.c20 = mk("conv_trans.2.0.weight", "conv_trans.2.0.bias", "c3", 64, 64)
+        self.c22 = mk("conv_trans.2.2.weight", None, "c3", 64, 64)
+        self.c30 = mk("conv_trans.3.0.weight", "conv_trans.3.0.bias", "c3", 64, 128)
+        self.c32 = mk("conv_trans.3.2.weight", None, "c3", 128, 128)
+        self.ct4 = mk("conv_trans.4.weight", "conv_trans.4.bias", "ct", 128, 128)
+        self.c6 = mk("conv_trans.6.weight", "conv_trans.6.bias", "c3", 128, 64)
+        self.cout = mk("output.weight", "output.bias", "c3", 64, out_ch)
+        self.convs = [self.conv0] + [c for pair in self.rb for c in pair] + [self.ct0, self.c20, self.c22, self.c30,
+                                                                            self.c32, self.ct4, self.c6, self.cout]
+        self.act = None
+        self.shape = None
+
+    def repack(self):
+        for c in self.convs:
+            c.repack()
+
+    def alloc(self, NS, h, w):
+        """activation storage for NS samples (NS = T*B when training, B for inference)."""
+        if self.shape == (NS, h, w):
+            return
+        dev, dt = self.flat.device, self.dt
+        e = lambda n, hh, ww, c: torch.empty(n, hh, ww, c, dtype=dt, device=dev)
+        a = {"in0": e(NS, h, w, 64), "a": [e(NS, h, w, 64) for _ in range(self.nrb + 1)],
+             "h": [e(NS, h, w, 64) for _ in range(self.nrb)], "u0": e(NS, 2 * h, 2 * w, 64),
+             "hh": e(NS, 2 * h, 2 * w, 64), "u1": e(NS, 2 * h, 2 * w, 64), "h2": e(NS, 2 * h, 2 * w, 128),
+             "u2": e(NS, 2 * h, 2 * w, 128), "u3": e(NS, 4 * h, 4 * w, 128), "u4": e(NS, 4 * h, 4 * w, 64)}
+        self.act, self.shape = a, (NS, h, w)
+        self.grad = None
+
+    def forward(self, s0, B, out_buf, out_off, out_n_stride):
+        """runs samples [s0, s0+B) of act['in0'] through the net; sigmoid output goes to out_buf (fp32 NCHW)."""
+        a = self.act
+        sl = slice(s0, s0 + B)
+        self.conv0.fwd(a["in0"][sl], a["a"][0][sl], act=L.ACT_RELU)
+        for i, (c1, c2) in enumerate(self.rb):
+            c1.fwd(a["a"][i][sl], a["h"][i][sl], act=L.ACT_RELU)
+            c2.fwd(a["h"][i][sl], a["a"][i + 1][sl], res=a["a"][i][sl])
+        self.ct0.fwd(a["a"][self.nrb][sl], a["u0"][sl], act=L.ACT_RELU)
+        self.c20.fwd(a["u0"][sl], a["hh"][sl], act=L.ACT_RELU)
+        self.c22.fwd(a["hh"][sl], a["u1"][sl])
+        self.c30.fwd(a["u1"][sl], a["h2"][sl], act=L.ACT_RELU)
+        self.c32.fwd(a["h2"][sl], a["u2"][sl])
+        self.ct4.fwd(a["u2"][sl], a["u3"][sl], act=L.ACT_RELU)
+        self.c6.fwd(a["u3"][sl], a["u4"][sl], act=L.ACT_RELU)
+        self.cout.fwd(a["u4"][sl], None, act=L.ACT_SIGMOID, nchw=(out_buf, out_off, out_n_stride, self.out_ch))
+
+    def _alloc_grad(self):
+        NS, h, w = self.shape
+        dev, dt = self.flat.device, self.dt
+        e = lambda hh, ww, c: torch.empty(NS, hh, ww, c, dtype=dt, device=dev)
+        self.grad = {"dpre": e(4 * h, 4 * w, 32), "hr64": e(4 * h, 4 * w, 64), "hr128": e(4 * h, 4 * w, 128),
+                     "m128a": e(2 * h, 2 * w, 128), "m128b": e(2 * h, 2 * w, 128), "m64a": e(2 * h, 2 * w, 64),
+                     "m64b": e(2 * h, 2 * w, 64), "l64a": e(h, w, 64), "l64b": e(h, w, 64), "l64c": e(h, w, 64)}
+
+    def backward(self):
+        """consumes grad['dpre'] (d loss / d pre-sigmoid, all NS samples) and accumulates every weight/bias gradient."""
+        a, g = self.act, self.grad
+        RELU = L.MASK_RELU
+        self.cout.wgrad(a["u4"], g["dpre"])                                   # output bias grad: see TecoGANStep
+        self.cout.dgrad(g["dpre"], g["hr64"], mask=a["u4"], mask_mode=RELU, bias_grad_of=self.c6)
+        self.c6.wgrad(a["u3"], g["hr64"])
+        self.c6.dgrad(g["hr64"], g["hr128"], mask=a["u3"], mask_mode=RELU, bias_grad_of=self.ct4)
+        self.ct4.wgrad(a["u2"], g["hr128"])
+        self.ct4.dgrad(g["hr128"], g["m128a"])
+        self.c32.wgrad(a["h2"], g["m128a"])
+        self.c32.dgrad(g["m128a"], g["m128b"], mask=a["h2"], mask_mode=RELU, bias_grad_of=self.c30)
+        self.c30.wgrad(a["u1"], g["m128b"])
+        self.c30.dgrad(g["m128b"], g["m64a"])
+        self.c22.wgrad(a["hh"], g["m64a"])
+        self.c22.dgrad(g["m64a"], g["m64b"], mask=a["hh"], mask_mode=RELU, bias_grad_of=self.c20)
+        self.c20.wgrad(a["u0"], g["m64b"])
+        self.c20.dgrad(g["m64b"], g["m64a"], mask=a["u0"], mask_mode=RELU, bias_grad_of=self.ct0)
+        self.ct0.wgrad(a["a"][self.nrb], g["m64a"])
+        d_a, t1, t2 = g["l64a"], g["l64b"], g["l64c"]
+        self.ct0.dgrad(g["m64a"], d_a)
+        for i in range(self.nrb - 1, -1, -1):
+            c1, c2 = self.rb[i]
+            c2.wgrad(a["h"][i], d_a)
+            c2.dgrad(d_a, t1, mask=a["h"][i], mask_mode=RELU, bias_grad_of=c1)
+            c1.wgrad(a["a"][i], t1)
+            if i > 0:
+                c1.dgrad(t1, t2, res=d_a)
+            else:  # a[0] = relu(conv0(in0)): fold its relu' and conv0's bias gradient into the same epilogue
+                c1.dgrad(t1, t2, res=d_a, mask=a["a"][0], mask_mode=RELU, bias_grad_of=self.conv0)
+            d_a, t2 = t2, d_a
+        self.conv0.wgrad(a["in0"], d_a)
+
+
+# =============================================================================================================
+def discriminator_shapes(resblocks=4, ch=128, fc_in=48):
+    s = OrderedDict()
+    s["conv.0.weight"], s["conv.0.bias"] = (64, 27, 3, 3), (64,)
+    stage_c = {1: 64, 2: ch, 3: ch}
+    blk = {1: (64, 64), 2: (ch, 64), 3: (ch, ch), 4: (64, ch), 5: (3, 64)}
+    for st in (1, 2, 3):
+        co, ci = blk[st]
+        s[f"block{st}.0.weight"] = (co, ci, 4, 4)
+        s[f"block{st}.1.weight"], s[f"block{st}.1.bias"] = (co,), (co,)
+        c = stage_c[st]
+        for j in range(resblocks):
+            s[f"resids{st}.{j}.0.0.weight"], s[f"resids{st}.{j}.0.0.bias"] = (c, c, 3, 3), (c,)
+            s[f"resids{st}.{j}.0.2.weight"] = (c, c, 3, 3)
+            s[f"resids{st}.{j}.1.weight"], s[f"resids{st}.{j}.1.bias"] = (c,), (c,)
+    for k in (4, 5):
+        co, ci = blk[k]
+        s[f"block{k}.0.weight"] = (co, ci, 4, 4)
+        s[f"block{k}.1.weight"], s[f"block{k}.1.bias"] = (co,), (co,)
+    s["fc.weight"], s["fc.bias"] = (1, fc_in), (1,)
+    return s
+
+
+def discriminator_bn_names(resblocks=4):
+    names = []
+    for st in (1, 2, 3):
+        names.append(f"block{st}.1")
+        names += [f"resids{st}.{j}.1" for j in range(resblocks)]
+    return names + ["block4.1", "block5.1"]
+
+
+def make_bn_buffers(shapes, resblocks, device):
+    """running_mean / running_var padded to 32 (kernels read the padded length); state_dict sees the first C entries."""
+    bufs = OrderedDict()
+    for bn in discriminator_bn_names(resblocks):
+        c = shapes[bn + ".weight"][0]
+        bufs[bn + ".running_mean"] = torch.zeros(pad32(c), device=device)
+        bufs[bn + ".running_var"] = torch.ones(pad32(c), device=device)
+        bufs[bn + ".num_batches_tracked"] = torch.zeros((), dtype=torch.long, device=device)
+    return bufs
+
+
+class DiscriminatorEngine:
+    """code/models.py:97-146 on HIP kernels.  The reference calls D twice per step (real, fake) with separate BN batch
+    statistics; here both calls run as ONE batch of 2*tb samples whose BN statistics are kept per half (groups=2)."""
+
+    def __init__(self, flat, bufs, dtype_t, resblocks=4, ch=128):
+        self.flat, self.dt, self.nrb, self.ch = flat, dtype_t, resblocks, ch
+        self.ws = Workspace(flat.device)
+        self.arena = Arena(64 * 1024, flat.device)
+        mk = lambda w, b, kind, ci, co, dg=True: Conv(flat, w, b, ConvSpec(kind, ci, co), dtype_t, self.ws, need_dgrad=dg)
+        bn = lambda p, c: BatchNorm(flat, p, c, bufs, dtype_t, self.arena)
+        self.conv0 = mk("conv.0.weight", "conv.0.bias", "c3", 27, 64, dg=False)
+        cin = {1: 64, 2: 64, 3: ch, 4: ch, 5: 64}
+        cout = {1: 64, 2: ch, 3: ch, 4: 64, 5: 3}
+        self.blk = {k: (mk(f"block{k}.0.weight", None, "c4s2", cin[k], cout[k]), bn(f"block{k}.1", cout[k]))
+                    for k in range(1, 6)}
+        self.res = {st: [(mk(f"resids{st}.{j}.0.0.weight", f"resids{st}.{j}.0.0.bias", "c3", cout[st], cout[st]),
+                          mk(f"resids{st}.{j}.0.2.weight", None, "c3", cout[st], cout[st]),
+                          bn(f"resids{st}.{j}.1", cout[st])) for j in range(resblocks)] for st in (1, 2, 3)}
+        self.cout = cout
+        self.fc_w, self.fc_b = flat.view(flat.p, "fc.weight"), flat.padded(flat.p, "fc.bias")
+        self.g_fc_w, self.g_fc_b = flat.view(flat.g, "fc.weight"), flat.padded(flat.g, "fc.bias")
+        self.convs = [self.conv0] + [self.blk[k][0] for k in range(1, 6)] + [c for st in (1, 2, 3) for (c1, c2, _) in
+                                                                             self.res[st] for c in (c1, c2)]
+        self.shape = None
+
+    def repack(self):
+        for c in self.convs:
+            c.repack()
+
+    def alloc(self, N, H):
+        if self.shape == (N, H):
+            return
+        dev, dt = self.flat.device, self.dt
+        e = lambda hh, c: torch.empty(N, hh, hh, pad32(c), dtype=dt, device=dev)
+        a = {"in": e(H, 27), "c0": e(H, 64), "z": {}, "n": {}, "h": {}, "r": {}, "net": {}}
+        hh = H
+        for k in range(1, 6):
+            hh //= 2
+            a["z"][k], a["n"][k] = e(hh, self.cout[k]), e(hh, self.cout[k])
+            if k <= 3:
+                a["h"][k] = [e(hh, self.cout[k]) for _ in range(self.nrb)]
+                a["r"][k] = [e(hh, self.cout[k]) for _ in range(self.nrb)]
+                a["net"][k] = [e(hh, self.cout[k]) for _ in range(self.nrb)]
+        self.act, self.shape = a, (N, H)
+        self.prob = torch.empty(N, device=dev)
+        self.fc_hw = (H // 32) ** 2
+        if self.fc_w.numel() != 3 * self.fc_hw:
+            raise L.TecoganHipError(f"fc expects {self.fc_w.numel()} inputs but the D input gives {3 * self.fc_hw} "
+                                    "(code/models.py:123 hard-wires 48 = 128x128 HR)")
+        g = {}
+        hh = H
+        for k in range(1, 6):
+            hh //= 2
+            g[k] = [e(hh, self.cout[k]) for _ in range(3)]
+        self.gbuf = g
+        self.g_c0 = e(H, 64)
+        self.dlogit = torch.empty(N, device=dev)
+
+    def stage_out(self, k):
+        return self.act["net"][k][self.nrb - 1] if (k <= 3 and self.nrb > 0) else self.act["n"][k]
+
+    def layers(self):
+        return [self.stage_out(1), self.stage_out(2), self.stage_out(3), self.act["n"][4]]
+
+    def forward(self, groups=2, update_stats=True):
+        a = self.act
+        self.conv0.fwd(a["in"], a["c0"], act=L.ACT_LRELU)
+        prev = a["c0"]
+        for k in range(1, 6):
+            conv, bn = self.blk[k]
+            conv.fwd(prev, a["z"][k], stats=bn.stats, groups=groups)
+            bn.apply(a["z"][k], a["n"][k], L.ACT_LRELU, groups, update=update_stats)
+            net = a["n"][k]
+            if k <= 3:
+                for j, (c1, c2, bnj) in enumerate(self.res[k]):
+                    c1.fwd(net, a["h"][k][j], act=L.ACT_RELU)
+                    c2.fwd(a["h"][k][j], a["r"][k][j], stats=bnj.stats, groups=groups)
+                    bnj.apply(a["r"][k][j], a["net"][k][j], L.ACT_NONE, groups, skip=net, update=update_stats)
+                    net = a["net"][k][j]
+            prev = net
+        N = a["in"].shape[0]
+        K.fc_head_fwd(a["n"][5], self.fc_w, self.fc_b, self.prob, N, self.fc_hw, 3, 32)
+
+    def backward(self, groups=2):
+        """consumes self.dlogit; accumulates all D gradients."""
+        a = self.act
+        N = a["in"].shape[0]
+        g5 = self.gbuf[5]
+        K.fc_head_bwd(a["n"][5], self.fc_w, self.dlogit, g5[0], self.g_fc_w, self.g_fc_b, N, self.fc_hw, 3, 32)
+        d_net = g5[0]  # gradient w.r.t. n[5]
+        for k in range(5, 0, -1):
+            gk = self.gbuf[k]
+            if k <= 3:
+                # d_net is the gradient w.r.t. the stage output; walk the residual blocks backwards
+                for j in range(self.nrb - 1, -1, -1):
+                    c1, c2, bnj = self.res[k][j]
+                    net_in = a["net"][k][j - 1] if j > 0 else a["n"][k]
+                    free = [b for b in gk if b is not d_net]
+                    d_r, d_h = free[0], free[1]
+                    bnj.backward(d_net, None, a["r"][k][j], d_r, L.ACT_NONE, groups)
+                    c2.wgrad(a["h"][k][j], d_r)
+                    c2.dgrad(d_r, d_h, mask=a["h"][k][j], mask_mode=L.MASK_RELU, bias_grad_of=c1)
+                    c1.wgrad(net_in, d_h)
+                    c1.dgrad(d_h, d_r, res=d_net)
+                    d_net = d_r
+            conv, bn = self.blk[k]
+            free = [b for b in gk if b is not d_net]
+            d_z = free[0]
+            bn.backward(d_net, a["n"][k], a["z"][k], d_z, L.ACT_LRELU, groups)
+            prev = self.stage_out(k - 1) if k > 1 else a["c0"]
+            conv.wgrad(prev, d_z)
+            if k > 1:
+                d_prev = self.gbuf[k - 1][0]
+                conv.dgrad(d_z, d_prev)
+                d_net = d_prev
+            else:
+                conv.dgrad(d_z, self.g_c0, mask=a["c0"], mask_mode=L.MASK_LRELU, bias_grad_of=self.conv0)
+                self.conv0.wgrad(a["in"], self.g_c0)

@@ -296,8 +296,9 @@ def loss_finalize(prob, acc, scalars, dlogit, tb, cfg):
             "tg_loss_finalize")
 
 
-def adam(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
-    bc1 = 1.0 - beta1 ** step
-    bc2 = 1.0 - beta2 ** step
-    L.check(L.load().tg_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, bc1, bc2,
-                             grad_scale, _stream()), "tg_adam")
+def adam_hyper(lr, beta1, beta2, eps, step, grad_scale=1.0):
+    return [lr, beta1, beta2, eps, 1.0 - beta1 ** step, 1.0 - beta2 ** step, grad_scale, 0.0]
+
+
+def adam(p, g, m, v, hyper_dev):
+    L.check(L.load().tg_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper_dev), _stream()), "tg_adam")

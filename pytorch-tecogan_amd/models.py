@@ -1,0 +1,225 @@
+"""nn.Module surface of the reference's code/models.py (generator :61-86, discriminator :97-146, f_net :22-50).
+
+The modules are parameter containers with the reference's state_dict keys, shapes, registration order and default
+initialisation; their forward runs the HIP engines of engine.py.  There is no torch-op forward: without
+the HIP library the modules raise.  The first forward / training step after a device move re-binds the parameters as
+views of one flat fp32 buffer per network (this is what lets one Adam launch and one RCCL all-reduce cover a network).
+"""
+import math
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import engine as E
+from . import kernels as K
+from .step import RecurrentGenerator
+
+
+def compute_dtype(args=None):
+    """bf16 by default (BASELINE config 2); TECOGAN_DTYPE=fp32 or args.tg_dtype='fp32' selects the fp32 parity mode."""
+    name = getattr(args, "tg_dtype", None) or os.environ.get("TECOGAN_DTYPE", "bf16")
+    name = str(name).lower()
+    if name in ("fp32", "f32", "float32"):
+        return torch.float32
+    if name in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    raise ValueError(f"unsupported compute dtype {name!r} (use bf16 or fp32)")
+
+
+class _Node(nn.Module):
+    """anonymous container so that dotted reference names ('resids.3.0.weight') become a module tree."""
+
+    def forward(self, *a, **k):  # pragma: no cover - never called
+        raise RuntimeError("parameter container")
+
+
+def _fan_in(shape):
+    return shape[1] * shape[2] * shape[3]  # torch uses size(1)*receptive field for Conv2d AND ConvTranspose2d
+
+
+def _build_tree(root, shapes, bn_prefixes=(), gen=None):
+    """registers parameters (PyTorch default init: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), +), same bound for
+    the bias; BN weight 1 / bias 0) under nested _Node modules, in the order of `shapes`."""
+    last_bound = 1.0
+    for name, shp in shapes.items():
+        parts = name.split(".")
+        node = root
+        for p in parts[:-1]:
+            if p not in node._modules:
+                node.add_module(p, _Node())
+            node = node._modules[p]
+        prefix = ".".join(parts[:-1])
+        if prefix in bn_prefixes:
+            t = torch.ones(shp) if parts[-1] == "weight" else torch.zeros(shp)
+        elif len(shp) == 4:
+            last_bound = 1.0 / math.sqrt(_fan_in(shp))
+            t = torch.empty(shp).uniform_(-last_bound, last_bound, generator=gen)
+        elif len(shp) == 2:  # denselayer: xavier_uniform weight (code/ops.py:87), default Linear bias
+            b = math.sqrt(6.0 / (shp[0] + shp[1]))
+            t = torch.empty(shp).uniform_(-b, b, generator=gen)
+            last_bound = 1.0 / math.sqrt(shp[1])
+        else:
+            t = torch.empty(shp).uniform_(-last_bound, last_bound, generator=gen)
+        node.register_parameter(parts[-1], nn.Parameter(t))
+    for prefix in bn_prefixes:
+        node = root
+        for p in prefix.split("."):
+            node = node._modules[p]
+        c = node.weight.shape[0]
+        node.register_buffer("running_mean", torch.zeros(c))
+        node.register_buffer("running_var", torch.ones(c))
+        node.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class _HipModule(nn.Module):
+    """common flat-buffer binding logic"""
+
+    _shapes = None
+
+    def _bound(self):
+        flat = getattr(self, "_flat", None)
+        if flat is None:
+            return False
+        first, last = self._edge_params
+        for name, p in (first, last):  # a device move / load replaces every Parameter's storage, so two probes suffice
+            if p.data_ptr() != flat.view(flat.p, name).data_ptr() or p.device != flat.p.device:
+                return False
+        return True
+
+    def _bind(self, dtype_t):
+        """(re)creates the flat buffers on the parameters' device and makes every Parameter a view of them."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise L.TecoganHipError("the HIP path needs the module on a GPU: call .cuda() first (no CPU fallback)")
+        L.load()
+        if self._bound() and self._dtype == dtype_t:
+            return
+        old_flat = getattr(self, "_flat", None)
+        flat = E.FlatParams(self._shapes, dev)
+        for name, p in self.named_parameters():
+            v = flat.view(flat.p, name)
+            v.copy_(p.data)
+            if old_flat is not None and old_flat.p.device == dev:
+                flat.view(flat.m, name).copy_(old_flat.view(old_flat.m, name))
+                flat.view(flat.v, name).copy_(old_flat.view(old_flat.v, name))
+            p.data = v
+            p.grad = flat.view(flat.g, name)
+        named = list(self.named_parameters())
+        self._edge_params = (named[0], named[-1])
+        self._flat, self._dtype = flat, dtype_t
+        self._make_engine(flat, dtype_t)
+        self._engine.repack()
+
+    def flat_params(self):
+        return self._flat
+
+    def engine(self, dtype_t=None):
+        self._bind(dtype_t or getattr(self, "_dtype", None) or compute_dtype(self._args))
+        return self._engine
+
+
+class generator(_HipModule):
+    """code/models.py:61-86.  forward(x[B,51,h,w]) -> [B,3,4h,4w] (inference; the training step drives the engine
+    directly and batches the backward over all frames)."""
+
+    def __init__(self, gen_output_channels, args=None):
+        super().__init__()
+        if args is None:
+            raise ValueError("No args is provided for generator")
+        self._args = args
+        self.num = int(args.num_resblock)
+        self._out_ch = int(gen_output_channels)
+        if self._out_ch > 4:
+            raise ValueError("gen_output_channels > 4 is not supported by the NCHW store epilogue")
+        self._shapes = E.generator_shapes(self.num, self._out_ch)
+        _build_tree(self, self._shapes)
+        self._rec = None
+
+    def _make_engine(self, flat, dtype_t):
+        self._engine = E.GeneratorEngine(flat, dtype_t, self.num, self._out_ch)
+        self._rec = None
+
+    def forward(self, x):
+        eng = self.engine()
+        B, C_, h, w = x.shape
+        if C_ != 51:
+            raise ValueError("generator expects 51 input channels (3 LR + 48 packed warped HR)")
+        eng.alloc(B, h, w)
+        K.nchw_to_nhwc(x.contiguous().float(), C_ * h * w, eng.act["in0"], B, C_, h, w)
+        out = torch.empty(B, self._out_ch, 4 * h, 4 * w, dtype=torch.float32, device=x.device)
+        eng.forward(0, B, out, 0, self._out_ch * 16 * h * w)
+        return out
+
+    def recurrent(self, frames, use_graph=False):
+        """(B,T,3,h,w) LR frames -> (B,T,3,4h,4w): the whole inference loop of main.py:171-219 on device."""
+        eng = self.engine()
+        B, T, _, h, w = frames.shape
+        if self._rec is None or (self._rec.B, self._rec.h, self._rec.w, self._rec.use_graph) != (B, h, w, use_graph):
+            self._rec = RecurrentGenerator(eng, B, h, w, frames.device, use_graph)
+        return self._rec.run(frames.contiguous().float())
+
+
+class discriminator(_HipModule):
+    """code/models.py:97-146.  forward(x[N,27,H,W]) -> (prob[N,1], [4 feature maps]); BN in training mode."""
+
+    def __init__(self, args=None):
+        super().__init__()
+        if args is None:
+            raise ValueError("No args is provided for discriminator")
+        self._args = args
+        self.resblocks = int(args.discrim_resblocks)
+        self.channels = int(args.discrim_channels)
+        fc_in = 3 * (int(getattr(args, "crop_size", 32)) * 4 // 32) ** 2 if getattr(args, "tg_fc_auto", False) else 48
+        self._shapes = E.discriminator_shapes(self.resblocks, self.channels, fc_in)
+        _build_tree(self, self._shapes, bn_prefixes=E.discriminator_bn_names(self.resblocks))
+
+    def _make_engine(self, flat, dtype_t):
+        # BN buffers: kernels read 32-padded vectors; the registered buffers become views of the first C entries
+        bufs = E.make_bn_buffers(self._shapes, self.resblocks, flat.device)
+        for prefix in E.discriminator_bn_names(self.resblocks):
+            node = self
+            for p in prefix.split("."):
+                node = node._modules[p]
+            c = node.weight.shape[0]
+            for key in ("running_mean", "running_var"):
+                bufs[f"{prefix}.{key}"][:c].copy_(getattr(node, key))
+                node._buffers[key] = bufs[f"{prefix}.{key}"][:c]
+            bufs[f"{prefix}.num_batches_tracked"].copy_(node.num_batches_tracked)
+            node._buffers["num_batches_tracked"] = bufs[f"{prefix}.num_batches_tracked"]
+        self._engine = E.DiscriminatorEngine(flat, bufs, dtype_t, self.resblocks, self.channels)
+
+    def forward(self, x):
+        eng = self.engine()
+        N, C_, H, W = x.shape
+        if C_ != 27 or H != W:
+            raise ValueError("discriminator expects [N,27,H,H]")
+        eng.alloc(N, H)
+        K.nchw_to_nhwc(x.contiguous().float(), C_ * H * W, eng.act["in"], N, C_, H, W)
+        eng.arena.zero()
+        eng.forward(groups=1, update_stats=True)
+        layers = [K.to_nchw(l, l.shape[3]) for l in eng.layers()]
+        return eng.prob.clone().view(N, 1), layers
+
+
+class f_net(nn.Module):
+    """code/models.py:22-50: defined and imported by the reference but never instantiated (main.py:231 is commented
+    out), so no HIP forward exists for it yet; the class keeps the parameter names/shapes for checkpoints."""
+
+    def __init__(self):
+        super().__init__()
+        s = OrderedDict()
+        chans = [("down1", 3, 32), ("down2", 32, 64), ("down3", 64, 128), ("down4", 128, 256), ("up1", 256, 512),
+                 ("up2", 512, 256), ("up3", 256, 128), ("up4", 128, 64)]
+        for name, ci, co in chans:
+            s[f"{name}.0.weight"], s[f"{name}.0.bias"] = (co, ci, 3, 3), (co,)
+            s[f"{name}.2.weight"], s[f"{name}.2.bias"] = (co, co, 3, 3), (co,)
+        s["output_block.0.weight"], s["output_block.0.bias"] = (32, 64, 3, 3), (32,)
+        s["output_block.2.weight"], s["output_block.2.bias"] = (2, 32, 3, 3), (2,)
+        self._shapes = s
+        _build_tree(self, s)
+
+    def forward(self, x):
+        raise NotImplementedError("f_net is dead code in the reference hot path (never called); HIP forward not built")

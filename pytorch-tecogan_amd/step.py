@@ -1,0 +1,294 @@
+"""One TecoGAN training step (code/train.py:49-370) as a static sequence of HIP kernel launches on preallocated
+buffers - which is what makes it hipGraph-capturable - plus the generator-only recurrent inference loop
+(main.py:171-219).  See SURVEY.md Appendix B for the behavioural spec this follows, quirks included:
+  * pseudo-flow = bilinear x4 of the previous LR frame's first two channels, reinterpreted (not permuted) as a grid;
+  * HR / fake warp grids rounded to fp16, real / LR warp grids fp32;
+  * gen_flow_back built from rows 0..B-1 of a (3B,6,h,h) reshape (mixes batch elements);
+  * fake D input reuses the TARGET frames as its first 9 channels; both D inputs detached from G;
+  * reported gen_loss = content + 2*ratio*t_adv + layer_sum*dt_ratio (aliased tensor), gradient of G = content only;
+  * BN running statistics updated twice per step (real pass, then fake pass).
+Data parallel: sequences are sharded over ranks; the flat G and D gradient buffers are all-reduced over RCCL, the G
+all-reduce overlapping the D backward pass."""
+import torch
+
+from . import _lib as L
+from . import kernels as K
+from .kernels import pad32
+
+LAYER_NORM = (12.0, 14.0, 24.0, 100.0)  # code/train.py:214
+
+SCALAR_NAMES = ["D_layer_0_loss", "D_layer_1_loss", "D_layer_2_loss", "D_layer_3_loss", "D_layer_loss_sum",
+                "gen_loss", "l2_warp_loss", "t_adversarial_loss", "t_discrim_loss", "t_discrim_real_output",
+                "t_discrim_fake_output", "content", "t_balance", "PingPang"]
+
+
+def _i64(vals, device):
+    return torch.tensor(vals, dtype=torch.int64, device=device)
+
+
+class TecoGANStep:
+    def __init__(self, G, D, B, T, h, args, device, use_graph=False, process_group=None, world_size=1):
+        """G: GeneratorEngine, D: DiscriminatorEngine (already bound to flat parameter buffers on `device`)."""
+        if getattr(args, "pingpang", False):
+            raise NotImplementedError("pingpang=True is not implemented on the HIP path yet (default is False)")
+        if not getattr(args, "Dt_mergeDs", True):
+            raise RuntimeError("Dt_mergeDs=False feeds 9 channels into a 27-channel conv in the reference and raises "
+                               "there too (SURVEY.md 8a8)")
+        if float(getattr(args, "vgg_scaling", -1.0)) > 0.0:
+            raise NotImplementedError("vgg_scaling>0 crashes in the reference (code/train.py:126 vs :30); not built")
+        self.G, self.D, self.B, self.T, self.h, self.args, self.dev = G, D, B, T, h, args, device
+        self.H = H = 4 * h
+        self.K = T // 3
+        if self.K < 1:
+            raise ValueError("RNN_N must be >= 3")
+        self.tsize = 3 * self.K
+        self.tb = B * self.K
+        self.use_graph, self.pg, self.world = use_graph, process_group, world_size
+        f32 = dict(dtype=torch.float32, device=device)
+        self.x = torch.empty(B, T, 3, h, h, **f32)
+        self.y = torch.empty(B, T, 3, H, H, **f32)
+        self.gen = torch.empty(B, T, 3, H, H, **f32)
+        self.flow = torch.empty(B, T - 1, 2, H, H, **f32)
+        self.tvel = torch.empty(B * self.tsize, H, H, 2, **f32)
+        self.target = torch.empty(self.tb, 27, H, H, **f32)
+        self.acc = torch.zeros(16, **f32)
+        self.scalars = torch.zeros(16, **f32)
+        # per-step host parameters (loss config, Adam bias corrections, lr) travel through ONE small async copy from a
+        # ring of pinned slots, so the CPU may run many steps ahead of the GPU without overwriting a pending copy
+        self.params_dev = torch.zeros(32, **f32)
+        self.cfg = self.params_dev[0:16]
+        self.hyper = self.params_dev[16:32].view(2, 8)
+        self.ring = torch.zeros(256, 32, dtype=torch.float32).pin_memory()
+        self.ring_i = 0
+        G.alloc(T * B, h, h)
+        G._alloc_grad()
+        D.alloc(2 * self.tb, H)
+        self._tables()
+        self.graphs = None
+        self.adam_t = [0, 0]
+        self.border = (H - int(H * args.crop_dt)) // 2 if args.crop_dt < 1.0 else 0
+
+    # ----------------------------------------------------------------------------------------------------------
+    def _tables(self):
+        B, T, h, H, Kt = self.B, self.T, self.h, self.H, self.K
+        hh, HH = h * h, H * H
+        dev = self.dev
+        xo = lambda b, t, c=0: ((b * T + t) * 3 + c) * hh
+        # pseudo-flow planes: x[b,t,c] (t<T-1, c<2) -> flow[b,t,c]   (code/train.py:71-77)
+        src, dst = [], []
+        for b in range(B):
+            for t in range(T - 1):
+                for c in range(2):
+                    src.append(xo(b, t, c))
+                    dst.append(((b * (T - 1) + t) * 2 + c) * HH)
+        self.flow_src, self.flow_dst, self.n_flow = _i64(src, dev), _i64(dst, dev), len(src)
+        # LR warp (logged loss only): img x[b,t], grid block = x[b,t+1,0:2], reference x[b,t+1]  (code/train.py:78-84,247-249)
+        img, grd = [], []
+        for b in range(B):
+            for t in range(T - 1):
+                img.append(xo(b, t))
+                grd.append(xo(b, t + 1))
+        self.lrw_img, self.lrw_grid = _i64(img, dev), _i64(grd, dev)
+        # T_vel blocks (code/train.py:138-158): (b, j, r) -> r=0 flow[b,3j], r=1 zeros, r=2 2*up4(4*back)-1
+        csrc, cdst = [], []
+        for b in range(B):
+            for j in range(Kt):
+                csrc += [((b * (T - 1) + 3 * j) * 2) * HH, -1]
+                cdst += [((b * self.tsize + 3 * j) * 2) * HH, ((b * self.tsize + 3 * j + 1) * 2) * HH]
+        self.tv_csrc, self.tv_cdst, self.n_tvc = _i64(csrc, dev), _i64(cdst, dev), len(csrc)
+        # "back" planes: cat(x[:,2:ts:3], x[:,1:ts:3], dim=1) viewed as (B*K, 6, h, h); only rows 0..B-1 are used.
+        frames = list(range(2, self.tsize, 3)) + list(range(1, self.tsize, 3))  # 2K frames per batch element
+        bsrc, bdst = [], []
+        for b in range(B):
+            for j in range(Kt):
+                for comp in range(2):
+                    P = 6 * b + 2 * j + comp if Kt == 3 else (2 * Kt) * b + 2 * j + comp
+                    # plane P of the flattened (B, 2K, 3, h, h) tensor
+                    bb, f, c = P // (2 * Kt * 3), (P // 3) % (2 * Kt), P % 3
+                    bsrc.append(xo(bb, frames[f], c))
+                    bdst.append((((b * self.tsize + 3 * j + 2) * 2) + comp) * HH)
+        self.tv_bsrc, self.tv_bdst, self.n_tvb = _i64(bsrc, dev), _i64(bdst, dev), len(bsrc)
+
+    # ----------------------------------------------------------------------------------------------------------
+    def _host_params(self, global_step, lr_g, lr_d, betas_g, betas_d, eps_g, eps_d):
+        a = self.args
+        B, T, h, H = self.B, self.T, self.h, self.H
+        slot = self.ring[self.ring_i % self.ring.shape[0]]
+        self.ring_i += 1
+        c = [0.0] * 32
+        c[0] = B * T * 3 * H                      # content: mean over (BT,3,H) of sum over W
+        c[1] = B * (T - 1) * 3 * h                # warp loss
+        for i, l in enumerate(self.D.layers()):
+            c[2 + i] = self.tb * l.shape[3] * l.shape[1]  # mean over (tb, C, Hl) of sum over W
+            c[12 + i] = LAYER_NORM[i]
+        c[6], c[7] = a.EPS, a.ratio
+        c[8] = min(a.Dt_ratio_max, a.Dt_ratio_0 + a.Dt_ratio_add * float(global_step))
+        c[9] = 1.0 if a.D_LAYERLOSS else 0.0
+        c[10], c[11] = 0.0, a.pp_scaling
+        self.dt_ratio = c[8]
+        gs = 1.0 / self.world
+        c[16:24] = K.adam_hyper(lr_g, betas_g[0], betas_g[1], eps_g, self.adam_t[0] + 1, gs)
+        c[24:32] = K.adam_hyper(lr_d, betas_d[0], betas_d[1], eps_d, self.adam_t[1] + 1, gs)
+        slot.copy_(torch.tensor(c, dtype=torch.float32))
+        self.params_dev.copy_(slot, non_blocking=True)
+
+    # ----------------------------------------------------------------------------------------------------------
+    def _forward_and_g_backward(self):
+        G, D, B, T, h, H = self.G, self.D, self.B, self.T, self.h, self.H
+        hh, HH = h * h, H * H
+        self.acc.zero_()
+        D.arena.zero()
+        G.flat.g.zero_()
+        D.flat.g.zero_()
+        K.up4_planes(self.x, self.flow_src, self.flow, self.flow_dst, self.n_flow, h, h, pre=4.0)
+        K.warp_nchw(self.x, self.lrw_img, self.x, self.lrw_grid, B * (T - 1), 3, h, h, h, h, False, sq_ref=self.x,
+                    sq_off=self.lrw_grid, loss_acc=self.acc[1:2])
+        for t in range(T):
+            dst = G.act["in0"][t * B:(t + 1) * B]
+            if t == 0:
+                K.gen_input(self.x, 0, T * 3 * hh, None, 0, 0, None, 0, 0, dst, B, h, h)
+            else:
+                K.gen_input(self.x, t * 3 * hh, T * 3 * hh, self.gen, (t - 1) * 3 * HH, T * 3 * HH, self.flow,
+                            (t - 1) * 2 * HH, (T - 1) * 2 * HH, dst, B, h, h)
+            G.forward(t * B, B, self.gen, t * 3 * HH, T * 3 * HH)
+        K.copy_blocks(self.flow, self.tv_csrc, self.tvel, self.tv_cdst, self.n_tvc, 2 * HH)
+        K.up4_planes(self.x, self.tv_bsrc, self.tvel, self.tv_bdst, self.n_tvb, h, h, pre=4.0, post_a=2.0, post_b=-1.0)
+        K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"], B, T, self.K, h, self.border)
+        D.forward(groups=2, update_stats=True)
+        if self.args.D_LAYERLOSS:
+            for i, l in enumerate(D.layers()):
+                n = self.tb * l.shape[1] * l.shape[2]
+                K.absdiff_sum(l[:self.tb], l[self.tb:], self.acc, 2 + i, n, l.shape[3], l.shape[3])
+        K.content_loss(self.gen, self.y, G.grad["dpre"], self.acc, B, T, H, H, 1.0 / (B * T * 3 * H))
+        K.loss_finalize(D.prob, self.acc, self.scalars, D.dlogit, self.tb, self.cfg)
+        G.cout.gbias[:3] += self.acc[8:11]
+        K.nhwc_to_nchw(D.act["in"], self.target, 27 * HH, self.tb, 27, H, H)
+        G.backward()
+
+    def _d_backward(self):
+        self.D.backward(groups=2)
+
+    def _update(self):
+        G, D = self.G, self.D
+        K.adam(G.flat.p, G.flat.g, G.flat.m, G.flat.v, self.hyper[0])
+        K.adam(D.flat.p, D.flat.g, D.flat.m, D.flat.v, self.hyper[1])
+        G.repack()
+        D.repack()
+
+    def _run_eager(self):
+        self._forward_and_g_backward()
+        work = self._allreduce(self.G.flat.g)
+        self._d_backward()
+        work2 = self._allreduce(self.D.flat.g)
+        for w in (work, work2):
+            if w is not None:
+                w.wait()
+        self._update()
+
+    def _allreduce(self, buf):
+        if self.pg is None or self.world == 1:
+            return None
+        import torch.distributed as dist
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _capture(self):
+        """three hipGraphs (forward + G backward | D backward | Adam + repack) so that the RCCL all-reduces sit between
+        them; single process replays them back to back."""
+        pool = torch.cuda.graph_pool_handle()
+        self.G.ws.frozen = self.D.ws.frozen = True
+        gs = []
+        for fn in (self._forward_and_g_backward, self._d_backward, self._update):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                fn()
+            gs.append(g)
+        self.graphs = gs
+
+    def _run_graphs(self):
+        g1, g2, g3 = self.graphs
+        g1.replay()
+        w1 = self._allreduce(self.G.flat.g)
+        g2.replay()
+        w2 = self._allreduce(self.D.flat.g)
+        for w in (w1, w2):
+            if w is not None:
+                w.wait()
+        g3.replay()
+
+    # ----------------------------------------------------------------------------------------------------------
+    def run(self, x, y, global_step, lr_g, lr_d, betas_g=(0.9, 0.999), betas_d=(0.9, 0.999), eps_g=1e-8, eps_d=1e-8):
+        """x (B,T,3,h,h), y (B,T,3,H,H) fp32 device tensors.  Returns nothing; results live in self.gen / self.scalars /
+        self.target and the parameter / optimiser buffers are updated in place."""
+        if x.shape != self.x.shape or y.shape != self.y.shape:
+            raise ValueError(f"step built for {tuple(self.x.shape)} / {tuple(self.y.shape)}")
+        self.x.copy_(x)
+        self.y.copy_(y)
+        self._host_params(global_step + 1, lr_g, lr_d, betas_g, betas_d, eps_g, eps_d)
+        if self.use_graph:
+            if self.graphs is None:
+                self._run_eager()          # warm-up: one-time attribute setup, workspace growth
+                self.adam_t = [self.adam_t[0] + 1, self.adam_t[1] + 1]
+                torch.cuda.synchronize()
+                self._capture()
+                return
+            self._run_graphs()
+        else:
+            self._run_eager()
+        self.adam_t = [self.adam_t[0] + 1, self.adam_t[1] + 1]
+
+
+class RecurrentGenerator:
+    """Generator-only recurrent inference (main.py:171-219) without the per-frame CPU<->GPU bounces; the per-frame
+    step (warp -> pack -> G) can be captured once as a hipGraph and replayed for every frame."""
+
+    def __init__(self, G, B, h, w, device, use_graph=False):
+        self.G, self.B, self.h, self.w, self.dev, self.use_graph = G, B, h, w, device, use_graph
+        H, W = 4 * h, 4 * w
+        f32 = dict(dtype=torch.float32, device=device)
+        self.lr = torch.empty(B, 3, h, w, **f32)
+        self.prev_lr = torch.empty(B, 3, h, w, **f32)
+        self.prev = torch.zeros(B, 3, H, W, **f32)
+        self.out = torch.empty(B, 3, H, W, **f32)
+        self.flow = torch.empty(B, 2, H, W, **f32)
+        hh, HH = h * w, H * W
+        src, dst = [], []
+        for b in range(B):
+            for c in range(2):
+                src.append((b * 3 + c) * hh)
+                dst.append((b * 2 + c) * HH)
+        self.fsrc, self.fdst = _i64(src, device), _i64(dst, device)
+        G.alloc(B, h, w)
+        self.graph = None
+
+    def _frame(self):
+        G, B, h, w = self.G, self.B, self.h, self.w
+        H, W = 4 * h, 4 * w
+        K.up4_planes(self.prev_lr, self.fsrc, self.flow, self.fdst, 2 * B, h, w, pre=4.0)
+        K.gen_input(self.lr, 0, 3 * h * w, self.prev, 0, 3 * H * W, self.flow, 0, 2 * H * W, G.act["in0"], B, h, w)
+        G.forward(0, B, self.out, 0, 3 * H * W)
+
+    def run(self, frames):
+        """frames (B,T,3,h,w) fp32 device -> (B,T,3,4h,4w)."""
+        B, T = frames.shape[:2]
+        h, w = self.h, self.w
+        outs = torch.empty(B, T, 3, 4 * h, 4 * w, dtype=torch.float32, device=self.dev)
+        self.lr.copy_(frames[:, 0])
+        K.gen_input(self.lr, 0, 3 * h * w, None, 0, 0, None, 0, 0, self.G.act["in0"], B, h, w)
+        self.G.forward(0, B, self.out, 0, 3 * 16 * h * w)
+        outs[:, 0].copy_(self.out)
+        for t in range(1, T):
+            self.prev.copy_(self.out)
+            self.prev_lr.copy_(frames[:, t - 1])
+            self.lr.copy_(frames[:, t])
+            if self.use_graph:
+                if self.graph is None:
+                    self._frame()
+                    torch.cuda.synchronize()
+                    self.graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph):
+                        self._frame()
+                self.graph.replay()
+            else:
+                self._frame()
+            outs[:, t].copy_(self.out)
+        return outs

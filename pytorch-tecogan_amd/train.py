@@ -1,0 +1,121 @@
+"""Drop-in for the reference's code/train.py: FRVSR_Train / TecoGAN with the same signature, side effects (both
+modules' parameters / BN buffers and both optimisers updated in place) and the same `Network` result tuple
+(code/train.py:354-377).  The arithmetic runs in step.TecoGANStep on HIP kernels."""
+import collections
+import os
+
+import torch
+
+from . import _lib as L
+from .models import compute_dtype
+from .step import TecoGANStep
+
+Network = collections.namedtuple(
+    "Network",
+    "gen_output, learning_rate, update_list, update_list_name, update_list_avg, global_step, d_loss, gen_loss, "
+    "fnet_loss ,tb, target")
+
+_STEPS = {}
+
+
+def _dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.group.WORLD, dist.get_world_size()
+    return None, 1
+
+
+def _bind_optimizer(opt, module):
+    """makes torch.optim.Adam's state tensors views of the engine's flat moment buffers, so optimizer.state_dict()
+    (checkpoint ABI, main.py:308-317) stays meaningful although the update is one fused HIP launch."""
+    flat = module.flat_params()
+    tag = (id(flat), id(opt))
+    if getattr(opt, "_tg_bound", None) == tag:
+        return
+    shared_step = None
+    for name, p in module.named_parameters():
+        st = opt.state.get(p, None)
+        m, v = flat.view(flat.m, name), flat.view(flat.v, name)
+        if st and "exp_avg" in st and st["exp_avg"].data_ptr() != m.data_ptr():
+            m.copy_(st["exp_avg"].to(m.device))
+            v.copy_(st["exp_avg_sq"].to(v.device))
+            if shared_step is None:
+                shared_step = torch.tensor(float(st["step"]))
+        if shared_step is None:
+            shared_step = torch.tensor(0.0)
+        opt.state[p] = {"step": shared_step, "exp_avg": m, "exp_avg_sq": v}
+    opt._tg_bound = tag
+    opt._tg_step = shared_step
+
+
+def get_step(generator_F, discriminator_F, B, T, h, args, device, dtype_t=None, use_graph=None):
+    dtype_t = dtype_t or compute_dtype(args)
+    if use_graph is None:
+        use_graph = os.environ.get("TECOGAN_GRAPH", "1") != "0"
+    Ge, De = generator_F.engine(dtype_t), discriminator_F.engine(dtype_t)
+    key = (id(Ge), id(De), B, T, h, use_graph)
+    st = _STEPS.get(key)
+    if st is None:
+        pg, world = _dist_info()
+        st = TecoGANStep(Ge, De, B, T, h, args, device, use_graph=use_graph, process_group=pg, world_size=world)
+        _STEPS.clear()  # one live configuration: activation buffers are large
+        _STEPS[key] = st
+    return st
+
+
+def TecoGAN(r_inputs, r_targets, discriminator_F, generator_F, args, Global_step, counter1, counter2, optimizer_g,
+            optimizer_d, GAN_FLAG=True):
+    """code/train.py:49-370."""
+    if not GAN_FLAG:
+        raise NotImplementedError("GAN_FLAG=False leaves discrim_loss undefined in the reference (code/train.py:340)")
+    if not r_inputs.is_cuda:
+        raise L.TecoganHipError("FRVSR_Train needs device tensors; there is no CPU path")
+    B, T = r_inputs.shape[0], r_inputs.shape[1]
+    if int(args.RNN_N) != T:
+        raise ValueError("r_inputs.shape[1] must equal args.RNN_N")
+    if T // 3 != 3:
+        raise RuntimeError("the reference's D-input reshape only works for RNN_N in {9,10,11} (code/train.py:143-145)")
+    h = int(args.crop_size)
+    st = get_step(generator_F, discriminator_F, B, T, h, args, r_inputs.device)
+    _bind_optimizer(optimizer_g, generator_F)
+    _bind_optimizer(optimizer_d, discriminator_F)
+    gg, gd = optimizer_g.param_groups[0], optimizer_d.param_groups[0]
+    st.adam_t = [int(optimizer_g._tg_step), int(optimizer_d._tg_step)]
+    st.run(r_inputs.float(), r_targets.float(), Global_step, gg["lr"], gd["lr"], gg["betas"], gd["betas"], gg["eps"],
+           gd["eps"])
+    optimizer_g._tg_step += 1
+    optimizer_d._tg_step += 1
+    return _network(st, args, Global_step + 1, counter1, counter2)
+
+
+def _network(st, args, global_step, counter1, counter2):
+    s = st.scalars.clone()  # device scalars; no host synchronisation happens here (the reference forces three)
+    names, vals = [], []
+    if args.D_LAYERLOSS:
+        vals += [s[0], s[1], s[2], s[3], s[4]]
+        names += ["D_layer_%d_loss" % i for i in range(4)] + ["D_layer_loss_sum"]
+    gen_loss = s[5]
+    vals += [gen_loss, s[6]]  # l2_content_loss holds the aliased total (code/train.py:244,293,299)
+    names += ["l2_content_loss", "l2_warp_loss"]
+    vals += [s[7], s[8], s[9], s[10], gen_loss]
+    names += ["t_adversarial_loss", "t_discrim_loss", "t_discrim_real_output", "t_discrim_fake_output", "All_loss_Gen"]
+    tb = 0.99 * s[12]
+    # EMA(0.99) re-created every call: avg_k = 0.99*u_k + 0.01*avg_{k-1}, avg_{-1}=0 (code/train.py:324-333)
+    stacked = torch.stack(vals)
+    avg, shadow = [], torch.zeros((), device=s.device)
+    for i in range(len(vals)):
+        shadow = 0.99 * stacked[i] + 0.01 * shadow
+        avg.append(shadow)
+    dt_ratio = torch.tensor(st.dt_ratio)
+    avg += [tb, dt_ratio, counter1, counter2]
+    names_all = names + ["t_balance", "Dst_ratio", "withD_counter", "w_o_D_counter"]
+    return Network(gen_output=st.gen, learning_rate=args.learning_rate, update_list=vals, update_list_name=names_all,
+                   update_list_avg=avg, global_step=global_step, d_loss=s[8], gen_loss=gen_loss, fnet_loss=gen_loss,
+                   tb=tb, target=st.target)
+
+
+def FRVSR_Train(r_inputs, r_targets, args, discriminator_F, generator_F, step, counter1, counter2, optimizer_g,
+                optimizer_d):
+    """code/train.py:374-377."""
+    return TecoGAN(r_inputs, r_targets, discriminator_F, generator_F, args, step, counter1, counter2, optimizer_g,
+                   optimizer_d)
