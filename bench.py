@@ -128,11 +128,24 @@ def roofline_pass(st, dtype):
     return fam
 
 
+def usable_cores():
+    """cores this process may actually use: min(affinity mask, cgroup v2 cpu.max quota) - the GPU box shows 256 logical
+    CPUs but grants a 16-CPU quota, and 256 oneDNN threads on 16 CPUs are orders of magnitude slower than 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(B, n_steps):
     """the oracle (CPU restatement of the reference step) on this box's host cores; same synthetic workload shape."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import tecogan_oracle as orc
-    threads = os.cpu_count() or 1
+    threads = usable_cores()
     torch.set_num_threads(threads)
     args = orc.default_args()
     x, y = synth(B, 10, 32, 1)
@@ -148,7 +161,7 @@ def cpu_baseline(B, n_steps):
     dt = (time.perf_counter() - t0) / n_steps
     return dict(value=round(B * 10 / dt, 3), unit="HR-frames/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{n_steps} full train steps (B={B}, T=10, 32->128, fp32) after 1 warm-up, {dt:.2f} s/step, "
-                       f"os.cpu_count()={os.cpu_count()}")
+                       f"os.cpu_count()={os.cpu_count()}, usable (affinity/cgroup quota)={threads}")
 
 
 def main():
@@ -238,7 +251,7 @@ def main():
                                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
                                             for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}}
         if not a.no_cpu_baseline:
-            log(f"cpu baseline: oracle, {a.cpu_steps}+1 steps on {os.cpu_count()} host cores")
+            log(f"cpu baseline: oracle, {a.cpu_steps}+1 steps on {usable_cores()} usable host cores")
             res["cpu_baseline"] = cpu_baseline(B, a.cpu_steps)
         print(json.dumps(res), flush=True)
     barrier()
