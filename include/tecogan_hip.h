@@ -73,7 +73,8 @@ typedef struct {
   int32_t tile_cfg;             /* 0 auto; otherwise a TG_TILE_* id (tuning / tests) */
 } tg_conv_desc;
 
-enum { TG_TILE_AUTO = 0, TG_TILE_64x256 = 1, TG_TILE_64x64 = 2, TG_TILE_128x128 = 3, TG_TILE_32x128 = 4 };
+enum { TG_TILE_AUTO = 0, TG_TILE_64x256 = 1, TG_TILE_64x64 = 2, TG_TILE_128x128 = 3, TG_TILE_32x128 = 4,
+       TG_TILE_32x64 = 5, TG_TILE_64x128 = 6 };  /* <output channels>x<pixels> per workgroup */
 
 int tg_abi_version(void);
 const char* tg_error_string(int code);
@@ -89,6 +90,10 @@ int64_t tg_packed_weight_bytes(int dtype, int nslots, int cout_p, int cin_p);
  * aten::conv2d / conv_transpose2d (code/ops.py:45-63). */
 int tg_pack_conv_weights(int dtype, const float* w, void* packed, int cout, int cin, int cout_p, int cin_p,
                          int64_t s_co, int64_t s_ci, int nslots, const int32_t* slot_off_dev, void* stream);
+
+/* The same for every conv of a network in ONE launch.  jobs_dev: njobs x 9 int64 on the device =
+ * {w ptr, packed ptr, s_row, s_k, rows, K, rows_p, K_p, nslots}; slot t reads kernel offset t. */
+int tg_pack_conv_weights_multi(int dtype, const int64_t* jobs_dev, int njobs, int blocks_per_job, void* stream);
 
 /* Gather convolution on MFMA: conv3x3 (code/models.py:54-58,68,73-76,102 via code/ops.py:57-63), conv4x4 stride 2
  * (code/models.py:90-94), conv-transpose k3 s2 p1 op1 as four sub-pixel classes (code/ops.py:45-54;

@@ -36,7 +36,7 @@ struct ConvK {
   char* out;
   float* stats;
   int N, IH, IW, Cin, OH, OW, Cout, S, OS;
-  int tiles_x, tiles_y, nchunks, tg;
+  int tiles_x, tiles_y, nchunks, tg, cg;
   int act, mask_mode, stats_mode, stats_groups, out_mode, c_real;
   long long out_n_stride;
   int a_rows_max;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_a = smem;
-  char* lds_w = smem + (size_t)p.a_rows_max * kRowBytes;
+  char* lds_w = smem + (size_t)p.cg * p.a_rows_max * kRowBytes;
 
   const ConvClassK& cl = p.cls[blockIdx.z];
   const int tid = threadIdx.x;
@@ -113,43 +113,103 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
   const size_t in_pix_bytes = (size_t)p.Cin * TR::kBytes;
   const char* in_n = p.in + (size_t)n * p.IH * p.IW * in_pix_bytes;
 
-  for (int c = 0; c < p.nchunks; ++c) {
+  // K loop: stages of (chunk group x tap group).  Each stage issues ALL of its global loads before the first LDS store
+  // (UA/UW loads in flight per thread): with one workgroup per CU on the small recurrent-pass layers nothing else hides
+  // the L2/HBM latency, and a load->store->load chain costs one round trip per 16 bytes.
+  constexpr int UA = 4, UW = 8;
+  const int a_stride = p.a_rows_max * kRowBytes;  // LDS bytes of one chunk's activation patch
+  const float inv_iw = 1.0f / (float)cl.iw;
+  for (int c0 = 0; c0 < p.nchunks; c0 += p.cg) {
+    const int cn = min(p.cg, p.nchunks - c0);
     for (int t0 = 0; t0 < ntaps; t0 += p.tg) {
       const int tn = min(p.tg, ntaps - t0);
       __syncthreads();  // previous fragment reads are done before LDS is overwritten
       if (t0 == 0) {
-        for (int i = tid; i < prow_n * 4; i += 256) {
-          const int prow = i >> 2, s = i & 3;
-          const int py = prow / cl.iw, px = prow - py * cl.iw;
-          const int iy = iy0 + py, ix = ix0 + px;
-          u32x4 v = {0u, 0u, 0u, 0u};
-          if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
-            v = *reinterpret_cast<const u32x4*>(in_n + ((size_t)iy * p.IW + ix) * in_pix_bytes + (size_t)c * 64 + s * 16);
-          *reinterpret_cast<u32x4*>(lds_a + prow * kRowBytes + s * 16) = v;
+        // activation patch: (row, col) of a patch pixel via an exact float reciprocal (no integer division: there is no
+        // hardware int-div and at one wave per SIMD ~35 VALU per divide is microseconds over a stage)
+        const int total = prow_n * 4;
+        for (int cc = 0; cc < cn; ++cc) {
+          const char* src_c = in_n + (size_t)(c0 + cc) * 64;
+          char* dst_c = lds_a + cc * a_stride;
+          for (int base = tid; base < total; base += 256 * UA) {
+            u32x4 v[UA];
+            int dst[UA];
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+              const int i = base + u * 256;
+              v[u] = u32x4{0u, 0u, 0u, 0u};
+              dst[u] = -1;
+              if (i < total) {
+                const int s = i & 3, prow = i >> 2;
+                const int py = (int)(((float)prow + 0.5f) * inv_iw), px = prow - py * cl.iw;
+                const int iy = iy0 + py, ix = ix0 + px;
+                dst[u] = prow * kRowBytes + s * 16;
+                if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
+                  v[u] = *reinterpret_cast<const u32x4*>(src_c + ((size_t)iy * p.IW + ix) * in_pix_bytes + s * 16);
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < UA; ++u)
+              if (dst[u] >= 0) *reinterpret_cast<u32x4*>(dst_c + dst[u]) = v[u];
+          }
         }
       }
-      for (int i = tid; i < tn * CO_TILE * 4; i += 256) {
-        const int r = i >> 2, s = i & 3;
-        const int tt = r / CO_TILE, row = r - tt * CO_TILE;
-        const int slot = cl.widx[t0 + tt];
-        const char* src = p.w + (((size_t)slot * p.nchunks + c) * p.Cout + co_base + row) * 64 + s * 16;
-        *reinterpret_cast<u32x4*>(lds_w + r * kRowBytes + s * 16) = *reinterpret_cast<const u32x4*>(src);
+      {
+        // weights: for one (chunk, tap) the CO_TILE packed rows are CONTIGUOUS in global memory, so the copy is a plain
+        // 16-byte-per-thread block copy; UW (chunk, tap) blocks are in flight before the first LDS store.
+        constexpr int PIECES = CO_TILE * 4, PPT = (PIECES + 255) / 256;
+        const int nq = cn * tn;
+        for (int q0 = 0; q0 < nq; q0 += UW) {
+          u32x4 v[UW][PPT];
+#pragma unroll
+          for (int u = 0; u < UW; ++u) {
+            const int qq = q0 + u;  // uniform
+            if (qq < nq) {
+              const int cc = qq / tn, tt = qq - cc * tn;  // scalar (wave-uniform) arithmetic
+              const int slot = cl.widx[t0 + tt];
+              const char* src = p.w + (((size_t)slot * p.nchunks + c0 + cc) * p.Cout + co_base) * 64;
+#pragma unroll
+              for (int k = 0; k < PPT; ++k) {
+                const int piece = tid + k * 256;
+                if (PIECES % 256 == 0 || piece < PIECES) v[u][k] = *reinterpret_cast<const u32x4*>(src + piece * 16);
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UW; ++u) {
+            const int qq = q0 + u;
+            if (qq < nq) {
+              const int cc = qq / tn, tt = qq - cc * tn;
+              char* dstw = lds_w + (cc * p.tg + tt) * CO_TILE * kRowBytes;
+#pragma unroll
+              for (int k = 0; k < PPT; ++k) {
+                const int piece = tid + k * 256;
+                if (PIECES % 256 == 0 || piece < PIECES)
+                  *reinterpret_cast<u32x4*>(dstw + (piece >> 2) * kRowBytes + (piece & 3) * 16) = v[u][k];
+              }
+            }
+          }
+        }
       }
       __syncthreads();
 
-      for (int tt = 0; tt < tn; ++tt) {
-        const int dy = cl.dy[t0 + tt] - cl.dymin, dx = cl.dx[t0 + tt] - cl.dxmin;
-        Frag wf[CT];
+      for (int cc = 0; cc < cn; ++cc) {
+        const char* la = lds_a + cc * a_stride;
+        for (int tt = 0; tt < tn; ++tt) {
+          const int dy = cl.dy[t0 + tt] - cl.dymin, dx = cl.dx[t0 + tt] - cl.dxmin;
+          const char* lw = lds_w + (cc * p.tg + tt) * CO_TILE * kRowBytes;
+          Frag wf[CT];
 #pragma unroll
-        for (int a = 0; a < CT; ++a)
-          wf[a] = *reinterpret_cast<const Frag*>(lds_w + (tt * CO_TILE + (wc * CT + a) * 16 + idx) * kRowBytes + g * 16);
+          for (int a = 0; a < CT; ++a)
+            wf[a] = *reinterpret_cast<const Frag*>(lw + ((wc * CT + a) * 16 + idx) * kRowBytes + g * 16);
 #pragma unroll
-        for (int b = 0; b < PT; ++b) {
-          const int ty = wp * PT + b;
-          const int prow = (ty * p.S + dy) * cl.iw + idx * p.S + dx;
-          const Frag xf = *reinterpret_cast<const Frag*>(lds_a + prow * kRowBytes + g * 16);
+          for (int b = 0; b < PT; ++b) {
+            const int ty = wp * PT + b;
+            const int prow = (ty * p.S + dy) * cl.iw + idx * p.S + dx;
+            const Frag xf = *reinterpret_cast<const Frag*>(la + prow * kRowBytes + g * 16);
 #pragma unroll
-          for (int a = 0; a < CT; ++a) acc[a][b] = Mma<T>::run(wf[a], xf, acc[a][b]);
+            for (int a = 0; a < CT; ++a) acc[a][b] = Mma<T>::run(wf[a], xf, acc[a][b]);
+          }
         }
       }
     }
@@ -308,6 +368,8 @@ int dispatch_conv(int cfg, const ConvK& k, dim3 grid, size_t lds, hipStream_t st
     case TG_TILE_64x64: return launch_conv<T, 2, 2, 2, 2>(k, grid, lds, st);
     case TG_TILE_128x128: return launch_conv<T, 4, 4, 2, 2>(k, grid, lds, st);
     case TG_TILE_32x128: return launch_conv<T, 2, 2, 1, 4>(k, grid, lds, st);
+    case TG_TILE_32x64: return launch_conv<T, 2, 1, 1, 4>(k, grid, lds, st);
+    case TG_TILE_64x128: return launch_conv<T, 4, 2, 1, 4>(k, grid, lds, st);
   }
   return TG_E_UNSUPPORTED;
 }
@@ -318,6 +380,8 @@ TileCfg tile_cfg(int cfg) {
     case TG_TILE_64x64: return {64, 4};
     case TG_TILE_128x128: return {128, 8};
     case TG_TILE_32x128: return {32, 8};
+    case TG_TILE_32x64: return {32, 4};
+    case TG_TILE_64x128: return {64, 8};
   }
   return {0, 0};
 }
@@ -371,11 +435,12 @@ extern "C" int tg_conv(const tg_conv_desc* d, const void* in, const void* w_pack
       const long long ohc = (d->OH - d->cls[c].ooy + d->OS - 1) / d->OS, owc = (d->OW - d->cls[c].oox + d->OS - 1) / d->OS;
       px += (long long)d->N * ohc * owc;
     }
+    // measured per layer shape under hipGraph replay (tools/microbench.py, profiles/r01_*_microbench.log)
     if (d->Cout % 64) cfg = TG_TILE_32x128;
-    else if (d->S > 1) cfg = (d->Cout % 128 == 0) ? TG_TILE_128x128 : TG_TILE_64x64;
-    else if (px < 64 * 1024) cfg = TG_TILE_64x64;
-    else if (d->Cout % 128 == 0) cfg = TG_TILE_128x128;
-    else cfg = TG_TILE_64x256;
+    else if (d->S > 1) cfg = (d->Cout % 128 == 0 && px >= 16384) ? TG_TILE_128x128 : (px >= 32768 ? TG_TILE_64x128 : TG_TILE_64x64);
+    else if (d->Cout % 128 == 0 && px >= 16384) cfg = TG_TILE_128x128;
+    else if (px >= 32768) cfg = TG_TILE_64x256;
+    else cfg = TG_TILE_64x64;
   }
   const TileCfg tc = tile_cfg(cfg);
   if (!tc.co_tile || d->Cout % tc.co_tile) return TG_E_UNSUPPORTED;
@@ -415,18 +480,68 @@ extern "C" int tg_conv(const tg_conv_desc* d, const void* in, const void* w_pack
   k.a_rows_max = max_rows;
   const size_t a_bytes = (size_t)max_rows * kRowBytes;
   const size_t w_tap = (size_t)tc.co_tile * kRowBytes;
-  const size_t budget = 72 * 1024;  // two workgroups per CU
-  int tg = max_taps;
-  while (tg > 1 && a_bytes + tg * w_tap > budget) --tg;
-  size_t lds = a_bytes + tg * w_tap;
-  if (lds > 160 * 1024) return TG_E_UNSUPPORTED;
-  lds = std::max<size_t>(lds, 4 * 2 * tc.co_tile * sizeof(float));  // stats scratch
-  k.tg = tg;
   k.tiles_x = (max_owc + 15) / 16;
   k.tiles_y = (max_ohc + tc.th - 1) / tc.th;
   const long long gx = (long long)k.tiles_x * k.tiles_y * d->N;
   if (gx > 0x7fffffffLL) return TG_E_UNSUPPORTED;
+  const long long wgs = gx * (d->Cout / tc.co_tile) * d->ncls;
+  // LDS budget: a grid that cannot give every CU two workgroups anyway may use (almost) the whole 160 KB so that all
+  // of K is staged in one or two stages; big grids keep two workgroups per CU for cross-workgroup latency hiding.
+  const size_t budget = wgs <= 512 ? 150 * 1024 : 72 * 1024;
+  int tg = max_taps;
+  while (tg > 1 && a_bytes + tg * w_tap > budget) --tg;
+  int cg = 1;
+  if (tg == max_taps)
+    while (cg < k.nchunks && (size_t)(cg + 1) * (a_bytes + tg * w_tap) <= budget) ++cg;
+  size_t lds = (size_t)cg * (a_bytes + tg * w_tap);
+  if (lds > 160 * 1024) return TG_E_UNSUPPORTED;
+  lds = std::max<size_t>(lds, 4 * 2 * tc.co_tile * sizeof(float));  // stats scratch
+  k.tg = tg;
+  k.cg = cg;
   dim3 grid((unsigned)gx, (unsigned)(d->Cout / tc.co_tile), (unsigned)d->ncls);
   hipStream_t st = (hipStream_t)stream;
   return d->dtype == TG_BF16 ? dispatch_conv<BF16>(cfg, k, grid, lds, st) : dispatch_conv<F32>(cfg, k, grid, lds, st);
+}
+
+// ---------------------------------------------------------------------------------------- table-driven repack
+// One launch repacks every conv of a network (forward and dgrad copies): blockIdx.y selects the job.
+// Job = 9 x int64: w ptr, packed ptr, s_row, s_k, rows, K, rows_p, K_p, nslots  (slot t reads kernel offset t).
+namespace {
+template <typename T>
+__global__ void pack_multi_kernel(const long long* __restrict__ jobs) {
+  using TR = ElemTraits<T>;
+  const long long* j = jobs + 9 * blockIdx.y;
+  const float* w = reinterpret_cast<const float*>(j[0]);
+  char* packed = reinterpret_cast<char*>(j[1]);
+  const long long s_co = j[2], s_ci = j[3];
+  const int cout = (int)j[4], cin = (int)j[5], cout_p = (int)j[6], cin_p = (int)j[7], nslots = (int)j[8];
+  const int nchunks = cin_p / TR::kChunk;
+  const long long total = (long long)nslots * nchunks * cout_p * TR::kChunk;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int kc = (int)(i % TR::kChunk);
+    long long r = i / TR::kChunk;
+    const int row = (int)(r % cout_p);
+    r /= cout_p;
+    const int c = (int)(r % nchunks);
+    const int slot = (int)(r / nchunks);
+    const int co = row_to_channel<T>(row);
+    const int ci = c * TR::kChunk + kc;
+    float v = 0.f;
+    if (co < cout && ci < cin) v = w[co * s_co + ci * s_ci + slot];
+    store_elem<T>(packed, i, v);
+  }
+}
+}  // namespace
+
+extern "C" int tg_pack_conv_weights_multi(int dtype, const int64_t* jobs_dev, int njobs, int blocks_per_job,
+                                          void* stream) {
+  if (!jobs_dev || njobs <= 0 || blocks_per_job <= 0) return TG_E_BADARG;
+  dim3 grid((unsigned)blocks_per_job, (unsigned)njobs);
+  if (dtype == TG_BF16)
+    hipLaunchKernelGGL(pack_multi_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, (const long long*)jobs_dev);
+  else if (dtype == TG_F32)
+    hipLaunchKernelGGL(pack_multi_kernel<F32>, grid, dim3(256), 0, (hipStream_t)stream, (const long long*)jobs_dev);
+  else
+    return TG_E_BADARG;
+  return tg_launch_status();
 }

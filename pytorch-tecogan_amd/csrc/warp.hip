@@ -139,42 +139,40 @@ __global__ void warp_nchw_kernel(const float* __restrict__ img, const long long*
   }
 }
 
+// One thread per HR pixel (16 per LR pixel): this kernel sits on the serial recurrent path between two generator
+// passes, so it is organised for latency (3 bilinear samples per thread, HR-row-major thread order so that the grid and
+// image reads of a wave are contiguous) rather than for wide stores.
 template <typename T>
 __global__ void gen_input_kernel(const float* __restrict__ lr, long long lr_n_stride, const float* __restrict__ prev,
                                  long long prev_n_stride, const float* __restrict__ grid, long long grid_n_stride,
                                  char* __restrict__ dst, int B, int h, int w) {
-  using TR = ElemTraits<T>;
   const int H = 4 * h, W = 4 * w;
-  const long long total = (long long)B * h * w;
+  const long long total = (long long)B * H * W;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % w);
-    const long long r = i / w;
-    const int y = (int)(r % h);
-    const int b = (int)(r / h);
-    float v[64];
+    const int X = (int)(i % W);
+    const long long r = i / W;
+    const int Y = (int)(r % H);
+    const int b = (int)(r / H);
+    const int x = X >> 2, jj = X & 3, y = Y >> 2, ii = Y & 3;
+    const long long pix = ((long long)b * h + y) * w + x;  // destination LR pixel, 64 channels
+    if ((ii | jj) == 0) {
 #pragma unroll
-    for (int c = 0; c < 64; ++c) v[c] = 0.f;
+      for (int c = 0; c < 3; ++c) store_elem<T>(dst, pix * 64 + c, lr[b * lr_n_stride + ((long long)c * h + y) * w + x]);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) v[c] = lr[b * lr_n_stride + ((long long)c * h + y) * w + x];
+      for (int c = 51; c < 64; ++c) store_elem<T>(dst, pix * 64 + c, 0.f);
+    }
+    float v[3] = {0.f, 0.f, 0.f};
     if (prev) {
-      const float* gb = grid + b * grid_n_stride;
+      const long long pos = (long long)Y * W + X;
+      const float* gb = grid + b * grid_n_stride + 2 * pos;
+      const Bilin bl = bilin_setup(fp16_round(gb[0]), fp16_round(gb[1]), W, H);
       const float* pb = prev + b * prev_n_stride;
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const long long pos = (long long)(4 * y + ii) * W + 4 * x + jj;
-          const Bilin bl = bilin_setup(fp16_round(gb[2 * pos]), fp16_round(gb[2 * pos + 1]), W, H);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float s = bilin_sample(bl, pb + (long long)c * H * W, W);
-            v[3 + c * 16 + ii * 4 + jj] = __fmul_rn(__fadd_rn(s, 1.f), 0.5f);  // deprocess: (w+1)/2
-          }
-        }
+      for (int c = 0; c < 3; ++c)
+        v[c] = __fmul_rn(__fadd_rn(bilin_sample(bl, pb + (long long)c * H * W, W), 1.f), 0.5f);  // deprocess: (w+1)/2
     }
-    char* o = dst + i * 64 * TR::kBytes;
 #pragma unroll
-    for (int k = 0; k < 64 / TR::kVec; ++k) Vec<T>::store(o + k * 16, v + k * TR::kVec);
+    for (int c = 0; c < 3; ++c) store_elem<T>(dst, pix * 64 + 3 + c * 16 + ii * 4 + jj, v[c]);
   }
 }
 
@@ -307,12 +305,12 @@ extern "C" int tg_gen_input(int dtype, const float* lr, int64_t lr_n_stride, con
                             const float* grid, int64_t grid_n_stride, void* dst, int B, int h, int w, void* stream) {
   if (!lr || !dst || B <= 0 || h <= 0 || w <= 0 || (prev && !grid)) return TG_E_BADARG;
   if (!tg_aligned16(dst)) return TG_E_ALIGN;
-  const int g = grid_for((long long)B * h * w, 64);
+  const int g = grid_for((long long)B * h * w * 16, 256);
   if (dtype == TG_BF16)
-    hipLaunchKernelGGL(gen_input_kernel<BF16>, dim3(g), dim3(64), 0, (hipStream_t)stream, lr, (long long)lr_n_stride,
+    hipLaunchKernelGGL(gen_input_kernel<BF16>, dim3(g), dim3(256), 0, (hipStream_t)stream, lr, (long long)lr_n_stride,
                        prev, (long long)prev_n_stride, grid, (long long)grid_n_stride, (char*)dst, B, h, w);
   else if (dtype == TG_F32)
-    hipLaunchKernelGGL(gen_input_kernel<F32>, dim3(g), dim3(64), 0, (hipStream_t)stream, lr, (long long)lr_n_stride,
+    hipLaunchKernelGGL(gen_input_kernel<F32>, dim3(g), dim3(256), 0, (hipStream_t)stream, lr, (long long)lr_n_stride,
                        prev, (long long)prev_n_stride, grid, (long long)grid_n_stride, (char*)dst, B, h, w);
   else
     return TG_E_BADARG;

@@ -69,24 +69,50 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     const int iy0 = ty0 * p.S + p.dymin, ix0 = tx0 * p.S + p.dxmin;
 
     __syncthreads();
+    // all global loads of a batch are issued before the first LDS store (one workgroup per CU: nothing else hides latency)
+    constexpr int U = 8;
     const char* xn = p.x + (size_t)n * p.XH * p.XW * xpix_bytes + (size_t)a0 * TR::kBytes;
-    for (int i = tid; i < prow_n * XV; i += 256) {
-      const int prow = i / XV, s = i - prow * XV;
-      const int py = prow / p.iw, px = prow - py * p.iw;
-      const int iy = iy0 + py, ix = ix0 + px;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (iy >= 0 && iy < p.XH && ix >= 0 && ix < p.XW)
-        v = *reinterpret_cast<const u32x4*>(xn + ((size_t)iy * p.XW + ix) * xpix_bytes + s * 16);
-      *reinterpret_cast<u32x4*>(lds_x + prow * XROW + s * 16) = v;
+    for (int base = tid; base < prow_n * XV; base += 256 * U) {
+      u32x4 v[U];
+      int dst[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * 256;
+        v[u] = u32x4{0u, 0u, 0u, 0u};
+        dst[u] = -1;
+        if (i < prow_n * XV) {
+          const int prow = i / XV, s = i - prow * XV;
+          const int py = prow / p.iw, px = prow - py * p.iw;
+          const int iy = iy0 + py, ix = ix0 + px;
+          dst[u] = prow * XROW + s * 16;
+          if (iy >= 0 && iy < p.XH && ix >= 0 && ix < p.XW)
+            v[u] = *reinterpret_cast<const u32x4*>(xn + ((size_t)iy * p.XW + ix) * xpix_bytes + s * 16);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<u32x4*>(lds_x + dst[u]) = v[u];
     }
     const char* yn = p.y + (size_t)n * p.YH * p.YW * ypix_bytes + (size_t)b0 * TR::kBytes;
-    for (int i = tid; i < ypix * YV; i += 256) {
-      const int prow = i / YV, s = i - prow * YV;
-      const int yy = ty0 + (prow >> p.tw_log2), xx = tx0 + (prow & (tw - 1));
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (yy < p.YH && xx < p.YW)
-        v = *reinterpret_cast<const u32x4*>(yn + ((size_t)yy * p.YW + xx) * ypix_bytes + s * 16);
-      *reinterpret_cast<u32x4*>(lds_y + prow * YROW + s * 16) = v;
+    for (int base = tid; base < ypix * YV; base += 256 * U) {
+      u32x4 v[U];
+      int dst[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * 256;
+        v[u] = u32x4{0u, 0u, 0u, 0u};
+        dst[u] = -1;
+        if (i < ypix * YV) {
+          const int prow = i / YV, s = i - prow * YV;
+          const int yy = ty0 + (prow >> p.tw_log2), xx = tx0 + (prow & (tw - 1));
+          dst[u] = prow * YROW + s * 16;
+          if (yy < p.YH && xx < p.YW)
+            v[u] = *reinterpret_cast<const u32x4*>(yn + ((size_t)yy * p.YW + xx) * ypix_bytes + s * 16);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<u32x4*>(lds_y + dst[u]) = v[u];
     }
     __syncthreads();
 
@@ -161,21 +187,48 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     }
 }
 
-__global__ void wgrad_finalize_kernel(const float* __restrict__ slab, int nsplit, int ntaps, int ca_p, int cb_p, int ca,
-                                      int cb, float* __restrict__ grad, long long s_a, long long s_b,
-                                      const int* __restrict__ slot_off, int accumulate) {
+// 256 threads = 32 consecutive output elements x 8 split lanes: every lane sums its share of the slabs with 4 independent
+// loads in flight, then the 8 partial sums are combined through LDS.  (A thread-per-element loop over up to 256 slabs
+// was a 28 us latency chain per layer.)
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ slab, int nsplit, int ntaps,
+                                                            int ca_p, int cb_p, int ca, int cb, float* __restrict__ grad,
+                                                            long long s_a, long long s_b,
+                                                            const int* __restrict__ slot_off, int accumulate) {
+  __shared__ float sh[8][33];
   const long long total = (long long)ntaps * ca * cb;
   const size_t slab_sz = (size_t)ntaps * ca_p * cb_p;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int b = (int)(i % cb);
-    const long long r = i / cb;
-    const int a = (int)(r % ca);
-    const int t = (int)(r / ca);
-    const size_t off = ((size_t)t * ca_p + a) * cb_p + b;
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  for (long long e0 = (long long)blockIdx.x * 32; e0 < total; e0 += (long long)gridDim.x * 32) {
+    const long long i = e0 + el;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slab[k * slab_sz + off];
-    float* dst = grad + a * s_a + b * s_b + slot_off[t];
-    *dst = accumulate ? *dst + s : s;
+    int a = 0, b = 0, t = 0;
+    if (i < total) {
+      b = (int)(i % cb);
+      const long long r = i / cb;
+      a = (int)(r % ca);
+      t = (int)(r / ca);
+      const float* src = slab + ((size_t)t * ca_p + a) * cb_p + b;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int k = sl;
+      for (; k + 24 < nsplit; k += 32) {
+        s0 += src[(size_t)k * slab_sz];
+        s1 += src[(size_t)(k + 8) * slab_sz];
+        s2 += src[(size_t)(k + 16) * slab_sz];
+        s3 += src[(size_t)(k + 24) * slab_sz];
+      }
+      for (; k < nsplit; k += 8) s0 += src[(size_t)k * slab_sz];
+      s = (s0 + s1) + (s2 + s3);
+    }
+    sh[sl][el] = s;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) tsum += sh[q][el];
+      float* dst = grad + a * s_a + b * s_b + slot_off[t];
+      *dst = accumulate ? *dst + tsum : tsum;
+    }
+    __syncthreads();
   }
 }
 
@@ -289,7 +342,7 @@ extern "C" int tg_wgrad_finalize(const float* slab, int nsplit, int ntaps, int c
   if (!slab || !grad || !slot_off_dev || nsplit <= 0 || ntaps <= 0 || ca <= 0 || cb <= 0 || ca > ca_p || cb > cb_p)
     return TG_E_BADARG;
   const long long total = (long long)ntaps * ca * cb;
-  const int blocks = (int)std::min<long long>((total + 255) / 256, 1024);
+  const int blocks = (int)std::min<long long>((total + 31) / 32, 4096);
   hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slab, nsplit, ntaps, ca_p,
                      cb_p, ca, cb, grad, (long long)s_a, (long long)s_b, slot_off_dev, accumulate);
   return tg_launch_status();

@@ -147,13 +147,32 @@ class Conv:
         key = ("w", N, XH, XW, YH, YW)
         ent = self._desc.get(key)
         if ent is None:
-            nsplit = K.wgrad_nsplit(N, YH, YW, S)
+            nsplit = K.wgrad_nsplit(N, YH, YW, S, K.wgrad_blocks(len(taps), cx, cy))
             ent = (K.make_wgrad_desc(self.tg, N, XH, XW, cx, YH, YW, cy, S, taps, nsplit), nsplit)
             self._desc[key] = ent
         d, nsplit = ent
         slab = self.ws.get_slab(nsplit * len(taps) * cx * cy)
         K.wgrad(d, X, Y, slab)
         K.wgrad_finalize(slab, nsplit, len(taps), cx, cy, ca, cb, self.gw, s_a, s_b, self.slots, True)
+
+
+class Repacker:
+    """fp32 master weights -> packed compute copies (forward + dgrad) of every conv of a network in one launch."""
+
+    def __init__(self, convs, dtype_t, device):
+        jobs = []
+        for c in convs:
+            for packed, (rows, Kd, s_row, s_k) in ((c.wf, c.spec.fwd_pack()), (c.wb, c.spec.dgrad_pack())):
+                if packed is None:
+                    continue
+                jobs.append([c.w.data_ptr(), packed.data_ptr(), s_row, s_k, rows, Kd, pad32(rows), pad32(Kd),
+                             c.spec.nslots])
+        self.jobs = torch.tensor(jobs, dtype=torch.int64, device=device)
+        self.n, self.tg = len(jobs), K.tg_dtype(dtype_t)
+
+    def run(self):
+        L.check(L.load().tg_pack_conv_weights_multi(self.tg, self.jobs.data_ptr(), self.n, 16,
+                                                    torch.cuda.current_stream().cuda_stream), "tg_pack_conv_weights_multi")
 
 
 class BatchNorm:
@@ -238,10 +257,10 @@ class GeneratorEngine:
                                                                             self.c32, self.ct4, self.c6, self.cout]
         self.act = None
         self.shape = None
+        self.repacker = Repacker(self.convs, dtype_t, flat.device)
 
     def repack(self):
-        for c in self.convs:
-            c.repack()
+        self.repacker.run()
 
     def alloc(self, NS, h, w):
         """activation storage for NS samples (NS = T*B when training, B for inference)."""
@@ -381,10 +400,10 @@ class DiscriminatorEngine:
         self.convs = [self.conv0] + [self.blk[k][0] for k in range(1, 6)] + [c for st in (1, 2, 3) for (c1, c2, _) in
                                                                              self.res[st] for c in (c1, c2)]
         self.shape = None
+        self.repacker = Repacker(self.convs, dtype_t, flat.device)
 
     def repack(self):
-        for c in self.convs:
-            c.repack()
+        self.repacker.run()
 
     def alloc(self, N, H):
         if self.shape == (N, H):

@@ -181,11 +181,24 @@ def wgrad_finalize(slab, nsplit, ntaps, ca_p, cb_p, ca, cb, grad, s_a, s_b, slot
                                        _ptr(slots), int(accumulate), _stream()), "tg_wgrad_finalize")
 
 
-def wgrad_nsplit(N, YH, YW, S):
-    """Number of pixel splits: enough workgroups to fill the chip without drowning the layer in slab traffic."""
+def wgrad_nsplit(N, YH, YW, S, blocks=1):
+    """Number of pixel splits.  The kernel runs one workgroup per CU (its accumulators take most of the register file), so
+    the best split count is the one that gives every CU exactly one workgroup: 256 / (channel blocks) - measured per layer
+    with tools/microbench.py.  Never more splits than pixel tiles."""
     tw, th = (16, 4) if S == 2 else ((32, 4) if YW > 16 else (16, 8))
     tiles = N * ((YW + tw - 1) // tw) * ((YH + th - 1) // th)
-    return max(1, min(256, tiles // 4, tiles))
+    return max(1, min(tiles, 256 // max(1, blocks)))
+
+
+def wgrad_blocks(ntaps, cx_p, cy_p):
+    """(X-channel blocks) * (Y-channel blocks) of the wgrad launch, mirroring pick_cfg() in wgrad_mfma.hip."""
+    if ntaps == 16:
+        return (cx_p // 64) * (cy_p // 32)
+    if cx_p % 64:
+        return (cx_p // 32) * (cy_p // 64)
+    if cy_p % 64:
+        return (cx_p // 64) * (cy_p // 32)
+    return (cx_p // 64) * (cy_p // 64)
 
 
 # ---------------------------------------------------------------------------------------------------------
