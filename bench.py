@@ -113,12 +113,14 @@ def roofline_pass(st, dtype):
     E.Conv.fwd = timed(lab_fwd, fl_fwd, orig_fwd)
     E.Conv.dgrad = timed(lab_dgrad, fl_dgrad, orig_dgrad)
     E.Conv.wgrad = timed(lambda self, *a: f"wgrad<{dtype},{self.spec.nslots}taps>(+finalize)", fl_wgrad, orig_wgrad)
+    side = (st.sB, st.sC)
+    st.sB = st.sC = torch.cuda.current_stream()  # serialise the fork/join schedule: isolated per-launch durations
     try:
-        st._forward_and_g_backward()
-        st._d_backward()
+        st._forward_backward(True)
         torch.cuda.synchronize()
     finally:
         E.Conv.fwd, E.Conv.dgrad, E.Conv.wgrad = orig_fwd, orig_dgrad, orig_wgrad
+        st.sB, st.sC = side
     fam = {}
     for label, fl, e0, e1 in recs:
         d = fam.setdefault(label, dict(launches=0, flops=0.0, ms=0.0))

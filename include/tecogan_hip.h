@@ -143,9 +143,10 @@ int tg_warp_nchw(const float* img, const int64_t* img_off_dev, const float* grid
  * rest 0.  prev==null gives the first-frame input (zeros).  (code/train.py:86-88,95-107; main.py:191-213) */
 int tg_gen_input(int dtype, const float* lr, int64_t lr_n_stride, const float* prev, int64_t prev_n_stride,
                  const float* grid, int64_t grid_n_stride, void* dst, int B, int h, int w, void* stream);
-/* Discriminator input [2*tb][H][H][32]: real rows then fake rows (code/train.py:160-198). */
+/* Discriminator input [2*tb][H][H][32]: real rows then fake rows (code/train.py:160-198).  half<0: both halves into
+ * dst; half=0/1: only the real/fake half, dst pointing at that half's first row. */
 int tg_d_assemble(int dtype, const float* x, const float* y, const float* gen, const float* tvel, void* dst, int B,
-                  int T, int K, int h, int border, void* stream);
+                  int T, int K, int h, int border, int half, void* stream);
 /* dst[dst_off[i] + e] = src_off[i] < 0 ? 0 : src[src_off[i] + e], e < len: assembles T_vel (code/train.py:147-158)
  * from the pseudo-flow blocks, zero blocks and (with tg_up4_planes) the "back" flow planes. */
 int tg_copy_blocks(const float* src, const int64_t* src_off_dev, float* dst, const int64_t* dst_off_dev, int nblocks,
@@ -177,9 +178,9 @@ int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const float* b, co
                     int nblocks, int64_t len, void* stream);
 /* content loss partial sum and d(pre-sigmoid) for the generator output (code/train.py:239-241):
  * acc[0] += sum (gen-y)^2 ; dpre[nhwc] = gscale * 2*(gen-y) * gen*(1-gen) ; acc[8+c] += sum dpre[c] (output bias grad).  gen/y are NCHW fp32 (B,T,3,H,W);
- * dpre is NHWC [T*B][H][W][32] in (t,b) order. */
+ * dpre is NHWC [(t1-t0)*B][H][W][32] in (t,b) order and covers frames t0 <= t < t1 only. */
 int tg_content_loss(int dtype, const float* gen, const float* y, void* dpre, float* acc, int B, int T, int H, int W,
-                    float gscale, void* stream);
+                    float gscale, int t0, int t1, void* stream);
 /* All step scalars on device + d(logit) for the discriminator loss (code/train.py:287-333). */
 int tg_loss_finalize(const float* prob, const float* acc, float* scalars, float* dlogit, int tb, const float* cfg,
                      void* stream);

@@ -76,7 +76,9 @@ def sample_idx(n, k=256):
 
 
 def t2n(t):
-    return t.detach().cpu().float().numpy()
+    # clone: for a CPU fp32 tensor .cpu().float() is the identity and .numpy() would alias the LIVE parameter / buffer,
+    # which later steps keep updating in place
+    return t.detach().cpu().float().clone().numpy()
 
 
 class GradTap:

@@ -241,17 +241,17 @@ __global__ __launch_bounds__(256) void absdiff_sum_kernel(const char* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void content_loss_kernel(const float* __restrict__ gen, const float* __restrict__ y,
                                                           char* __restrict__ dpre, float* __restrict__ acc, int B,
-                                                          int T_, int H, int W, float gscale) {
+                                                          int T_, int H, int W, float gscale, int t0, int t1) {
   using TR = ElemTraits<T>;
   __shared__ float sh[4];
   const long long HW = (long long)H * W;
-  const long long total = (long long)B * T_ * HW;
+  const long long total = (long long)B * (t1 - t0) * HW;  // frames [t0,t1); dpre holds only those, frame-major
   float s = 0.f, cs[3] = {0.f, 0.f, 0.f};
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += 256LL * gridDim.x) {
     const long long pos = i % HW;
     const long long r = i / HW;
     const int b = (int)(r % B);
-    const int t = (int)(r / B);  // destination order is (t, b): the batched backward sees frame-major samples
+    const int t = t0 + (int)(r / B);  // destination order is (t, b): the batched backward sees frame-major samples
     const long long src = ((long long)b * T_ + t) * 3 * HW + pos;
     float v[32];
 #pragma unroll
@@ -454,11 +454,11 @@ extern "C" int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const f
 }
 
 extern "C" int tg_content_loss(int dtype, const float* gen, const float* y, void* dpre, float* acc, int B, int T,
-                               int H, int W, float gscale, void* stream) {
-  if (!gen || !y || !acc || B <= 0 || T <= 0 || H <= 0 || W <= 0) return TG_E_BADARG;
-  const long long total = (long long)B * T * H * W;
-  TG_DISPATCH(dtype, content_loss_kernel, dim3(grid_for(total, 512, 1024)), dim3(256), (hipStream_t)stream, gen, y,
-              (char*)dpre, acc, B, T, H, W, gscale);
+                               int H, int W, float gscale, int t0, int t1, void* stream) {
+  if (!gen || !y || !acc || B <= 0 || T <= 0 || H <= 0 || W <= 0 || t0 < 0 || t1 > T || t0 >= t1) return TG_E_BADARG;
+  const long long total = (long long)B * (t1 - t0) * H * W;
+  TG_DISPATCH(dtype, content_loss_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), (hipStream_t)stream, gen, y,
+              (char*)dpre, acc, B, T, H, W, gscale, t0, t1);
   return tg_launch_status();
 }
 

@@ -179,19 +179,19 @@ __global__ void gen_input_kernel(const float* __restrict__ lr, long long lr_n_st
 template <typename T>
 __global__ void d_assemble_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                   const float* __restrict__ gen, const float* __restrict__ tvel, char* __restrict__ dst,
-                                  int B, int T_, int K, int h, int border) {
+                                  int B, int T_, int K, int h, int border, int half) {
   using TR = ElemTraits<T>;
   const int H = 4 * h;
   const int tb = B * K;
   const long long HH = (long long)H * H;
-  const long long total = 2LL * tb * HH;
+  const long long total = (half < 0 ? 2LL : 1LL) * tb * HH;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int X = (int)(i % H);
     long long r = i / H;
     const int Y = (int)(r % H);
     r /= H;
     const int m = (int)(r % tb);
-    const int fake = (int)(r / tb);
+    const int fake = half < 0 ? (int)(r / tb) : half;  // half>=0: only that half is produced (dst points at its rows)
     const int b = m / K, j = m % K;
     const long long pos = (long long)Y * H + X;
     const bool inside = Y >= border && Y < H - border && X >= border && X < H - border;
@@ -318,16 +318,17 @@ extern "C" int tg_gen_input(int dtype, const float* lr, int64_t lr_n_stride, con
 }
 
 extern "C" int tg_d_assemble(int dtype, const float* x, const float* y, const float* gen, const float* tvel, void* dst,
-                             int B, int T, int K, int h, int border, void* stream) {
-  if (!x || !y || !gen || !tvel || !dst || B <= 0 || T < 3 * K || K <= 0 || h <= 0 || border < 0) return TG_E_BADARG;
+                             int B, int T, int K, int h, int border, int half, void* stream) {
+  if (!x || !y || !gen || !tvel || !dst || B <= 0 || T < 3 * K || K <= 0 || h <= 0 || border < 0 || half > 1)
+    return TG_E_BADARG;
   if (!tg_aligned16(dst)) return TG_E_ALIGN;
-  const long long total = 2LL * B * K * 16 * h * h;
+  const long long total = (half < 0 ? 2LL : 1LL) * B * K * 16 * h * h;
   if (dtype == TG_BF16)
     hipLaunchKernelGGL(d_assemble_kernel<BF16>, dim3(grid_for(total, 128)), dim3(128), 0, (hipStream_t)stream, x, y,
-                       gen, tvel, (char*)dst, B, T, K, h, border);
+                       gen, tvel, (char*)dst, B, T, K, h, border, half);
   else if (dtype == TG_F32)
     hipLaunchKernelGGL(d_assemble_kernel<F32>, dim3(grid_for(total, 128)), dim3(128), 0, (hipStream_t)stream, x, y,
-                       gen, tvel, (char*)dst, B, T, K, h, border);
+                       gen, tvel, (char*)dst, B, T, K, h, border, half);
   else
     return TG_E_BADARG;
   return tg_launch_status();

@@ -186,12 +186,16 @@ class BatchNorm:
         self.red = arena.take(2 * 2 * self.Cp).view(2, 2, self.Cp)
         self.save = torch.empty(2, 2, self.Cp, device=flat.device)
 
-    def apply(self, z, y, act, groups, skip=None, update=True):
+    def apply(self, z, y, act, groups, skip=None, update=True, half=None):
+        """half=None: z holds `groups` equal sample groups.  half=g: z holds only group g of 2 (the reference's g-th D
+        call of the step); statistics slot g is used and the running statistics get ONE update."""
         N, H, W, C_ = z.shape
-        K.bn_apply(z, self.stats, self.gamma, self.beta, y, self.save, N, H * W, C_, groups, act, skip=skip,
+        stats, save = (self.stats, self.save) if half is None else (self.stats[half], self.save[half])
+        g = groups if half is None else 1
+        K.bn_apply(z, stats, self.gamma, self.beta, y, save, N, H * W, C_, g, act, skip=skip,
                    running_mean=self.rm if update else None, running_var=self.rv if update else None)
         if update:
-            self.nbt += groups
+            self.nbt += g
 
     def backward(self, dy, yact, z, dz, act, groups):
         N, H, W, C_ = z.shape
@@ -292,17 +296,27 @@ class GeneratorEngine:
         self.c6.fwd(a["u3"][sl], a["u4"][sl], act=L.ACT_RELU)
         self.cout.fwd(a["u4"][sl], None, act=L.ACT_SIGMOID, nchw=(out_buf, out_off, out_n_stride, self.out_ch))
 
-    def _alloc_grad(self):
+    def _alloc_grad(self, chunk=None):
+        """gradient scratch for a backward chunk of `chunk` samples (default: all)."""
         NS, h, w = self.shape
+        NC = chunk or NS
         dev, dt = self.flat.device, self.dt
-        e = lambda hh, ww, c: torch.empty(NS, hh, ww, c, dtype=dt, device=dev)
+        e = lambda hh, ww, c: torch.empty(NC, hh, ww, c, dtype=dt, device=dev)
         self.grad = {"dpre": e(4 * h, 4 * w, 32), "hr64": e(4 * h, 4 * w, 64), "hr128": e(4 * h, 4 * w, 128),
                      "m128a": e(2 * h, 2 * w, 128), "m128b": e(2 * h, 2 * w, 128), "m64a": e(2 * h, 2 * w, 64),
                      "m64b": e(2 * h, 2 * w, 64), "l64a": e(h, w, 64), "l64b": e(h, w, 64), "l64c": e(h, w, 64)}
 
-    def backward(self):
-        """consumes grad['dpre'] (d loss / d pre-sigmoid, all NS samples) and accumulates every weight/bias gradient."""
-        a, g = self.act, self.grad
+    def backward(self, s0=0, s1=None, dpre=None):
+        """consumes grad['dpre'][:s1-s0] (d loss / d pre-sigmoid of samples [s0,s1)) and ACCUMULATES every weight/bias
+        gradient.  The T passes are independent in backward (inputs are detached, code/train.py:90,108), so any
+        sample range may be processed as one batch; ranges must not run concurrently (they add into the same grads)."""
+        NS = self.shape[0]
+        s1 = NS if s1 is None else s1
+        n = s1 - s0
+        a = {k: ([t[s0:s1] for t in v] if isinstance(v, list) else v[s0:s1]) for k, v in self.act.items()}
+        g = {k: v[:n] for k, v in self.grad.items()}
+        if dpre is not None:
+            g["dpre"] = dpre
         RELU = L.MASK_RELU
         self.cout.wgrad(a["u4"], g["dpre"])                                   # output bias grad: see TecoGANStep
         self.cout.dgrad(g["dpre"], g["hr64"], mask=a["u4"], mask_mode=RELU, bias_grad_of=self.c6)
@@ -440,24 +454,34 @@ class DiscriminatorEngine:
     def layers(self):
         return [self.stage_out(1), self.stage_out(2), self.stage_out(3), self.act["n"][4]]
 
-    def forward(self, groups=2, update_stats=True):
+    def forward(self, groups=2, update_stats=True, half=None):
+        """half=None: the whole batch (`groups` BN groups).  half=0/1: only the real / fake half of a 2-group batch (lets
+        the real half run while the generator is still producing the frames the fake half needs)."""
         a = self.act
-        self.conv0.fwd(a["in"], a["c0"], act=L.ACT_LRELU)
-        prev = a["c0"]
+        N = a["in"].shape[0]
+        if half is None:
+            sl, st_of = slice(0, N), (lambda bn: bn.stats)
+        else:
+            hb = N // 2
+            sl, st_of = slice(half * hb, (half + 1) * hb), (lambda bn: bn.stats[half])
+            groups = 1
+        v = lambda t: t[sl]
+        self.conv0.fwd(v(a["in"]), v(a["c0"]), act=L.ACT_LRELU)
+        prev = v(a["c0"])
         for k in range(1, 6):
             conv, bn = self.blk[k]
-            conv.fwd(prev, a["z"][k], stats=bn.stats, groups=groups)
-            bn.apply(a["z"][k], a["n"][k], L.ACT_LRELU, groups, update=update_stats)
-            net = a["n"][k]
+            conv.fwd(prev, v(a["z"][k]), stats=st_of(bn), groups=groups)
+            bn.apply(v(a["z"][k]), v(a["n"][k]), L.ACT_LRELU, groups, update=update_stats, half=half)
+            net = v(a["n"][k])
             if k <= 3:
                 for j, (c1, c2, bnj) in enumerate(self.res[k]):
-                    c1.fwd(net, a["h"][k][j], act=L.ACT_RELU)
-                    c2.fwd(a["h"][k][j], a["r"][k][j], stats=bnj.stats, groups=groups)
-                    bnj.apply(a["r"][k][j], a["net"][k][j], L.ACT_NONE, groups, skip=net, update=update_stats)
-                    net = a["net"][k][j]
+                    c1.fwd(net, v(a["h"][k][j]), act=L.ACT_RELU)
+                    c2.fwd(v(a["h"][k][j]), v(a["r"][k][j]), stats=st_of(bnj), groups=groups)
+                    bnj.apply(v(a["r"][k][j]), v(a["net"][k][j]), L.ACT_NONE, groups, skip=net, update=update_stats,
+                              half=half)
+                    net = v(a["net"][k][j])
             prev = net
-        N = a["in"].shape[0]
-        K.fc_head_fwd(a["n"][5], self.fc_w, self.fc_b, self.prob, N, self.fc_hw, 3, 32)
+        K.fc_head_fwd(v(a["n"][5]), self.fc_w, self.fc_b, self.prob[sl], sl.stop - sl.start, self.fc_hw, 3, 32)
 
     def backward(self, groups=2):
         """consumes self.dlogit; accumulates all D gradients."""

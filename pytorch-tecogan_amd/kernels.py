@@ -260,9 +260,9 @@ def gen_input(lr, lr_off, lr_n_stride, prev, prev_off, prev_n_stride, grid, grid
                              _stream()), "tg_gen_input")
 
 
-def d_assemble(x, y, gen, tvel, dst, B, T, K, h, border):
+def d_assemble(x, y, gen, tvel, dst, B, T, K, h, border, half=-1):
     L.check(L.load().tg_d_assemble(tg_dtype(dst.dtype), _ptr(x), _ptr(y), _ptr(gen), _ptr(tvel), _ptr(dst), B, T, K, h,
-                                   border, _stream()), "tg_d_assemble")
+                                   border, half, _stream()), "tg_d_assemble")
 
 
 def bn_apply(z, stats, gamma, beta, y, save, N, HW, C_, groups, act, skip=None, running_mean=None, running_var=None,
@@ -298,10 +298,10 @@ def absdiff_sum(a, b, acc, acc_idx, npix, C_, Cp):
                                     _stream()), "tg_absdiff_sum")
 
 
-def content_loss(gen, y, dpre, acc, B, T, H, W, gscale):
+def content_loss(gen, y, dpre, acc, B, T, H, W, gscale, t0=0, t1=None):
     dt = tg_dtype(dpre.dtype) if dpre is not None else L.TG_F32
-    L.check(L.load().tg_content_loss(dt, _ptr(gen), _ptr(y), _ptr(dpre), _ptr(acc), B, T, H, W, gscale, _stream()),
-            "tg_content_loss")
+    L.check(L.load().tg_content_loss(dt, _ptr(gen), _ptr(y), _ptr(dpre), _ptr(acc), B, T, H, W, gscale, t0,
+                                     T if t1 is None else t1, _stream()), "tg_content_loss")
 
 
 def loss_finalize(prob, acc, scalars, dlogit, tb, cfg):

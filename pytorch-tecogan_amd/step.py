@@ -9,6 +9,8 @@ buffers - which is what makes it hipGraph-capturable - plus the generator-only r
   * BN running statistics updated twice per step (real pass, then fake pass).
 Data parallel: sequences are sharded over ranks; the flat G and D gradient buffers are all-reduced over RCCL, the G
 all-reduce overlapping the D backward pass."""
+import os
+
 import torch
 
 from . import _lib as L
@@ -61,7 +63,17 @@ class TecoGANStep:
         self.ring = torch.zeros(256, 32, dtype=torch.float32).pin_memory()
         self.ring_i = 0
         G.alloc(T * B, h, h)
-        G._alloc_grad()
+        # Frame-chunked G backward overlapping the rest of the chain was measured SLOWER (13.8 / 14.8 / 16.8 ms per step at
+        # 1 / 2 / 5 chunks): the dense backward launches hold every CU's LDS, so the chain's latency-critical launches
+        # queue behind them.  Default: one chunk, after the chain.
+        nchunk = max(1, min(T, int(os.environ.get("TECOGAN_GBWD_CHUNKS", "1"))))
+        bounds = [round(i * T / nchunk) for i in range(nchunk + 1)]
+        self.chunks = [(bounds[i], bounds[i + 1]) for i in range(nchunk)]
+        cmax = max(t1 - t0 for t0, t1 in self.chunks) * B
+        G._alloc_grad(cmax)
+        # one d(pre-sigmoid) buffer per chunk: chunk i+1's loss kernel must not overwrite what chunk i's backward reads
+        self.dpre = [torch.empty((t1 - t0) * B, H, H, 32, dtype=G.dt, device=device) for t0, t1 in self.chunks]
+        self.sB, self.sC = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
         D.alloc(2 * self.tb, H)
         self._tables()
         self.graphs = None
@@ -133,9 +145,17 @@ class TecoGANStep:
         self.params_dev.copy_(slot, non_blocking=True)
 
     # ----------------------------------------------------------------------------------------------------------
-    def _forward_and_g_backward(self):
+    def _forward_backward(self, include_d_backward):
+        """Everything up to (and including) the backward passes, as a fork/join over three streams so that the serial
+        generator chain (<= 64 workgroups per launch at B=4) shares the chip with independent dense work:
+            main : pseudo-flow, T_vel | G pass 0 .. T-1 (each: warp+pack, 41 convs) | content loss per frame chunk
+            sB   : D input (real) -> D forward (real half)  ...............| D input (fake) -> D forward (fake half)
+                   -> layer losses -> loss scalars, d(logit) -> [D backward when single-GPU]
+            sC   : G backward of frame chunk 0 (while the chain is still producing chunk 1), then chunk 1, ...
+        Captured in a hipGraph the fork/join become graph edges."""
         G, D, B, T, h, H = self.G, self.D, self.B, self.T, self.h, self.H
         hh, HH = h * h, H * H
+        main, sB, sC = torch.cuda.current_stream(), self.sB, self.sC
         self.acc.zero_()
         D.arena.zero()
         G.flat.g.zero_()
@@ -143,6 +163,15 @@ class TecoGANStep:
         K.up4_planes(self.x, self.flow_src, self.flow, self.flow_dst, self.n_flow, h, h, pre=4.0)
         K.warp_nchw(self.x, self.lrw_img, self.x, self.lrw_grid, B * (T - 1), 3, h, h, h, h, False, sq_ref=self.x,
                     sq_off=self.lrw_grid, loss_acc=self.acc[1:2])
+        K.copy_blocks(self.flow, self.tv_csrc, self.tvel, self.tv_cdst, self.n_tvc, 2 * HH)
+        K.up4_planes(self.x, self.tv_bsrc, self.tvel, self.tv_bdst, self.n_tvb, h, h, pre=4.0, post_a=2.0, post_b=-1.0)
+        tb = self.tb
+        sB.wait_stream(main)
+        with torch.cuda.stream(sB):
+            K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"][:tb], B, T, self.K, h, self.border, half=0)
+            K.nhwc_to_nchw(D.act["in"][:tb], self.target, 27 * HH, tb, 27, H, H)
+            D.forward(update_stats=True, half=0)
+        ci = 0
         for t in range(T):
             dst = G.act["in0"][t * B:(t + 1) * B]
             if t == 0:
@@ -151,19 +180,27 @@ class TecoGANStep:
                 K.gen_input(self.x, t * 3 * hh, T * 3 * hh, self.gen, (t - 1) * 3 * HH, T * 3 * HH, self.flow,
                             (t - 1) * 2 * HH, (T - 1) * 2 * HH, dst, B, h, h)
             G.forward(t * B, B, self.gen, t * 3 * HH, T * 3 * HH)
-        K.copy_blocks(self.flow, self.tv_csrc, self.tvel, self.tv_cdst, self.n_tvc, 2 * HH)
-        K.up4_planes(self.x, self.tv_bsrc, self.tvel, self.tv_bdst, self.n_tvb, h, h, pre=4.0, post_a=2.0, post_b=-1.0)
-        K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"], B, T, self.K, h, self.border)
-        D.forward(groups=2, update_stats=True)
-        if self.args.D_LAYERLOSS:
-            for i, l in enumerate(D.layers()):
-                n = self.tb * l.shape[1] * l.shape[2]
-                K.absdiff_sum(l[:self.tb], l[self.tb:], self.acc, 2 + i, n, l.shape[3], l.shape[3])
-        K.content_loss(self.gen, self.y, G.grad["dpre"], self.acc, B, T, H, H, 1.0 / (B * T * 3 * H))
-        K.loss_finalize(D.prob, self.acc, self.scalars, D.dlogit, self.tb, self.cfg)
+            if t + 1 == self.chunks[ci][1]:
+                t0, t1 = self.chunks[ci]
+                K.content_loss(self.gen, self.y, self.dpre[ci], self.acc, B, T, H, H, 1.0 / (B * T * 3 * H), t0, t1)
+                sC.wait_stream(main)
+                with torch.cuda.stream(sC):
+                    G.backward(t0 * B, t1 * B, dpre=self.dpre[ci])
+                ci += 1
+        sB.wait_stream(main)  # all frames generated, content-loss sum complete
+        with torch.cuda.stream(sB):
+            K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"][tb:], B, T, self.K, h, self.border, half=1)
+            D.forward(update_stats=True, half=1)
+            if self.args.D_LAYERLOSS:
+                for i, l in enumerate(D.layers()):
+                    n = tb * l.shape[1] * l.shape[2]
+                    K.absdiff_sum(l[:tb], l[tb:], self.acc, 2 + i, n, l.shape[3], l.shape[3])
+            K.loss_finalize(D.prob, self.acc, self.scalars, D.dlogit, tb, self.cfg)
+            if include_d_backward:
+                D.backward(groups=2)
+        main.wait_stream(sB)
+        main.wait_stream(sC)
         G.cout.gbias[:3] += self.acc[8:11]
-        K.nhwc_to_nchw(D.act["in"], self.target, 27 * HH, self.tb, 27, H, H)
-        G.backward()
 
     def _d_backward(self):
         self.D.backward(groups=2)
@@ -175,45 +212,43 @@ class TecoGANStep:
         G.repack()
         D.repack()
 
-    def _run_eager(self):
-        self._forward_and_g_backward()
-        work = self._allreduce(self.G.flat.g)
-        self._d_backward()
-        work2 = self._allreduce(self.D.flat.g)
-        for w in (work, work2):
-            if w is not None:
-                w.wait()
-        self._update()
-
     def _allreduce(self, buf):
         if self.pg is None or self.world == 1:
             return None
         import torch.distributed as dist
         return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
-    def _capture(self):
-        """three hipGraphs (forward + G backward | D backward | Adam + repack) so that the RCCL all-reduces sit between
-        them; single process replays them back to back."""
-        pool = torch.cuda.graph_pool_handle()
-        self.G.ws.frozen = self.D.ws.frozen = True
-        gs = []
-        for fn in (self._forward_and_g_backward, self._d_backward, self._update):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
-                fn()
-            gs.append(g)
-        self.graphs = gs
+    def _segments(self):
+        """single GPU: [forward + both backward passes | update].  Data parallel: the D backward is its own segment so
+        that the RCCL all-reduce of the G gradients (launched between segments) overlaps it."""
+        if self.world == 1:
+            return [lambda: self._forward_backward(True), None, self._update]
+        return [lambda: self._forward_backward(False), self._d_backward, self._update]
 
-    def _run_graphs(self):
-        g1, g2, g3 = self.graphs
-        g1.replay()
+    def _run(self, segs):
+        segs[0]()
         w1 = self._allreduce(self.G.flat.g)
-        g2.replay()
+        if segs[1] is not None:
+            segs[1]()
         w2 = self._allreduce(self.D.flat.g)
         for w in (w1, w2):
             if w is not None:
                 w.wait()
-        g3.replay()
+        segs[2]()
+
+    def _capture(self):
+        pool = torch.cuda.graph_pool_handle()
+        self.G.ws.frozen = self.D.ws.frozen = True
+        graphs = []
+        for fn in self._segments():
+            if fn is None:
+                graphs.append(None)
+                continue
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                fn()
+            graphs.append(g.replay)
+        self.graphs = graphs
 
     # ----------------------------------------------------------------------------------------------------------
     def run(self, x, y, global_step, lr_g, lr_d, betas_g=(0.9, 0.999), betas_d=(0.9, 0.999), eps_g=1e-8, eps_d=1e-8):
@@ -226,14 +261,14 @@ class TecoGANStep:
         self._host_params(global_step + 1, lr_g, lr_d, betas_g, betas_d, eps_g, eps_d)
         if self.use_graph:
             if self.graphs is None:
-                self._run_eager()          # warm-up: one-time attribute setup, workspace growth
+                self._run(self._segments())   # warm-up: one-time attribute setup, workspace growth
                 self.adam_t = [self.adam_t[0] + 1, self.adam_t[1] + 1]
                 torch.cuda.synchronize()
                 self._capture()
                 return
-            self._run_graphs()
+            self._run(self.graphs)
         else:
-            self._run_eager()
+            self._run(self._segments())
         self.adam_t = [self.adam_t[0] + 1, self.adam_t[1] + 1]
 
 

@@ -126,7 +126,10 @@ def test_step_b1_three_steps(golden_dir):
     np.testing.assert_allclose(dg["fc.weight"].numpy(), gold["d_grad_fc_weight"], rtol=1e-4, atol=1e-8)
     np.testing.assert_allclose(dg["block5.0.weight"].numpy(), gold["d_grad_block5_weight"], rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(dg["block1.1.weight"].numpy(), gold["d_grad_block1_bn_weight"], rtol=1e-3, atol=1e-7)
-    # Adam + BN double update after 3 steps
+    # Adam + BN double update: after the first step ...
+    assert int(gold["s0_block1.1.nbt"]) == 2 and int(gold["s1_block1.1.nbt"]) == 4
+    assert np.abs(gold["s0_post_output_weight"] - gold["s2_post_output_weight"]).max() > 1e-5  # fixtures are snapshots
+    # ... and after 3 steps
     np.testing.assert_allclose(gp["output.weight"].numpy(), gold["s2_post_output_weight"], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(dp["fc.weight"].numpy(), gold["s2_post_fc_weight"], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(dp["block5.0.weight"].numpy(), gold["s2_post_block5_weight"], rtol=1e-5, atol=1e-6)
