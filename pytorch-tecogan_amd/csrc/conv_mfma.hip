@@ -16,15 +16,35 @@
 // code/models.py:54-58,68,72-76,90-94,102 (via code/ops.py:45-63) and the autograd of code/train.py:336,340.
 #include "common.h"
 
+#ifdef TG_STAMP
+// Diagnostic build only (build.sh -DTG_STAMP): workgroup 0 records s_memtime at phase boundaries into a buffer of its own
+// that nothing else reads; the production library contains no stamp.
+__device__ long long tg_stamps[64];
+#define TG_STAMP_AT(i)                                                                 \
+  do {                                                                                 \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {   \
+      tg_stamps[i] = (long long)__builtin_amdgcn_s_memtime();                         \
+    }                                                                                  \
+  } while (0)
+extern "C" int tg_debug_read_stamps(long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_stamps), sizeof(long long) * n);
+}
+#else
+#define TG_STAMP_AT(i) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int kRowBytes = 80;  // 64 data bytes + 16 pad: keeps ds_read_b128 fragment reads at most 2-way conflicted
 
+// All fields are 32-bit on purpose: the struct lives in the kernarg segment and is indexed by blockIdx.z / the tap index;
+// with 8/16-bit members hipcc lowers every such access to a VECTOR global_load_ubyte/ushort + v_readfirstlane (a ~600-cycle
+// dependent round trip per access), with dwords it emits s_load_dword.
 struct ConvClassK {
   int ooy, oox, ntaps, dymin, dxmin, ih, iw;
-  int8_t dy[TG_MAX_TAPS];
-  int8_t dx[TG_MAX_TAPS];
-  int16_t widx[TG_MAX_TAPS];
+  int dy[TG_MAX_TAPS];
+  int dx[TG_MAX_TAPS];
+  int widx[TG_MAX_TAPS];
 };
 
 struct ConvK {
@@ -40,6 +60,9 @@ struct ConvK {
   int act, mask_mode, stats_mode, stats_groups, out_mode, c_real;
   long long out_n_stride;
   int a_rows_max;
+  int tap_table_off;  // LDS byte offset of the per-class tap offset table (generic path)
+  int flip;           // STD3: taps mirrored (input-gradient launch)
+  int std3;           // host-side: launch the compile-time 3x3 variant
   ConvClassK cls[TG_MAX_CLASSES];
 };
 
@@ -67,7 +90,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-template <typename T, int CT, int PT, int WC, int WP>
+// STD3: the launch is a plain 3x3 stride-1 conv (forward, or dgrad = taps mirrored) whose packed slot order is the tap
+// order.  Tap offsets are then compile-time, the 9-tap loop is fully unrolled and the compiler can keep many LDS fragment
+// reads in flight; the generic path (tap table per class) pays a dependent table lookup per k-step and is kept for the
+// stride-2 / sub-pixel launches.
+template <typename T, int CT, int PT, int WC, int WP, bool STD3>
 __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
   using TR = ElemTraits<T>;
   using Frag = typename Mma<T>::Frag;
@@ -84,6 +111,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
 
   const ConvClassK& cl = p.cls[blockIdx.z];
   const int tid = threadIdx.x;
+  TG_STAMP_AT(0);
   const int lane = tid & 63, wid = tid >> 6;
   const int wc = wid % WC, wp = wid / WC;
   const int idx = lane & 15, g = lane >> 4;
@@ -103,6 +131,9 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
   const int iy0 = ty0 * p.S + cl.dymin, ix0 = tx0 * p.S + cl.dxmin;
   const int prow_n = cl.ih * cl.iw;
   const int ntaps = cl.ntaps;
+  int* tap_off = reinterpret_cast<int*>(smem + p.tap_table_off);
+  if (!STD3 && tid < ntaps)
+    tap_off[tid] = ((cl.dy[tid] - cl.dymin) * cl.iw + (cl.dx[tid] - cl.dxmin)) * kRowBytes;  // visible after the first barrier
 
   f32x4 acc[CT][PT];
 #pragma unroll
@@ -116,99 +147,138 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
   // K loop: stages of (chunk group x tap group).  Each stage issues ALL of its global loads before the first LDS store
   // (UA/UW loads in flight per thread): with one workgroup per CU on the small recurrent-pass layers nothing else hides
   // the L2/HBM latency, and a load->store->load chain costs one round trip per 16 bytes.
-  constexpr int UA = 4, UW = 8;
+  // UA activation pieces and UW (chunk,tap) weight blocks per thread are loaded in ONE issue phase before any LDS store.
+  constexpr int UA = 6;
+  constexpr int UW = (CT * PT <= 4) ? 18 : 8;  // small tiles: the whole K of a 64-channel 3x3 layer in flight at once
+  constexpr int PIECES = CO_TILE * 4, PPT = (PIECES + 255) / 256;
   const int a_stride = p.a_rows_max * kRowBytes;  // LDS bytes of one chunk's activation patch
-  const float inv_iw = 1.0f / (float)cl.iw;
+  const float inv_iw = 1.0f / (float)cl.iw, inv_prow = 1.0f / (float)prow_n;
   for (int c0 = 0; c0 < p.nchunks; c0 += p.cg) {
     const int cn = min(p.cg, p.nchunks - c0);
     for (int t0 = 0; t0 < ntaps; t0 += p.tg) {
       const int tn = min(p.tg, ntaps - t0);
       __syncthreads();  // previous fragment reads are done before LDS is overwritten
-      if (t0 == 0) {
-        // activation patch: (row, col) of a patch pixel via an exact float reciprocal (no integer division: there is no
-        // hardware int-div and at one wave per SIMD ~35 VALU per divide is microseconds over a stage)
-        const int total = prow_n * 4;
-        for (int cc = 0; cc < cn; ++cc) {
-          const char* src_c = in_n + (size_t)(c0 + cc) * 64;
-          char* dst_c = lds_a + cc * a_stride;
-          for (int base = tid; base < total; base += 256 * UA) {
-            u32x4 v[UA];
-            int dst[UA];
+      const int total_a = (t0 == 0) ? cn * prow_n * 4 : 0;
+      const int nq = cn * tn;
+      int a_done = 0, q_done = 0;
+      while (a_done < total_a || q_done < nq) {
+        u32x4 va[UA];
+        int da[UA];
+        u32x4 vw[UW][PPT];
+        // ---- issue phase.  Patch coordinates use exact float reciprocals (no hardware integer divide; ~35 VALU each
+        // would be microseconds at one wave per SIMD).
 #pragma unroll
-            for (int u = 0; u < UA; ++u) {
-              const int i = base + u * 256;
-              v[u] = u32x4{0u, 0u, 0u, 0u};
-              dst[u] = -1;
-              if (i < total) {
-                const int s = i & 3, prow = i >> 2;
-                const int py = (int)(((float)prow + 0.5f) * inv_iw), px = prow - py * cl.iw;
-                const int iy = iy0 + py, ix = ix0 + px;
-                dst[u] = prow * kRowBytes + s * 16;
-                if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
-                  v[u] = *reinterpret_cast<const u32x4*>(src_c + ((size_t)iy * p.IW + ix) * in_pix_bytes + s * 16);
-              }
-            }
-#pragma unroll
-            for (int u = 0; u < UA; ++u)
-              if (dst[u] >= 0) *reinterpret_cast<u32x4*>(dst_c + dst[u]) = v[u];
+        for (int u = 0; u < UA; ++u) {
+          const int i = a_done + tid + u * 256;
+          va[u] = u32x4{0u, 0u, 0u, 0u};
+          da[u] = -1;
+          if (i < total_a) {
+            const int s = i & 3, r = i >> 2;
+            const int cc = (int)(((float)r + 0.5f) * inv_prow), prow = r - cc * prow_n;
+            const int py = (int)(((float)prow + 0.5f) * inv_iw), px = prow - py * cl.iw;
+            const int iy = iy0 + py, ix = ix0 + px;
+            da[u] = cc * a_stride + prow * kRowBytes + s * 16;
+            if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
+              va[u] = *reinterpret_cast<const u32x4*>(in_n + ((size_t)iy * p.IW + ix) * in_pix_bytes +
+                                                      (size_t)(c0 + cc) * 64 + s * 16);
           }
         }
-      }
-      {
-        // weights: for one (chunk, tap) the CO_TILE packed rows are CONTIGUOUS in global memory, so the copy is a plain
-        // 16-byte-per-thread block copy; UW (chunk, tap) blocks are in flight before the first LDS store.
-        constexpr int PIECES = CO_TILE * 4, PPT = (PIECES + 255) / 256;
-        const int nq = cn * tn;
-        for (int q0 = 0; q0 < nq; q0 += UW) {
-          u32x4 v[UW][PPT];
+        // weights: for one (chunk, tap) the CO_TILE packed rows are contiguous in global memory: a plain block copy
 #pragma unroll
-          for (int u = 0; u < UW; ++u) {
-            const int qq = q0 + u;  // uniform
-            if (qq < nq) {
-              const int cc = qq / tn, tt = qq - cc * tn;  // scalar (wave-uniform) arithmetic
-              const int slot = cl.widx[t0 + tt];
-              const char* src = p.w + (((size_t)slot * p.nchunks + c0 + cc) * p.Cout + co_base) * 64;
-#pragma unroll
-              for (int k = 0; k < PPT; ++k) {
-                const int piece = tid + k * 256;
-                if (PIECES % 256 == 0 || piece < PIECES) v[u][k] = *reinterpret_cast<const u32x4*>(src + piece * 16);
-              }
+        for (int u = 0; u < UW; ++u) {
+          const int qq = q_done + u;  // wave-uniform
+          if (qq < nq) {
+            int cc, tt, slot;
+            if constexpr (STD3) {  // tn == 9, slot == tap: compile-time split of the block index, no table access
+              cc = (q_done + u) / 9;
+              tt = (q_done + u) - cc * 9;
+              slot = tt;
+            } else {
+              cc = qq / tn;
+              tt = qq - cc * tn;
+              slot = cl.widx[t0 + tt];
             }
-          }
+            const char* src = p.w + (((size_t)slot * p.nchunks + c0 + cc) * p.Cout + co_base) * 64;
 #pragma unroll
-          for (int u = 0; u < UW; ++u) {
-            const int qq = q0 + u;
-            if (qq < nq) {
-              const int cc = qq / tn, tt = qq - cc * tn;
-              char* dstw = lds_w + (cc * p.tg + tt) * CO_TILE * kRowBytes;
-#pragma unroll
-              for (int k = 0; k < PPT; ++k) {
-                const int piece = tid + k * 256;
-                if (PIECES % 256 == 0 || piece < PIECES)
-                  *reinterpret_cast<u32x4*>(dstw + (piece >> 2) * kRowBytes + (piece & 3) * 16) = v[u][k];
-              }
+            for (int k = 0; k < PPT; ++k) {
+              const int piece = tid + k * 256;
+              if (PIECES % 256 == 0 || piece < PIECES) vw[u][k] = *reinterpret_cast<const u32x4*>(src + piece * 16);
             }
           }
         }
+        // ---- store phase
+        TG_STAMP_AT(1);
+#pragma unroll
+        for (int u = 0; u < UA; ++u)
+          if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_a + da[u]) = va[u];
+        TG_STAMP_AT(2);
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+          const int qq = q_done + u;
+          if (qq < nq) {
+            const int cc = STD3 ? (q_done + u) / 9 : qq / tn;
+            const int tt = STD3 ? (q_done + u) - cc * 9 : qq - cc * tn;
+            char* dstw = lds_w + (cc * p.tg + tt) * CO_TILE * kRowBytes;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+              const int piece = tid + k * 256;
+              if (PIECES % 256 == 0 || piece < PIECES)
+                *reinterpret_cast<u32x4*>(dstw + (piece >> 2) * kRowBytes + (piece & 3) * 16) = vw[u][k];
+            }
+          }
+        }
+        a_done += 256 * UA;
+        q_done += UW;
+        TG_STAMP_AT(3);
       }
       __syncthreads();
+      TG_STAMP_AT(4);
 
-      for (int cc = 0; cc < cn; ++cc) {
-        const char* la = lds_a + cc * a_stride;
-        for (int tt = 0; tt < tn; ++tt) {
-          const int dy = cl.dy[t0 + tt] - cl.dymin, dx = cl.dx[t0 + tt] - cl.dxmin;
-          const char* lw = lds_w + (cc * p.tg + tt) * CO_TILE * kRowBytes;
-          Frag wf[CT];
+      if constexpr (STD3) {
+        // whole 3x3 in one tap group (host guarantees tg == 9): offsets are compile-time multiples of the patch pitch
+        const int pitch = cl.iw * kRowBytes;
+        int xbase[PT];
 #pragma unroll
-          for (int a = 0; a < CT; ++a)
-            wf[a] = *reinterpret_cast<const Frag*>(lw + ((wc * CT + a) * 16 + idx) * kRowBytes + g * 16);
+        for (int b = 0; b < PT; ++b) xbase[b] = (wp * PT + b) * pitch + idx * kRowBytes + g * 16;
+        const int wbase = (wc * CT * 16 + idx) * kRowBytes + g * 16;
+        for (int cc = 0; cc < cn; ++cc) {
+          const char* la = lds_a + cc * a_stride;
+          const char* lw = lds_w + cc * 9 * CO_TILE * kRowBytes + wbase;
 #pragma unroll
-          for (int b = 0; b < PT; ++b) {
-            const int ty = wp * PT + b;
-            const int prow = (ty * p.S + dy) * cl.iw + idx * p.S + dx;
-            const Frag xf = *reinterpret_cast<const Frag*>(la + prow * kRowBytes + g * 16);
+          for (int tt = 0; tt < 9; ++tt) {
+            const int r = p.flip ? 2 - tt / 3 : tt / 3, c = p.flip ? 2 - tt % 3 : tt % 3;
+            const int toff = r * pitch + c * kRowBytes;
+            Frag wf[CT];
 #pragma unroll
-            for (int a = 0; a < CT; ++a) acc[a][b] = Mma<T>::run(wf[a], xf, acc[a][b]);
+            for (int a = 0; a < CT; ++a)
+              wf[a] = *reinterpret_cast<const Frag*>(lw + (tt * CO_TILE + a * 16) * kRowBytes);
+#pragma unroll
+            for (int b = 0; b < PT; ++b) {
+              const Frag xf = *reinterpret_cast<const Frag*>(la + xbase[b] + toff);
+#pragma unroll
+              for (int a = 0; a < CT; ++a) acc[a][b] = Mma<T>::run(wf[a], xf, acc[a][b]);
+            }
+          }
+        }
+      } else {
+        for (int cc = 0; cc < cn; ++cc) {
+          const char* la = lds_a + cc * a_stride;
+#pragma unroll 2
+          for (int tt = 0; tt < tn; ++tt) {
+            const int toff = tap_off[t0 + tt];  // LDS table: ((dy-dymin)*iw + dx-dxmin) * row bytes
+            const char* lw = lds_w + (cc * p.tg + tt) * CO_TILE * kRowBytes;
+            Frag wf[CT];
+#pragma unroll
+            for (int a = 0; a < CT; ++a)
+              wf[a] = *reinterpret_cast<const Frag*>(lw + ((wc * CT + a) * 16 + idx) * kRowBytes + g * 16);
+#pragma unroll
+            for (int b = 0; b < PT; ++b) {
+              const int ty = wp * PT + b;
+              const int prow = (ty * cl.iw + idx) * p.S;
+              const Frag xf = *reinterpret_cast<const Frag*>(la + prow * kRowBytes + toff + g * 16);
+#pragma unroll
+              for (int a = 0; a < CT; ++a) acc[a][b] = Mma<T>::run(wf[a], xf, acc[a][b]);
+            }
           }
         }
       }
@@ -216,6 +286,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
   }
 
   // ---------------------------------------------------------------- epilogue
+  TG_STAMP_AT(5);
   const int q = g;  // accumulator rows 4q..4q+3 of each 16-row tile live in this lane
   float s1[NG][E], s2[NG][E];
 #pragma unroll
@@ -285,6 +356,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
     }
   }
 
+  TG_STAMP_AT(6);
   if (p.stats_mode) {  // uniform branch
 #pragma unroll
     for (int a = 0; a < NG; ++a)
@@ -348,9 +420,9 @@ struct TileCfg {
   int co_tile, th;
 };
 
-template <typename T, int CT, int PT, int WC, int WP>
-int launch_conv(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
-  auto fn = conv_gather_kernel<T, CT, PT, WC, WP>;
+template <typename T, int CT, int PT, int WC, int WP, bool STD3>
+int launch_conv_impl(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+  auto fn = conv_gather_kernel<T, CT, PT, WC, WP, STD3>;
   static bool attr_done = false;  // one-time function attribute (benign race: idempotent)
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -359,6 +431,12 @@ int launch_conv(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
   }
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k);
   return tg_launch_status();
+}
+
+template <typename T, int CT, int PT, int WC, int WP>
+int launch_conv(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
+  return k.std3 ? launch_conv_impl<T, CT, PT, WC, WP, true>(k, grid, lds, st)
+                : launch_conv_impl<T, CT, PT, WC, WP, false>(k, grid, lds, st);
 }
 
 template <typename T>
@@ -493,7 +571,23 @@ extern "C" int tg_conv(const tg_conv_desc* d, const void* in, const void* w_pack
   int cg = 1;
   if (tg == max_taps)
     while (cg < k.nchunks && (size_t)(cg + 1) * (a_bytes + tg * w_tap) <= budget) ++cg;
+  // plain 3x3 stride-1 pattern (forward: dy=t/3-1, dx=t%3-1; dgrad: mirrored), slots in tap order, all 9 taps staged together
+  k.std3 = 0;
+  k.flip = 0;
+  if (d->ncls == 1 && d->S == 1 && d->OS == 1 && d->cls[0].ntaps == 9 && tg == 9) {
+    bool fwd = true, bwd = true;
+    for (int t = 0; t < 9; ++t) {
+      const tg_conv_class& s0 = d->cls[0];
+      if (s0.widx[t] != t) fwd = bwd = false;
+      if (s0.dy[t] != t / 3 - 1 || s0.dx[t] != t % 3 - 1) fwd = false;
+      if (s0.dy[t] != 1 - t / 3 || s0.dx[t] != 1 - t % 3) bwd = false;
+    }
+    k.std3 = (fwd || bwd) ? 1 : 0;
+    k.flip = (!fwd && bwd) ? 1 : 0;
+  }
   size_t lds = (size_t)cg * (a_bytes + tg * w_tap);
+  k.tap_table_off = (int)lds;
+  lds += TG_MAX_TAPS * sizeof(int);
   if (lds > 160 * 1024) return TG_E_UNSUPPORTED;
   lds = std::max<size_t>(lds, 4 * 2 * tc.co_tile * sizeof(float));  // stats scratch
   k.tg = tg;
