@@ -57,6 +57,7 @@ struct ConvK {
   float* stats;
   int N, IH, IW, Cin, OH, OW, Cout, S, OS;
   int tiles_x, tiles_y, nchunks, tg, cg;
+  int tx_log2, ty_log2;  // log2 of the tile counts, or -1
   int act, mask_mode, stats_mode, stats_groups, out_mode, c_real;
   long long out_n_stride;
   int a_rows_max;
@@ -116,15 +117,23 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
   const int wc = wid % WC, wp = wid / WC;
   const int idx = lane & 15, g = lane >> 4;
 
-  int bx = blockIdx.x;
-  const int txb = bx % p.tiles_x;
-  bx /= p.tiles_x;
-  const int tyb = bx % p.tiles_y;
-  const int n = bx / p.tiles_y;
+  // block decode without integer division when the tile counts are powers of two (every shape of the TecoGAN step)
+  int bx = blockIdx.x, txb, tyb, n;
+  if (p.tx_log2 >= 0 && p.ty_log2 >= 0) {
+    txb = bx & (p.tiles_x - 1);
+    tyb = (bx >> p.tx_log2) & (p.tiles_y - 1);
+    n = bx >> (p.tx_log2 + p.ty_log2);
+  } else {
+    txb = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    tyb = bx % p.tiles_y;
+    n = bx / p.tiles_y;
+  }
   const int co_base = blockIdx.y * CO_TILE;
 
-  const int OHc = (p.OH - cl.ooy + p.OS - 1) / p.OS;
-  const int OWc = (p.OW - cl.oox + p.OS - 1) / p.OS;
+  const int os_sh = p.OS - 1;  // OS is 1 or 2
+  const int OHc = (p.OH - cl.ooy + p.OS - 1) >> os_sh;
+  const int OWc = (p.OW - cl.oox + p.OS - 1) >> os_sh;
   const int ty0 = tyb * TH, tx0 = txb * 16;
   if (ty0 >= OHc || tx0 >= OWc) return;  // whole tile outside this class's grid (uniform per workgroup)
 
@@ -143,6 +152,19 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
 
   const size_t in_pix_bytes = (size_t)p.Cin * TR::kBytes;
   const char* in_n = p.in + (size_t)n * p.IH * p.IW * in_pix_bytes;
+
+  // bias for this lane's output channels, fetched now so that its latency hides under the K loop
+  float bias_r[NG][E];
+#pragma unroll
+  for (int a = 0; a < NG; ++a) {
+    const int ch0 = (TR::kBytes == 2) ? co_base + (wc * CT + 2 * a) * 16 + 8 * g : co_base + (wc * CT + a) * 16 + 4 * g;
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) t = *reinterpret_cast<const f32x4*>(p.bias + ch0 + e);
+      bias_r[a][e] = t[0]; bias_r[a][e + 1] = t[1]; bias_r[a][e + 2] = t[2]; bias_r[a][e + 3] = t[3];
+    }
+  }
 
   // K loop: stages of (chunk group x tap group).  Each stage issues ALL of its global loads before the first LDS store
   // (UA/UW loads in flight per thread): with one workgroup per CU on the small recurrent-pass layers nothing else hides
@@ -317,10 +339,8 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
         for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j];
       }
       if (valid) {
-        if (p.bias) {
 #pragma unroll
-          for (int e = 0; e < E; ++e) v[e] += p.bias[ch0 + e];
-        }
+        for (int e = 0; e < E; ++e) v[e] += bias_r[a][e];
         const size_t eoff = (pix * p.Cout + ch0) * TR::kBytes;
         if (p.res) {
           float r[E];
@@ -560,6 +580,10 @@ extern "C" int tg_conv(const tg_conv_desc* d, const void* in, const void* w_pack
   const size_t w_tap = (size_t)tc.co_tile * kRowBytes;
   k.tiles_x = (max_owc + 15) / 16;
   k.tiles_y = (max_ohc + tc.th - 1) / tc.th;
+  auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+  k.tx_log2 = ilog2(k.tiles_x);
+  k.ty_log2 = ilog2(k.tiles_y);
+  if (d->OS > 2) return TG_E_UNSUPPORTED;
   const long long gx = (long long)k.tiles_x * k.tiles_y * d->N;
   if (gx > 0x7fffffffLL) return TG_E_UNSUPPORTED;
   const long long wgs = gx * (d->Cout / tc.co_tile) * d->ncls;

@@ -269,16 +269,23 @@ __global__ __launch_bounds__(256) void content_loss_kernel(const float* __restri
       for (int k = 0; k < 32 / TR::kVec; ++k) Vec<T>::store(o + k * 16, v + k * TR::kVec);
     }
   }
+  // block-level reduction, then ONE atomic per block and quantity: thousands of waves adding to the same four words
+  // serialise at the memory side (measured: 428 us with per-wave atomics)
+  __shared__ float shc[4][4];
   s = wave_sum(s);
 #pragma unroll
   for (int c = 0; c < 3; ++c) cs[c] = wave_sum(cs[c]);
   if ((threadIdx.x & 63) == 0) {
     sh[threadIdx.x >> 6] = s;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) atomicAdd(acc + 8 + c, cs[c]);  // output-layer bias gradient
+    for (int c = 0; c < 3; ++c) shc[c][threadIdx.x >> 6] = cs[c];
   }
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
+  if (threadIdx.x >= 1 && threadIdx.x <= 3) {
+    const int c = threadIdx.x - 1;
+    atomicAdd(acc + 8 + c, shc[c][0] + shc[c][1] + shc[c][2] + shc[c][3]);  // output-layer bias gradient
+  }
 }
 
 __global__ void absdiff_nchw_kernel(const float* __restrict__ a, const long long* __restrict__ a_off,
@@ -457,7 +464,7 @@ extern "C" int tg_content_loss(int dtype, const float* gen, const float* y, void
                                int H, int W, float gscale, int t0, int t1, void* stream) {
   if (!gen || !y || !acc || B <= 0 || T <= 0 || H <= 0 || W <= 0 || t0 < 0 || t1 > T || t0 >= t1) return TG_E_BADARG;
   const long long total = (long long)B * (t1 - t0) * H * W;
-  TG_DISPATCH(dtype, content_loss_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), (hipStream_t)stream, gen, y,
+  TG_DISPATCH(dtype, content_loss_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), (hipStream_t)stream, gen, y,
               (char*)dpre, acc, B, T, H, W, gscale, t0, t1);
   return tg_launch_status();
 }

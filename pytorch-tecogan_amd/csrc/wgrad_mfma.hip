@@ -59,7 +59,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
   const size_t xpix_bytes = (size_t)p.Cx * TR::kBytes, ypix_bytes = (size_t)p.Cy * TR::kBytes;
   const int prow_n = p.ih * p.iw;
 
-  for (int tile = blockIdx.x; tile < p.tiles_total; tile += p.nsplit) {
+  // Software pipeline over this workgroup's pixel tiles: the global loads of tile i+1 are issued (into registers) right
+  // after tile i has been written to LDS and stay in flight while the MFMAs of tile i run.  The kernel runs one
+  // workgroup per CU (its accumulators fill the register file), so no other workgroup would hide that latency.
+  constexpr int UX = (TR::kBytes == 2) ? 11 : 22;  // 16-byte pieces per thread: X patch up to 10x34 pixels x A_BLK channels
+  constexpr int UY = (TR::kBytes == 2) ? 4 : 8;    //                            Y tile 128 pixels x B_BLK channels
+  u32x4 vx[UX], vy[UY];
+  const float inv_iw = 1.0f / (float)p.iw;
+  const int nx = prow_n * XV, ny = ypix * YV;
+
+  auto issue = [&](int tile) {
     int r = tile;
     const int txb = r % p.tiles_x;
     r /= p.tiles_x;
@@ -67,54 +76,55 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     const int n = r / p.tiles_y;
     const int ty0 = tyb * p.th, tx0 = txb * tw;
     const int iy0 = ty0 * p.S + p.dymin, ix0 = tx0 * p.S + p.dxmin;
-
-    __syncthreads();
-    // all global loads of a batch are issued before the first LDS store (one workgroup per CU: nothing else hides latency)
-    constexpr int U = 8;
     const char* xn = p.x + (size_t)n * p.XH * p.XW * xpix_bytes + (size_t)a0 * TR::kBytes;
-    for (int base = tid; base < prow_n * XV; base += 256 * U) {
-      u32x4 v[U];
-      int dst[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = base + u * 256;
-        v[u] = u32x4{0u, 0u, 0u, 0u};
-        dst[u] = -1;
-        if (i < prow_n * XV) {
-          const int prow = i / XV, s = i - prow * XV;
-          const int py = prow / p.iw, px = prow - py * p.iw;
-          const int iy = iy0 + py, ix = ix0 + px;
-          dst[u] = prow * XROW + s * 16;
-          if (iy >= 0 && iy < p.XH && ix >= 0 && ix < p.XW)
-            v[u] = *reinterpret_cast<const u32x4*>(xn + ((size_t)iy * p.XW + ix) * xpix_bytes + s * 16);
-        }
+    for (int u = 0; u < UX; ++u) {
+      const int i = tid + u * 256;
+      vx[u] = u32x4{0u, 0u, 0u, 0u};
+      if (i < nx) {
+        const int prow = i / XV, s2 = i - prow * XV;  // XV is a power of two
+        const int py = (int)(((float)prow + 0.5f) * inv_iw), px = prow - py * p.iw;
+        const int iy = iy0 + py, ix = ix0 + px;
+        if (iy >= 0 && iy < p.XH && ix >= 0 && ix < p.XW)
+          vx[u] = *reinterpret_cast<const u32x4*>(xn + ((size_t)iy * p.XW + ix) * xpix_bytes + s2 * 16);
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (dst[u] >= 0) *reinterpret_cast<u32x4*>(lds_x + dst[u]) = v[u];
     }
     const char* yn = p.y + (size_t)n * p.YH * p.YW * ypix_bytes + (size_t)b0 * TR::kBytes;
-    for (int base = tid; base < ypix * YV; base += 256 * U) {
-      u32x4 v[U];
-      int dst[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = base + u * 256;
-        v[u] = u32x4{0u, 0u, 0u, 0u};
-        dst[u] = -1;
-        if (i < ypix * YV) {
-          const int prow = i / YV, s = i - prow * YV;
-          const int yy = ty0 + (prow >> p.tw_log2), xx = tx0 + (prow & (tw - 1));
-          dst[u] = prow * YROW + s * 16;
-          if (yy < p.YH && xx < p.YW)
-            v[u] = *reinterpret_cast<const u32x4*>(yn + ((size_t)yy * p.YW + xx) * ypix_bytes + s * 16);
-        }
+    for (int u = 0; u < UY; ++u) {
+      const int i = tid + u * 256;
+      vy[u] = u32x4{0u, 0u, 0u, 0u};
+      if (i < ny) {
+        const int prow = i / YV, s2 = i - prow * YV;
+        const int yy = ty0 + (prow >> p.tw_log2), xx = tx0 + (prow & (tw - 1));
+        if (yy < p.YH && xx < p.YW)
+          vy[u] = *reinterpret_cast<const u32x4*>(yn + ((size_t)yy * p.YW + xx) * ypix_bytes + s2 * 16);
       }
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < p.tiles_total) issue(tile);
+  for (; tile < p.tiles_total; tile += p.nsplit) {
+    __syncthreads();  // the previous tile's fragment reads are done
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (dst[u] >= 0) *reinterpret_cast<u32x4*>(lds_y + dst[u]) = v[u];
+    for (int u = 0; u < UX; ++u) {
+      const int i = tid + u * 256;
+      if (i < nx) {
+        const int prow = i / XV, s2 = i - prow * XV;
+        *reinterpret_cast<u32x4*>(lds_x + prow * XROW + s2 * 16) = vx[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UY; ++u) {
+      const int i = tid + u * 256;
+      if (i < ny) {
+        const int prow = i / YV, s2 = i - prow * YV;
+        *reinterpret_cast<u32x4*>(lds_y + prow * YROW + s2 * 16) = vy[u];
+      }
     }
     __syncthreads();
+    if (tile + p.nsplit < p.tiles_total) issue(tile + p.nsplit);  // in flight during the MFMAs below
 
     for (int k0 = 0; k0 < ypix; k0 += 32) {
       if constexpr (TR::kBytes == 2) {
@@ -316,6 +326,11 @@ extern "C" int tg_wgrad(const tg_wgrad_desc* d, const void* x, const void* y, fl
   const int eb = d->dtype == TG_BF16 ? 2 : 4;
   const size_t lds = (size_t)tw * th * (c.b_blk * eb + 16) + (size_t)k.ih * k.iw * (c.a_blk * eb + 16);
   if (lds > 160 * 1024) return TG_E_UNSUPPORTED;
+  {  // register staging capacity of the kernel (UX / UY pieces per thread)
+    const int xv = c.a_blk * eb / 16, yv = c.b_blk * eb / 16;
+    const int ux = d->dtype == TG_BF16 ? 11 : 22, uy = d->dtype == TG_BF16 ? 4 : 8;
+    if (k.ih * k.iw * xv > 256 * ux || tw * th * yv > 256 * uy) return TG_E_UNSUPPORTED;
+  }
   dim3 grid((unsigned)d->nsplit, (unsigned)((d->Cx / c.a_blk) * k.b_blocks));
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == TG_BF16) {
