@@ -15,6 +15,7 @@ import torch
 
 from . import _lib as L
 from . import kernels as K
+from . import parallel
 from .kernels import pad32
 
 LAYER_NORM = (12.0, 14.0, 24.0, 100.0)  # code/train.py:214
@@ -26,6 +27,51 @@ SCALAR_NAMES = ["D_layer_0_loss", "D_layer_1_loss", "D_layer_2_loss", "D_layer_3
 
 def _i64(vals, device):
     return torch.tensor(vals, dtype=torch.int64, device=device)
+
+
+def build_tables(B, T, h, K):
+    """Element-offset tables that drive tg_up4_planes / tg_copy_blocks / tg_warp_nchw (pure host logic, unit-tested on CPU).
+    x is (B,T,3,h,h), flow (B,T-1,2,H,H), T_vel (B*3K,H,H,2) == blocks of 2*H*H floats."""
+    H = 4 * h
+    hh, HH = h * h, H * H
+    tsize = 3 * K
+    xo = lambda b, t, c=0: ((b * T + t) * 3 + c) * hh
+    out = {}
+    # pseudo-flow planes: x[b,t,c] (t<T-1, c<2) -> flow[b,t,c]   (code/train.py:71-77)
+    src, dst = [], []
+    for b in range(B):
+        for t in range(T - 1):
+            for c in range(2):
+                src.append(xo(b, t, c))
+                dst.append(((b * (T - 1) + t) * 2 + c) * HH)
+    out["flow_src"], out["flow_dst"] = src, dst
+    # LR warp (logged loss only): img x[b,t], grid block = x[b,t+1,0:2], reference x[b,t+1]  (code/train.py:78-84,247-249)
+    img, grd = [], []
+    for b in range(B):
+        for t in range(T - 1):
+            img.append(xo(b, t))
+            grd.append(xo(b, t + 1))
+    out["lrw_img"], out["lrw_grid"] = img, grd
+    # T_vel blocks (code/train.py:138-158): (b, j, r) -> r=0 flow[b,3j], r=1 zeros, r=2 2*up4(4*back)-1
+    csrc, cdst = [], []
+    for b in range(B):
+        for j in range(K):
+            csrc += [((b * (T - 1) + 3 * j) * 2) * HH, -1]
+            cdst += [((b * tsize + 3 * j) * 2) * HH, ((b * tsize + 3 * j + 1) * 2) * HH]
+    out["tv_csrc"], out["tv_cdst"] = csrc, cdst
+    # "back" planes: cat(x[:,2:ts:3], x[:,1:ts:3], dim=1) is (B,2K,3,h,h); the reference views it as (B*K,6,h,h) and keeps
+    # rows 0..B-1 only, i.e. the FIRST 6B planes of the flattened tensor (for K=3 that mixes batch elements).
+    frames = list(range(2, tsize, 3)) + list(range(1, tsize, 3))
+    bsrc, bdst = [], []
+    for b in range(B):
+        for j in range(K):
+            for comp in range(2):
+                P = 2 * K * b + 2 * j + comp
+                bb, f, c = P // (2 * K * 3), (P // 3) % (2 * K), P % 3
+                bsrc.append(xo(bb, frames[f], c))
+                bdst.append((((b * tsize + 3 * j + 2) * 2) + comp) * HH)
+    out["tv_bsrc"], out["tv_bdst"] = bsrc, bdst
+    return out
 
 
 class TecoGANStep:
@@ -82,44 +128,12 @@ class TecoGANStep:
 
     # ----------------------------------------------------------------------------------------------------------
     def _tables(self):
-        B, T, h, H, Kt = self.B, self.T, self.h, self.H, self.K
-        hh, HH = h * h, H * H
+        t = build_tables(self.B, self.T, self.h, self.K)
         dev = self.dev
-        xo = lambda b, t, c=0: ((b * T + t) * 3 + c) * hh
-        # pseudo-flow planes: x[b,t,c] (t<T-1, c<2) -> flow[b,t,c]   (code/train.py:71-77)
-        src, dst = [], []
-        for b in range(B):
-            for t in range(T - 1):
-                for c in range(2):
-                    src.append(xo(b, t, c))
-                    dst.append(((b * (T - 1) + t) * 2 + c) * HH)
-        self.flow_src, self.flow_dst, self.n_flow = _i64(src, dev), _i64(dst, dev), len(src)
-        # LR warp (logged loss only): img x[b,t], grid block = x[b,t+1,0:2], reference x[b,t+1]  (code/train.py:78-84,247-249)
-        img, grd = [], []
-        for b in range(B):
-            for t in range(T - 1):
-                img.append(xo(b, t))
-                grd.append(xo(b, t + 1))
-        self.lrw_img, self.lrw_grid = _i64(img, dev), _i64(grd, dev)
-        # T_vel blocks (code/train.py:138-158): (b, j, r) -> r=0 flow[b,3j], r=1 zeros, r=2 2*up4(4*back)-1
-        csrc, cdst = [], []
-        for b in range(B):
-            for j in range(Kt):
-                csrc += [((b * (T - 1) + 3 * j) * 2) * HH, -1]
-                cdst += [((b * self.tsize + 3 * j) * 2) * HH, ((b * self.tsize + 3 * j + 1) * 2) * HH]
-        self.tv_csrc, self.tv_cdst, self.n_tvc = _i64(csrc, dev), _i64(cdst, dev), len(csrc)
-        # "back" planes: cat(x[:,2:ts:3], x[:,1:ts:3], dim=1) viewed as (B*K, 6, h, h); only rows 0..B-1 are used.
-        frames = list(range(2, self.tsize, 3)) + list(range(1, self.tsize, 3))  # 2K frames per batch element
-        bsrc, bdst = [], []
-        for b in range(B):
-            for j in range(Kt):
-                for comp in range(2):
-                    P = 6 * b + 2 * j + comp if Kt == 3 else (2 * Kt) * b + 2 * j + comp
-                    # plane P of the flattened (B, 2K, 3, h, h) tensor
-                    bb, f, c = P // (2 * Kt * 3), (P // 3) % (2 * Kt), P % 3
-                    bsrc.append(xo(bb, frames[f], c))
-                    bdst.append((((b * self.tsize + 3 * j + 2) * 2) + comp) * HH)
-        self.tv_bsrc, self.tv_bdst, self.n_tvb = _i64(bsrc, dev), _i64(bdst, dev), len(bsrc)
+        self.flow_src, self.flow_dst, self.n_flow = _i64(t["flow_src"], dev), _i64(t["flow_dst"], dev), len(t["flow_src"])
+        self.lrw_img, self.lrw_grid = _i64(t["lrw_img"], dev), _i64(t["lrw_grid"], dev)
+        self.tv_csrc, self.tv_cdst, self.n_tvc = _i64(t["tv_csrc"], dev), _i64(t["tv_cdst"], dev), len(t["tv_csrc"])
+        self.tv_bsrc, self.tv_bdst, self.n_tvb = _i64(t["tv_bsrc"], dev), _i64(t["tv_bdst"], dev), len(t["tv_bsrc"])
 
     # ----------------------------------------------------------------------------------------------------------
     def _host_params(self, global_step, lr_g, lr_d, betas_g, betas_d, eps_g, eps_d):
@@ -213,10 +227,7 @@ class TecoGANStep:
         D.repack()
 
     def _allreduce(self, buf):
-        if self.pg is None or self.world == 1:
-            return None
-        import torch.distributed as dist
-        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        return parallel.allreduce_sum_async(buf, self.pg, self.world)
 
     def _segments(self):
         """single GPU: [forward + both backward passes | update].  Data parallel: the D backward is its own segment so

@@ -7,6 +7,7 @@ import os
 import torch
 
 from . import _lib as L
+from . import parallel
 from .models import compute_dtype
 from .step import TecoGANStep
 
@@ -17,12 +18,6 @@ Network = collections.namedtuple(
 
 _STEPS = {}
 
-
-def _dist_info():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return dist.group.WORLD, dist.get_world_size()
-    return None, 1
 
 
 def _bind_optimizer(opt, module):
@@ -56,7 +51,7 @@ def get_step(generator_F, discriminator_F, B, T, h, args, device, dtype_t=None, 
     key = (id(Ge), id(De), B, T, h, use_graph)
     st = _STEPS.get(key)
     if st is None:
-        pg, world = _dist_info()
+        pg, world = parallel.dist_info()
         st = TecoGANStep(Ge, De, B, T, h, args, device, use_graph=use_graph, process_group=pg, world_size=world)
         _STEPS.clear()  # one live configuration: activation buffers are large
         _STEPS[key] = st

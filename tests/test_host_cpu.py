@@ -1,0 +1,246 @@
+"""CPU-only tests (no GPU, no compute calls into the HIP library): the C-ABI library loads and exports every symbol the
+header declares; the host-side geometry / packing / index tables that drive the kernels are correct (checked by emulating the
+kernel contracts with plain torch on CPU against torch's own convolutions and the oracle); module surface and error
+behaviour match the reference."""
+import argparse
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import pytorch_tecogan_amd  # noqa: E402,F401
+from pytorch_tecogan_amd import _lib as L  # noqa: E402
+from pytorch_tecogan_amd import engine as E  # noqa: E402
+from pytorch_tecogan_amd import kernels as K  # noqa: E402
+from pytorch_tecogan_amd import models as M  # noqa: E402
+from pytorch_tecogan_amd import step as S  # noqa: E402
+import tecogan_oracle as orc  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------------ C ABI
+def test_capi_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "tecogan_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tg_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    lib = L.load()  # raises if the .so is missing: there is no fallback
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/tecogan_hip.h but not exported"
+    assert declared == set(L.EXPORTED), declared ^ set(L.EXPORTED)
+    assert lib.tg_abi_version() == 1
+    assert lib.tg_error_string(-2) == b"unsupported shape"
+
+
+def test_capi_argument_validation_without_gpu():
+    """validation happens before any launch, so these status codes can be checked on a CPU-only box"""
+    lib = L.load()
+    d = K.make_conv_desc(K.ConvSpec("c3", 64, 64).fwd_geom(), L.TG_BF16, 1, 8, 8, 64, 8, 8, 64)
+    import ctypes
+    assert lib.tg_conv(ctypes.byref(d), None, None, None, None, None, None, None, None) == -1  # TG_E_BADARG
+    d2 = K.make_conv_desc(K.ConvSpec("c3", 64, 64).fwd_geom(), L.TG_BF16, 1, 8, 8, 48, 8, 8, 64)
+    assert lib.tg_conv(ctypes.byref(d2), 16, 16, None, None, None, 16, None, None) == -3  # channels not multiple of 32
+    assert lib.tg_adam(None, None, None, None, 10, None, None) == -1
+    assert lib.tg_packed_weight_bytes(L.TG_BF16, 9, 64, 64) == 9 * 64 * 64 * 2
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libtecogan_hip.so")
+    with pytest.raises(L.TecoganHipError):
+        L.load()
+
+
+# ------------------------------------------------------------------------------------------------ geometry
+def emulate_gather_conv(geom, x, wp_slots, OH, OW):
+    """torch-CPU emulation of the tg_conv contract: out[n, cy*OS+ooy, cx*OS+oox] = sum_t in[n, cy*S+dy, cx*S+dx] @ W[slot]."""
+    N, Cin, IH, IW = x.shape
+    Cout = wp_slots.shape[1]
+    out = torch.zeros(N, Cout, OH, OW)
+    pad = 4
+    xp = F.pad(x, (pad, pad, pad, pad))
+    for ooy, oox, taps in geom.classes:
+        ohc = (OH - ooy + geom.OS - 1) // geom.OS
+        owc = (OW - oox + geom.OS - 1) // geom.OS
+        acc = torch.zeros(N, Cout, ohc, owc)
+        for dy, dx, slot in taps:
+            ys = pad + dy + geom.S * torch.arange(ohc)
+            xs = pad + dx + geom.S * torch.arange(owc)
+            ok = (ys < IH + 2 * pad) & (ys >= 0)
+            patch = xp[:, :, ys.clamp(0, IH + 2 * pad - 1)][:, :, :, xs.clamp(0, IW + 2 * pad - 1)]
+            patch = patch * ok.view(1, 1, -1, 1) * ((xs < IW + 2 * pad) & (xs >= 0)).view(1, 1, 1, -1)
+            acc += torch.einsum("nchw,oc->nohw", patch, wp_slots[slot])
+        out[:, :, ooy::geom.OS, oox::geom.OS] = acc
+    return out
+
+
+def slots_from_pack(w, rows, Kd, s_row, s_k, nslots):
+    """what tg_pack_conv_weights reads: packed[slot][row][k] = w.flat[row*s_row + k*s_k + slot]"""
+    flat = w.reshape(-1)
+    r = torch.arange(rows).view(-1, 1) * s_row
+    k = torch.arange(Kd).view(1, -1) * s_k
+    return torch.stack([flat[r + k + s] for s in range(nslots)])
+
+
+@pytest.mark.parametrize("kind,cin,cout,H,W", [("c3", 5, 7, 9, 6), ("c4s2", 6, 4, 8, 12), ("ct", 4, 6, 5, 7)])
+def test_conv_geometry_tables_forward_and_dgrad(kind, cin, cout, H, W):
+    rng = np.random.default_rng(0)
+    spec = K.ConvSpec(kind, cin, cout)
+    x = torch.from_numpy(rng.standard_normal((2, cin, H, W)).astype(np.float32))
+    w = torch.from_numpy(rng.standard_normal(spec.weight_shape).astype(np.float32))
+    OH, OW = spec.out_hw(H, W)
+
+    def ref(xx):
+        if kind == "c3":
+            return F.conv2d(xx, w, None, 1, 1)
+        if kind == "c4s2":
+            return F.conv2d(xx, w, None, 2, 1)
+        return F.conv_transpose2d(xx, w, None, 2, 1, 1)
+
+    got = emulate_gather_conv(spec.fwd_geom(), x, slots_from_pack(w, *spec.fwd_pack(), spec.nslots), OH, OW)
+    torch.testing.assert_close(got, ref(x), rtol=1e-4, atol=1e-4)
+    dout = torch.from_numpy(rng.standard_normal((2, cout, OH, OW)).astype(np.float32))
+    xr = x.clone().requires_grad_(True)
+    ref(xr).backward(dout)
+    got = emulate_gather_conv(spec.dgrad_geom(), dout, slots_from_pack(w, *spec.dgrad_pack(), spec.nslots), H, W)
+    torch.testing.assert_close(got, xr.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("kind,cin,cout,H,W", [("c3", 5, 7, 9, 6), ("c4s2", 6, 4, 8, 12), ("ct", 4, 6, 5, 7)])
+def test_wgrad_geometry_tables(kind, cin, cout, H, W):
+    rng = np.random.default_rng(1)
+    spec = K.ConvSpec(kind, cin, cout)
+    x = torch.from_numpy(rng.standard_normal((2, cin, H, W)).astype(np.float32))
+    w = torch.from_numpy(rng.standard_normal(spec.weight_shape).astype(np.float32)).requires_grad_(True)
+    OH, OW = spec.out_hw(H, W)
+    dout = torch.from_numpy(rng.standard_normal((2, cout, OH, OW)).astype(np.float32))
+    out = F.conv2d(x, w, None, 1, 1) if kind == "c3" else (F.conv2d(x, w, None, 2, 1) if kind == "c4s2" else
+                                                           F.conv_transpose2d(x, w, None, 2, 1, 1))
+    out.backward(dout)
+    x_is_in, Sx, taps, ca, cb, s_a, s_b = spec.wgrad_info()
+    X, Y = (x, dout) if x_is_in else (dout, x)
+    pad = 4
+    Xp = F.pad(X, (pad, pad, pad, pad))
+    YH, YW = Y.shape[2:]
+    grad = torch.zeros(w.numel())
+    for t, (dy, dx) in enumerate(taps):  # the tg_wgrad / tg_wgrad_finalize contract
+        ys = pad + dy + Sx * torch.arange(YH)
+        xs = pad + dx + Sx * torch.arange(YW)
+        patch = Xp[:, :, ys][:, :, :, xs]
+        dwt = torch.einsum("nahw,nbhw->ab", patch, Y)
+        a_idx = torch.arange(ca).view(-1, 1) * s_a
+        b_idx = torch.arange(cb).view(1, -1) * s_b
+        grad[(a_idx + b_idx + t).reshape(-1)] += dwt.reshape(-1)
+    torch.testing.assert_close(grad.view(w.shape), w.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_bf16_row_permutation_is_a_bijection_with_16_byte_epilogue_vectors():
+    rows = []
+    for R in range(64):
+        tile, r = R >> 4, R & 15
+        q, j = r >> 2, r & 3
+        rows.append(32 * (tile >> 1) + 8 * q + 4 * (tile & 1) + j)  # row_to_channel<BF16> of csrc/common.h
+    assert sorted(rows) == list(range(64))
+    for pair in range(2):  # lane q of tile pair u owns channels 32u+8q .. +7
+        for q in range(4):
+            chans = [rows[(2 * pair) * 16 + 4 * q + j] for j in range(4)] + [rows[(2 * pair + 1) * 16 + 4 * q + j] for j in range(4)]
+            assert chans == list(range(32 * pair + 8 * q, 32 * pair + 8 * q + 8))
+
+
+# ------------------------------------------------------------------------------------------------ step tables
+def test_step_tables_reproduce_flow_and_tvel_against_the_oracle():
+    B, T, h, Kt = 2, 10, 4, 3
+    H = 4 * h
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.random((B, T, 3, h, h), dtype=np.float32))
+    t = S.build_tables(B, T, h, Kt)
+    xf = x.reshape(-1)
+    hh, HH = h * h, H * H
+    # pseudo-flow via the plane table == oracle.pseudo_flow
+    flow = torch.zeros(B * (T - 1) * 2 * HH)
+    for so, do in zip(t["flow_src"], t["flow_dst"]):
+        flow[do:do + HH] = orc.up4(xf[so:so + hh].view(1, 1, h, h) * 4.0).reshape(-1)
+    ref_flow = orc.pseudo_flow(x)
+    assert torch.equal(flow.view_as(ref_flow), ref_flow)
+    # T_vel via copy-block + back-plane tables == oracle.t_velocity (including the rows-0..B-1 batch-mixing quirk)
+    tv = torch.full((B * 3 * Kt * 2 * HH,), float("nan"))
+    for so, do in zip(t["tv_csrc"], t["tv_cdst"]):
+        tv[do:do + 2 * HH] = 0.0 if so < 0 else flow[so:so + 2 * HH]
+    for so, do in zip(t["tv_bsrc"], t["tv_bdst"]):
+        tv[do:do + HH] = (orc.up4(xf[so:so + hh].view(1, 1, h, h) * 4.0) * 2.0 - 1.0).reshape(-1)
+    ref_tv = orc.t_velocity(x, ref_flow, 3 * Kt)
+    assert torch.equal(tv.view_as(ref_tv), ref_tv)
+    # LR-warp tables: image x[b,t], grid block x[b,t+1,0:2]
+    for n, (io, go) in enumerate(zip(t["lrw_img"], t["lrw_grid"])):
+        b, tt = divmod(n, T - 1)
+        assert torch.equal(xf[io:io + 3 * hh].view(3, h, h), x[b, tt])
+        assert torch.equal(xf[go:go + 2 * hh].view(2, h, h), x[b, tt + 1, 0:2])
+
+
+# ------------------------------------------------------------------------------------------------ module surface
+def _args(**kw):
+    a = dict(num_resblock=16, discrim_resblocks=4, discrim_channels=128, crop_size=32)
+    a.update(kw)
+    return argparse.Namespace(**a)
+
+
+def test_module_surface_matches_reference_checkpoint_abi():
+    G, D, Fn = M.generator(3, _args()), M.discriminator(_args()), M.f_net()
+    assert [(k, tuple(v.shape)) for k, v in G.named_parameters()] == list(orc.generator_param_shapes().items())
+    assert [(k, tuple(v.shape)) for k, v in D.named_parameters()] == list(orc.discriminator_param_shapes().items())
+    assert [(k, tuple(v.shape)) for k, v in Fn.named_parameters()] == list(orc.fnet_param_shapes().items())
+    assert sum(p.numel() for p in G.parameters()) == 1765251
+    assert sum(p.numel() for p in D.parameters()) == 3267383
+    assert sum(p.numel() for p in Fn.parameters()) == 7054594
+    sd = D.state_dict()
+    for bn in orc.discriminator_bn_names():
+        assert tuple(sd[bn + ".running_mean"].shape) == tuple(sd[bn + ".weight"].shape)
+        assert sd[bn + ".num_batches_tracked"].dtype == torch.long
+        assert float(sd[bn + ".weight"].min()) == 1.0 and float(sd[bn + ".bias"].abs().max()) == 0.0
+    # state dicts produced by the oracle's (reference-order) tables load strictly
+    G.load_state_dict(orc.init_params(orc.generator_param_shapes(), 1), strict=True)
+    with pytest.raises(ValueError):
+        M.generator(3)
+    with pytest.raises(ValueError):
+        M.discriminator()
+    G2 = M.generator(3, _args(num_resblock=2))
+    assert len([k for k in G2.state_dict() if k.startswith("resids.")]) == 6
+    # default init: U(-1/sqrt(fan_in), +) like torch's Conv2d
+    w = dict(G.named_parameters())["resids.0.0.weight"]
+    G3 = M.generator(3, _args())
+    w = dict(G3.named_parameters())["resids.0.0.weight"]
+    assert float(w.abs().max()) <= 1.0 / np.sqrt(64 * 9) + 1e-7 and float(w.abs().max()) > 0.9 / np.sqrt(64 * 9)
+
+
+def test_no_cpu_fallback():
+    G = M.generator(3, _args())
+    with pytest.raises(L.TecoganHipError):
+        G(torch.zeros(1, 51, 8, 8))
+    with pytest.raises(NotImplementedError):
+        M.f_net()(torch.zeros(1, 3, 32, 32))
+    from pytorch_tecogan_amd import train as TR
+    a = orc.default_args()
+    with pytest.raises(L.TecoganHipError):
+        TR.FRVSR_Train(torch.zeros(1, 10, 3, 32, 32), torch.zeros(1, 10, 3, 128, 128), a, None, None, 0, 0.0, 0.0, None, None)
+
+
+def test_flat_params_layout_and_padding():
+    flat = E.FlatParams(E.discriminator_shapes(4, 128), torch.device("cpu"))
+    assert flat.total % 32 == 0
+    for name, (off, n) in flat.offsets.items():
+        assert off % 32 == 0
+    assert flat.padded(flat.p, "block5.1.weight").numel() == 32  # 3 real BN channels, kernels read the padded 32
+    assert flat.view(flat.p, "fc.weight").shape == (1, 48)
+    assert E.discriminator_bn_names(4) == orc.discriminator_bn_names(4)
+    assert list(E.generator_shapes(16).items()) == list(orc.generator_param_shapes(16).items())
+
+
+def test_wgrad_split_rule():
+    assert K.wgrad_nsplit(40, 32, 32, 1, blocks=1) == 256
+    assert K.wgrad_nsplit(40, 64, 64, 1, blocks=4) == 64
+    assert K.wgrad_nsplit(1, 8, 8, 1, blocks=1) == 1  # never more splits than pixel tiles
+    assert K.wgrad_blocks(9, 128, 128) == 4 and K.wgrad_blocks(16, 64, 64) == 2 and K.wgrad_blocks(9, 32, 64) == 1

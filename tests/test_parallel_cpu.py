@@ -1,0 +1,143 @@
+"""Data-parallel path on CPU: world_size 2 over gloo.  Each rank owns one sequence, computes its gradients (CPU oracle),
+puts them into the same flat buffers the HIP engine uses and runs parallel.average_gradients_; the result must equal
+"both shards evaluated sequentially on one process with local BatchNorm, gradients averaged" (SURVEY.md 8e), the generator
+part must also equal the global-batch gradient (G has no cross-sample op), and both ranks must end with identical weights."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _synth(seed):
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.random((1, 10, 3, 32, 32), dtype=np.float32))
+    y = torch.from_numpy(rng.random((1, 10, 3, 128, 128), dtype=np.float32))
+    return x, y
+
+
+def _grads(orc, gp, dp, x, y, args):
+    g = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    d = {k: v.clone().requires_grad_(True) for k, v in dp.items()}
+    bufs = orc.init_bn_buffers(dp, args.discrim_resblocks)
+    f = orc.tecogan_forward(g, d, bufs, x, y, args, 0)
+    gg = torch.autograd.grad(f["gen_loss"], list(g.values()), retain_graph=True)
+    dg = torch.autograd.grad(f["d_loss"], list(d.values()))
+    return dict(zip(g.keys(), gg)), dict(zip(d.keys(), dg))
+
+
+def _worker(rank, world, port, q):
+    try:
+        for p in (ROOT, os.path.join(ROOT, "oracle")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        torch.set_num_threads(3)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import pytorch_tecogan_amd  # noqa: F401
+        from pytorch_tecogan_amd import engine as E
+        from pytorch_tecogan_amd import parallel
+        import tecogan_oracle as orc
+
+        args = orc.default_args(num_resblock=1, discrim_resblocks=1)
+        gshapes, dshapes = E.generator_shapes(1), E.discriminator_shapes(1, 128)
+        gp = orc.init_params(orc.generator_param_shapes(1), 7)
+        dp = orc.init_params(orc.discriminator_param_shapes(1, 128), 8)
+        lo, hi = parallel.shard_bounds(2, world, rank)
+        assert (lo, hi) == (rank, rank + 1)
+        x, y = _synth(20 + rank)
+        gg, dg = _grads(orc, gp, dp, x, y, args)
+        fg, fd = E.FlatParams(gshapes, torch.device("cpu")), E.FlatParams(dshapes, torch.device("cpu"))
+        for k in gp:
+            fg.view(fg.g, k).copy_(gg[k])
+        for k in dp:
+            fd.view(fd.g, k).copy_(dg[k])
+        group, w = parallel.dist_info()
+        assert w == world
+        parallel.average_gradients_([fg.g, fd.g], group, w)
+        og, od = orc.AdamState(gp, 1e-4), orc.AdamState(dp, 1e-4)
+        with torch.no_grad():
+            og.step(gp, {k: fg.view(fg.g, k) for k in gp})
+            od.step(dp, {k: fd.view(fd.g, k) for k in dp})
+        digest = torch.tensor([float(sum(v.double().sum() for v in gp.values())),
+                               float(sum(v.double().sum() for v in dp.values()))], dtype=torch.float64)
+        both = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(both, digest)
+        res = {"rank": rank, "digests": [b.tolist() for b in both]}
+        if rank == 0:
+            # sequential emulation on one process
+            gp0 = orc.init_params(orc.generator_param_shapes(1), 7)
+            dp0 = orc.init_params(orc.discriminator_param_shapes(1, 128), 8)
+            acc_g = {k: torch.zeros_like(v) for k, v in gp0.items()}
+            acc_d = {k: torch.zeros_like(v) for k, v in dp0.items()}
+            xs, ys = [], []
+            for r in range(world):
+                xr, yr = _synth(20 + r)
+                xs.append(xr)
+                ys.append(yr)
+                g1, d1 = _grads(orc, gp0, dp0, xr, yr, args)
+                for k in acc_g:
+                    acc_g[k] += g1[k] / world
+                for k in acc_d:
+                    acc_d[k] += d1[k] / world
+            rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))  # noqa: E731
+            res["g_vs_seq"] = max(rel(fg.view(fg.g, k), acc_g[k]) for k in gp0)
+            res["d_vs_seq"] = max(rel(fd.view(fd.g, k), acc_d[k]) for k in dp0)
+            # generator: averaged shard gradients == gradient of the global batch (no cross-sample coupling in G)
+            gB, _ = _grads(orc, gp0, dp0, torch.cat(xs), torch.cat(ys), args)
+            big = [k for k in gp0 if float(gB[k].norm()) > 1e-6]
+            res["g_vs_global"] = max(rel(fg.view(fg.g, k), gB[k]) for k in big)
+            og0, od0 = orc.AdamState(gp0, 1e-4), orc.AdamState(dp0, 1e-4)
+            with torch.no_grad():
+                og0.step(gp0, acc_g)
+                od0.step(dp0, acc_d)
+            res["w_vs_seq"] = max(rel(gp[k], gp0[k]) for k in gp0)
+        q.put(res)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put({"rank": rank, "error": traceback.format_exc()})
+        raise
+
+
+@pytest.mark.timeout(900)
+def test_gradient_averaging_over_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=800) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert "error" not in r, r.get("error")
+    r0 = next(r for r in results if r["rank"] == 0)
+    assert r0["g_vs_seq"] < 1e-6 and r0["d_vs_seq"] < 1e-6, r0
+    assert r0["g_vs_global"] < 2e-3, r0      # equal up to fp32 summation order (content-loss gradients cancel heavily)
+    assert r0["w_vs_seq"] < 1e-6, r0
+    for r in results:                          # replicas stay bit-identical
+        assert r["digests"][0] == r["digests"][1], r
+
+
+def test_shard_bounds():
+    from pytorch_tecogan_amd import parallel
+    assert [parallel.shard_bounds(32, 8, r) for r in (0, 7)] == [(0, 4), (28, 32)]
+    with pytest.raises(ValueError):
+        parallel.shard_bounds(10, 4, 0)
