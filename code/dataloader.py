@@ -1,0 +1,114 @@
+"""Data ingest with the reference's semantics (code/dataloader.py:15-98) on PIL + torch only (torchvision is not needed):
+  * train_dataset: every scene folder `<pre>_%04d` with >= 120 files contributes 110 sliding windows of 10 frames
+    (`col_high_%04d.png`), but __len__ is the number of SCENES (reference quirk, :78-79), so an epoch visits the first
+    len(scenes) windows; frames are resized to 4*crop (HR) and crop (LR) with bilinear filtering; frame 0 only gets an
+    independent RandomResizedCrop for LR and HR (:91-93).
+  * inference_dataset: one item per sub-folder, all frames resized to crop x crop.
+Not on the timed path; kept so that main.py is a drop-in."""
+import math
+import os
+import random
+
+import numpy as np
+import torch
+from PIL import Image
+from torch.utils.data import Dataset
+
+
+def _to_tensor(img):
+    a = np.asarray(img.convert("RGB"), dtype=np.float32) / 255.0
+    return torch.from_numpy(a).permute(2, 0, 1).contiguous()
+
+
+def _resize(img, size):
+    return img.resize((size, size), Image.BILINEAR)
+
+
+def _random_resized_crop(t, size, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0)):
+    """torchvision.transforms.RandomResizedCrop(size) on a CHW tensor: random area/aspect crop, bilinear resize back."""
+    _, H, W = t.shape
+    area = H * W
+    i = j = 0
+    h, w = H, W
+    for _ in range(10):
+        target = area * random.uniform(*scale)
+        ar = math.exp(random.uniform(math.log(ratio[0]), math.log(ratio[1])))
+        ww, hh = int(round(math.sqrt(target * ar))), int(round(math.sqrt(target / ar)))
+        if 0 < ww <= W and 0 < hh <= H:
+            i, j, h, w = random.randint(0, H - hh), random.randint(0, W - ww), hh, ww
+            break
+    crop = t[:, i:i + h, j:j + w].unsqueeze(0)
+    return torch.nn.functional.interpolate(crop, size=(size, size), mode="bilinear", align_corners=False,
+                                           antialias=True)[0]
+
+
+class inference_dataset(Dataset):
+    def __init__(self, args):
+        filedir = args.input_dir_LR
+        self.args = args
+        if (filedir is None) or (not os.path.exists(filedir)):
+            if (args.input_dir_HR is None) or (not os.path.exists(args.input_dir_HR)):
+                raise ValueError("Input directory not found")
+            filedir = args.input_dir_HR
+        self.filedir = filedir
+        self.items = os.listdir(filedir)
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, idx):
+        d = os.path.join(self.filedir, self.items[idx])
+        frames = [_to_tensor(_resize(Image.open(os.path.join(d, f)), self.args.crop_size)) for f in os.listdir(d)]
+        return torch.stack(frames, dim=0)
+
+
+class train_dataset(Dataset):
+    def __init__(self, args):
+        if args.input_video_dir == "":
+            raise ValueError("Video input directory input_video_dir is not provided")
+        if not os.path.exists(args.input_video_dir):
+            raise ValueError("Video input directory not found")
+        self.args = args
+        self.scenes = 0
+        self.windows = []
+        for dir_i in range(args.str_dir, args.end_dir + 1):
+            d = os.path.join(args.input_video_dir, "%s_%04d" % (args.input_video_pre, dir_i))
+            if not os.path.exists(d):
+                continue
+            if len(os.listdir(d)) < 120:
+                print("Skip %s, since folder doesn't contain enough frames!" % d)
+                continue
+            frames = [os.path.join(d, "col_high_%04d.png" % k) for k in range(args.max_frm + 1)]
+            self.scenes += 1
+            self.windows += [frames[i:i + 10] for i in range(110)]
+
+    def __len__(self):
+        return self.scenes  # reference quirk: scene count, not window count
+
+    def __getitem__(self, idx):
+        cs = self.args.crop_size
+        lr, hr = [], []
+        for i, path in enumerate(self.windows[idx]):
+            img = Image.open(path)
+            h_t, l_t = _to_tensor(_resize(img, 4 * cs)), _to_tensor(_resize(img, cs))
+            if i == 0:
+                h_t, l_t = _random_resized_crop(h_t, 4 * cs), _random_resized_crop(l_t, cs)
+            lr.append(l_t)
+            hr.append(h_t)
+        return [torch.stack(lr).float(), torch.stack(hr).float()]
+
+
+def video_frames(args):
+    """inferencetype == 'video' (main.py:145-161): needs OpenCV, which is optional."""
+    import cv2
+    cap = cv2.VideoCapture(args.input_dir_LR)
+    frames = []
+    for _ in range(int(cap.get(cv2.CAP_PROP_FRAME_COUNT))):
+        ok, frame = cap.read()
+        if not ok:
+            continue
+        frame = cv2.resize(cv2.cvtColor(frame, cv2.COLOR_BGR2RGB), (args.crop_size, args.crop_size),
+                           interpolation=cv2.INTER_AREA)
+        frames.append(torch.from_numpy(frame.astype(np.float32) / 255.0).permute(2, 0, 1))
+    cap.release()
+    return torch.stack(frames, dim=0).unsqueeze(0)

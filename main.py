@@ -1,0 +1,163 @@
+"""Entry point with the reference's command line (main.py:33-128 of dwight-foster/Pytorch-TecoGAN): same flags, defaults,
+start-up side effects and output file names; the training / inference loops call the MI355X implementation through the
+reference-named modules in ./code (FRVSR_Train, generator, discriminator).
+
+Extra flags (all optional): --synthetic N trains on N random sequences instead of --input_video_dir (no dataset needed),
+--tg_dtype {bf16,fp32}.  Multi-GPU: launch with torch.distributed.run; every rank then takes a disjoint shard of each batch.
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(1, os.path.join(os.path.dirname(os.path.abspath(__file__)), "code"))
+
+
+def str2bool(v):
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ("yes", "true", "t", "y", "1"):
+        return True
+    if v.lower() in ("no", "false", "f", "n", "0"):
+        return False
+    raise argparse.ArgumentTypeError("Boolean value expected.")
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="TecoGAN (MI355X-native)")
+    a = p.add_argument
+    a("--rand_seed", default=1, type=int); a("--input_dir_LR", default="", type=str)
+    a("--input_dir_len", default=-1, type=int); a("--input_dir_HR", default="", type=str)
+    a("--mode", default="train", type=str); a("--output_dir", default="output"); a("--output_pre", default="")
+    a("--output_name", default="output"); a("--output_ext", default="jpg"); a("--summary_dir", default="summary")
+    a("--videotype", default=".mp4", type=str); a("--inferencetype", default="dataset", type=str)
+    a("--g_checkpoint", default=None); a("--d_checkpoint", default=None)
+    a("--num_resblock", type=int, default=16); a("--discrim_resblocks", type=int, default=4)
+    a("--discrim_channels", type=int, default=128); a("--pre_trained_model", type=str2bool, default=False)
+    a("--vgg_ckpt", default=None); a("--cudaID", default="0", type=str); a("--queue_thread", default=8, type=int)
+    a("--RNN_N", default=10); a("--batch_size", default=4, type=int); a("--flip", default=True, type=str2bool)
+    a("--random_crop", default=True, type=str2bool); a("--movingFirstFrame", default=True, type=str2bool)
+    a("--crop_size", default=32, type=int); a("--input_video_dir", type=str, default="../TrainingDataPath")
+    a("--input_video_pre", default="scene", type=str); a("--str_dir", default=1000, type=int)
+    a("--end_dir", default=1400, type=int); a("--end_dir_val", default=2050, type=int); a("--max_frm", default=119, type=int)
+    a("--vgg_scaling", default=-0.002, type=float); a("--warp_scaling", default=1.0, type=float)
+    a("--pingpang", default=False, type=str2bool); a("--pp_scaling", default=1.0, type=float)
+    a("--EPS", default=1e-12, type=float); a("--learning_rate", default=0.0001, type=float)
+    a("--decay_step", default=250, type=int); a("--decay_rate", default=0.8, type=float)
+    a("--stair", default=False, type=str2bool); a("--beta", default=0.9, type=float); a("--adameps", default=1e-8, type=float)
+    a("--max_epochs", default=10000000, type=int); a("--ratio", default=0.01, type=float)
+    a("--Dt_mergeDs", default=True, type=str2bool); a("--Dt_ratio_0", default=1.0, type=float)
+    a("--Dt_ratio_add", default=0.0, type=float); a("--Dt_ratio_max", default=1.0, type=float)
+    a("--Dbalance", default=0.4, type=float); a("--crop_dt", default=0.75, type=float)
+    a("--D_LAYERLOSS", default=True, type=str2bool)
+    a("--synthetic", default=0, type=int, help="train on this many random sequences (no dataset)")
+    a("--tg_dtype", default=None, choices=[None, "bf16", "fp32"])
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    args.RNN_N = int(args.RNN_N)  # the reference leaves a CLI value as str (main.py:78-79)
+    if "LOCAL_RANK" not in os.environ:
+        os.environ["CUDA_VISIBLE_DEVICES"] = args.cudaID
+    if args.output_dir is None:
+        raise ValueError("The output directory is needed")
+    for d in (args.output_dir, args.summary_dir):
+        if not os.path.exists(d):
+            os.mkdir(d)
+
+    import numpy as np
+    import torch
+    from models import discriminator, generator
+    from train import FRVSR_Train
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    if args.mode == "inference":
+        if args.g_checkpoint is None:
+            raise ValueError("The checkpoint file is needed to perform the test")
+        if args.inferencetype == "dataset":
+            from dataloader import inference_dataset
+            loader = torch.utils.data.DataLoader(inference_dataset(args), batch_size=1, shuffle=False)
+        elif args.inferencetype == "video":
+            from dataloader import video_frames
+            loader = [video_frames(args)]
+        else:
+            raise ValueError("Invalid data type entered. Please use either video or dataset.")
+        G = generator(3, args=args).to(dev)
+        G.load_state_dict(torch.load(args.g_checkpoint, map_location=dev)["model_state_dict"])
+        from ops import save_as_gif
+        for batch_idx, r_inputs in enumerate(loader):
+            out = G.recurrent(r_inputs.to(dev), use_graph=True)  # whole recurrence on device, per-frame hipGraph
+            save_as_gif(out[0].cpu(), f"./{args.output_dir}/output{batch_idx}{args.videotype}")
+        return
+
+    if args.mode != "train":
+        raise ValueError("mode must be train or inference")
+
+    if args.synthetic:
+        rng = np.random.default_rng(args.rand_seed + rank)
+        T, cs = args.RNN_N, args.crop_size
+        data = [(torch.from_numpy(rng.random((T, 3, cs, cs), dtype=np.float32)),
+                 torch.from_numpy(rng.random((T, 3, 4 * cs, 4 * cs), dtype=np.float32))) for _ in range(args.synthetic)]
+        dataset = data
+    else:
+        from dataloader import train_dataset
+        dataset = train_dataset(args)
+    loader = torch.utils.data.DataLoader(dataset, batch_size=4, shuffle=True, drop_last=True)  # 4 is hard-coded (main.py:227)
+
+    G, D = generator(3, args=args).to(dev), discriminator(args=args).to(dev)
+    lr_d = args.learning_rate * (1.0 if args.Dt_mergeDs else 0.3)
+    opt_d = torch.optim.Adam(D.parameters(), lr_d, betas=(args.beta, 0.999), eps=args.adameps)
+    opt_g = torch.optim.Adam(G.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
+    sch_d = torch.optim.lr_scheduler.StepLR(opt_d, args.decay_step, args.decay_rate)
+    sch_g = torch.optim.lr_scheduler.StepLR(opt_g, args.decay_step, args.decay_rate)
+    epoch0 = 0
+    if args.pre_trained_model:
+        g_ck = torch.load(args.g_checkpoint, map_location=dev)
+        G.load_state_dict(g_ck["model_state_dict"])
+        opt_g.load_state_dict(g_ck["optimizer_state_dict"])
+        epoch0 = g_ck["epoch"]
+        d_ck = torch.load(args.d_checkpoint, map_location=dev)
+        D.load_state_dict(d_ck["model_state_dict"])
+        opt_d.load_state_dict(d_ck["optimizer_state_dict"])
+
+    since = time.time()
+    for e in range(epoch0, args.max_epochs):
+        g_loss = d_loss = 0.0
+        output = inputs = targets = None
+        for batch_idx, (inputs, targets) in enumerate(loader):
+            inputs, targets = inputs.to(dev, non_blocking=True), targets.to(dev, non_blocking=True)
+            output = FRVSR_Train(inputs, targets, args, D, G, batch_idx, 0.0, 0.0, opt_g, opt_d)
+            g_loss = g_loss + (output.gen_loss.data - g_loss) / (batch_idx + 1)   # running means stay on the device
+            d_loss = d_loss + (output.d_loss.data - d_loss) / (batch_idx + 1)
+        sch_d.step()
+        sch_g.step()
+        if rank == 0 and output is not None:
+            print("Epoch: {}".format(e + 1))
+            print("\nGenerator loss is: {} \nDiscriminator loss is: {}".format(float(g_loss), float(d_loss)))
+            print(f"\nGenerator lr is: {opt_g.param_groups[0]['lr']}, Discriminator lr is: {opt_d.param_groups[0]['lr']}")
+            try:
+                from ops import save_as_gif
+                idx = np.random.randint(0, targets.shape[0])
+                save_as_gif(output.gen_output[idx][:args.RNN_N].cpu(), "gan.gif")
+                save_as_gif(targets[idx].cpu(), "real.gif")
+                save_as_gif(inputs[idx].cpu(), "original.gif")
+            except ImportError:
+                pass  # imageio is optional
+            print("\nSaving model...")
+            torch.save({"epoch": e, "model_state_dict": G.state_dict(), "optimizer_state_dict": opt_g.state_dict()},
+                       "generator.pt")
+            torch.save({"model_state_dict": D.state_dict(), "optimizer_state_dict": opt_d.state_dict()}, "discrim.pt")
+            el = time.time() - since
+            print("\nTraining complete in {:.0f}m {:.0f}s".format(el // 60, el % 60))
+
+
+if __name__ == "__main__":
+    main()

@@ -244,3 +244,28 @@ def test_wgrad_split_rule():
     assert K.wgrad_nsplit(40, 64, 64, 1, blocks=4) == 64
     assert K.wgrad_nsplit(1, 8, 8, 1, blocks=1) == 1  # never more splits than pixel tiles
     assert K.wgrad_blocks(9, 128, 128) == 4 and K.wgrad_blocks(16, 64, 64) == 2 and K.wgrad_blocks(9, 32, 64) == 1
+
+
+def test_dataloader_semantics(tmp_path):
+    """code/dataloader.py quirks: __len__ = number of scenes, 10-frame windows, frame sizes, skip of short scenes."""
+    sys.path.insert(1, os.path.join(ROOT, "code"))
+    import dataloader as DL
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    for scene, nframes in ((1000, 120), (1001, 50)):
+        d = tmp_path / ("scene_%04d" % scene)
+        d.mkdir()
+        for k in range(nframes):
+            Image.fromarray(rng.integers(0, 255, (24, 24, 3), dtype=np.uint8)).save(d / ("col_high_%04d.png" % k))
+    a = argparse.Namespace(input_video_dir=str(tmp_path), input_video_pre="scene", str_dir=1000, end_dir=1002,
+                           max_frm=119, crop_size=8)
+    ds = DL.train_dataset(a)
+    assert len(ds) == 1 and len(ds.windows) == 110
+    lr, hr = ds[0]
+    assert lr.shape == (10, 3, 8, 8) and hr.shape == (10, 3, 32, 32) and lr.dtype == torch.float32
+    assert 0.0 <= float(lr.min()) and float(lr.max()) <= 1.0
+    with pytest.raises(ValueError):
+        DL.train_dataset(argparse.Namespace(input_video_dir="", input_video_pre="scene", str_dir=0, end_dir=1, max_frm=119,
+                                            crop_size=8))
+    inf = DL.inference_dataset(argparse.Namespace(input_dir_LR=str(tmp_path), input_dir_HR=None, crop_size=8))
+    assert len(inf) == 2 and inf[0].shape[1:] == (3, 8, 8)

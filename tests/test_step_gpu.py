@@ -255,3 +255,28 @@ def test_recurrent_inference_matches_oracle():
     for graph in (False, True):
         out = G.recurrent(x.cuda(), use_graph=graph)
         assert rel(out.cpu(), ref) < 1e-4
+
+
+def test_main_entry_point_synthetic_train_and_resume(tmp_path, monkeypatch):
+    """main.py keeps the reference CLI: one synthetic epoch, checkpoint files with the reference's keys, resume."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tg_main", os.path.join(ROOT, "main.py"))
+    tg_main = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tg_main)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("TECOGAN_GRAPH", "1")
+    hip_train._STEPS.clear()
+    tg_main.main(["--synthetic", "8", "--max_epochs", "1", "--tg_dtype", "bf16"])
+    g_ck = torch.load(tmp_path / "generator.pt")
+    d_ck = torch.load(tmp_path / "discrim.pt")
+    assert set(g_ck) == {"epoch", "model_state_dict", "optimizer_state_dict"}
+    assert set(d_ck) == {"model_state_dict", "optimizer_state_dict"}
+    assert list(g_ck["model_state_dict"].keys()) == list(orc.generator_param_shapes().keys())
+    assert len(g_ck["optimizer_state_dict"]["state"]) == 64 and len(d_ck["optimizer_state_dict"]["state"]) == 79
+    assert float(g_ck["optimizer_state_dict"]["state"][0]["step"]) == 2.0  # 8 sequences / batch 4
+    assert int(d_ck["model_state_dict"]["block1.1.num_batches_tracked"]) == 4
+    hip_train._STEPS.clear()
+    tg_main.main(["--synthetic", "4", "--max_epochs", "1", "--pre_trained_model", "true", "--g_checkpoint",
+                  str(tmp_path / "generator.pt"), "--d_checkpoint", str(tmp_path / "discrim.pt")])  # epoch0 == 0 -> runs 1 epoch
+    g2 = torch.load(tmp_path / "generator.pt")
+    assert float(g2["optimizer_state_dict"]["state"][0]["step"]) == 3.0
