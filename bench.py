@@ -107,7 +107,7 @@ def roofline_pass(st, dtype):
     def fl_dgrad(self, dout, out, *a):
         return conv_flops(self.spec, out.shape[0], out.shape[1], out.shape[2])
 
-    def fl_wgrad(self, x_in, dout):
+    def fl_wgrad(self, x_in, dout, *rest):
         return conv_flops(self.spec, x_in.shape[0], x_in.shape[1], x_in.shape[2])
 
     E.Conv.fwd = timed(lab_fwd, fl_fwd, orig_fwd)
@@ -115,12 +115,15 @@ def roofline_pass(st, dtype):
     E.Conv.wgrad = timed(lambda self, *a: f"wgrad<{dtype},{self.spec.nslots}taps>(+finalize)", fl_wgrad, orig_wgrad)
     side = (st.sB, st.sC)
     st.sB = st.sC = torch.cuda.current_stream()  # serialise the fork/join schedule: isolated per-launch durations
+    pools = (st.G.side.streams, st.D.side.streams)
+    st.G.side.streams, st.D.side.streams = [], []
     try:
         st._forward_backward(True)
         torch.cuda.synchronize()
     finally:
         E.Conv.fwd, E.Conv.dgrad, E.Conv.wgrad = orig_fwd, orig_dgrad, orig_wgrad
         st.sB, st.sC = side
+        st.G.side.streams, st.D.side.streams = pools
     fam = {}
     for label, fl, e0, e1 in recs:
         d = fam.setdefault(label, dict(launches=0, flops=0.0, ms=0.0))
@@ -175,9 +178,10 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=dev)
     os.environ["TECOGAN_GRAPH"] = "0" if a.no_graph else "1"
 
@@ -257,7 +261,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(B, a.cpu_steps)
         print(json.dumps(res), flush=True)
     barrier()
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

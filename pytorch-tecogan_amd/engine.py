@@ -10,6 +10,7 @@ Reference behaviour reproduced (file:line into the reference):
   detach structure         code/train.py:90,108,199  (no gradient through warp / recurrence / from D into G), hence the
                            T generator passes are independent in backward and are run as ONE batch of T*B samples.
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -138,8 +139,10 @@ class Conv:
             self._desc[key] = d
         K.conv(d, dout, self.wb, out, res=res, mask=mask, stats=st)
 
-    def wgrad(self, x_in, dout):
-        """accumulates dW into the flat gradient buffer (which the step zeroes first)."""
+    def wgrad(self, x_in, dout, side=None):
+        """accumulates dW into the flat gradient buffer (which the step zeroes first).  With `side` (a stream) the two
+        launches go there after waiting for everything enqueued so far on the current stream: weight gradients are leaves
+        of the backward graph, so they can run beside the dgrad chain.  Every conv owns its slab (no sharing hazards)."""
         x_is_in, S, taps, ca, cb, s_a, s_b = self.spec.wgrad_info()
         X, Y = (x_in, dout) if x_is_in else (dout, x_in)
         N, XH, XW, cx = X.shape
@@ -148,12 +151,49 @@ class Conv:
         ent = self._desc.get(key)
         if ent is None:
             nsplit = K.wgrad_nsplit(N, YH, YW, S, K.wgrad_blocks(len(taps), cx, cy))
-            ent = (K.make_wgrad_desc(self.tg, N, XH, XW, cx, YH, YW, cy, S, taps, nsplit), nsplit)
+            if self.ws.frozen:
+                raise L.TecoganHipError("new wgrad shape after graph capture")
+            slab = torch.empty(nsplit * len(taps) * cx * cy, dtype=torch.float32, device=X.device)
+            ent = (K.make_wgrad_desc(self.tg, N, XH, XW, cx, YH, YW, cy, S, taps, nsplit), nsplit, slab)
             self._desc[key] = ent
-        d, nsplit = ent
-        slab = self.ws.get_slab(nsplit * len(taps) * cx * cy)
-        K.wgrad(d, X, Y, slab)
-        K.wgrad_finalize(slab, nsplit, len(taps), cx, cy, ca, cb, self.gw, s_a, s_b, self.slots, True)
+        d, nsplit, slab = ent
+        if side is None:
+            K.wgrad(d, X, Y, slab)
+            K.wgrad_finalize(slab, nsplit, len(taps), cx, cy, ca, cb, self.gw, s_a, s_b, self.slots, True)
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            K.wgrad(d, X, Y, slab)
+            K.wgrad_finalize(slab, nsplit, len(taps), cx, cy, ca, cb, self.gw, s_a, s_b, self.slots, True)
+
+
+class SideStreams:
+    """round-robin pool of streams for the backward graph's leaf work (weight gradients).  Measured on MI355X at config 2:
+    9.42 ms/step with 0 side streams, 10.85 / 10.63 / 11.00 ms with 1 / 2 / 3 - the one-workgroup-per-CU wgrad launches and
+    the dgrad launches slow each other down more than they overlap - so the default pool is EMPTY (TECOGAN_WGRAD_STREAMS)."""
+
+    def __init__(self, device, n=2):
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(n)] if device.type == "cuda" and n > 0 else []
+        self.i = 0
+
+    def next(self):
+        if not self.streams:
+            return None
+        s = self.streams[self.i % len(self.streams)]
+        self.i += 1
+        return s
+
+    def prefork(self, origin):
+        """make every side stream part of the capture by forking it from the ORIGIN stream first.  HIP stream capture
+        (ROCm 7.0 / this PyTorch) segfaults when a non-origin captured stream waits on a side stream; forks from any
+        stream are fine as long as all joins go into the origin (tools/capture_probe.py)."""
+        for s in self.streams:
+            s.wait_stream(origin)
+
+    def join(self, into=None):
+        into = into or torch.cuda.current_stream()
+        for s in self.streams:
+            into.wait_stream(s)
 
 
 class Repacker:
@@ -297,55 +337,61 @@ class GeneratorEngine:
         self.cout.fwd(a["u4"][sl], None, act=L.ACT_SIGMOID, nchw=(out_buf, out_off, out_n_stride, self.out_ch))
 
     def _alloc_grad(self, chunk=None):
-        """gradient scratch for a backward chunk of `chunk` samples (default: all)."""
+        """gradient scratch for a backward chunk of `chunk` samples (default: all).  Every gradient tensor has its own
+        buffer: the weight-gradient launches run on side streams and may still be reading a buffer long after the dgrad
+        chain has moved on, so nothing is recycled within a step."""
         NS, h, w = self.shape
         NC = chunk or NS
         dev, dt = self.flat.device, self.dt
         e = lambda hh, ww, c: torch.empty(NC, hh, ww, c, dtype=dt, device=dev)
         self.grad = {"dpre": e(4 * h, 4 * w, 32), "hr64": e(4 * h, 4 * w, 64), "hr128": e(4 * h, 4 * w, 128),
                      "m128a": e(2 * h, 2 * w, 128), "m128b": e(2 * h, 2 * w, 128), "m64a": e(2 * h, 2 * w, 64),
-                     "m64b": e(2 * h, 2 * w, 64), "l64a": e(h, w, 64), "l64b": e(h, w, 64), "l64c": e(h, w, 64)}
+                     "m64b": e(2 * h, 2 * w, 64), "m64c": e(2 * h, 2 * w, 64),
+                     "dA": [e(h, w, 64) for _ in range(self.nrb + 1)], "dH": [e(h, w, 64) for _ in range(self.nrb)]}
+        self.side = SideStreams(dev, int(os.environ.get("TECOGAN_WGRAD_STREAMS", "0")))
 
     def backward(self, s0=0, s1=None, dpre=None):
         """consumes grad['dpre'][:s1-s0] (d loss / d pre-sigmoid of samples [s0,s1)) and ACCUMULATES every weight/bias
         gradient.  The T passes are independent in backward (inputs are detached, code/train.py:90,108), so any
-        sample range may be processed as one batch; ranges must not run concurrently (they add into the same grads)."""
+        sample range may be processed as one batch; ranges must not run concurrently (they add into the same grads).
+        The dgrad chain runs on the current stream, the weight gradients on the side streams."""
         NS = self.shape[0]
         s1 = NS if s1 is None else s1
         n = s1 - s0
         a = {k: ([t[s0:s1] for t in v] if isinstance(v, list) else v[s0:s1]) for k, v in self.act.items()}
-        g = {k: v[:n] for k, v in self.grad.items()}
+        g = {k: ([t[:n] for t in v] if isinstance(v, list) else v[:n]) for k, v in self.grad.items()}
         if dpre is not None:
             g["dpre"] = dpre
         RELU = L.MASK_RELU
-        self.cout.wgrad(a["u4"], g["dpre"])                                   # output bias grad: see TecoGANStep
+        sd = self.side
+        self.cout.wgrad(a["u4"], g["dpre"], sd.next())                         # output bias grad: see TecoGANStep
         self.cout.dgrad(g["dpre"], g["hr64"], mask=a["u4"], mask_mode=RELU, bias_grad_of=self.c6)
-        self.c6.wgrad(a["u3"], g["hr64"])
+        self.c6.wgrad(a["u3"], g["hr64"], sd.next())
         self.c6.dgrad(g["hr64"], g["hr128"], mask=a["u3"], mask_mode=RELU, bias_grad_of=self.ct4)
-        self.ct4.wgrad(a["u2"], g["hr128"])
+        self.ct4.wgrad(a["u2"], g["hr128"], sd.next())
         self.ct4.dgrad(g["hr128"], g["m128a"])
-        self.c32.wgrad(a["h2"], g["m128a"])
+        self.c32.wgrad(a["h2"], g["m128a"], sd.next())
         self.c32.dgrad(g["m128a"], g["m128b"], mask=a["h2"], mask_mode=RELU, bias_grad_of=self.c30)
-        self.c30.wgrad(a["u1"], g["m128b"])
+        self.c30.wgrad(a["u1"], g["m128b"], sd.next())
         self.c30.dgrad(g["m128b"], g["m64a"])
-        self.c22.wgrad(a["hh"], g["m64a"])
+        self.c22.wgrad(a["hh"], g["m64a"], sd.next())
         self.c22.dgrad(g["m64a"], g["m64b"], mask=a["hh"], mask_mode=RELU, bias_grad_of=self.c20)
-        self.c20.wgrad(a["u0"], g["m64b"])
-        self.c20.dgrad(g["m64b"], g["m64a"], mask=a["u0"], mask_mode=RELU, bias_grad_of=self.ct0)
-        self.ct0.wgrad(a["a"][self.nrb], g["m64a"])
-        d_a, t1, t2 = g["l64a"], g["l64b"], g["l64c"]
-        self.ct0.dgrad(g["m64a"], d_a)
+        self.c20.wgrad(a["u0"], g["m64b"], sd.next())
+        self.c20.dgrad(g["m64b"], g["m64c"], mask=a["u0"], mask_mode=RELU, bias_grad_of=self.ct0)
+        self.ct0.wgrad(a["a"][self.nrb], g["m64c"], sd.next())
+        dA, dH = g["dA"], g["dH"]
+        self.ct0.dgrad(g["m64c"], dA[self.nrb])
         for i in range(self.nrb - 1, -1, -1):
             c1, c2 = self.rb[i]
-            c2.wgrad(a["h"][i], d_a)
-            c2.dgrad(d_a, t1, mask=a["h"][i], mask_mode=RELU, bias_grad_of=c1)
-            c1.wgrad(a["a"][i], t1)
+            c2.wgrad(a["h"][i], dA[i + 1], sd.next())
+            c2.dgrad(dA[i + 1], dH[i], mask=a["h"][i], mask_mode=RELU, bias_grad_of=c1)
+            c1.wgrad(a["a"][i], dH[i], sd.next())
             if i > 0:
-                c1.dgrad(t1, t2, res=d_a)
+                c1.dgrad(dH[i], dA[i], res=dA[i + 1])
             else:  # a[0] = relu(conv0(in0)): fold its relu' and conv0's bias gradient into the same epilogue
-                c1.dgrad(t1, t2, res=d_a, mask=a["a"][0], mask_mode=RELU, bias_grad_of=self.conv0)
-            d_a, t2 = t2, d_a
-        self.conv0.wgrad(a["in0"], d_a)
+                c1.dgrad(dH[i], dA[i], res=dA[i + 1], mask=a["a"][0], mask_mode=RELU, bias_grad_of=self.conv0)
+        self.conv0.wgrad(a["in0"], dA[0], sd.next())
+        sd.join()
 
 
 # =============================================================================================================
@@ -439,14 +485,19 @@ class DiscriminatorEngine:
         if self.fc_w.numel() != 3 * self.fc_hw:
             raise L.TecoganHipError(f"fc expects {self.fc_w.numel()} inputs but the D input gives {3 * self.fc_hw} "
                                     "(code/models.py:123 hard-wires 48 = 128x128 HR)")
-        g = {}
+        g = {"dz": {}, "dn": {}, "dr": {}, "dh": {}, "dnet": {}}  # one buffer per gradient tensor (see GeneratorEngine)
         hh = H
         for k in range(1, 6):
             hh //= 2
-            g[k] = [e(hh, self.cout[k]) for _ in range(3)]
+            g["dz"][k], g["dn"][k] = e(hh, self.cout[k]), e(hh, self.cout[k])
+            if k <= 3:
+                g["dr"][k] = [e(hh, self.cout[k]) for _ in range(self.nrb)]
+                g["dh"][k] = [e(hh, self.cout[k]) for _ in range(self.nrb)]
+                g["dnet"][k] = [e(hh, self.cout[k]) for _ in range(self.nrb)]
         self.gbuf = g
         self.g_c0 = e(H, 64)
         self.dlogit = torch.empty(N, device=dev)
+        self.side = SideStreams(dev, int(os.environ.get("TECOGAN_WGRAD_STREAMS", "0")))
 
     def stage_out(self, k):
         return self.act["net"][k][self.nrb - 1] if (k <= 3 and self.nrb > 0) else self.act["n"][k]
@@ -483,38 +534,37 @@ class DiscriminatorEngine:
             prev = net
         K.fc_head_fwd(v(a["n"][5]), self.fc_w, self.fc_b, self.prob[sl], sl.stop - sl.start, self.fc_hw, 3, 32)
 
-    def backward(self, groups=2):
-        """consumes self.dlogit; accumulates all D gradients."""
-        a = self.act
+    def backward(self, groups=2, join=True):
+        """consumes self.dlogit; accumulates all D gradients.  dgrad / BN-backward chain on the current stream, weight
+        gradients on the side streams (join=False: the caller joins self.side into the capture's origin stream)."""
+        a, g, sd = self.act, self.gbuf, self.side
         N = a["in"].shape[0]
-        g5 = self.gbuf[5]
-        K.fc_head_bwd(a["n"][5], self.fc_w, self.dlogit, g5[0], self.g_fc_w, self.g_fc_b, N, self.fc_hw, 3, 32)
-        d_net = g5[0]  # gradient w.r.t. n[5]
+        K.fc_head_bwd(a["n"][5], self.fc_w, self.dlogit, g["dn"][5], self.g_fc_w, self.g_fc_b, N, self.fc_hw, 3, 32)
+        d_net = g["dn"][5]  # gradient w.r.t. the current stage's output
         for k in range(5, 0, -1):
-            gk = self.gbuf[k]
             if k <= 3:
-                # d_net is the gradient w.r.t. the stage output; walk the residual blocks backwards
                 for j in range(self.nrb - 1, -1, -1):
                     c1, c2, bnj = self.res[k][j]
                     net_in = a["net"][k][j - 1] if j > 0 else a["n"][k]
-                    free = [b for b in gk if b is not d_net]
-                    d_r, d_h = free[0], free[1]
+                    d_r, d_h = g["dr"][k][j], g["dh"][k][j]
+                    d_in = g["dnet"][k][j - 1] if j > 0 else g["dn"][k]
                     bnj.backward(d_net, None, a["r"][k][j], d_r, L.ACT_NONE, groups)
-                    c2.wgrad(a["h"][k][j], d_r)
+                    c2.wgrad(a["h"][k][j], d_r, sd.next())
                     c2.dgrad(d_r, d_h, mask=a["h"][k][j], mask_mode=L.MASK_RELU, bias_grad_of=c1)
-                    c1.wgrad(net_in, d_h)
-                    c1.dgrad(d_h, d_r, res=d_net)
-                    d_net = d_r
+                    c1.wgrad(net_in, d_h, sd.next())
+                    c1.dgrad(d_h, d_in, res=d_net)
+                    d_net = d_in
             conv, bn = self.blk[k]
-            free = [b for b in gk if b is not d_net]
-            d_z = free[0]
+            d_z = g["dz"][k]
             bn.backward(d_net, a["n"][k], a["z"][k], d_z, L.ACT_LRELU, groups)
             prev = self.stage_out(k - 1) if k > 1 else a["c0"]
-            conv.wgrad(prev, d_z)
+            conv.wgrad(prev, d_z, sd.next())
             if k > 1:
-                d_prev = self.gbuf[k - 1][0]
+                d_prev = g["dnet"][k - 1][self.nrb - 1] if (k - 1 <= 3 and self.nrb > 0) else g["dn"][k - 1]
                 conv.dgrad(d_z, d_prev)
                 d_net = d_prev
             else:
                 conv.dgrad(d_z, self.g_c0, mask=a["c0"], mask_mode=L.MASK_LRELU, bias_grad_of=self.conv0)
-                self.conv0.wgrad(a["in"], self.g_c0)
+                self.conv0.wgrad(a["in"], self.g_c0, sd.next())
+        if join:
+            sd.join()

@@ -7,14 +7,17 @@ segment has been enqueued and overlaps the D backward segment (step.TecoGANStep.
 
 BatchNorm statistics stay per rank (standard DDP; the reference's D is called on per-rank batches anyway), so an N-rank run
 equals "N shards evaluated with local BN, gradients averaged" - that is what tests/test_parallel_cpu.py checks on gloo."""
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def dist_info():
     """(process_group or None, world_size)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return dist.group.WORLD, dist.get_world_size()
+    if dist.is_available() and dist.is_initialized():
+        if dist.get_world_size() > 1 or os.environ.get("TECOGAN_FORCE_DP_SEGMENTS", "0") == "1":
+            return dist.group.WORLD, dist.get_world_size()
     return None, 1
 
 

@@ -117,9 +117,12 @@ class TecoGANStep:
         self.chunks = [(bounds[i], bounds[i + 1]) for i in range(nchunk)]
         cmax = max(t1 - t0 for t0, t1 in self.chunks) * B
         G._alloc_grad(cmax)
+        if nchunk > 1:
+            G.side.streams = []  # chunked backward runs on a forked stream: no nested joins under capture
         # one d(pre-sigmoid) buffer per chunk: chunk i+1's loss kernel must not overwrite what chunk i's backward reads
         self.dpre = [torch.empty((t1 - t0) * B, H, H, 32, dtype=G.dt, device=device) for t0, t1 in self.chunks]
         self.sB, self.sC = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+        self.dreal_early = os.environ.get("TECOGAN_DREAL_EARLY", "1") != "0"
         D.alloc(2 * self.tb, H)
         self._tables()
         self.graphs = None
@@ -159,7 +162,7 @@ class TecoGANStep:
         self.params_dev.copy_(slot, non_blocking=True)
 
     # ----------------------------------------------------------------------------------------------------------
-    def _forward_backward(self, include_d_backward):
+    def _forward_backward(self, include_d_backward, parts=None):
         """Everything up to (and including) the backward passes, as a fork/join over three streams so that the serial
         generator chain (<= 64 workgroups per launch at B=4) shares the chip with independent dense work:
             main : pseudo-flow, T_vel | G pass 0 .. T-1 (each: warp+pack, 41 convs) | content loss per frame chunk
@@ -170,6 +173,9 @@ class TecoGANStep:
         G, D, B, T, h, H = self.G, self.D, self.B, self.T, self.h, self.H
         hh, HH = h * h, H * H
         main, sB, sC = torch.cuda.current_stream(), self.sB, self.sC
+        on = (lambda name: True) if parts is None else (lambda name: name in parts)  # tools/step_breakdown.py only
+        G.side.prefork(main)
+        D.side.prefork(main)
         self.acc.zero_()
         D.arena.zero()
         G.flat.g.zero_()
@@ -180,13 +186,15 @@ class TecoGANStep:
         K.copy_blocks(self.flow, self.tv_csrc, self.tvel, self.tv_cdst, self.n_tvc, 2 * HH)
         K.up4_planes(self.x, self.tv_bsrc, self.tvel, self.tv_bdst, self.n_tvb, h, h, pre=4.0, post_a=2.0, post_b=-1.0)
         tb = self.tb
+        early = self.dreal_early
         sB.wait_stream(main)
         with torch.cuda.stream(sB):
-            K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"][:tb], B, T, self.K, h, self.border, half=0)
-            K.nhwc_to_nchw(D.act["in"][:tb], self.target, 27 * HH, tb, 27, H, H)
-            D.forward(update_stats=True, half=0)
+            if on("dreal") and early:
+                K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"][:tb], B, T, self.K, h, self.border, half=0)
+                K.nhwc_to_nchw(D.act["in"][:tb], self.target, 27 * HH, tb, 27, H, H)
+                D.forward(update_stats=True, half=0)
         ci = 0
-        for t in range(T):
+        for t in range(T if on("chain") else 0):
             dst = G.act["in0"][t * B:(t + 1) * B]
             if t == 0:
                 K.gen_input(self.x, 0, T * 3 * hh, None, 0, 0, None, 0, 0, dst, B, h, h)
@@ -194,26 +202,37 @@ class TecoGANStep:
                 K.gen_input(self.x, t * 3 * hh, T * 3 * hh, self.gen, (t - 1) * 3 * HH, T * 3 * HH, self.flow,
                             (t - 1) * 2 * HH, (T - 1) * 2 * HH, dst, B, h, h)
             G.forward(t * B, B, self.gen, t * 3 * HH, T * 3 * HH)
-            if t + 1 == self.chunks[ci][1]:
+            if t + 1 == self.chunks[ci][1] and on("gbwd"):
                 t0, t1 = self.chunks[ci]
                 K.content_loss(self.gen, self.y, self.dpre[ci], self.acc, B, T, H, H, 1.0 / (B * T * 3 * H), t0, t1)
-                sC.wait_stream(main)
-                with torch.cuda.stream(sC):
-                    G.backward(t0 * B, t1 * B, dpre=self.dpre[ci])
+                if len(self.chunks) > 1:  # experimental frame-chunked backward beside the chain (measured slower)
+                    sC.wait_stream(main)
+                    with torch.cuda.stream(sC):
+                        G.backward(t0 * B, t1 * B, dpre=self.dpre[ci])
                 ci += 1
         sB.wait_stream(main)  # all frames generated, content-loss sum complete
+        if len(self.chunks) == 1 and on("gbwd") and on("chain"):
+            # the chain is over, so the main (origin) stream carries the G backward's dgrad chain; its weight gradients
+            # fan out to G.side and join back into main
+            G.backward(0, T * B, dpre=self.dpre[0])
         with torch.cuda.stream(sB):
-            K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"][tb:], B, T, self.K, h, self.border, half=1)
-            D.forward(update_stats=True, half=1)
-            if self.args.D_LAYERLOSS:
+            if on("dfake") and early:
+                K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"][tb:], B, T, self.K, h, self.border, half=1)
+                D.forward(update_stats=True, half=1)
+            elif on("dfake"):  # both halves as ONE batch of 2*tb samples (BN statistics per half), after the chain
+                K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"], B, T, self.K, h, self.border, half=-1)
+                K.nhwc_to_nchw(D.act["in"][:tb], self.target, 27 * HH, tb, 27, H, H)
+                D.forward(groups=2, update_stats=True)
+            if self.args.D_LAYERLOSS and on("dfake"):
                 for i, l in enumerate(D.layers()):
                     n = tb * l.shape[1] * l.shape[2]
                     K.absdiff_sum(l[:tb], l[tb:], self.acc, 2 + i, n, l.shape[3], l.shape[3])
             K.loss_finalize(D.prob, self.acc, self.scalars, D.dlogit, tb, self.cfg)
-            if include_d_backward:
-                D.backward(groups=2)
+            if include_d_backward and on("dbwd"):
+                D.backward(groups=2, join=False)
         main.wait_stream(sB)
         main.wait_stream(sC)
+        D.side.join(main)
         G.cout.gbias[:3] += self.acc[8:11]
 
     def _d_backward(self):
@@ -227,12 +246,15 @@ class TecoGANStep:
         D.repack()
 
     def _allreduce(self, buf):
+        if self.pg is not None and os.environ.get("TECOGAN_FORCE_DP_SEGMENTS", "0") == "1":
+            import torch.distributed as dist  # test hook: exercise the RCCL call path even with one rank
+            return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         return parallel.allreduce_sum_async(buf, self.pg, self.world)
 
     def _segments(self):
         """single GPU: [forward + both backward passes | update].  Data parallel: the D backward is its own segment so
         that the RCCL all-reduce of the G gradients (launched between segments) overlaps it."""
-        if self.world == 1:
+        if self.world == 1 and os.environ.get("TECOGAN_FORCE_DP_SEGMENTS", "0") != "1":
             return [lambda: self._forward_backward(True), None, self._update]
         return [lambda: self._forward_backward(False), self._d_backward, self._update]
 

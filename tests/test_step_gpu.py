@@ -280,3 +280,25 @@ def test_main_entry_point_synthetic_train_and_resume(tmp_path, monkeypatch):
                   str(tmp_path / "generator.pt"), "--d_checkpoint", str(tmp_path / "discrim.pt")])  # epoch0 == 0 -> runs 1 epoch
     g2 = torch.load(tmp_path / "generator.pt")
     assert float(g2["optimizer_state_dict"]["state"][0]["step"]) == 3.0
+
+
+def test_data_parallel_segments_on_one_gpu(tmp_path):
+    """The 8-GPU run is the driver's; here the same code path (torch.distributed.run, RCCL process group, the three
+    graph segments with the all-reduces between them) is exercised with ONE rank and must reproduce the single-process
+    losses."""
+    import json
+    import subprocess
+    env = dict(os.environ, TECOGAN_FORCE_DP_SEGMENTS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
+           "--warmup", "2", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    dp = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2",
+                         "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    sp = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert dp["n_gpus"] == 1 and dp["config"]["parallelism"] == "dp1"
+    np.testing.assert_allclose(dp["final_losses"]["gen_loss"], sp["final_losses"]["gen_loss"], rtol=2e-3)
+    np.testing.assert_allclose(dp["final_losses"]["d_loss"], sp["final_losses"]["d_loss"], rtol=5e-2, atol=2e-3)
