@@ -60,14 +60,16 @@ def conv_flops(spec, N, H, W):
     return 2.0 * N * H * W * 9 * spec.cin * spec.cout  # conv-transpose: every input pixel meets all 9 taps
 
 
-def tile_label(K, L, spec_rows_p, S, px):
-    if spec_rows_p % 64:
-        return "32x128"
-    if S > 1:
-        return "128x128" if spec_rows_p % 128 == 0 else "64x64"
-    if px < 64 * 1024:
-        return "64x64"
-    return "128x128" if spec_rows_p % 128 == 0 else "64x256"
+TILE_PARAMS = {1: "4, 4, 1, 4", 2: "2, 2, 2, 2", 3: "4, 4, 2, 2", 4: "2, 2, 1, 4", 5: "2, 1, 1, 4", 6: "4, 2, 1, 4"}
+
+
+def kernel_name(conv, dtype):
+    """the rocprofv3 kernel name of the launch `conv` just made (template parameters from the C library's launch plan)"""
+    import ctypes
+    from pytorch_tecogan_amd import _lib as L
+    plan = L.load().tg_conv_pick_tile(ctypes.byref(conv.last_desc))
+    t = "BF16" if dtype == "bf16" else "F32"
+    return f"conv_gather_kernel<{t}, {TILE_PARAMS[plan & 255]}, {'true' if plan >> 8 else 'false'}>"
 
 
 def roofline_pass(st, dtype):
@@ -83,7 +85,7 @@ def roofline_pass(st, dtype):
             e0.record()
             r = fn(self, *a, **kw)
             e1.record()
-            recs.append((label_fn(self, *a), flops_fn(self, *a), e0, e1))
+            recs.append((label_fn(self, *a), flops_fn(self, *a), e0, e1))  # label AFTER the call: needs last_desc
             return r
         return wrapper
 
@@ -91,15 +93,10 @@ def roofline_pass(st, dtype):
         return x.shape[0], x.shape[1], x.shape[2]
 
     def lab_fwd(self, x, *a):
-        N, H, W = in_shape_fwd(self, x)
-        OH, OW = self.spec.out_hw(H, W)
-        g = self.spec.fwd_geom()
-        return f"conv_gather<{dtype},{tile_label(K, None, self.cout_p, g.S, N * OH * OW)}>"
+        return kernel_name(self, dtype)
 
     def lab_dgrad(self, dout, out, *a):
-        g = self.spec.dgrad_geom()
-        N, H, W = out.shape[0], out.shape[1], out.shape[2]
-        return f"conv_gather<{dtype},{tile_label(K, None, self.cin_p, g.S, N * H * W)}>"
+        return kernel_name(self, dtype)
 
     def fl_fwd(self, x, *a):
         return conv_flops(self.spec, *in_shape_fwd(self, x))
@@ -112,12 +109,17 @@ def roofline_pass(st, dtype):
 
     E.Conv.fwd = timed(lab_fwd, fl_fwd, orig_fwd)
     E.Conv.dgrad = timed(lab_dgrad, fl_dgrad, orig_dgrad)
-    E.Conv.wgrad = timed(lambda self, *a: f"wgrad<{dtype},{self.spec.nslots}taps>(+finalize)", fl_wgrad, orig_wgrad)
+    E.Conv.wgrad = timed(lambda self, *a: f"wgrad_kernel<{'BF16' if dtype == 'bf16' else 'F32'}, {self.spec.nslots}, ..> + "
+                         "wgrad_finalize_kernel", fl_wgrad, orig_wgrad)
     side = (st.sB, st.sC)
     st.sB = st.sC = torch.cuda.current_stream()  # serialise the fork/join schedule: isolated per-launch durations
     pools = (st.G.side.streams, st.D.side.streams)
     st.G.side.streams, st.D.side.streams = [], []
     try:
+        # park the GPU behind a ~60 ms spin kernel so that the host enqueues the whole eager step ahead of it: the event
+        # pairs then bracket back-to-back kernel executions, not host launch gaps (eager launches are host-bound here)
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(0.06 * 2.0e9))
         st._forward_backward(True)
         torch.cuda.synchronize()
     finally:
@@ -144,6 +146,20 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are separate
+    runs of this same command; they cannot be collected live).  gfx950 correction: FETCH_SIZE counts 64 B per 128-B request."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        tab = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    ent = tab.get(kernel)
+    if not ent:
+        return None, None
+    return int(ent["hbm_bytes_per_launch"]), "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, not live)"
 
 
 def cpu_baseline(B, n_steps):
@@ -247,9 +263,11 @@ def main():
             dom = max(fam, key=lambda k: fam[k]["ms"])
             d = fam[dom]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic(dom)
             res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
                                "peak": MFMA_PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
-                               "frac": round(ach / MFMA_PEAK_TFLOPS[a.dtype], 5), "traffic": None,
+                               "frac": round(ach / MFMA_PEAK_TFLOPS[a.dtype], 5), "traffic": traffic,
+                               "traffic_source": traffic_src,
                                "launches_per_step": d["launches"],
                                "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
                                "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3),

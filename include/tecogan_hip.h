@@ -98,6 +98,9 @@ int tg_pack_conv_weights_multi(int dtype, const int64_t* jobs_dev, int njobs, in
 /* Gather convolution on MFMA: conv3x3 (code/models.py:54-58,68,73-76,102 via code/ops.py:57-63), conv4x4 stride 2
  * (code/models.py:90-94), conv-transpose k3 s2 p1 op1 as four sub-pixel classes (code/ops.py:45-54;
  * code/models.py:72,74) and the input-gradient of each (aten::convolution_backward, code/train.py:336,340). */
+/* Launch plan of tg_conv for this descriptor: TG_TILE_* id (AUTO resolved) | (1<<8 if the compile-time 3x3 variant is
+ * used); negative TG_E_* on an invalid descriptor.  For tooling/benchmarks; launches nothing. */
+int tg_conv_pick_tile(const tg_conv_desc* d);
 int tg_conv(const tg_conv_desc* d, const void* in, const void* w_packed, const float* bias, const void* res,
             const void* mask, void* out, float* stats, void* stream);
 

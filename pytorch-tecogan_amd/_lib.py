@@ -46,6 +46,7 @@ _PROTOS = {
     "tg_packed_weight_bytes": (_L, [_I, _I, _I, _I]),
     "tg_pack_conv_weights": (_I, [_I, _P, _P, _I, _I, _I, _I, _L, _L, _I, _P, _P]),
     "tg_pack_conv_weights_multi": (_I, [_I, _P, _I, _I, _P]),
+    "tg_conv_pick_tile": (_I, [C.POINTER(ConvDesc)]),
     "tg_conv": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "tg_wgrad_slab_floats": (_L, [C.POINTER(WgradDesc)]),
     "tg_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P]),

@@ -509,23 +509,8 @@ extern "C" int tg_pack_conv_weights(int dtype, const float* w, void* packed, int
   return tg_launch_status();
 }
 
-extern "C" int tg_conv(const tg_conv_desc* d, const void* in, const void* w_packed, const float* bias, const void* res,
-                       const void* mask, void* out, float* stats, void* stream) {
-  if (!d || !in || !w_packed || !out) return TG_E_BADARG;
-  if (d->dtype != TG_F32 && d->dtype != TG_BF16) return TG_E_BADARG;
-  if (d->N <= 0 || d->IH <= 0 || d->IW <= 0 || d->OH <= 0 || d->OW <= 0 || d->S <= 0 || d->OS <= 0) return TG_E_BADARG;
-  if (d->ncls <= 0 || d->ncls > TG_MAX_CLASSES) return TG_E_BADARG;
-  if (d->Cin <= 0 || d->Cout <= 0 || d->Cin % 32 || d->Cout % 32) return TG_E_ALIGN;
-  if (!tg_aligned16(in) || !tg_aligned16(w_packed) || !tg_aligned16(out) || (res && !tg_aligned16(res)) ||
-      (mask && !tg_aligned16(mask)))
-    return TG_E_ALIGN;
-  if (d->mask_mode != TG_MASK_NONE && !mask) return TG_E_BADARG;
-  if (d->stats_mode < 0 || d->stats_mode > 2) return TG_E_BADARG;
-  if (d->stats_mode && (!stats || d->stats_groups <= 0 || d->N % d->stats_groups)) return TG_E_BADARG;
-  if (d->out_mode == TG_OUT_NCHW_F32 && (d->c_real <= 0 || d->c_real > 4 || d->out_n_stride <= 0)) return TG_E_BADARG;
-  if (d->out_mode != TG_OUT_NHWC && d->out_mode != TG_OUT_NCHW_F32) return TG_E_BADARG;
-  if (d->out_mode == TG_OUT_NCHW_F32 && (res || d->mask_mode)) return TG_E_UNSUPPORTED;
-
+// tile configuration of a launch (TG_TILE_AUTO resolved from the per-layer measurements)
+static int pick_tile(const tg_conv_desc* d) {
   int cfg = d->tile_cfg;
   if (cfg == TG_TILE_AUTO) {
     long long px = 0;
@@ -541,10 +526,36 @@ extern "C" int tg_conv(const tg_conv_desc* d, const void* in, const void* w_pack
     else if (d->Cout == 64 && d->ncls == 1 && d->Cin <= 64 && px <= 16384) cfg = TG_TILE_32x64;  // recurrent-pass trunk: 6.6 vs 7.7 us
     else cfg = TG_TILE_64x64;
   }
+  return cfg;
+}
+
+// validates the descriptor and derives the launch plan (tile config, LDS split, grid); shared by tg_conv and tg_conv_pick_tile
+static int prepare_conv(const tg_conv_desc* d, const void* in, const void* w_packed, const float* bias, const void* res,
+                        const void* mask, void* out, float* stats, bool check_ptrs, ConvK& k, dim3& grid, size_t& lds_out,
+                        int& cfg_out) {
+  if (!d) return TG_E_BADARG;
+  if (check_ptrs && (!in || !w_packed || !out)) return TG_E_BADARG;
+  if (d->dtype != TG_F32 && d->dtype != TG_BF16) return TG_E_BADARG;
+  if (d->N <= 0 || d->IH <= 0 || d->IW <= 0 || d->OH <= 0 || d->OW <= 0 || d->S <= 0 || d->OS <= 0) return TG_E_BADARG;
+  if (d->ncls <= 0 || d->ncls > TG_MAX_CLASSES) return TG_E_BADARG;
+  if (d->Cin <= 0 || d->Cout <= 0 || d->Cin % 32 || d->Cout % 32) return TG_E_ALIGN;
+  if (check_ptrs) {
+    if (!tg_aligned16(in) || !tg_aligned16(w_packed) || !tg_aligned16(out) || (res && !tg_aligned16(res)) ||
+        (mask && !tg_aligned16(mask)))
+      return TG_E_ALIGN;
+    if (d->mask_mode != TG_MASK_NONE && !mask) return TG_E_BADARG;
+    if (d->stats_mode && !stats) return TG_E_BADARG;
+  }
+  if (d->stats_mode < 0 || d->stats_mode > 2) return TG_E_BADARG;
+  if (d->stats_mode && (d->stats_groups <= 0 || d->N % d->stats_groups)) return TG_E_BADARG;
+  if (d->out_mode == TG_OUT_NCHW_F32 && (d->c_real <= 0 || d->c_real > 4 || d->out_n_stride <= 0)) return TG_E_BADARG;
+  if (d->out_mode != TG_OUT_NHWC && d->out_mode != TG_OUT_NCHW_F32) return TG_E_BADARG;
+  if (d->out_mode == TG_OUT_NCHW_F32 && (res || d->mask_mode)) return TG_E_UNSUPPORTED;
+
+  const int cfg = pick_tile(d);
   const TileCfg tc = tile_cfg(cfg);
   if (!tc.co_tile || d->Cout % tc.co_tile) return TG_E_UNSUPPORTED;
 
-  ConvK k;
   k.in = (const char*)in; k.w = (const char*)w_packed; k.bias = bias; k.res = (const char*)res;
   k.mask = (const char*)mask; k.out = (char*)out; k.stats = stats;
   k.N = d->N; k.IH = d->IH; k.IW = d->IW; k.Cin = d->Cin; k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout;
@@ -617,7 +628,29 @@ extern "C" int tg_conv(const tg_conv_desc* d, const void* in, const void* w_pack
   lds = std::max<size_t>(lds, 4 * 2 * tc.co_tile * sizeof(float));  // stats scratch
   k.tg = tg;
   k.cg = cg;
-  dim3 grid((unsigned)gx, (unsigned)(d->Cout / tc.co_tile), (unsigned)d->ncls);
+  grid = dim3((unsigned)gx, (unsigned)(d->Cout / tc.co_tile), (unsigned)d->ncls);
+  lds_out = lds;
+  cfg_out = cfg;
+  return TG_OK;
+}
+
+extern "C" int tg_conv_pick_tile(const tg_conv_desc* d) {
+  ConvK k;
+  dim3 grid;
+  size_t lds;
+  int cfg;
+  const int rc = prepare_conv(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, k, grid, lds, cfg);
+  return rc != TG_OK ? rc : (cfg | (k.std3 << 8));
+}
+
+extern "C" int tg_conv(const tg_conv_desc* d, const void* in, const void* w_packed, const float* bias, const void* res,
+                       const void* mask, void* out, float* stats, void* stream) {
+  ConvK k;
+  dim3 grid;
+  size_t lds;
+  int cfg;
+  const int rc = prepare_conv(d, in, w_packed, bias, res, mask, out, stats, true, k, grid, lds, cfg);
+  if (rc != TG_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   return d->dtype == TG_BF16 ? dispatch_conv<BF16>(cfg, k, grid, lds, st) : dispatch_conv<F32>(cfg, k, grid, lds, st);
 }

@@ -117,6 +117,7 @@ class Conv:
                                  out_mode=L.OUT_NCHW_F32 if nchw else L.OUT_NHWC, c_real=nchw[3] if nchw else 0,
                                  out_n_stride=nchw[2] if nchw else 0, tile_cfg=self.tile)
             self._desc[key] = d
+        self.last_desc = d
         if nchw:
             import ctypes
             buf, off = nchw[0], nchw[1]
@@ -137,6 +138,7 @@ class Conv:
             d = K.make_conv_desc(self.spec.dgrad_geom(), self.tg, N, OH, OW, self.cout_p, H, W, self.cin_p,
                                  mask_mode=mask_mode, stats_mode=1 if st is not None else 0, stats_groups=1)
             self._desc[key] = d
+        self.last_desc = d
         K.conv(d, dout, self.wb, out, res=res, mask=mask, stats=st)
 
     def wgrad(self, x_in, dout, side=None):
