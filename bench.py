@@ -76,7 +76,7 @@ def roofline_pass(st, dtype):
     """One eager step with a start/stop event pair around every MFMA launch; returns the per-family table."""
     from pytorch_tecogan_amd import engine as E
     from pytorch_tecogan_amd import kernels as K
-    recs = []
+    recs, replays = [], {}
     orig_fwd, orig_dgrad, orig_wgrad = E.Conv.fwd, E.Conv.dgrad, E.Conv.wgrad
 
     def timed(label_fn, flops_fn, fn):
@@ -85,7 +85,9 @@ def roofline_pass(st, dtype):
             e0.record()
             r = fn(self, *a, **kw)
             e1.record()
-            recs.append((label_fn(self, *a), flops_fn(self, *a), e0, e1))  # label AFTER the call: needs last_desc
+            lab = label_fn(self, *a)  # label AFTER the call: needs last_desc
+            recs.append((lab, flops_fn(self, *a), e0, e1))
+            replays.setdefault(lab, []).append(lambda: fn(self, *a, **kw))
             return r
         return wrapper
 
@@ -132,6 +134,19 @@ def roofline_pass(st, dtype):
         d["launches"] += 1
         d["flops"] += fl
         d["ms"] += e0.elapsed_time(e1)
+    # An event pair costs several microseconds of its own, which matters for the ~7 us recurrent-pass launches.  The
+    # dominant family is therefore re-timed as ONE bracket around all of its launches (same arguments, back to back,
+    # GPU parked first): that is the average duration rocprofv3 --kernel-trace reports, plus the inter-kernel gap.
+    dom = max(fam, key=lambda k: fam[k]["ms"])
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(0.03 * 2.0e9))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for call in replays[dom]:
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    fam[dom]["ms_bracketed_once"] = e0.elapsed_time(e1)
     return fam
 
 
@@ -262,14 +277,16 @@ def main():
             fam = roofline_pass(st, a.dtype)
             dom = max(fam, key=lambda k: fam[k]["ms"])
             d = fam[dom]
-            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            dom_ms = d.get("ms_bracketed_once", d["ms"])
+            ach = d["flops"] / (dom_ms * 1e-3) / 1e12
             traffic, traffic_src = pmc_traffic(dom)
             res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
                                "peak": MFMA_PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
                                "frac": round(ach / MFMA_PEAK_TFLOPS[a.dtype], 5), "traffic": traffic,
                                "traffic_source": traffic_src,
                                "launches_per_step": d["launches"],
-                               "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+                               "avg_launch_us": round(dom_ms * 1e3 / d["launches"], 2),
+                               "avg_launch_us_with_event_pair_per_launch": round(d["ms"] * 1e3 / d["launches"], 2),
                                "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3),
                                "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}

@@ -171,140 +171,198 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
   // the L2/HBM latency, and a load->store->load chain costs one round trip per 16 bytes.
   // UA activation pieces and UW (chunk,tap) weight blocks per thread are loaded in ONE issue phase before any LDS store.
   constexpr int UA = 6;
-  constexpr int UW = (CT * PT <= 4) ? 18 : 8;  // small tiles: the whole K of a 64-channel 3x3 layer in flight at once
+  constexpr int UW = (CT * PT <= 4) ? 18 : 9;  // small tiles: the whole K of a 64-channel 3x3 layer in flight at once
   constexpr int PIECES = CO_TILE * 4, PPT = (PIECES + 255) / 256;
   const int a_stride = p.a_rows_max * kRowBytes;  // LDS bytes of one chunk's activation patch
   const float inv_iw = 1.0f / (float)cl.iw, inv_prow = 1.0f / (float)prow_n;
-  for (int c0 = 0; c0 < p.nchunks; c0 += p.cg) {
-    const int cn = min(p.cg, p.nchunks - c0);
-    for (int t0 = 0; t0 < ntaps; t0 += p.tg) {
-      const int tn = min(p.tg, ntaps - t0);
-      __syncthreads();  // previous fragment reads are done before LDS is overwritten
-      const int total_a = (t0 == 0) ? cn * prow_n * 4 : 0;
-      const int nq = cn * tn;
-      int a_done = 0, q_done = 0;
-      while (a_done < total_a || q_done < nq) {
-        u32x4 va[UA];
-        int da[UA];
-        u32x4 vw[UW][PPT];
-        // ---- issue phase.  Patch coordinates use exact float reciprocals (no hardware integer divide; ~35 VALU each
-        // would be microseconds at one wave per SIMD).
+  if constexpr (STD3) {
+    // ---- 3x3 fast path, software-pipelined over chunk groups: the global loads of group i+1 are issued right after
+    // group i has been written to LDS and stay in flight (in registers) while the MFMAs of group i run.  The host
+    // guarantees that one group fits one issue: cg*prow_n*4 <= 256*UA pieces and cg*9 <= UW weight blocks.
+    const int pitch = cl.iw * kRowBytes;
+    int xbase[PT];
 #pragma unroll
-        for (int u = 0; u < UA; ++u) {
-          const int i = a_done + tid + u * 256;
-          va[u] = u32x4{0u, 0u, 0u, 0u};
-          da[u] = -1;
-          if (i < total_a) {
-            const int s = i & 3, r = i >> 2;
-            const int cc = (int)(((float)r + 0.5f) * inv_prow), prow = r - cc * prow_n;
-            const int py = (int)(((float)prow + 0.5f) * inv_iw), px = prow - py * cl.iw;
-            const int iy = iy0 + py, ix = ix0 + px;
-            da[u] = cc * a_stride + prow * kRowBytes + s * 16;
-            if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
-              va[u] = *reinterpret_cast<const u32x4*>(in_n + ((size_t)iy * p.IW + ix) * in_pix_bytes +
-                                                      (size_t)(c0 + cc) * 64 + s * 16);
-          }
+    for (int b = 0; b < PT; ++b) xbase[b] = (wp * PT + b) * pitch + idx * kRowBytes + g * 16;
+    const int wbase = (wc * CT * 16 + idx) * kRowBytes + g * 16;
+    u32x4 va[UA];
+    int da[UA];
+    u32x4 vw[UW][PPT];
+    auto issue = [&](int c0, int cn) {
+      const int total_a = cn * prow_n * 4;
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        const int i = tid + u * 256;
+        va[u] = u32x4{0u, 0u, 0u, 0u};
+        da[u] = -1;
+        if (i < total_a) {
+          const int s = i & 3, r = i >> 2;
+          const int cc = (int)(((float)r + 0.5f) * inv_prow), prow = r - cc * prow_n;
+          const int py = (int)(((float)prow + 0.5f) * inv_iw), px = prow - py * cl.iw;
+          const int iy = iy0 + py, ix = ix0 + px;
+          da[u] = cc * a_stride + prow * kRowBytes + s * 16;
+          if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
+            va[u] = *reinterpret_cast<const u32x4*>(in_n + ((size_t)iy * p.IW + ix) * in_pix_bytes +
+                                                    (size_t)(c0 + cc) * 64 + s * 16);
         }
-        // weights: for one (chunk, tap) the CO_TILE packed rows are contiguous in global memory: a plain block copy
-#pragma unroll
-        for (int u = 0; u < UW; ++u) {
-          const int qq = q_done + u;  // wave-uniform
-          if (qq < nq) {
-            int cc, tt, slot;
-            if constexpr (STD3) {  // tn == 9, slot == tap: compile-time split of the block index, no table access
-              cc = (q_done + u) / 9;
-              tt = (q_done + u) - cc * 9;
-              slot = tt;
-            } else {
-              cc = qq / tn;
-              tt = qq - cc * tn;
-              slot = cl.widx[t0 + tt];
-            }
-            const char* src = p.w + (((size_t)slot * p.nchunks + c0 + cc) * p.Cout + co_base) * 64;
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-              const int piece = tid + k * 256;
-              if (PIECES % 256 == 0 || piece < PIECES) vw[u][k] = *reinterpret_cast<const u32x4*>(src + piece * 16);
-            }
-          }
-        }
-        // ---- store phase
-        TG_STAMP_AT(1);
-#pragma unroll
-        for (int u = 0; u < UA; ++u)
-          if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_a + da[u]) = va[u];
-        TG_STAMP_AT(2);
-#pragma unroll
-        for (int u = 0; u < UW; ++u) {
-          const int qq = q_done + u;
-          if (qq < nq) {
-            const int cc = STD3 ? (q_done + u) / 9 : qq / tn;
-            const int tt = STD3 ? (q_done + u) - cc * 9 : qq - cc * tn;
-            char* dstw = lds_w + (cc * p.tg + tt) * CO_TILE * kRowBytes;
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-              const int piece = tid + k * 256;
-              if (PIECES % 256 == 0 || piece < PIECES)
-                *reinterpret_cast<u32x4*>(dstw + (piece >> 2) * kRowBytes + (piece & 3) * 16) = vw[u][k];
-            }
-          }
-        }
-        a_done += 256 * UA;
-        q_done += UW;
-        TG_STAMP_AT(3);
       }
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        if (u < cn * 9) {  // wave-uniform; (chunk, tap) split is compile-time, slot == tap
+          const int cc = u / 9, tt = u - cc * 9;
+          const char* src = p.w + (((size_t)tt * p.nchunks + c0 + cc) * p.Cout + co_base) * 64;
+#pragma unroll
+          for (int k = 0; k < PPT; ++k) {
+            const int piece = tid + k * 256;
+            if (PIECES % 256 == 0 || piece < PIECES) vw[u][k] = *reinterpret_cast<const u32x4*>(src + piece * 16);
+          }
+        }
+      }
+    };
+    auto store = [&](int cn) {
+#pragma unroll
+      for (int u = 0; u < UA; ++u)
+        if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_a + da[u]) = va[u];
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        if (u < cn * 9) {
+          char* dstw = lds_w + u * CO_TILE * kRowBytes;  // [cc][tt] with tg == 9
+#pragma unroll
+          for (int k = 0; k < PPT; ++k) {
+            const int piece = tid + k * 256;
+            if (PIECES % 256 == 0 || piece < PIECES)
+              *reinterpret_cast<u32x4*>(dstw + (piece >> 2) * kRowBytes + (piece & 3) * 16) = vw[u][k];
+          }
+        }
+      }
+    };
+    issue(0, min(p.cg, p.nchunks));
+    for (int c0 = 0; c0 < p.nchunks; c0 += p.cg) {
+      const int cn = min(p.cg, p.nchunks - c0);
+      __syncthreads();  // previous fragment reads are done before LDS is overwritten
+      TG_STAMP_AT(1);
+      store(cn);
+      TG_STAMP_AT(3);
       __syncthreads();
       TG_STAMP_AT(4);
-
-      if constexpr (STD3) {
-        // whole 3x3 in one tap group (host guarantees tg == 9): offsets are compile-time multiples of the patch pitch
-        const int pitch = cl.iw * kRowBytes;
-        int xbase[PT];
+      const int c1 = c0 + p.cg;
+      if (c1 < p.nchunks) issue(c1, min(p.cg, p.nchunks - c1));
+      for (int cc = 0; cc < cn; ++cc) {
+        const char* la = lds_a + cc * a_stride;
+        const char* lw = lds_w + cc * 9 * CO_TILE * kRowBytes + wbase;
 #pragma unroll
-        for (int b = 0; b < PT; ++b) xbase[b] = (wp * PT + b) * pitch + idx * kRowBytes + g * 16;
-        const int wbase = (wc * CT * 16 + idx) * kRowBytes + g * 16;
-        for (int cc = 0; cc < cn; ++cc) {
-          const char* la = lds_a + cc * a_stride;
-          const char* lw = lds_w + cc * 9 * CO_TILE * kRowBytes + wbase;
+        for (int tt = 0; tt < 9; ++tt) {
+          const int r = p.flip ? 2 - tt / 3 : tt / 3, c = p.flip ? 2 - tt % 3 : tt % 3;
+          const int toff = r * pitch + c * kRowBytes;
+          Frag wf[CT];
 #pragma unroll
-          for (int tt = 0; tt < 9; ++tt) {
-            const int r = p.flip ? 2 - tt / 3 : tt / 3, c = p.flip ? 2 - tt % 3 : tt % 3;
-            const int toff = r * pitch + c * kRowBytes;
-            Frag wf[CT];
+          for (int a = 0; a < CT; ++a) wf[a] = *reinterpret_cast<const Frag*>(lw + (tt * CO_TILE + a * 16) * kRowBytes);
 #pragma unroll
-            for (int a = 0; a < CT; ++a)
-              wf[a] = *reinterpret_cast<const Frag*>(lw + (tt * CO_TILE + a * 16) * kRowBytes);
+          for (int b = 0; b < PT; ++b) {
+            const Frag xf = *reinterpret_cast<const Frag*>(la + xbase[b] + toff);
 #pragma unroll
-            for (int b = 0; b < PT; ++b) {
-              const Frag xf = *reinterpret_cast<const Frag*>(la + xbase[b] + toff);
-#pragma unroll
-              for (int a = 0; a < CT; ++a) acc[a][b] = Mma<T>::run(wf[a], xf, acc[a][b]);
-            }
+            for (int a = 0; a < CT; ++a) acc[a][b] = Mma<T>::run(wf[a], xf, acc[a][b]);
           }
         }
-      } else {
-        for (int cc = 0; cc < cn; ++cc) {
-          const char* la = lds_a + cc * a_stride;
-#pragma unroll 2
-          for (int tt = 0; tt < tn; ++tt) {
-            const int toff = tap_off[t0 + tt];  // LDS table: ((dy-dymin)*iw + dx-dxmin) * row bytes
-            const char* lw = lds_w + (cc * p.tg + tt) * CO_TILE * kRowBytes;
-            Frag wf[CT];
-#pragma unroll
-            for (int a = 0; a < CT; ++a)
-              wf[a] = *reinterpret_cast<const Frag*>(lw + ((wc * CT + a) * 16 + idx) * kRowBytes + g * 16);
-#pragma unroll
-            for (int b = 0; b < PT; ++b) {
-              const int ty = wp * PT + b;
-              const int prow = (ty * cl.iw + idx) * p.S;
-              const Frag xf = *reinterpret_cast<const Frag*>(la + prow * kRowBytes + toff + g * 16);
-#pragma unroll
-              for (int a = 0; a < CT; ++a) acc[a][b] = Mma<T>::run(wf[a], xf, acc[a][b]);
+      }
+    }
+  } else {
+    for (int c0 = 0; c0 < p.nchunks; c0 += p.cg) {
+      const int cn = min(p.cg, p.nchunks - c0);
+      for (int t0 = 0; t0 < ntaps; t0 += p.tg) {
+        const int tn = min(p.tg, ntaps - t0);
+        __syncthreads();  // previous fragment reads are done before LDS is overwritten
+        const int total_a = (t0 == 0) ? cn * prow_n * 4 : 0;
+        const int nq = cn * tn;
+        int a_done = 0, q_done = 0;
+        while (a_done < total_a || q_done < nq) {
+          u32x4 va[UA];
+          int da[UA];
+          u32x4 vw[UW][PPT];
+          // ---- issue phase.  Patch coordinates use exact float reciprocals (no hardware integer divide; ~35 VALU each
+          // would be microseconds at one wave per SIMD).
+  #pragma unroll
+          for (int u = 0; u < UA; ++u) {
+            const int i = a_done + tid + u * 256;
+            va[u] = u32x4{0u, 0u, 0u, 0u};
+            da[u] = -1;
+            if (i < total_a) {
+              const int s = i & 3, r = i >> 2;
+              const int cc = (int)(((float)r + 0.5f) * inv_prow), prow = r - cc * prow_n;
+              const int py = (int)(((float)prow + 0.5f) * inv_iw), px = prow - py * cl.iw;
+              const int iy = iy0 + py, ix = ix0 + px;
+              da[u] = cc * a_stride + prow * kRowBytes + s * 16;
+              if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
+                va[u] = *reinterpret_cast<const u32x4*>(in_n + ((size_t)iy * p.IW + ix) * in_pix_bytes +
+                                                        (size_t)(c0 + cc) * 64 + s * 16);
+            }
+          }
+          // weights: for one (chunk, tap) the CO_TILE packed rows are contiguous in global memory: a plain block copy
+  #pragma unroll
+          for (int u = 0; u < UW; ++u) {
+            const int qq = q_done + u;  // wave-uniform
+            if (qq < nq) {
+              const int cc = qq / tn, tt = qq - cc * tn;
+              const int slot = cl.widx[t0 + tt];
+              const char* src = p.w + (((size_t)slot * p.nchunks + c0 + cc) * p.Cout + co_base) * 64;
+  #pragma unroll
+              for (int k = 0; k < PPT; ++k) {
+                const int piece = tid + k * 256;
+                if (PIECES % 256 == 0 || piece < PIECES) vw[u][k] = *reinterpret_cast<const u32x4*>(src + piece * 16);
+              }
+            }
+          }
+          // ---- store phase
+          TG_STAMP_AT(1);
+  #pragma unroll
+          for (int u = 0; u < UA; ++u)
+            if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_a + da[u]) = va[u];
+          TG_STAMP_AT(2);
+  #pragma unroll
+          for (int u = 0; u < UW; ++u) {
+            const int qq = q_done + u;
+            if (qq < nq) {
+              const int cc = qq / tn, tt = qq - cc * tn;
+              char* dstw = lds_w + (cc * p.tg + tt) * CO_TILE * kRowBytes;
+  #pragma unroll
+              for (int k = 0; k < PPT; ++k) {
+                const int piece = tid + k * 256;
+                if (PIECES % 256 == 0 || piece < PIECES)
+                  *reinterpret_cast<u32x4*>(dstw + (piece >> 2) * kRowBytes + (piece & 3) * 16) = vw[u][k];
+              }
+            }
+          }
+          a_done += 256 * UA;
+          q_done += UW;
+          TG_STAMP_AT(3);
+        }
+        __syncthreads();
+        TG_STAMP_AT(4);
+
+        {
+          for (int cc = 0; cc < cn; ++cc) {
+            const char* la = lds_a + cc * a_stride;
+  #pragma unroll 2
+            for (int tt = 0; tt < tn; ++tt) {
+              const int toff = tap_off[t0 + tt];  // LDS table: ((dy-dymin)*iw + dx-dxmin) * row bytes
+              const char* lw = lds_w + (cc * p.tg + tt) * CO_TILE * kRowBytes;
+              Frag wf[CT];
+  #pragma unroll
+              for (int a = 0; a < CT; ++a)
+                wf[a] = *reinterpret_cast<const Frag*>(lw + ((wc * CT + a) * 16 + idx) * kRowBytes + g * 16);
+  #pragma unroll
+              for (int b = 0; b < PT; ++b) {
+                const int ty = wp * PT + b;
+                const int prow = (ty * cl.iw + idx) * p.S;
+                const Frag xf = *reinterpret_cast<const Frag*>(la + prow * kRowBytes + toff + g * 16);
+  #pragma unroll
+                for (int a = 0; a < CT; ++a) acc[a][b] = Mma<T>::run(wf[a], xf, acc[a][b]);
+              }
             }
           }
         }
       }
     }
+
   }
 
   // ---------------------------------------------------------------- epilogue
@@ -518,12 +576,15 @@ static int pick_tile(const tg_conv_desc* d) {
       const long long ohc = (d->OH - d->cls[c].ooy + d->OS - 1) / d->OS, owc = (d->OW - d->cls[c].oox + d->OS - 1) / d->OS;
       px += (long long)d->N * ohc * owc;
     }
-    // measured per layer shape under hipGraph replay (tools/microbench.py, profiles/r01_*_microbench.log)
+    // measured per layer shape under hipGraph replay (tools/microbench.py, profiles/r01_*_microbench*.log)
+    const bool plain3x3 = d->ncls == 1 && d->S == 1 && d->OS == 1 && d->cls[0].ntaps == 9;
     if (d->Cout % 64) cfg = TG_TILE_32x128;
     else if (d->S > 1) cfg = (d->Cout % 128 == 0 && px >= 16384) ? TG_TILE_128x128 : (px >= 32768 ? TG_TILE_64x128 : TG_TILE_64x64);
+    else if (plain3x3 && px <= 16384) cfg = TG_TILE_32x64;                   // recurrent-pass and deep-D layers
+    else if (plain3x3 && (long long)px * d->Cout / 128 > 400000) cfg = (d->Cout % 128 == 0) ? TG_TILE_128x128 : TG_TILE_64x256;
+    else if (plain3x3) cfg = TG_TILE_64x256;
     else if (d->Cout % 128 == 0 && px >= 16384) cfg = TG_TILE_128x128;
     else if (px >= 32768) cfg = TG_TILE_64x256;
-    else if (d->Cout == 64 && d->ncls == 1 && d->Cin <= 64 && px <= 16384) cfg = TG_TILE_32x64;  // recurrent-pass trunk: 6.6 vs 7.7 us
     else cfg = TG_TILE_64x64;
   }
   return cfg;
@@ -601,25 +662,37 @@ static int prepare_conv(const tg_conv_desc* d, const void* in, const void* w_pac
   const long long wgs = gx * (d->Cout / tc.co_tile) * d->ncls;
   // LDS budget: a grid that cannot give every CU two workgroups anyway may use (almost) the whole 160 KB so that all
   // of K is staged in one or two stages; big grids keep two workgroups per CU for cross-workgroup latency hiding.
-  const size_t budget = wgs <= 512 ? 150 * 1024 : 72 * 1024;
+  // plain 3x3 stride-1 pattern (forward: dy=t/3-1, dx=t%3-1; dgrad: mirrored), slots in tap order -> pipelined STD3 kernel
+  bool pat_fwd = false, pat_bwd = false;
+  if (d->ncls == 1 && d->S == 1 && d->OS == 1 && d->cls[0].ntaps == 9) {
+    pat_fwd = pat_bwd = true;
+    for (int t = 0; t < 9; ++t) {
+      const tg_conv_class& s0 = d->cls[0];
+      if (s0.widx[t] != t) pat_fwd = pat_bwd = false;
+      if (s0.dy[t] != t / 3 - 1 || s0.dx[t] != t % 3 - 1) pat_fwd = false;
+      if (s0.dy[t] != 1 - t / 3 || s0.dx[t] != 1 - t % 3) pat_bwd = false;
+    }
+  }
+  // measured (profiles/r01_*_microbench*.log): the pipelined kernel wins up to ~1000 workgroups (latency-bound launches);
+  // beyond that two co-resident workgroups of the plain kernel hide latency better than one pipelined workgroup per CU
+  const bool pattern = (pat_fwd || pat_bwd) && (wgs <= 1024 || (k.nchunks >= 4 && wgs <= 2048));
+  // LDS budget: small grids (<= 2 workgroups per CU anyway) and the software-pipelined 3x3 kernel (it hides its own load
+  // latency) may use almost all 160 KB; the generic kernel on big grids keeps two workgroups per CU.
+  const size_t budget = (wgs <= 512 || pattern) ? 150 * 1024 : 72 * 1024;
   int tg = max_taps;
   while (tg > 1 && a_bytes + tg * w_tap > budget) --tg;
   int cg = 1;
   if (tg == max_taps)
     while (cg < k.nchunks && (size_t)(cg + 1) * (a_bytes + tg * w_tap) <= budget) ++cg;
-  // plain 3x3 stride-1 pattern (forward: dy=t/3-1, dx=t%3-1; dgrad: mirrored), slots in tap order, all 9 taps staged together
   k.std3 = 0;
   k.flip = 0;
-  if (d->ncls == 1 && d->S == 1 && d->OS == 1 && d->cls[0].ntaps == 9 && tg == 9) {
-    bool fwd = true, bwd = true;
-    for (int t = 0; t < 9; ++t) {
-      const tg_conv_class& s0 = d->cls[0];
-      if (s0.widx[t] != t) fwd = bwd = false;
-      if (s0.dy[t] != t / 3 - 1 || s0.dx[t] != t % 3 - 1) fwd = false;
-      if (s0.dy[t] != 1 - t / 3 || s0.dx[t] != 1 - t % 3) bwd = false;
-    }
-    k.std3 = (fwd || bwd) ? 1 : 0;
-    k.flip = (!fwd && bwd) ? 1 : 0;
+  if (pattern && tg == 9 && max_rows * 4 <= 256 * 6) {
+    k.std3 = 1;
+    k.flip = (!pat_fwd && pat_bwd) ? 1 : 0;
+    // one chunk group must fit one issue phase of the pipelined kernel: UA = 6 pieces, UW = 18 / 9 weight blocks per thread
+    const bool small_cfg = (cfg == TG_TILE_64x64 || cfg == TG_TILE_32x128 || cfg == TG_TILE_32x64);
+    const int uw = small_cfg ? 18 : 9;
+    while (cg > 1 && (cg * max_rows * 4 > 256 * 6 || cg * 9 > uw)) --cg;
   }
   size_t lds = (size_t)cg * (a_bytes + tg * w_tap);
   k.tap_table_off = (int)lds;
