@@ -71,6 +71,8 @@ typedef struct {
   int32_t c_real;               /* TG_OUT_NCHW_F32: number of real channels stored (<=4) */
   int64_t out_n_stride;         /* TG_OUT_NCHW_F32: element stride between samples of `out` */
   int32_t tile_cfg;             /* 0 auto; otherwise a TG_TILE_* id (tuning / tests) */
+  int32_t stats_replicas;       /* 0/1: statistics go to stats[groups][2][Cout]; R (power of two): spread over
+                                   stats[R][groups][2][Cout] by pixel-tile index, fold with tg_reduce_replicas */
 } tg_conv_desc;
 
 enum { TG_TILE_AUTO = 0, TG_TILE_64x256 = 1, TG_TILE_64x64 = 2, TG_TILE_128x128 = 3, TG_TILE_32x128 = 4,
@@ -187,6 +189,9 @@ int tg_content_loss(int dtype, const float* gen, const float* y, void* dpre, flo
 /* All step scalars on device + d(logit) for the discriminator loss (code/train.py:287-333). */
 int tg_loss_finalize(const float* prob, const float* acc, float* scalars, float* dlogit, int tb, const float* cfg,
                      void* stream);
+
+/* dst[i] (+)= sum_r src[r*stride + i], i < n: folds the replicated per-channel statistics of tg_conv. */
+int tg_reduce_replicas(const float* src, int replicas, int stride, int n, float* dst, int accumulate, void* stream);
 
 /* ---- optimiser (torch.optim.Adam as built at main.py:239-243) ------------------------------------------- */
 /* hyper_dev (device floats): lr, beta1, beta2, eps, 1-beta1^t, 1-beta2^t, grad_scale - in memory so that a captured

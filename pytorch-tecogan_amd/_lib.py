@@ -29,7 +29,8 @@ class ConvDesc(C.Structure):
                 ("OH", C.c_int32), ("OW", C.c_int32), ("Cout", C.c_int32), ("S", C.c_int32), ("OS", C.c_int32),
                 ("ncls", C.c_int32), ("cls", ConvClass * MAX_CLASSES), ("act", C.c_int32), ("mask_mode", C.c_int32),
                 ("stats_mode", C.c_int32), ("stats_groups", C.c_int32), ("out_mode", C.c_int32),
-                ("c_real", C.c_int32), ("out_n_stride", C.c_int64), ("tile_cfg", C.c_int32)]
+                ("c_real", C.c_int32), ("out_n_stride", C.c_int64), ("tile_cfg", C.c_int32),
+                ("stats_replicas", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -67,6 +68,7 @@ _PROTOS = {
     "tg_absdiff_nchw": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
     "tg_content_loss": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P]),
     "tg_loss_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P]),
+    "tg_reduce_replicas": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "tg_adam": (_I, [_P, _P, _P, _P, _L, _P, _P]),
 }
 

@@ -58,7 +58,7 @@ struct ConvK {
   int N, IH, IW, Cin, OH, OW, Cout, S, OS;
   int tiles_x, tiles_y, nchunks, tg, cg;
   int tx_log2, ty_log2;  // log2 of the tile counts, or -1
-  int act, mask_mode, stats_mode, stats_groups, out_mode, c_real;
+  int act, mask_mode, stats_mode, stats_groups, stats_replicas, out_mode, c_real;
   long long out_n_stride;
   int a_rows_max;
   int tap_table_off;  // LDS byte offset of the per-class tap offset table (generic path)
@@ -171,8 +171,10 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
   // the L2/HBM latency, and a load->store->load chain costs one round trip per 16 bytes.
   // UA activation pieces and UW (chunk,tap) weight blocks per thread are loaded in ONE issue phase before any LDS store.
   constexpr int UA = 6;
-  constexpr int UW = (CT * PT <= 4) ? 18 : 9;  // small tiles: the whole K of a 64-channel 3x3 layer in flight at once
   constexpr int PIECES = CO_TILE * 4, PPT = (PIECES + 255) / 256;
+  // small tiles: the whole K of a 64-channel 3x3 layer in flight at once; big tiles: one 3x3 chunk (pipelined kernel) or
+  // fewer blocks in the generic kernel, whose 128-channel tiles otherwise lose occupancy to the staging registers
+  constexpr int UW = (CT * PT <= 4) ? 18 : ((STD3 || PPT == 1) ? 9 : 5);
   const int a_stride = p.a_rows_max * kRowBytes;  // LDS bytes of one chunk's activation patch
   const float inv_iw = 1.0f / (float)cl.iw, inv_prow = 1.0f / (float)prow_n;
   if constexpr (STD3) {
@@ -466,7 +468,10 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < WP; ++w) s += red[(w * 2 + which) * CO_TILE + chn];
-      atomicAdd(p.stats + ((size_t)grp * 2 + which) * p.Cout + co_base + chn, s);
+      // replica = low bits of the pixel-tile index: thousands of workgroups adding to the same words serialise at the
+      // memory side (a 5120-workgroup dgrad spent 240 us on this); tg_reduce_replicas folds the replicas afterwards
+      const size_t rep = (size_t)(blockIdx.x & (p.stats_replicas - 1)) * p.stats_groups * 2 * p.Cout;
+      atomicAdd(p.stats + rep + ((size_t)grp * 2 + which) * p.Cout + co_base + chn, s);
     }
   }
 }
@@ -581,8 +586,7 @@ static int pick_tile(const tg_conv_desc* d) {
     if (d->Cout % 64) cfg = TG_TILE_32x128;
     else if (d->S > 1) cfg = (d->Cout % 128 == 0 && px >= 16384) ? TG_TILE_128x128 : (px >= 32768 ? TG_TILE_64x128 : TG_TILE_64x64);
     else if (plain3x3 && px <= 16384) cfg = TG_TILE_32x64;                   // recurrent-pass and deep-D layers
-    else if (plain3x3 && (long long)px * d->Cout / 128 > 400000) cfg = (d->Cout % 128 == 0) ? TG_TILE_128x128 : TG_TILE_64x256;
-    else if (plain3x3) cfg = TG_TILE_64x256;
+    else if (plain3x3) cfg = TG_TILE_64x256;                                 // best for every larger 3x3 launch measured
     else if (d->Cout % 128 == 0 && px >= 16384) cfg = TG_TILE_128x128;
     else if (px >= 32768) cfg = TG_TILE_64x256;
     else cfg = TG_TILE_64x64;
@@ -623,6 +627,8 @@ static int prepare_conv(const tg_conv_desc* d, const void* in, const void* w_pac
   k.S = d->S; k.OS = d->OS;
   k.act = d->act; k.mask_mode = d->mask_mode; k.stats_mode = d->stats_mode; k.stats_groups = d->stats_groups;
   k.out_mode = d->out_mode; k.c_real = d->c_real; k.out_n_stride = d->out_n_stride;
+  k.stats_replicas = d->stats_replicas > 1 ? d->stats_replicas : 1;
+  if (k.stats_replicas & (k.stats_replicas - 1)) return TG_E_BADARG;  // power of two
   const int chunk = d->dtype == TG_BF16 ? 32 : 16;
   k.nchunks = d->Cin / chunk;
 

@@ -484,6 +484,25 @@ extern "C" int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, 
   return tg_launch_status();
 }
 
+namespace {
+__global__ void reduce_replicas_kernel(const float* __restrict__ src, int replicas, int stride, int n,
+                                       float* __restrict__ dst, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int r = 0; r < replicas; ++r) s += src[(size_t)r * stride + i];
+  dst[i] = accumulate ? dst[i] + s : s;
+}
+}  // namespace
+
+extern "C" int tg_reduce_replicas(const float* src, int replicas, int stride, int n, float* dst, int accumulate,
+                                  void* stream) {
+  if (!src || !dst || replicas <= 0 || n <= 0 || stride < n) return TG_E_BADARG;
+  hipLaunchKernelGGL(reduce_replicas_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, replicas,
+                     stride, n, dst, accumulate);
+  return tg_launch_status();
+}
+
 extern "C" int tg_abi_version(void) { return TG_ABI_VERSION; }
 
 extern "C" const char* tg_error_string(int code) {

@@ -110,14 +110,23 @@ class Conv:
         N, H, W, _ = x.shape
         OH, OW = self.spec.out_hw(H, W)
         key = ("f", N, H, W, act, res is not None, stats is not None, groups, nchw is not None and nchw[2:])
-        d = self._desc.get(key)
-        if d is None:
+        ent = self._desc.get(key)
+        if ent is None:
+            R = K.stats_replicas_for(N * OH * OW) if stats is not None else 1
             d = K.make_conv_desc(self.spec.fwd_geom(), self.tg, N, H, W, self.cin_p, OH, OW, self.cout_p, act=act,
                                  stats_mode=2 if stats is not None else 0, stats_groups=groups,
                                  out_mode=L.OUT_NCHW_F32 if nchw else L.OUT_NHWC, c_real=nchw[3] if nchw else 0,
-                                 out_n_stride=nchw[2] if nchw else 0, tile_cfg=self.tile)
-            self._desc[key] = d
+                                 out_n_stride=nchw[2] if nchw else 0, tile_cfg=self.tile, stats_replicas=R)
+            scratch = torch.zeros(R * groups * 2 * self.cout_p, device=x.device) if R > 1 else None
+            ent = (d, R, scratch)
+            self._desc[key] = ent
+        d, R, scratch = ent
         self.last_desc = d
+        if R > 1:  # statistics through replicas (atomic contention), folded into the caller's buffer afterwards
+            scratch.zero_()
+            K.conv(d, x, self.wf, out, bias=self.bias, res=res, stats=scratch)
+            K.reduce_replicas(scratch, R, groups * 2 * self.cout_p, groups * 2 * self.cout_p, stats, accumulate=True)
+            return
         if nchw:
             import ctypes
             buf, off = nchw[0], nchw[1]
@@ -133,12 +142,22 @@ class Conv:
         _, H, W, _ = out.shape
         st = bias_grad_of.gbias if bias_grad_of is not None else None
         key = ("d", N, OH, OW, mask_mode, res is not None, st is not None)
-        d = self._desc.get(key)
-        if d is None:
+        ent = self._desc.get(key)
+        if ent is None:
+            R = K.stats_replicas_for(N * H * W) if st is not None else 1
             d = K.make_conv_desc(self.spec.dgrad_geom(), self.tg, N, OH, OW, self.cout_p, H, W, self.cin_p,
-                                 mask_mode=mask_mode, stats_mode=1 if st is not None else 0, stats_groups=1)
-            self._desc[key] = d
+                                 mask_mode=mask_mode, stats_mode=1 if st is not None else 0, stats_groups=1,
+                                 stats_replicas=R)
+            scratch = torch.zeros(R * 2 * self.cin_p, device=dout.device) if R > 1 else None
+            ent = (d, R, scratch)
+            self._desc[key] = ent
+        d, R, scratch = ent
         self.last_desc = d
+        if R > 1:  # bias gradient through replicas (see tg_conv_desc.stats_replicas)
+            scratch.zero_()
+            K.conv(d, dout, self.wb, out, res=res, mask=mask, stats=scratch)
+            K.reduce_replicas(scratch, R, 2 * self.cin_p, self.cin_p, st, accumulate=True)  # slot [0] = per-channel sums
+            return
         K.conv(d, dout, self.wb, out, res=res, mask=mask, stats=st)
 
     def wgrad(self, x_in, dout, side=None):

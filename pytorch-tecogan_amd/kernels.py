@@ -129,7 +129,8 @@ class ConvSpec:
 
 
 def make_conv_desc(geom: Geom, dtype, N, IH, IW, cin_p, OH, OW, cout_p, act=L.ACT_NONE, mask_mode=L.MASK_NONE,
-                   stats_mode=0, stats_groups=1, out_mode=L.OUT_NHWC, c_real=0, out_n_stride=0, tile_cfg=L.TILE_AUTO):
+                   stats_mode=0, stats_groups=1, out_mode=L.OUT_NHWC, c_real=0, out_n_stride=0, tile_cfg=L.TILE_AUTO,
+                   stats_replicas=1):
     d = L.ConvDesc()
     d.dtype = dtype
     d.N, d.IH, d.IW, d.Cin, d.OH, d.OW, d.Cout = N, IH, IW, cin_p, OH, OW, cout_p
@@ -141,7 +142,24 @@ def make_conv_desc(geom: Geom, dtype, N, IH, IW, cin_p, OH, OW, cout_p, act=L.AC
             c.dy[t], c.dx[t], c.widx[t] = dy, dx, w
     d.act, d.mask_mode, d.stats_mode, d.stats_groups = act, mask_mode, stats_mode, stats_groups
     d.out_mode, d.c_real, d.out_n_stride, d.tile_cfg = out_mode, c_real, out_n_stride, tile_cfg
+    d.stats_replicas = stats_replicas
     return d
+
+
+def stats_replicas_for(n_pixels):
+    """replica count for the per-channel statistics of a conv launch: keep <= ~64 workgroups (of >= 64 pixels) per replica."""
+    tiles = max(1, n_pixels // 256)
+    if tiles < 1024:  # measured: the extra zero + fold launches cost more than the contention below ~1000 workgroups
+        return 1
+    r = 1
+    while r < 64 and tiles // r > 64:
+        r *= 2
+    return r
+
+
+def reduce_replicas(src, replicas, stride, n, dst, accumulate=True):
+    L.check(L.load().tg_reduce_replicas(_ptr(src), replicas, stride, n, _ptr(dst), int(accumulate), _stream()),
+            "tg_reduce_replicas")
 
 
 def conv(desc, x, w_packed, out, bias=None, res=None, mask=None, stats=None):

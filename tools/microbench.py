@@ -102,14 +102,14 @@ def main():
         bench_conv("c3", 64, 64, 4, 64, 64, "fwd", bf, small)
         bench_conv("c3", 64, 128, 4, 64, 64, "fwd", bf, ["64x64", "32x64", "128x128", "64x256"])
         bench_conv("c3", 128, 128, 4, 64, 64, "fwd", bf, ["64x64", "32x64", "128x128", "64x256"])
-        bench_conv("ct", 128, 128, 4, 64, 64, "fwd", bf, ["64x64", "128x128", "64x256"])
+        bench_conv("ct", 128, 128, 4, 64, 64, "fwd", bf, ["64x64", "128x128", "64x256", "64x128"])
         bench_conv("c3", 128, 64, 4, 128, 128, "fwd", bf, ["64x64", "32x64", "64x256"])
         bench_conv("c3", 64, 3, 4, 128, 128, "fwd", bf, ["32x128", "32x64"])
         big = ["64x64", "64x256", "128x128"]
         bench_conv("c3", 64, 64, 40, 32, 32, "dgrad", bf, big)
         bench_conv("c3", 128, 128, 40, 64, 64, "dgrad", bf, big)
         bench_conv("c3", 128, 64, 40, 128, 128, "dgrad", bf, big)
-        bench_conv("ct", 128, 128, 40, 64, 64, "dgrad", bf, big)
+        bench_conv("ct", 128, 128, 40, 64, 64, "dgrad", bf, big + ["64x128"])
         bench_conv("c3", 64, 3, 40, 128, 128, "dgrad", bf, big)
         bench_conv("c3", 27, 64, 24, 128, 128, "fwd", bf, big)
         bench_conv("c4s2", 64, 64, 24, 128, 128, "fwd", bf, ["64x64", "128x128", "32x64"])
