@@ -125,6 +125,10 @@ int tg_wgrad(const tg_wgrad_desc* d, const void* x, const void* y, float* slab, 
 int tg_wgrad_finalize(const float* slab, int nsplit, int ntaps, int ca_p, int cb_p, int ca, int cb, float* grad,
                       int64_t s_a, int64_t s_b, const int32_t* slot_off_dev, int accumulate, void* stream);
 
+/* The same for every conv of a network in ONE launch (always accumulates; slot t adds kernel offset t).
+ * jobs_dev: njobs x 10 int64 = {slab ptr, grad ptr, s_a, s_b, nsplit, ntaps, ca_p, cb_p, ca, cb}. */
+int tg_wgrad_finalize_multi(const int64_t* jobs_dev, int njobs, int blocks_per_job, void* stream);
+
 /* ---- layout converters ------------------------------------------------------------------------------- */
 /* NCHW fp32 (strided samples) -> NHWC `dtype` with zero channel padding. */
 int tg_nchw_to_nhwc(int dtype, const float* src, int64_t src_n_stride, void* dst, int N, int C, int Cp, int H, int W,

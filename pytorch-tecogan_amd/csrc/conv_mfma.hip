@@ -587,6 +587,7 @@ static int pick_tile(const tg_conv_desc* d) {
     else if (d->S > 1) cfg = (d->Cout % 128 == 0 && px >= 16384) ? TG_TILE_128x128 : (px >= 32768 ? TG_TILE_64x128 : TG_TILE_64x64);
     else if (plain3x3 && px <= 16384) cfg = TG_TILE_32x64;                   // recurrent-pass and deep-D layers
     else if (plain3x3) cfg = TG_TILE_64x256;                                 // best for every larger 3x3 launch measured
+    else if (d->ncls == 4 && d->Cout % 128 == 0 && px >= 16384) cfg = TG_TILE_64x128;  // conv-transpose forward: 22.7 vs 27.2 us
     else if (d->Cout % 128 == 0 && px >= 16384) cfg = TG_TILE_128x128;
     else if (px >= 32768) cfg = TG_TILE_64x256;
     else cfg = TG_TILE_64x64;

@@ -308,8 +308,9 @@ __global__ void absdiff_nchw_kernel(const float* __restrict__ a, const long long
 // cfg layout (floats): 0 content_div, 1 warp_div, 2..5 layer_div, 6 EPS, 7 ratio, 8 dt_ratio, 9 use_layerloss,
 //                      10 pp_div (0 = no pingpang), 11 pp_scaling, 12..15 layer_norm
 // acc layout: 0 content sumsq, 1 warp sumsq, 2..5 layer absdiff sums, 6 pingpang abs sum
-// scalars out: 0..3 layer losses, 4 layer_sum, 5 gen_loss total (aliased tensor), 6 warp loss, 7 t_adv, 8 d_loss,
-//              9 mean p_real, 10 mean p_fake, 11 content, 12 t_balance, 13 pingpang
+// scalars out (48 floats): 0..3 layer losses, 4 layer_sum, 5 gen_loss total (aliased tensor), 6 warp loss, 7 t_adv,
+//              8 d_loss, 9 mean p_real, 10 mean p_fake, 11 content, 12 t_balance, 13 pingpang, 14 tb, 15 len(update_list),
+//              16.. update_list, 32.. update_list_avg
 __global__ void loss_finalize_kernel(const float* __restrict__ prob, const float* __restrict__ acc,
                                      float* __restrict__ sc, float* __restrict__ dlogit, int tb,
                                      const float* __restrict__ cfg) {
@@ -350,6 +351,18 @@ __global__ void loss_finalize_kernel(const float* __restrict__ prob, const float
   if (cfg[9] != 0.f) total += layer_sum * cfg[8];
   sc[5] = total; sc[7] = t_adv; sc[8] = d_loss; sc[9] = mr; sc[10] = mf;
   sc[12] = real_l + t_adv;
+  sc[14] = 0.99f * sc[12];  // tb: a fresh EMA(0.99) seeded with zero every call (code/train.py:324-327)
+  // update_list in the reference's order and its running average avg_k = 0.99*u_k + 0.01*avg_{k-1} (code/train.py:329-333):
+  // sc[16..] = update_list values, sc[32..] = update_list_avg
+  int n = 0;
+  float* ul = sc + 16;
+  if (cfg[9] != 0.f) { for (int i = 0; i < 5; ++i) ul[n++] = sc[i]; }
+  ul[n++] = total; ul[n++] = sc[6];
+  if (cfg[10] != 0.f) ul[n++] = pp;
+  ul[n++] = t_adv; ul[n++] = d_loss; ul[n++] = mr; ul[n++] = mf; ul[n++] = total;
+  float shadow = 0.f;
+  for (int i = 0; i < n; ++i) { shadow = 0.99f * ul[i] + 0.01f * shadow; sc[32 + i] = shadow; }
+  sc[15] = (float)n;
 }
 
 // hyper (device): 0 lr, 1 beta1, 2 beta2, 3 eps, 4 1-beta1^t, 5 1-beta2^t, 6 grad scale (1/world for data parallel).

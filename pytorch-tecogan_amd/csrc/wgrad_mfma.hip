@@ -242,6 +242,51 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
   }
 }
 
+// All weight gradients of a network folded in ONE launch: blockIdx.y selects the job.
+// Job = 10 x int64: slab ptr, grad ptr, s_a, s_b, nsplit, ntaps, ca_p, cb_p, ca, cb  (slot t adds kernel offset t).
+__global__ __launch_bounds__(256) void wgrad_finalize_multi_kernel(const long long* __restrict__ jobs) {
+  __shared__ float sh[8][33];
+  const long long* j = jobs + 10 * blockIdx.y;
+  const float* slab = reinterpret_cast<const float*>(j[0]);
+  float* grad = reinterpret_cast<float*>(j[1]);
+  const long long s_a = j[2], s_b = j[3];
+  const int nsplit = (int)j[4], ntaps = (int)j[5], ca_p = (int)j[6], cb_p = (int)j[7], ca = (int)j[8], cb = (int)j[9];
+  const long long total = (long long)ntaps * ca * cb;
+  const size_t slab_sz = (size_t)ntaps * ca_p * cb_p;
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  for (long long e0 = (long long)blockIdx.x * 32; e0 < total; e0 += (long long)gridDim.x * 32) {
+    const long long i = e0 + el;
+    float s = 0.f;
+    int a = 0, b = 0, t = 0;
+    if (i < total) {
+      b = (int)(i % cb);
+      const long long r = i / cb;
+      a = (int)(r % ca);
+      t = (int)(r / ca);
+      const float* src = slab + ((size_t)t * ca_p + a) * cb_p + b;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int k = sl;
+      for (; k + 24 < nsplit; k += 32) {
+        s0 += src[(size_t)k * slab_sz];
+        s1 += src[(size_t)(k + 8) * slab_sz];
+        s2 += src[(size_t)(k + 16) * slab_sz];
+        s3 += src[(size_t)(k + 24) * slab_sz];
+      }
+      for (; k < nsplit; k += 8) s0 += src[(size_t)k * slab_sz];
+      s = (s0 + s1) + (s2 + s3);
+    }
+    sh[sl][el] = s;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) tsum += sh[q][el];
+      grad[a * s_a + b * s_b + t] += tsum;
+    }
+    __syncthreads();
+  }
+}
+
 struct WgCfg {
   int a_blk, b_blk;
 };
@@ -360,5 +405,12 @@ extern "C" int tg_wgrad_finalize(const float* slab, int nsplit, int ntaps, int c
   const int blocks = (int)std::min<long long>((total + 31) / 32, 4096);
   hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slab, nsplit, ntaps, ca_p,
                      cb_p, ca, cb, grad, (long long)s_a, (long long)s_b, slot_off_dev, accumulate);
+  return tg_launch_status();
+}
+
+extern "C" int tg_wgrad_finalize_multi(const int64_t* jobs_dev, int njobs, int blocks_per_job, void* stream) {
+  if (!jobs_dev || njobs <= 0 || blocks_per_job <= 0) return TG_E_BADARG;
+  hipLaunchKernelGGL(wgrad_finalize_multi_kernel, dim3((unsigned)blocks_per_job, (unsigned)njobs), dim3(256), 0,
+                     (hipStream_t)stream, (const long long*)jobs_dev);
   return tg_launch_status();
 }

@@ -96,6 +96,8 @@ class Conv:
         self.wb = torch.empty_like(self.wf) if need_dgrad else None
         self.tile = tile
         self._desc = {}
+        self.defer_finalize = False
+        self.fin_job = None
 
     def repack(self):
         s = self.spec
@@ -178,6 +180,10 @@ class Conv:
             ent = (K.make_wgrad_desc(self.tg, N, XH, XW, cx, YH, YW, cy, S, taps, nsplit), nsplit, slab)
             self._desc[key] = ent
         d, nsplit, slab = ent
+        self.fin_job = [slab.data_ptr(), self.gw.data_ptr(), s_a, s_b, nsplit, len(taps), cx, cy, ca, cb]
+        if self.defer_finalize:  # the network folds every slab in one launch (Finalizer) after its backward pass
+            K.wgrad(d, X, Y, slab)
+            return
         if side is None:
             K.wgrad(d, X, Y, slab)
             K.wgrad_finalize(slab, nsplit, len(taps), cx, cy, ca, cb, self.gw, s_a, s_b, self.slots, True)
@@ -234,6 +240,35 @@ class Repacker:
     def run(self):
         L.check(L.load().tg_pack_conv_weights_multi(self.tg, self.jobs.data_ptr(), self.n, 16,
                                                     torch.cuda.current_stream().cuda_stream), "tg_pack_conv_weights_multi")
+
+
+def _defer_finalize():
+    """one fold launch per network needs every slab to survive until the end of the backward pass and the fold to run after
+    all weight-gradient launches: not compatible with side-stream wgrads."""
+    return os.environ.get("TECOGAN_DEFER_FINALIZE", "1") != "0" and int(os.environ.get("TECOGAN_WGRAD_STREAMS", "0")) == 0
+
+
+class Finalizer:
+    """folds the weight-gradient slabs of every conv of a network into the flat gradient buffer with ONE launch (instead
+    of one ~9 us launch per conv).  The job table is rebuilt only when a conv's launch shape changed."""
+
+    def __init__(self, convs, device):
+        self.convs, self.dev, self.key, self.jobs = convs, device, None, None
+        for c in convs:
+            c.defer_finalize = True
+
+    def disable(self):
+        for c in self.convs:
+            c.defer_finalize = False
+
+    def run(self):
+        jobs = [c.fin_job for c in self.convs if c.fin_job is not None]
+        key = tuple(tuple(j) for j in jobs)
+        if key != self.key:
+            self.jobs = torch.tensor(jobs, dtype=torch.int64, device=self.dev)
+            self.key = key
+        L.check(L.load().tg_wgrad_finalize_multi(self.jobs.data_ptr(), len(jobs), 64,
+                                                 torch.cuda.current_stream().cuda_stream), "tg_wgrad_finalize_multi")
 
 
 class BatchNorm:
@@ -323,6 +358,7 @@ class GeneratorEngine:
         self.act = None
         self.shape = None
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
+        self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
 
     def repack(self):
         self.repacker.run()
@@ -413,6 +449,8 @@ class GeneratorEngine:
                 c1.dgrad(dH[i], dA[i], res=dA[i + 1], mask=a["a"][0], mask_mode=RELU, bias_grad_of=self.conv0)
         self.conv0.wgrad(a["in0"], dA[0], sd.next())
         sd.join()
+        if self.finalizer is not None and s1 == NS:  # last (or only) sample range of the step
+            self.finalizer.run()
 
 
 # =============================================================================================================
@@ -482,6 +520,7 @@ class DiscriminatorEngine:
                                                                              self.res[st] for c in (c1, c2)]
         self.shape = None
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
+        self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
 
     def repack(self):
         self.repacker.run()
@@ -589,3 +628,5 @@ class DiscriminatorEngine:
                 self.conv0.wgrad(a["in"], self.g_c0, sd.next())
         if join:
             sd.join()
+        if self.finalizer is not None:
+            self.finalizer.run()

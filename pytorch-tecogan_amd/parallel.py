@@ -2,8 +2,8 @@
 
 The reference has no distributed code at all; this is new.  Per step and per network ONE flat fp32
 gradient buffer is all-reduced (sum) over RCCL ("nccl" backend == RCCL on ROCm; gloo on CPU for the tests) and the
-1/world scaling is folded into the fused Adam kernel (hyper[6]).  The G all-reduce is launched as soon as the G backward
-segment has been enqueued and overlaps the D backward segment (step.TecoGANStep._run).
+1/world scaling is folded into the fused Adam kernel (hyper[6]).  Both all-reduces are launched (async, concurrently) right
+after the forward+backward graph segment and awaited before the update segment (step.TecoGANStep._run).
 
 BatchNorm statistics stay per rank (standard DDP; the reference's D is called on per-rank batches anyway), so an N-rank run
 equals "N shards evaluated with local BN, gradients averaged" - that is what tests/test_parallel_cpu.py checks on gloo."""

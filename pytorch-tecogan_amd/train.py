@@ -84,26 +84,21 @@ def TecoGAN(r_inputs, r_targets, discriminator_F, generator_F, args, Global_step
 
 
 def _network(st, args, global_step, counter1, counter2):
-    s = st.scalars.clone()  # device scalars; no host synchronisation happens here (the reference forces three)
-    names, vals = [], []
+    """Network tuple of code/train.py:354-370 from the device scalars written by tg_loss_finalize (update_list, its EMA
+    and tb are computed in that kernel; nothing here launches work besides one 192-byte copy, and nothing synchronises)."""
+    s = st.scalars.clone()
+    names = []
     if args.D_LAYERLOSS:
-        vals += [s[0], s[1], s[2], s[3], s[4]]
         names += ["D_layer_%d_loss" % i for i in range(4)] + ["D_layer_loss_sum"]
-    gen_loss = s[5]
-    vals += [gen_loss, s[6]]  # l2_content_loss holds the aliased total (code/train.py:244,293,299)
-    names += ["l2_content_loss", "l2_warp_loss"]
-    vals += [s[7], s[8], s[9], s[10], gen_loss]
+    names += ["l2_content_loss", "l2_warp_loss"]  # l2_content_loss holds the aliased total (code/train.py:244,293,299)
     names += ["t_adversarial_loss", "t_discrim_loss", "t_discrim_real_output", "t_discrim_fake_output", "All_loss_Gen"]
-    tb = 0.99 * s[12]
-    # EMA(0.99) re-created every call: avg_k = 0.99*u_k + 0.01*avg_{k-1}, avg_{-1}=0 (code/train.py:324-333)
-    stacked = torch.stack(vals)
-    avg, shadow = [], torch.zeros((), device=s.device)
-    for i in range(len(vals)):
-        shadow = 0.99 * stacked[i] + 0.01 * shadow
-        avg.append(shadow)
-    dt_ratio = torch.tensor(st.dt_ratio)
-    avg += [tb, dt_ratio, counter1, counter2]
+    n = len(names)
+    vals = [s[16 + i] for i in range(n)]
+    avg = [s[32 + i] for i in range(n)]
+    tb = s[14]
+    avg += [tb, torch.tensor(st.dt_ratio), counter1, counter2]
     names_all = names + ["t_balance", "Dst_ratio", "withD_counter", "w_o_D_counter"]
+    gen_loss = s[5]
     return Network(gen_output=st.gen, learning_rate=args.learning_rate, update_list=vals, update_list_name=names_all,
                    update_list_avg=avg, global_step=global_step, d_loss=s[8], gen_loss=gen_loss, fnet_loss=gen_loss,
                    tb=tb, target=st.target)
