@@ -117,6 +117,7 @@ typedef struct {
   int8_t dy[TG_MAX_TAPS];
   int8_t dx[TG_MAX_TAPS];
   int32_t nsplit;               /* number of pixel-range splits (= slabs) */
+  int32_t taps_per_wg;          /* 0: every workgroup owns all taps; 3 (3x3) / 4 (4x4): taps are split over blockIdx.z */
 } tg_wgrad_desc;
 
 int64_t tg_wgrad_slab_floats(const tg_wgrad_desc* d);

@@ -36,7 +36,8 @@ class ConvDesc(C.Structure):
 class WgradDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("N", C.c_int32), ("XH", C.c_int32), ("XW", C.c_int32), ("Cx", C.c_int32),
                 ("YH", C.c_int32), ("YW", C.c_int32), ("Cy", C.c_int32), ("S", C.c_int32), ("ntaps", C.c_int32),
-                ("dy", C.c_int8 * MAX_TAPS), ("dx", C.c_int8 * MAX_TAPS), ("nsplit", C.c_int32)]
+                ("dy", C.c_int8 * MAX_TAPS), ("dx", C.c_int8 * MAX_TAPS), ("nsplit", C.c_int32),
+                ("taps_per_wg", C.c_int32)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float

@@ -22,15 +22,18 @@ struct WgradK {
   float* slab;
   int N, XH, XW, Cx, YH, YW, Cy, S;
   int ntaps;
-  int8_t dy[TG_MAX_TAPS];
-  int8_t dx[TG_MAX_TAPS];
+  int dy[TG_MAX_TAPS];  // 32-bit: dynamically indexed kernarg bytes would become vector loads (see conv_mfma.hip)
+  int dx[TG_MAX_TAPS];
   int dymin, dxmin, ih, iw;
   int tw_log2, th;
   int tiles_x, tiles_y, tiles_total, nsplit;
   int b_blocks;
 };
 
-template <typename T, int NTAPS, int AW, int BT>
+// TPW = taps per workgroup (blockIdx.z selects the tap group).  With TPW == NTAPS a workgroup owns every tap (best when it
+// walks many pixel tiles); TPW = 3 (4 for 4x4) cuts the fp32 slab each workgroup writes - and the fold reads back - by
+// NTAPS/TPW for the same number of workgroups: small layers were bound by exactly that traffic (256 x 147 KB per layer).
+template <typename T, int NTAPS, int TPW, int AW, int BT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
   using TR = ElemTraits<T>;
   constexpr int BW = 4 / AW;
@@ -50,9 +53,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
   const int a_blk = blockIdx.y / p.b_blocks, b_blk = blockIdx.y % p.b_blocks;
   const int a0 = a_blk * A_BLK, b0 = b_blk * B_BLK;
 
-  f32x4 acc[NTAPS][BT];
+  const int tap0 = blockIdx.z * TPW;
+  f32x4 acc[TPW][BT];
 #pragma unroll
-  for (int t = 0; t < NTAPS; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int b = 0; b < BT; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -147,8 +151,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
         const int ty_hi = k_hi >> p.tw_log2, tx_hi = k_hi & (tw - 1);
         const int cha = (wa * 16 + 4 * pp) * 2;
 #pragma unroll
-        for (int t = 0; t < NTAPS; ++t) {
-          const int oy = p.dy[t] - p.dymin, ox = p.dx[t] - p.dxmin;
+        for (int t = 0; t < TPW; ++t) {
+          const int oy = p.dy[tap0 + t] - p.dymin, ox = p.dx[tap0 + t] - p.dxmin;
           const int r_lo = (ty_lo * p.S + oy) * p.iw + tx_lo * p.S + ox;
           const int r_hi = (ty_hi * p.S + oy) * p.iw + tx_hi * p.S + ox;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -171,8 +175,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
             bv[b] = *reinterpret_cast<const float*>(lds_y + k * YROW + ((wb * BT + b) * 16 + idx) * 4);
           const int ty = k >> p.tw_log2, tx = k & (tw - 1);
 #pragma unroll
-          for (int t = 0; t < NTAPS; ++t) {
-            const int rr = (ty * p.S + p.dy[t] - p.dymin) * p.iw + tx * p.S + p.dx[t] - p.dxmin;
+          for (int t = 0; t < TPW; ++t) {
+            const int rr = (ty * p.S + p.dy[tap0 + t] - p.dymin) * p.iw + tx * p.S + p.dx[tap0 + t] - p.dxmin;
             const float av = *reinterpret_cast<const float*>(lds_x + rr * XROW + (wa * 16 + idx) * 4);
 #pragma unroll
             for (int b = 0; b < BT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[b], acc[t][b], 0, 0, 0);
@@ -185,14 +189,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
   // slab[split][t][a][b]; accumulator rows 4g+j are the X channel, column idx the Y channel
   float* slab = p.slab + (size_t)blockIdx.x * NTAPS * p.Cx * p.Cy;
 #pragma unroll
-  for (int t = 0; t < NTAPS; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
       const int bch = b0 + (wb * BT + b) * 16 + idx;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int ach = a0 + wa * 16 + 4 * g + j;
-        slab[((size_t)t * p.Cx + ach) * p.Cy + bch] = acc[t][b][j];
+        slab[((size_t)(tap0 + t) * p.Cx + ach) * p.Cy + bch] = acc[t][b][j];
       }
     }
 }
@@ -291,9 +295,9 @@ struct WgCfg {
   int a_blk, b_blk;
 };
 
-template <typename T, int NTAPS, int AW, int BT>
+template <typename T, int NTAPS, int TPW, int AW, int BT>
 int launch_wgrad(const WgradK& k, dim3 grid, size_t lds, hipStream_t st) {
-  auto fn = wgrad_kernel<T, NTAPS, AW, BT>;
+  auto fn = wgrad_kernel<T, NTAPS, TPW, AW, BT>;
   static bool attr_done = false;
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -376,23 +380,28 @@ extern "C" int tg_wgrad(const tg_wgrad_desc* d, const void* x, const void* y, fl
     const int ux = d->dtype == TG_BF16 ? 11 : 22, uy = d->dtype == TG_BF16 ? 4 : 8;
     if (k.ih * k.iw * xv > 256 * ux || tw * th * yv > 256 * uy) return TG_E_UNSUPPORTED;
   }
-  dim3 grid((unsigned)d->nsplit, (unsigned)((d->Cx / c.a_blk) * k.b_blocks));
+  const int tpw = d->taps_per_wg > 0 ? d->taps_per_wg : d->ntaps;
+  if (!((d->ntaps == 9 && (tpw == 9 || tpw == 3)) || (d->ntaps == 16 && (tpw == 16 || tpw == 4)))) return TG_E_UNSUPPORTED;
+  dim3 grid((unsigned)d->nsplit, (unsigned)((d->Cx / c.a_blk) * k.b_blocks), (unsigned)(d->ntaps / tpw));
   hipStream_t st = (hipStream_t)stream;
+  const bool split = tpw != d->ntaps;
+#define TG_WG(T_, NT_, TP_, AW_, BT_) return launch_wgrad<T_, NT_, TP_, AW_, BT_>(k, grid, lds, st)
   if (d->dtype == TG_BF16) {
     switch (cfg) {
-      case 0: return launch_wgrad<BF16, 9, 4, 4>(k, grid, lds, st);
-      case 1: return launch_wgrad<BF16, 9, 2, 2>(k, grid, lds, st);
-      case 2: return launch_wgrad<BF16, 9, 4, 2>(k, grid, lds, st);
-      case 3: return launch_wgrad<BF16, 16, 4, 2>(k, grid, lds, st);
+      case 0: if (split) TG_WG(BF16, 9, 3, 4, 4); else TG_WG(BF16, 9, 9, 4, 4);
+      case 1: if (split) TG_WG(BF16, 9, 3, 2, 2); else TG_WG(BF16, 9, 9, 2, 2);
+      case 2: if (split) TG_WG(BF16, 9, 3, 4, 2); else TG_WG(BF16, 9, 9, 4, 2);
+      case 3: if (split) TG_WG(BF16, 16, 4, 4, 2); else TG_WG(BF16, 16, 16, 4, 2);
     }
   } else {
     switch (cfg) {
-      case 0: return launch_wgrad<F32, 9, 4, 4>(k, grid, lds, st);
-      case 1: return launch_wgrad<F32, 9, 2, 2>(k, grid, lds, st);
-      case 2: return launch_wgrad<F32, 9, 4, 2>(k, grid, lds, st);
-      case 3: return launch_wgrad<F32, 16, 4, 2>(k, grid, lds, st);
+      case 0: if (split) TG_WG(F32, 9, 3, 4, 4); else TG_WG(F32, 9, 9, 4, 4);
+      case 1: if (split) TG_WG(F32, 9, 3, 2, 2); else TG_WG(F32, 9, 9, 2, 2);
+      case 2: if (split) TG_WG(F32, 9, 3, 4, 2); else TG_WG(F32, 9, 9, 4, 2);
+      case 3: if (split) TG_WG(F32, 16, 4, 4, 2); else TG_WG(F32, 16, 16, 4, 2);
     }
   }
+#undef TG_WG
   return TG_E_UNSUPPORTED;
 }
 

@@ -173,11 +173,11 @@ class Conv:
         key = ("w", N, XH, XW, YH, YW)
         ent = self._desc.get(key)
         if ent is None:
-            nsplit = K.wgrad_nsplit(N, YH, YW, S, K.wgrad_blocks(len(taps), cx, cy))
+            nsplit, tpw = K.wgrad_plan(N, YH, YW, S, len(taps), cx, cy)
             if self.ws.frozen:
                 raise L.TecoganHipError("new wgrad shape after graph capture")
             slab = torch.empty(nsplit * len(taps) * cx * cy, dtype=torch.float32, device=X.device)
-            ent = (K.make_wgrad_desc(self.tg, N, XH, XW, cx, YH, YW, cy, S, taps, nsplit), nsplit, slab)
+            ent = (K.make_wgrad_desc(self.tg, N, XH, XW, cx, YH, YW, cy, S, taps, nsplit, tpw), nsplit, slab)
             self._desc[key] = ent
         d, nsplit, slab = ent
         self.fin_job = [slab.data_ptr(), self.gw.data_ptr(), s_a, s_b, nsplit, len(taps), cx, cy, ca, cb]

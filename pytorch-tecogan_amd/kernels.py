@@ -181,8 +181,9 @@ def pack_weights(dtype_t, w, rows, K, s_row, s_k, nslots, slots, out=None):
     return out
 
 
-def make_wgrad_desc(dtype, N, XH, XW, cx_p, YH, YW, cy_p, S, taps, nsplit):
+def make_wgrad_desc(dtype, N, XH, XW, cx_p, YH, YW, cy_p, S, taps, nsplit, taps_per_wg=0):
     d = L.WgradDesc()
+    d.taps_per_wg = taps_per_wg
     d.dtype, d.N, d.XH, d.XW, d.Cx, d.YH, d.YW, d.Cy, d.S = dtype, N, XH, XW, cx_p, YH, YW, cy_p, S
     d.ntaps, d.nsplit = len(taps), nsplit
     for t, (dy, dx) in enumerate(taps):
@@ -206,6 +207,18 @@ def wgrad_nsplit(N, YH, YW, S, blocks=1):
     tw, th = (16, 4) if S == 2 else ((32, 4) if YW > 16 else (16, 8))
     tiles = N * ((YW + tw - 1) // tw) * ((YH + th - 1) // th)
     return max(1, min(tiles, 256 // max(1, blocks)))
+
+
+def wgrad_plan(N, YH, YW, S, ntaps, cx_p, cy_p):
+    """(nsplit, taps_per_wg).  Layers with few pixel tiles split the taps over workgroups (3 of 9 / 4 of 16 each): the fp32
+    slab traffic (nsplit x taps x Cx x Cy x 4 B written, then read by the fold) is what bounds them; layers with thousands
+    of tiles keep all taps in one workgroup (each staged tile is then used for every tap)."""
+    tw, th = (16, 4) if S == 2 else ((32, 4) if YW > 16 else (16, 8))
+    tiles = N * ((YW + tw - 1) // tw) * ((YH + th - 1) // th)
+    blocks = wgrad_blocks(ntaps, cx_p, cy_p)
+    if ntaps == 9 and tiles <= 512 and blocks == 1:  # measured: 21 vs 25 us on the 64-channel 32x32 trunk layers (N=40);
+        return max(1, min(tiles, 256 // 3)), 3       # slower on every larger layer (tools/microbench.py wgrad)
+    return max(1, min(tiles, 256 // max(1, blocks))), 0
 
 
 def wgrad_blocks(ntaps, cx_p, cy_p):

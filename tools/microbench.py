@@ -78,16 +78,22 @@ def bench_wgrad(kind, cin, cout, N, H, W, dt, splits):
     slots = K.slot_table(len(taps), DEV)
     res = []
     for ns in splits:
-        nsplit = ns if ns > 0 else K.wgrad_nsplit(N, Y.shape[1], Y.shape[2], S, K.wgrad_blocks(len(taps), X.shape[3], Y.shape[3]))
+        tpw = 0
+        if ns == 0:
+            nsplit, tpw = K.wgrad_plan(N, Y.shape[1], Y.shape[2], S, len(taps), X.shape[3], Y.shape[3])
+        elif ns < 0:
+            nsplit, tpw = -ns, (3 if len(taps) == 9 else 4)
+        else:
+            nsplit = ns
         desc = K.make_wgrad_desc(K.tg_dtype(dt), N, X.shape[1], X.shape[2], X.shape[3], Y.shape[1], Y.shape[2], Y.shape[3],
-                                 S, taps, nsplit)
+                                 S, taps, nsplit, tpw)
         slab = torch.empty(nsplit * len(taps) * X.shape[3] * Y.shape[3], device=DEV)
 
         def fn():
             K.wgrad(desc, X, Y, slab)
             K.wgrad_finalize(slab, nsplit, len(taps), X.shape[3], Y.shape[3], ca, cb, grad, s_a, s_b, slots, True)
         us = time_graph(fn)
-        res.append(f"ns={nsplit}: {us:7.1f} us {flops / us / 1e6:6.1f} TF/s")
+        res.append(f"ns={nsplit}{'/tpw' + str(tpw) if tpw else ''}: {us:7.1f} us {flops / us / 1e6:6.1f} TF/s")
     print(f"wgrad {kind:4s} {cin:3d}->{cout:3d} N={N:2d} {H}x{W} {str(dt)[6:]:8s} | " + " | ".join(res), flush=True)
 
 
@@ -118,7 +124,7 @@ def main():
         bench_conv("c3", 128, 128, 24, 16, 16, "fwd", bf, ["64x64", "32x64", "128x128"])
         bench_conv("c4s2", 64, 64, 24, 128, 128, "dgrad", bf, big)
     if what in ("wgrad", "all"):
-        sp = [0, 32, 64, 128, 256]
+        sp = [0, -32, -85, -128, 128, 256]
         bench_wgrad("c3", 64, 64, 40, 32, 32, bf, sp)
         bench_wgrad("c3", 64, 64, 40, 64, 64, bf, sp)
         bench_wgrad("c3", 128, 128, 40, 64, 64, bf, sp)
