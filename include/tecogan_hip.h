@@ -188,9 +188,11 @@ int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const float* b, co
                     int nblocks, int64_t len, void* stream);
 /* content loss partial sum and d(pre-sigmoid) for the generator output (code/train.py:239-241):
  * acc[0] += sum (gen-y)^2 ; dpre[nhwc] = gscale * 2*(gen-y) * gen*(1-gen) ; acc[8+c] += sum dpre[c] (output bias grad).  gen/y are NCHW fp32 (B,T,3,H,W);
- * dpre is NHWC [(t1-t0)*B][H][W][32] in (t,b) order and covers frames t0 <= t < t1 only. */
+ * dpre is NHWC [(t1-t0)*B][H][W][32] in (t,b) order and covers frames t0 <= t < t1 only.
+ * pp_T > 0 (ping-pong, T == 2*pp_T-1): acc[6] += sum |gen_t - gen_{2(pp_T-1)-t}| over t < pp_T-1 and the gradient
+ * pp_coef*sign(gen_t - gen_partner) is added before the sigmoid derivative (code/train.py:275-283). */
 int tg_content_loss(int dtype, const float* gen, const float* y, void* dpre, float* acc, int B, int T, int H, int W,
-                    float gscale, int t0, int t1, void* stream);
+                    float gscale, int t0, int t1, int pp_T, float pp_coef, void* stream);
 /* All step scalars on device + d(logit) for the discriminator loss (code/train.py:287-333). */
 int tg_loss_finalize(const float* prob, const float* acc, float* scalars, float* dlogit, int tb, const float* cfg,
                      void* stream);

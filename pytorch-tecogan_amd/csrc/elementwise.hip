@@ -241,18 +241,23 @@ __global__ __launch_bounds__(256) void absdiff_sum_kernel(const char* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void content_loss_kernel(const float* __restrict__ gen, const float* __restrict__ y,
                                                           char* __restrict__ dpre, float* __restrict__ acc, int B,
-                                                          int T_, int H, int W, float gscale, int t0, int t1) {
+                                                          int T_, int H, int W, float gscale, int t0, int t1, int pp_T,
+                                                          float pp_coef) {
   using TR = ElemTraits<T>;
   __shared__ float sh[4];
   const long long HW = (long long)H * W;
   const long long total = (long long)B * (t1 - t0) * HW;  // frames [t0,t1); dpre holds only those, frame-major
-  float s = 0.f, cs[3] = {0.f, 0.f, 0.f};
+  float s = 0.f, cs[3] = {0.f, 0.f, 0.f}, pps = 0.f;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += 256LL * gridDim.x) {
     const long long pos = i % HW;
     const long long r = i / HW;
     const int b = (int)(r % B);
     const int t = t0 + (int)(r / B);  // destination order is (t, b): the batched backward sees frame-major samples
     const long long src = ((long long)b * T_ + t) * 3 * HW + pos;
+    // ping-pong term (code/train.py:275-283): frames t and 2(T-1)-t of the doubled sequence should agree; the loss
+    // mean|gen_t - gen_partner| enters the generator loss with weight 2*pp_scaling (aliased gen_loss/fnet_loss tensors)
+    const bool pp = pp_T > 0 && t != pp_T - 1;
+    const long long psrc = pp ? ((long long)b * T_ + (2 * (pp_T - 1) - t)) * 3 * HW + pos : 0;
     float v[32];
 #pragma unroll
     for (int c = 0; c < 32; ++c) v[c] = 0.f;
@@ -260,7 +265,13 @@ __global__ __launch_bounds__(256) void content_loss_kernel(const float* __restri
     for (int c = 0; c < 3; ++c) {
       const float g = gen[src + c * HW], d = g - y[src + c * HW];
       s += d * d;
-      v[c] = gscale * 2.f * d * g * (1.f - g);
+      float dg = gscale * 2.f * d;
+      if (pp) {
+        const float e = g - gen[psrc + c * HW];
+        dg += pp_coef * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+        if (t < pp_T - 1) pps += fabsf(e);  // every pair once
+      }
+      v[c] = dg * g * (1.f - g);
       cs[c] += v[c];
     }
     if (dpre) {
@@ -273,15 +284,18 @@ __global__ __launch_bounds__(256) void content_loss_kernel(const float* __restri
   // serialise at the memory side (measured: 428 us with per-wave atomics)
   __shared__ float shc[4][4];
   s = wave_sum(s);
+  pps = wave_sum(pps);
 #pragma unroll
   for (int c = 0; c < 3; ++c) cs[c] = wave_sum(cs[c]);
   if ((threadIdx.x & 63) == 0) {
     sh[threadIdx.x >> 6] = s;
+    shc[3][threadIdx.x >> 6] = pps;
 #pragma unroll
     for (int c = 0; c < 3; ++c) shc[c][threadIdx.x >> 6] = cs[c];
   }
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
+  if (threadIdx.x == 4 && pp_T > 0) atomicAdd(acc + 6, shc[3][0] + shc[3][1] + shc[3][2] + shc[3][3]);
   if (threadIdx.x >= 1 && threadIdx.x <= 3) {
     const int c = threadIdx.x - 1;
     atomicAdd(acc + 8 + c, shc[c][0] + shc[c][1] + shc[c][2] + shc[c][3]);  // output-layer bias gradient
@@ -474,11 +488,12 @@ extern "C" int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const f
 }
 
 extern "C" int tg_content_loss(int dtype, const float* gen, const float* y, void* dpre, float* acc, int B, int T,
-                               int H, int W, float gscale, int t0, int t1, void* stream) {
+                               int H, int W, float gscale, int t0, int t1, int pp_T, float pp_coef, void* stream) {
   if (!gen || !y || !acc || B <= 0 || T <= 0 || H <= 0 || W <= 0 || t0 < 0 || t1 > T || t0 >= t1) return TG_E_BADARG;
+  if (pp_T != 0 && T != 2 * pp_T - 1) return TG_E_BADARG;  // ping-pong: the sequence is x followed by reverse(x)[1:]
   const long long total = (long long)B * (t1 - t0) * H * W;
   TG_DISPATCH(dtype, content_loss_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), (hipStream_t)stream, gen, y,
-              (char*)dpre, acc, B, T, H, W, gscale, t0, t1);
+              (char*)dpre, acc, B, T, H, W, gscale, t0, t1, pp_T, pp_coef);
   return tg_launch_status();
 }
 

@@ -329,10 +329,10 @@ def absdiff_sum(a, b, acc, acc_idx, npix, C_, Cp):
                                     _stream()), "tg_absdiff_sum")
 
 
-def content_loss(gen, y, dpre, acc, B, T, H, W, gscale, t0=0, t1=None):
+def content_loss(gen, y, dpre, acc, B, T, H, W, gscale, t0=0, t1=None, pp_T=0, pp_coef=0.0):
     dt = tg_dtype(dpre.dtype) if dpre is not None else L.TG_F32
     L.check(L.load().tg_content_loss(dt, _ptr(gen), _ptr(y), _ptr(dpre), _ptr(acc), B, T, H, W, gscale, t0,
-                                     T if t1 is None else t1, _stream()), "tg_content_loss")
+                                     T if t1 is None else t1, pp_T, pp_coef, _stream()), "tg_content_loss")
 
 
 def loss_finalize(prob, acc, scalars, dlogit, tb, cfg):

@@ -29,7 +29,7 @@ def _i64(vals, device):
     return torch.tensor(vals, dtype=torch.int64, device=device)
 
 
-def build_tables(B, T, h, K):
+def build_tables(B, T, h, K, pingpang=False):
     """Element-offset tables that drive tg_up4_planes / tg_copy_blocks / tg_warp_nchw (pure host logic, unit-tested on CPU).
     x is (B,T,3,h,h), flow (B,T-1,2,H,H), T_vel (B*3K,H,H,2) == blocks of 2*H*H floats."""
     H = 4 * h
@@ -63,7 +63,13 @@ def build_tables(B, T, h, K):
     # rows 0..B-1 only, i.e. the FIRST 6B planes of the flattened tensor (for K=3 that mixes batch elements).
     frames = list(range(2, tsize, 3)) + list(range(1, tsize, 3))
     bsrc, bdst = [], []
-    for b in range(B):
+    if pingpang:  # VNxt = flip(flow, time)[:, 1:ts:3], raw (code/train.py:154): plain block copies, no "back" planes
+        for b in range(B):
+            for j in range(K):
+                csrc.append(((b * (T - 1) + (T - 2 - (1 + 3 * j))) * 2) * HH)
+                cdst.append(((b * tsize + 3 * j + 2) * 2) * HH)
+        out["tv_csrc"], out["tv_cdst"] = csrc, cdst
+    for b in range(B if not pingpang else 0):
         for j in range(K):
             for comp in range(2):
                 P = 2 * K * b + 2 * j + comp
@@ -77,13 +83,16 @@ def build_tables(B, T, h, K):
 class TecoGANStep:
     def __init__(self, G, D, B, T, h, args, device, use_graph=False, process_group=None, world_size=1):
         """G: GeneratorEngine, D: DiscriminatorEngine (already bound to flat parameter buffers on `device`)."""
-        if getattr(args, "pingpang", False):
-            raise NotImplementedError("pingpang=True is not implemented on the HIP path yet (default is False)")
         if not getattr(args, "Dt_mergeDs", True):
             raise RuntimeError("Dt_mergeDs=False feeds 9 channels into a 27-channel conv in the reference and raises "
                                "there too (SURVEY.md 8a8)")
         if float(getattr(args, "vgg_scaling", -1.0)) > 0.0:
             raise NotImplementedError("vgg_scaling>0 crashes in the reference (code/train.py:126 vs :30); not built")
+        # ping-pong (code/train.py:56-62): the step runs on x followed by reverse(x)[1:], i.e. 2T-1 frames
+        self.pingpang = bool(getattr(args, "pingpang", False))
+        self.T_in = T
+        if self.pingpang:
+            T = 2 * T - 1
         self.G, self.D, self.B, self.T, self.h, self.args, self.dev = G, D, B, T, h, args, device
         self.H = H = 4 * h
         self.K = T // 3
@@ -134,7 +143,7 @@ class TecoGANStep:
 
     # ----------------------------------------------------------------------------------------------------------
     def _tables(self):
-        t = build_tables(self.B, self.T, self.h, self.K)
+        t = build_tables(self.B, self.T, self.h, self.K, self.pingpang)
         dev = self.dev
         self.flow_src, self.flow_dst, self.n_flow = _i64(t["flow_src"], dev), _i64(t["flow_dst"], dev), len(t["flow_src"])
         self.lrw_img, self.lrw_grid = _i64(t["lrw_img"], dev), _i64(t["lrw_grid"], dev)
@@ -156,7 +165,8 @@ class TecoGANStep:
         c[6], c[7] = a.EPS, a.ratio
         c[8] = min(a.Dt_ratio_max, a.Dt_ratio_0 + a.Dt_ratio_add * float(global_step))
         c[9] = 1.0 if a.D_LAYERLOSS else 0.0
-        c[10], c[11] = 0.0, a.pp_scaling
+        c[10] = float(B * (self.T_in - 1) * 3 * H * H) if self.pingpang else 0.0
+        c[11] = a.pp_scaling
         self.dt_ratio = c[8]
         gs = 1.0 / self.world
         c[16:24] = K.adam_hyper(lr_g, betas_g[0], betas_g[1], eps_g, self.adam_t[0] + 1, gs)
@@ -187,8 +197,11 @@ class TecoGANStep:
         K.warp_nchw(self.x, self.lrw_img, self.x, self.lrw_grid, B * (T - 1), 3, h, h, h, h, False, sq_ref=self.x,
                     sq_off=self.lrw_grid, loss_acc=self.acc[1:2])
         K.copy_blocks(self.flow, self.tv_csrc, self.tvel, self.tv_cdst, self.n_tvc, 2 * HH)
-        K.up4_planes(self.x, self.tv_bsrc, self.tvel, self.tv_bdst, self.n_tvb, h, h, pre=4.0, post_a=2.0, post_b=-1.0)
+        if self.n_tvb:
+            K.up4_planes(self.x, self.tv_bsrc, self.tvel, self.tv_bdst, self.n_tvb, h, h, pre=4.0, post_a=2.0, post_b=-1.0)
         tb = self.tb
+        pp_T = self.T_in if self.pingpang else 0
+        pp_coef = (2.0 * self.args.pp_scaling / (B * (self.T_in - 1) * 3 * H * H)) if (self.pingpang and self.args.pp_scaling > 0) else 0.0
         early = self.dreal_early
         sB.wait_stream(main)
         with torch.cuda.stream(sB):
@@ -207,7 +220,8 @@ class TecoGANStep:
             G.forward(t * B, B, self.gen, t * 3 * HH, T * 3 * HH)
             if t + 1 == self.chunks[ci][1] and on("gbwd"):
                 t0, t1 = self.chunks[ci]
-                K.content_loss(self.gen, self.y, self.dpre[ci], self.acc, B, T, H, H, 1.0 / (B * T * 3 * H), t0, t1)
+                K.content_loss(self.gen, self.y, self.dpre[ci], self.acc, B, T, H, H, 1.0 / (B * T * 3 * H), t0, t1, pp_T,
+                               pp_coef)
                 if len(self.chunks) > 1:  # experimental frame-chunked backward beside the chain (measured slower)
                     sC.wait_stream(main)
                     with torch.cuda.stream(sC):
@@ -292,10 +306,14 @@ class TecoGANStep:
     def run(self, x, y, global_step, lr_g, lr_d, betas_g=(0.9, 0.999), betas_d=(0.9, 0.999), eps_g=1e-8, eps_d=1e-8):
         """x (B,T,3,h,h), y (B,T,3,H,H) fp32 device tensors.  Returns nothing; results live in self.gen / self.scalars /
         self.target and the parameter / optimiser buffers are updated in place."""
-        if x.shape != self.x.shape or y.shape != self.y.shape:
-            raise ValueError(f"step built for {tuple(self.x.shape)} / {tuple(self.y.shape)}")
-        self.x.copy_(x)
-        self.y.copy_(y)
+        Ti = self.T_in
+        if tuple(x.shape) != (self.B, Ti, 3, self.h, self.h) or tuple(y.shape) != (self.B, Ti, 3, self.H, self.H):
+            raise ValueError(f"step built for B={self.B}, T={Ti}, crop {self.h}; got {tuple(x.shape)} / {tuple(y.shape)}")
+        self.x[:, :Ti].copy_(x)
+        self.y[:, :Ti].copy_(y)
+        if self.pingpang:  # reverse(x)[1:] appended (data movement only)
+            self.x[:, Ti:].copy_(torch.flip(x, dims=[1])[:, 1:])
+            self.y[:, Ti:].copy_(torch.flip(y, dims=[1])[:, 1:])
         self._host_params(global_step + 1, lr_g, lr_d, betas_g, betas_d, eps_g, eps_d)
         if self.use_graph:
             if self.graphs is None:

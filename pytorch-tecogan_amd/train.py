@@ -48,7 +48,7 @@ def get_step(generator_F, discriminator_F, B, T, h, args, device, dtype_t=None, 
     if use_graph is None:
         use_graph = os.environ.get("TECOGAN_GRAPH", "1") != "0"
     Ge, De = generator_F.engine(dtype_t), discriminator_F.engine(dtype_t)
-    key = (id(Ge), id(De), B, T, h, use_graph)
+    key = (id(Ge), id(De), B, T, h, use_graph, bool(getattr(args, "pingpang", False)))
     st = _STEPS.get(key)
     if st is None:
         pg, world = parallel.dist_info()
@@ -68,7 +68,7 @@ def TecoGAN(r_inputs, r_targets, discriminator_F, generator_F, args, Global_step
     B, T = r_inputs.shape[0], r_inputs.shape[1]
     if int(args.RNN_N) != T:
         raise ValueError("r_inputs.shape[1] must equal args.RNN_N")
-    if T // 3 != 3:
+    if T // 3 != 3 and not getattr(args, "pingpang", False):
         raise RuntimeError("the reference's D-input reshape only works for RNN_N in {9,10,11} (code/train.py:143-145)")
     h = int(args.crop_size)
     st = get_step(generator_F, discriminator_F, B, T, h, args, r_inputs.device)
@@ -91,6 +91,8 @@ def _network(st, args, global_step, counter1, counter2):
     if args.D_LAYERLOSS:
         names += ["D_layer_%d_loss" % i for i in range(4)] + ["D_layer_loss_sum"]
     names += ["l2_content_loss", "l2_warp_loss"]  # l2_content_loss holds the aliased total (code/train.py:244,293,299)
+    if getattr(args, "pingpang", False):
+        names += ["PingPang"]
     names += ["t_adversarial_loss", "t_discrim_loss", "t_discrim_real_output", "t_discrim_fake_output", "All_loss_Gen"]
     n = len(names)
     vals = [s[16 + i] for i in range(n)]

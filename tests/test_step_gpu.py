@@ -152,6 +152,40 @@ def test_step_fp32_vs_golden_and_oracle(golden_dir, oracle_b1, monkeypatch):
     assert float(st["step"]) == 1.0 and float(st["exp_avg"].abs().sum()) > 0
 
 
+@pytest.mark.parametrize("name,seed,over", [
+    ("step_b1_pingpang", 3, dict(pingpang=True)),
+    ("step_b1_nolayerloss", 4, dict(D_LAYERLOSS=False)),
+    ("step_b1_cropdt1", 5, dict(crop_dt=1.0)),
+    ("step_b1_rb2", 6, dict(num_resblock=2, discrim_resblocks=1)),
+])
+def test_step_variants_vs_golden(golden_dir, monkeypatch, name, seed, over):
+    """the flag variants of the step the reference runs, against fixtures from the real reference"""
+    monkeypatch.setenv("TECOGAN_GRAPH", "0")
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    args, G, D, og, od, gp, dp = build(seed, "fp32", **over)
+    x, y = synth(1, 10, 32, seed)
+    out = train.FRVSR_Train(x.cuda(), y.cuda(), args, D, G, 0, 0.0, 0.0, og, od)
+    torch.cuda.synchronize()
+    assert list(gold["s0_names"]) == list(out.update_list_name)
+    got = np.array([float(v) for v in out.update_list])
+    np.testing.assert_allclose(got, gold["s0_update_list"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(float(out.gen_loss), float(gold["s0_gen_loss"]), rtol=1e-3)
+    np.testing.assert_allclose(float(out.d_loss), float(gold["s0_d_loss"]), rtol=1e-3)
+    go = out.gen_output.cpu()
+    assert go.shape[1] == (19 if over.get("pingpang") else 10)
+    np.testing.assert_allclose(go.reshape(-1)[sample_idx(go.numel())].numpy(), gold["s0_gen_sample"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(float(go.double().sum()), float(gold["s0_gen_sum"]), rtol=1e-5)
+    tg = out.target.cpu()
+    np.testing.assert_allclose(tg.reshape(-1)[sample_idx(tg.numel())].numpy(), gold["s0_target_sample"], rtol=1e-4, atol=1e-6)
+    gnorm = np.array([float(p.grad.double().norm()) for _, p in G.named_parameters()])
+    np.testing.assert_allclose(gnorm, gold["s0_g_grad_norms"], rtol=1e-3)
+    dnorm = np.array([float(p.grad.double().norm()) for _, p in D.named_parameters()])
+    np.testing.assert_allclose(dnorm, gold["s0_d_grad_norms"], rtol=2e-2, atol=1e-9)
+    sdG, sdD = G.state_dict(), D.state_dict()
+    np.testing.assert_allclose(sdG["output.weight"].cpu().numpy(), gold["s0_post_output_weight"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(sdD["fc.weight"].cpu().numpy(), gold["s0_post_fc_weight"], rtol=1e-5, atol=1e-7)
+
+
 def test_step_fp32_three_steps_teacher_forced(golden_dir, monkeypatch):
     """three consecutive steps; the oracle is re-synchronised to the HIP weights before every compared step."""
     monkeypatch.setenv("TECOGAN_GRAPH", "0")
