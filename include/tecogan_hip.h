@@ -37,7 +37,7 @@ enum {
   TG_E_ALIGN = -3        /* channel count not a multiple of 32, pointer not 16-byte aligned */
 };
 
-enum { TG_ACT_NONE = 0, TG_ACT_RELU = 1, TG_ACT_LRELU = 2, TG_ACT_SIGMOID = 3 };
+enum { TG_ACT_NONE = 0, TG_ACT_RELU = 1, TG_ACT_LRELU = 2, TG_ACT_SIGMOID = 3, TG_ACT_TANH24 = 4 /* 24*tanh, code/models.py:50 */ };
 enum { TG_MASK_NONE = 0, TG_MASK_RELU = 1, TG_MASK_LRELU = 2 };
 enum { TG_OUT_NHWC = 0, TG_OUT_NCHW_F32 = 1 };
 
@@ -137,6 +137,12 @@ int tg_nchw_to_nhwc(int dtype, const float* src, int64_t src_n_stride, void* dst
 int tg_nhwc_to_nchw(int dtype, const void* src, float* dst, int64_t dst_n_stride, int N, int C, int Cp, int H, int W,
                     void* stream);
 
+/* ---- f_net resampling (code/models.py:9-24: nn.MaxPool2d(2) / nn.Upsample(scale_factor=2, bilinear)) --------- */
+/* NHWC `dtype`, C % 32 == 0.  maxpool2: [N][H][W][C] -> [N][H/2][W/2][C] (H, W even).  up2_bilinear: -> [N][2H][2W][C],
+ * align_corners=False. */
+int tg_maxpool2(int dtype, const void* src, void* dst, int N, int H, int W, int C, void* stream);
+int tg_up2_bilinear(int dtype, const void* src, void* dst, int N, int H, int W, int C, void* stream);
+
 /* ---- flow / warp / packing (code/train.py:71-111,138-198; code/ops.py:98-100) -------------------------- */
 /* dst_plane[i] = post_a * bilinear_x4(pre * src_plane[i]) + post_b ; planes are h*w (src) and 4h*4w (dst) fp32,
  * addressed by element offsets (nn.Upsample(scale_factor=4, bilinear, align_corners=False)). */
@@ -187,7 +193,7 @@ int tg_absdiff_sum(int dtype, const void* a, const void* b, float* acc, int64_t 
 int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const float* b, const int64_t* b_off_dev, float* acc,
                     int nblocks, int64_t len, void* stream);
 /* content loss partial sum and d(pre-sigmoid) for the generator output (code/train.py:239-241):
- * acc[0] += sum (gen-y)^2 ; dpre[nhwc] = gscale * 2*(gen-y) * gen*(1-gen) ; acc[8+c] += sum dpre[c] (output bias grad).  gen/y are NCHW fp32 (B,T,3,H,W);
+ * acc (>= 16 floats): acc[0] += sum (gen-y)^2 ; dpre[nhwc] = gscale * 2*(gen-y) * gen*(1-gen) ; acc[8+c] += sum dpre[c] (output bias grad).  gen/y are NCHW fp32 (B,T,3,H,W);
  * dpre is NHWC [(t1-t0)*B][H][W][32] in (t,b) order and covers frames t0 <= t < t1 only.
  * pp_T > 0 (ping-pong, T == 2*pp_T-1): acc[6] += sum |gen_t - gen_{2(pp_T-1)-t}| over t < pp_T-1 and the gradient
  * pp_coef*sign(gen_t - gen_partner) is added before the sigmoid derivative (code/train.py:275-283). */

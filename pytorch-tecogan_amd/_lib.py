@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtecogan_hip.so")
 
 TG_F32, TG_BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_TANH24 = 0, 1, 2, 3, 4
 MASK_NONE, MASK_RELU, MASK_LRELU = 0, 1, 2
 OUT_NHWC, OUT_NCHW_F32 = 0, 1
 TILE_AUTO, TILE_64x256, TILE_64x64, TILE_128x128, TILE_32x128 = 0, 1, 2, 3, 4
@@ -56,6 +56,8 @@ _PROTOS = {
     "tg_wgrad_finalize_multi": (_I, [_P, _I, _I, _P]),
     "tg_nchw_to_nhwc": (_I, [_I, _P, _L, _P, _I, _I, _I, _I, _I, _P]),
     "tg_nhwc_to_nchw": (_I, [_I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "tg_maxpool2": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
+    "tg_up2_bilinear": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "tg_up4_planes": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P]),
     "tg_copy_blocks": (_I, [_P, _P, _P, _P, _I, _L, _P]),
     "tg_warp_nchw": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

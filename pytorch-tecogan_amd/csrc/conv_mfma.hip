@@ -88,6 +88,10 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == TG_ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == TG_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
   if (act == TG_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+  if (act == TG_ACT_TANH24) {  // f_net output 24*tanh(v), code/models.py:50
+    const float t = __expf(-2.f * fabsf(v));
+    return copysignf(24.f * (1.f - t) / (1.f + t), v);
+  }
   return v;
 }
 

@@ -454,6 +454,69 @@ class GeneratorEngine:
 
 
 # =============================================================================================================
+FNET_BLOCKS = (("down1", 3, 32), ("down2", 32, 64), ("down3", 64, 128), ("down4", 128, 256), ("up1", 256, 512),
+               ("up2", 512, 256), ("up3", 256, 128), ("up4", 128, 64))
+
+
+def fnet_shapes():
+    s = OrderedDict()
+    for name, ci, co in FNET_BLOCKS:
+        s[f"{name}.0.weight"], s[f"{name}.0.bias"] = (co, ci, 3, 3), (co,)
+        s[f"{name}.2.weight"], s[f"{name}.2.bias"] = (co, co, 3, 3), (co,)
+    s["output_block.0.weight"], s["output_block.0.bias"] = (32, 64, 3, 3), (32,)
+    s["output_block.2.weight"], s["output_block.2.bias"] = (2, 32, 3, 3), (2,)
+    return s
+
+
+class FNetEngine:
+    """code/models.py:9-50, forward only: four (conv-lrelu-conv-lrelu-maxpool) encoder blocks, four
+    (conv-lrelu-conv-lrelu-bilinear x2) decoder blocks, conv-lrelu-conv, 24*tanh.  The reference never instantiates f_net
+    (main.py:231 is commented out), so there is no training path for it to mirror."""
+
+    def __init__(self, flat, dtype_t):
+        self.flat, self.dt = flat, dtype_t
+        self.ws = Workspace(flat.device)
+        mk = lambda pre, ci, co: Conv(flat, pre + ".weight", pre + ".bias", ConvSpec("c3", ci, co), dtype_t, self.ws,
+                                      need_dgrad=False)
+        self.blocks = [(name, mk(name + ".0", ci, co), mk(name + ".2", co, co), co) for name, ci, co in FNET_BLOCKS]
+        self.o0, self.o2 = mk("output_block.0", 64, 32), mk("output_block.2", 32, 2)
+        self.convs = [c for _, a, b, _ in self.blocks for c in (a, b)] + [self.o0, self.o2]
+        self.repacker = Repacker(self.convs, dtype_t, flat.device)
+        self.shape, self.act = None, None
+
+    def repack(self):
+        self.repacker.run()
+
+    def alloc(self, N, h, w):
+        if h % 16 or w % 16:
+            raise ValueError("f_net needs H and W divisible by 16 (four 2x2 max-pools)")
+        if self.shape == (N, h, w):
+            return
+        dev, dt = self.flat.device, self.dt
+        e = lambda hh, ww, c: torch.empty(N, hh, ww, pad32(c), dtype=dt, device=dev)
+        bufs, hh, ww = [], h, w
+        for i, (_, _, _, co) in enumerate(self.blocks):
+            a, b = e(hh, ww, co), e(hh, ww, co)
+            hh, ww = (hh // 2, ww // 2) if i < 4 else (hh * 2, ww * 2)
+            bufs.append((a, b, e(hh, ww, co)))
+        self.act = {"in": e(h, w, 3), "blocks": bufs, "o0": e(h, w, 32)}
+        self.shape = (N, h, w)
+
+    def forward(self, out):
+        """act['in'] -> out [N,2,h,w] fp32 NCHW"""
+        N, h, w = self.shape
+        x = self.act["in"]
+        tg = K.tg_dtype(self.dt)
+        for i, (_, c0, c2, _) in enumerate(self.blocks):
+            a, b, r = self.act["blocks"][i]
+            c0.fwd(x, a, act=L.ACT_LRELU)
+            c2.fwd(a, b, act=L.ACT_LRELU)
+            (K.maxpool2 if i < 4 else K.up2_bilinear)(b, r)
+            x = r
+        self.o0.fwd(x, self.act["o0"], act=L.ACT_LRELU)
+        self.o2.fwd(self.act["o0"], None, act=L.ACT_TANH24, nchw=(out, 0, 2 * h * w, 2))
+
+
 def discriminator_shapes(resblocks=4, ch=128, fc_in=48):
     s = OrderedDict()
     s["conv.0.weight"], s["conv.0.bias"] = (64, 27, 3, 3), (64,)

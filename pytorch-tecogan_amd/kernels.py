@@ -245,6 +245,16 @@ def nhwc_to_nchw(src, dst, n_stride, N, C_, H, W):
             "tg_nhwc_to_nchw")
 
 
+def maxpool2(src, dst):
+    N, H, W, C_ = src.shape
+    L.check(L.load().tg_maxpool2(tg_dtype(src.dtype), _ptr(src), _ptr(dst), N, H, W, C_, _stream()), "tg_maxpool2")
+
+
+def up2_bilinear(src, dst):
+    N, H, W, C_ = src.shape
+    L.check(L.load().tg_up2_bilinear(tg_dtype(src.dtype), _ptr(src), _ptr(dst), N, H, W, C_, _stream()), "tg_up2_bilinear")
+
+
 def to_nhwc(x, dtype_t):
     """[N,C,H,W] fp32 device tensor -> [N,H,W,pad32(C)] of dtype_t."""
     N, C_, H, W = x.shape

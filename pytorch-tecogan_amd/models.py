@@ -204,22 +204,27 @@ class discriminator(_HipModule):
         return eng.prob.clone().view(N, 1), layers
 
 
-class f_net(nn.Module):
+class f_net(_HipModule):
     """code/models.py:22-50: defined and imported by the reference but never instantiated (main.py:231 is commented
-    out), so no HIP forward exists for it yet; the class keeps the parameter names/shapes for checkpoints."""
+    out; the step uses the pseudo-flow instead).  Same parameter names/shapes/init; forward(x[N,3,h,w]) -> [N,2,h,w]
+    (24*tanh) runs on the HIP kernels, inference only (the reference has no training path through it)."""
 
-    def __init__(self):
+    def __init__(self, args=None):
         super().__init__()
-        s = OrderedDict()
-        chans = [("down1", 3, 32), ("down2", 32, 64), ("down3", 64, 128), ("down4", 128, 256), ("up1", 256, 512),
-                 ("up2", 512, 256), ("up3", 256, 128), ("up4", 128, 64)]
-        for name, ci, co in chans:
-            s[f"{name}.0.weight"], s[f"{name}.0.bias"] = (co, ci, 3, 3), (co,)
-            s[f"{name}.2.weight"], s[f"{name}.2.bias"] = (co, co, 3, 3), (co,)
-        s["output_block.0.weight"], s["output_block.0.bias"] = (32, 64, 3, 3), (32,)
-        s["output_block.2.weight"], s["output_block.2.bias"] = (2, 32, 3, 3), (2,)
-        self._shapes = s
-        _build_tree(self, s)
+        self._args = args
+        self._shapes = E.fnet_shapes()
+        _build_tree(self, self._shapes)
+
+    def _make_engine(self, flat, dtype_t):
+        self._engine = E.FNetEngine(flat, dtype_t)
 
     def forward(self, x):
-        raise NotImplementedError("f_net is dead code in the reference hot path (never called); HIP forward not built")
+        eng = self.engine()
+        N, C_, h, w = x.shape
+        if C_ != 3:
+            raise ValueError("f_net expects 3 input channels (code/models.py:26)")
+        eng.alloc(N, h, w)
+        K.nchw_to_nhwc(x.contiguous().float(), C_ * h * w, eng.act["in"], N, C_, h, w)
+        out = torch.empty(N, 2, h, w, dtype=torch.float32, device=x.device)
+        eng.forward(out)
+        return out

@@ -174,6 +174,17 @@ def test_step_tables_reproduce_flow_and_tvel_against_the_oracle():
         tv[do:do + HH] = (orc.up4(xf[so:so + hh].view(1, 1, h, h) * 4.0) * 2.0 - 1.0).reshape(-1)
     ref_tv = orc.t_velocity(x, ref_flow, 3 * Kt)
     assert torch.equal(tv.view_as(ref_tv), ref_tv)
+    # ping-pong: 2T-1 frames, K = 6, VNxt = flip(flow)[:, 1:ts:3] copied raw (no back planes)
+    Tp, Kp = 2 * T - 1, (2 * T - 1) // 3
+    xp = torch.cat([x, torch.flip(x, dims=[1])[:, 1:]], dim=1)
+    tp = S.build_tables(B, Tp, h, Kp, pingpang=True)
+    assert tp["tv_bsrc"] == []
+    fp = orc.pseudo_flow(xp)
+    tvp = torch.full((B * 3 * Kp * 2 * HH,), float("nan"))
+    for so, do in zip(tp["tv_csrc"], tp["tv_cdst"]):
+        tvp[do:do + 2 * HH] = 0.0 if so < 0 else fp.reshape(-1)[so:so + 2 * HH]
+    ref_tvp = orc.t_velocity(xp, fp, 3 * Kp, pingpang=True)
+    assert torch.equal(tvp.view_as(ref_tvp), ref_tvp)
     # LR-warp tables: image x[b,t], grid block x[b,t+1,0:2]
     for n, (io, go) in enumerate(zip(t["lrw_img"], t["lrw_grid"])):
         b, tt = divmod(n, T - 1)
@@ -220,7 +231,7 @@ def test_no_cpu_fallback():
     G = M.generator(3, _args())
     with pytest.raises(L.TecoganHipError):
         G(torch.zeros(1, 51, 8, 8))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(L.TecoganHipError):
         M.f_net()(torch.zeros(1, 3, 32, 32))
     from pytorch_tecogan_amd import train as TR
     a = orc.default_args()

@@ -412,7 +412,7 @@ def test_content_loss_and_absdiff(dt):
     loss = torch.mean(torch.sum(torch.square(torch.sigmoid(pre) - y).reshape(B * T, 3, H, H), dim=[3]))
     gscale = 1.0 / (B * T * 3 * H)
     ref_dpre = (2 * (gen - y) * gen * (1 - gen) * gscale)
-    acc = torch.zeros(8, device=DEV)
+    acc = torch.zeros(16, device=DEV)
     dpre = torch.empty(T * B, H, H, 32, dtype=dt, device=DEV)
     K.content_loss(gen.to(DEV), y.to(DEV), dpre, acc, B, T, H, H, gscale)
     torch.testing.assert_close(acc[0].cpu() * gscale, loss.detach(), rtol=1e-5, atol=1e-6)
@@ -421,3 +421,50 @@ def test_content_loss_and_absdiff(dt):
     a, b2 = q(rnd((4, 64, 8, 8), 40), dt), q(rnd((4, 64, 8, 8), 41), dt)
     K.absdiff_sum(K.to_nhwc(a.to(DEV), dt), K.to_nhwc(b2.to(DEV), dt), acc, 3, 4 * 64, 64, 64)
     torch.testing.assert_close(acc[3].cpu(), (a - b2).abs().sum(), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_content_loss_pingpong_term(dt):
+    """code/train.py:275-283: pp = mean|gen[:, :n-1] - flip(gen)[:, :n-1]| on the 2n-1 frame sequence; its gradient
+    (weight 2*pp_scaling) is fused into the pre-sigmoid gradient of the content loss."""
+    B, n, H = 2, 3, 16
+    T = 2 * n - 1
+    gen = rnd((B, T, 3, H, H), 48, 0.05, 0.95)
+    y = rnd((B, T, 3, H, H), 49, 0, 1)
+    pre = torch.log(gen / (1 - gen)).requires_grad_(True)
+    g = torch.sigmoid(pre)
+    content = torch.mean(torch.sum(torch.square(g - y).reshape(B * T, 3, H, H), dim=[3]))
+    pp = torch.mean(torch.abs(g[:, 0:n - 1] - torch.flip(g, dims=[1])[:, :n - 1]))
+    pp_scaling = 0.7
+    (content + 2.0 * pp * pp_scaling).backward()
+    gscale = 1.0 / (B * T * 3 * H)
+    pp_div = B * (n - 1) * 3 * H * H
+    acc = torch.zeros(16, device=DEV)
+    dpre = torch.empty(T * B, H, H, 32, dtype=dt, device=DEV)
+    K.content_loss(gen.to(DEV), y.to(DEV), dpre, acc, B, T, H, H, gscale, pp_T=n, pp_coef=2.0 * pp_scaling / pp_div)
+    torch.testing.assert_close(acc[0].cpu() * gscale, content.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(acc[6].cpu() / pp_div, pp.detach(), rtol=1e-5, atol=1e-7)
+    got = K.to_nchw(dpre, 3).cpu().reshape(T, B, 3, H, H).transpose(0, 1)
+    torch.testing.assert_close(got, pre.grad, rtol=1e-2 if dt != torch.float32 else 1e-4, atol=1e-6)
+    # the sequence must be x ++ reverse(x)[1:]
+    assert L.load().tg_content_loss(K.tg_dtype(dt), gen.to(DEV).data_ptr(), y.to(DEV).data_ptr(), dpre.data_ptr(),
+                                    acc.data_ptr(), B, T, H, H, gscale, 0, T, n + 1, 0.0, None) == -1
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N,H,W,C_", [(2, 8, 12, 32), (1, 16, 16, 96), (3, 2, 2, 512)])
+def test_fnet_resampling_kernels(N, H, W, C_, dt):
+    """nn.MaxPool2d(2) and nn.Upsample(scale_factor=2, bilinear) of f_net (code/models.py:9-24) on NHWC"""
+    x = q(rnd((N, C_, H, W), 50 + C_), dt)
+    xd = K.to_nhwc(x.to(DEV), dt)
+    pooled = torch.empty(N, H // 2, W // 2, C_, dtype=dt, device=DEV)
+    K.maxpool2(xd, pooled)
+    assert torch.equal(K.to_nchw(pooled, C_).cpu(), F.max_pool2d(x, 2))
+    up = torch.empty(N, 2 * H, 2 * W, C_, dtype=dt, device=DEV)
+    K.up2_bilinear(xd, up)
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    torch.testing.assert_close(K.to_nchw(up, C_).cpu(), ref, rtol=1e-6 if dt == torch.float32 else 1e-2,
+                               atol=1e-6 if dt == torch.float32 else 1e-2)
+    lib = L.load()
+    assert lib.tg_maxpool2(K.tg_dtype(dt), xd.data_ptr(), pooled.data_ptr(), N, 3, W, C_, None) == -1
+    assert lib.tg_up2_bilinear(K.tg_dtype(dt), xd.data_ptr(), up.data_ptr(), N, H, W, 40, None) == -3

@@ -269,6 +269,18 @@ def test_modules_forward_match_golden(golden_dir):
         np.testing.assert_allclose(l.cpu().reshape(-1)[sample_idx(l.numel())].numpy(), u[f"d_layer{i}_sample"],
                                    rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(D.state_dict()["block1.1.running_mean"].cpu().numpy(), u["d_block1_rm"], rtol=1e-3, atol=1e-6)
+    # f_net (dead code in the reference step, kept usable): fixture from the reference module
+    Fn = models.f_net(args)
+    Fn.load_state_dict(orc.init_params(orc.fnet_param_shapes(), 13))
+    Fn = Fn.cuda()
+    fo = Fn(torch.from_numpy(u["f_in"]).cuda())
+    np.testing.assert_allclose(fo.cpu().numpy(), u["f_out"], rtol=1e-3, atol=1e-4)
+    args16 = orc.default_args()
+    args16.tg_dtype = "bf16"
+    Fb = models.f_net(args16)
+    Fb.load_state_dict(orc.init_params(orc.fnet_param_shapes(), 13))
+    fb = Fb.cuda()(torch.from_numpy(u["f_in"]).cuda())
+    assert rel(fb.cpu(), u["f_out"]) < 3e-2
     with pytest.raises(ValueError):
         models.generator(3)
     with pytest.raises(ValueError):
