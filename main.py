@@ -3,7 +3,7 @@ start-up side effects and output file names; the training / inference loops call
 reference-named modules in ./code (FRVSR_Train, generator, discriminator).
 
 Extra flags (all optional): --synthetic N trains on N random sequences instead of --input_video_dir (no dataset needed),
---tg_dtype {bf16,fp32}.  Multi-GPU: launch with torch.distributed.run; every rank then takes a disjoint shard of each batch.
+--tg_dtype {bf16,fp32}, --tg_extend true (shapes the reference cannot run, e.g. 64->256 seq-16).  Multi-GPU: launch with torch.distributed.run; every rank then takes a disjoint shard of each batch.
 """
 import argparse
 import os
@@ -52,6 +52,9 @@ def build_parser():
     a("--D_LAYERLOSS", default=True, type=str2bool)
     a("--synthetic", default=0, type=int, help="train on this many random sequences (no dataset)")
     a("--tg_dtype", default=None, choices=[None, "bf16", "fp32"])
+    a("--tg_extend", default=False, type=str2bool,
+      help="opt-in extension beyond what the reference can execute: RNN_N outside 9..11 and crop_size != 32 "
+           "(discriminator fc sized from crop_size); parity with the reference is undefined there")
     return p
 
 

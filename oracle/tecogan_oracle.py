@@ -328,8 +328,11 @@ def recurrent_generator(gp, x, flow, num_resblock=16, fp16_grid=True):
     return torch.stack(outs, dim=1)
 
 
-def t_velocity(x, flow, t_size, pingpang=False):
-    """code/train.py:138-158 -> (B*t_size, H, H, 2) detached grid block."""
+def t_velocity(x, flow, t_size, pingpang=False, extended=False):
+    """code/train.py:138-158 -> (B*t_size, H, H, 2) detached grid block.
+    extended=True (NOT reference behaviour, parity unpinned; SURVEY.md 8a8): for t_size//3 != 3 the reference's
+    reshape(B*K, 6, h, h)[0:B] -> (B, K, 2, H, H) raises; the extension keeps the first B*K*2 planes of the flattened
+    tensor, which is exactly what the reference keeps when K == 3."""
     B = x.shape[0]
     h = x.shape[-1]
     H = 4 * h
@@ -337,8 +340,11 @@ def t_velocity(x, flow, t_size, pingpang=False):
     v_pre = flow[:, 0:t_size:3]
     v_mid = torch.zeros_like(v_pre)
     if not pingpang:
-        back_in = torch.cat((x[:, 2:t_size:3], x[:, 1:t_size:3]), dim=1).reshape(B * K, 6, h, h)
-        back = up4(back_in[0:B] * 4.0).reshape(B, K, 2, H, H)  # rows 0..B-1 only (reference quirk)
+        back_in = torch.cat((x[:, 2:t_size:3], x[:, 1:t_size:3]), dim=1)
+        if extended and K != 3:
+            back = up4(back_in.reshape(1, B * 2 * K * 3, h, h)[:, :B * K * 2] * 4.0).reshape(B, K, 2, H, H)
+        else:
+            back = up4(back_in.reshape(B * K, 6, h, h)[0:B] * 4.0).reshape(B, K, 2, H, H)  # rows 0..B-1 only (quirk)
         v_nxt = back * 2.0 - 1.0
     else:
         v_nxt = torch.flip(flow, dims=[1])[:, 1:t_size:3]
@@ -430,7 +436,7 @@ def tecogan_forward(gp, dp, dbufs, x, y, args, global_step, counter1=0.0, counte
 
     names, vals = [], []
     t_size = 3 * (T // 3)
-    t_vel = t_velocity(x, flow, t_size, args.pingpang)
+    t_vel = t_velocity(x, flow, t_size, args.pingpang, bool(getattr(args, "tg_extend", False)))
     real_in, fake_in = d_inputs(x, y, gen, t_vel, t_size, args.crop_dt)
     p_real, L_real = discriminator_forward(dp, dbufs, real_in, int(args.discrim_resblocks), update_stats)
     p_fake, L_fake = discriminator_forward(dp, dbufs, fake_in.detach(), int(args.discrim_resblocks), update_stats)

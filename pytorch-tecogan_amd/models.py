@@ -172,7 +172,8 @@ class discriminator(_HipModule):
         self._args = args
         self.resblocks = int(args.discrim_resblocks)
         self.channels = int(args.discrim_channels)
-        fc_in = 3 * (int(getattr(args, "crop_size", 32)) * 4 // 32) ** 2 if getattr(args, "tg_fc_auto", False) else 48
+        auto = getattr(args, "tg_fc_auto", False) or getattr(args, "tg_extend", False)
+        fc_in = 3 * (int(getattr(args, "crop_size", 32)) * 4 // 32) ** 2 if auto else 48  # 48 hard-coded at :123
         self._shapes = E.discriminator_shapes(self.resblocks, self.channels, fc_in)
         _build_tree(self, self._shapes, bn_prefixes=E.discriminator_bn_names(self.resblocks))
 

@@ -68,8 +68,9 @@ def TecoGAN(r_inputs, r_targets, discriminator_F, generator_F, args, Global_step
     B, T = r_inputs.shape[0], r_inputs.shape[1]
     if int(args.RNN_N) != T:
         raise ValueError("r_inputs.shape[1] must equal args.RNN_N")
-    if T // 3 != 3 and not getattr(args, "pingpang", False):
-        raise RuntimeError("the reference's D-input reshape only works for RNN_N in {9,10,11} (code/train.py:143-145)")
+    if T // 3 != 3 and not getattr(args, "pingpang", False) and not getattr(args, "tg_extend", False):
+        raise RuntimeError("the reference's D-input reshape only works for RNN_N in {9,10,11} (code/train.py:143-145); "
+                           "args.tg_extend=True opts into the documented extension (DESIGN.md, parity unpinned)")
     h = int(args.crop_size)
     st = get_step(generator_F, discriminator_F, B, T, h, args, r_inputs.device)
     _bind_optimizer(optimizer_g, generator_F)

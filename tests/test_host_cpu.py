@@ -185,6 +185,23 @@ def test_step_tables_reproduce_flow_and_tvel_against_the_oracle():
         tvp[do:do + 2 * HH] = 0.0 if so < 0 else fp.reshape(-1)[so:so + 2 * HH]
     ref_tvp = orc.t_velocity(xp, fp, 3 * Kp, pingpang=True)
     assert torch.equal(tvp.view_as(ref_tvp), ref_tvp)
+    # opt-in extension for RNN_N//3 != 3 (the reference raises there): first B*K*2 planes of the flattened back tensor;
+    # identical to the reference rule at K == 3
+    assert torch.equal(orc.t_velocity(x, ref_flow, 9, extended=True), ref_tv)
+    Te, Ke = 16, 5
+    xe = torch.from_numpy(rng.random((B, Te, 3, h, h), dtype=np.float32))
+    te = S.build_tables(B, Te, h, Ke)
+    fe = orc.pseudo_flow(xe)
+    tve = torch.full((B * 3 * Ke * 2 * HH,), float("nan"))
+    for so, do in zip(te["tv_csrc"], te["tv_cdst"]):
+        tve[do:do + 2 * HH] = 0.0 if so < 0 else fe.reshape(-1)[so:so + 2 * HH]
+    for so, do in zip(te["tv_bsrc"], te["tv_bdst"]):
+        tve[do:do + HH] = (orc.up4(xe.reshape(-1)[so:so + hh].view(1, 1, h, h) * 4.0) * 2.0 - 1.0).reshape(-1)
+    ref_tve = orc.t_velocity(xe, fe, 3 * Ke, extended=True)
+    # (ATen's CPU bilinear kernel rounds differently for a 20-channel image than for single planes: last-bit only)
+    torch.testing.assert_close(tve.view_as(ref_tve), ref_tve, rtol=0, atol=2e-6)
+    with pytest.raises(RuntimeError):
+        orc.t_velocity(xe, fe, 3 * Ke)  # reference behaviour: the reshape fails
     # LR-warp tables: image x[b,t], grid block x[b,t+1,0:2]
     for n, (io, go) in enumerate(zip(t["lrw_img"], t["lrw_grid"])):
         b, tt = divmod(n, T - 1)

@@ -186,6 +186,41 @@ def test_step_variants_vs_golden(golden_dir, monkeypatch, name, seed, over):
     np.testing.assert_allclose(sdD["fc.weight"].cpu().numpy(), gold["s0_post_fc_weight"], rtol=1e-5, atol=1e-7)
 
 
+def test_step_extension_config4_shape_vs_oracle(monkeypatch):
+    """BASELINE config 4 shape (64->256, seq-16; one sequence here): the reference raises there (RNN_N//3 != 3, fc=48),
+    so this runs the documented opt-in extension (args.tg_extend) against the oracle's statement of the same extension.
+    Parity with the reference itself is unpinned for this shape."""
+    monkeypatch.setenv("TECOGAN_GRAPH", "0")
+    over = dict(RNN_N=16, crop_size=64, tg_extend=True)
+    args = orc.default_args(**over)
+    args.tg_dtype = "fp32"
+    with pytest.raises(RuntimeError):
+        a2 = orc.default_args(RNN_N=16)
+        a2.tg_dtype = "fp32"
+        G0, D0 = models.generator(3, a2).cuda(), models.discriminator(a2).cuda()
+        train.FRVSR_Train(torch.zeros(1, 16, 3, 32, 32).cuda(), torch.zeros(1, 16, 3, 128, 128).cuda(), a2, D0, G0, 0,
+                          0.0, 0.0, None, None)
+    gp = orc.init_params(orc.generator_param_shapes(16), 107)
+    dp = orc.init_params(orc.discriminator_param_shapes(4, 128, fc_in=192), 207)
+    G, D = models.generator(3, args), models.discriminator(args)
+    G.load_state_dict(gp)
+    D.load_state_dict(dp, strict=False)
+    G, D = G.cuda(), D.cuda()
+    og = torch.optim.Adam(G.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
+    od = torch.optim.Adam(D.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
+    x, y = synth(1, 16, 64, 7)
+    torch.set_num_threads(max(1, os.cpu_count() // 2))
+    f = orc.tecogan_forward(gp, dp, orc.init_bn_buffers(dp), x, y, args, 0)
+    out = train.FRVSR_Train(x.cuda(), y.cuda(), args, D, G, 0, 0.0, 0.0, og, od)
+    got = np.array([float(v) for v in out.update_list])
+    exp = np.array([float(v) for v in f["update_list"]])
+    np.testing.assert_allclose(got, exp, rtol=1e-3, atol=1e-6)
+    assert rel(out.gen_output.cpu(), f["gen"]) < 1e-4
+    assert out.target.shape == (5, 27, 256, 256)
+    assert rel(out.target.cpu(), f["real_in"]) < 1e-5
+    assert float(og.state[next(iter(G.parameters()))]["step"]) == 1.0
+
+
 def test_step_fp32_three_steps_teacher_forced(golden_dir, monkeypatch):
     """three consecutive steps; the oracle is re-synchronised to the HIP weights before every compared step."""
     monkeypatch.setenv("TECOGAN_GRAPH", "0")
