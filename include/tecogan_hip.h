@@ -118,16 +118,26 @@ typedef struct {
   int8_t dx[TG_MAX_TAPS];
   int32_t nsplit;               /* number of pixel-range splits (= slabs) */
   int32_t taps_per_wg;          /* 0: every workgroup owns all taps; 3 (3x3) / 4 (4x4): taps are split over blockIdx.z */
+  int32_t y_sum;                /* 1: every slab also carries sum over pixels of Y[.][b] (Cy floats behind the taps) = the
+                                 * bias gradient of a conv whose Y operand is its output gradient */
 } tg_wgrad_desc;
 
 int64_t tg_wgrad_slab_floats(const tg_wgrad_desc* d);
 int tg_wgrad(const tg_wgrad_desc* d, const void* x, const void* y, float* slab, void* stream);
-/* grad[a*s_a + b*s_b + slot_off[t]] (+)= sum_split slab[split][t][a][b]  for a<ca, b<cb.  Writes the PyTorch layout. */
+/* The same launch for `njobs` layers of identical shape (e.g. the 33 64-channel 3x3 layers of the generator trunk, whose
+ * backward passes all exist once the dgrad chain is done): jobs_dev = njobs x {x, y, slab} device pointers as int64.  One
+ * grid covers every layer, so the chip is filled by layers x splits and each layer needs ~njobs times fewer slabs. */
+int tg_wgrad_multi(const tg_wgrad_desc* d, const int64_t* jobs_dev, int njobs, void* stream);
+/* grad[a*s_a + b*s_b + slot_off[t]] (+)= sum_split slab[split][t][a][b]  for a<ca, b<cb.  Writes the PyTorch layout.
+ * slab_stride = floats per split as tg_wgrad wrote them (tg_wgrad_slab_floats / nsplit).  bias_grad non-null (slabs
+ * written with y_sum=1): bias_grad[b] += sum_split of the channel sums. */
 int tg_wgrad_finalize(const float* slab, int nsplit, int ntaps, int ca_p, int cb_p, int ca, int cb, float* grad,
-                      int64_t s_a, int64_t s_b, const int32_t* slot_off_dev, int accumulate, void* stream);
+                      int64_t s_a, int64_t s_b, const int32_t* slot_off_dev, int accumulate, float* bias_grad,
+                      int64_t slab_stride, void* stream);
 
 /* The same for every conv of a network in ONE launch (always accumulates; slot t adds kernel offset t).
- * jobs_dev: njobs x 10 int64 = {slab ptr, grad ptr, s_a, s_b, nsplit, ntaps, ca_p, cb_p, ca, cb}. */
+ * jobs_dev: njobs x 12 int64 = {slab ptr, grad ptr, s_a, s_b, nsplit, ntaps, ca_p, cb_p, ca, cb, bias-grad ptr or 0,
+ * slab stride in floats}. */
 int tg_wgrad_finalize_multi(const int64_t* jobs_dev, int njobs, int blocks_per_job, void* stream);
 
 /* ---- layout converters ------------------------------------------------------------------------------- */

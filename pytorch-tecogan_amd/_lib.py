@@ -37,7 +37,7 @@ class WgradDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("N", C.c_int32), ("XH", C.c_int32), ("XW", C.c_int32), ("Cx", C.c_int32),
                 ("YH", C.c_int32), ("YW", C.c_int32), ("Cy", C.c_int32), ("S", C.c_int32), ("ntaps", C.c_int32),
                 ("dy", C.c_int8 * MAX_TAPS), ("dx", C.c_int8 * MAX_TAPS), ("nsplit", C.c_int32),
-                ("taps_per_wg", C.c_int32)]
+                ("taps_per_wg", C.c_int32), ("y_sum", C.c_int32)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -52,7 +52,8 @@ _PROTOS = {
     "tg_conv": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "tg_wgrad_slab_floats": (_L, [C.POINTER(WgradDesc)]),
     "tg_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P]),
-    "tg_wgrad_finalize": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _L, _L, _P, _I, _P]),
+    "tg_wgrad_multi": (_I, [C.POINTER(WgradDesc), _P, _I, _P]),
+    "tg_wgrad_finalize": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _L, _L, _P, _I, _P, _L, _P]),
     "tg_wgrad_finalize_multi": (_I, [_P, _I, _I, _P]),
     "tg_nchw_to_nhwc": (_I, [_I, _P, _L, _P, _I, _I, _I, _I, _I, _P]),
     "tg_nhwc_to_nchw": (_I, [_I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),

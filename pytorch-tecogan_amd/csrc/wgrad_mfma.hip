@@ -20,6 +20,7 @@ struct WgradK {
   const char* x;
   const char* y;
   float* slab;
+  const long long* jobs;  // non-null: blockIdx.x = job * nsplit + split, and x / y / slab come from jobs[3*job ..]
   int N, XH, XW, Cx, YH, YW, Cy, S;
   int ntaps;
   int dy[TG_MAX_TAPS];  // 32-bit: dynamically indexed kernarg bytes would become vector loads (see conv_mfma.hip)
@@ -28,7 +29,21 @@ struct WgradK {
   int tw_log2, th;
   int tiles_x, tiles_y, tiles_total, nsplit;
   int b_blocks;
+  int ysum;  // 1: also write sum over pixels of Y (the conv's bias gradient) behind the taps of every slab
 };
+
+template <typename T> __device__ __forceinline__ void unpack16(const u32x4& v, float* f);
+template <> __device__ __forceinline__ void unpack16<BF16>(const u32x4& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(v[i] << 16);
+    f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+  }
+}
+template <> __device__ __forceinline__ void unpack16<F32>(const u32x4& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v[i]);
+}
 
 // TPW = taps per workgroup (blockIdx.z selects the tap group).  With TPW == NTAPS a workgroup owns every tap (best when it
 // walks many pixel tiles); TPW = 3 (4 for 4x4) cuts the fp32 slab each workgroup writes - and the fold reads back - by
@@ -53,7 +68,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
   const int a_blk = blockIdx.y / p.b_blocks, b_blk = blockIdx.y % p.b_blocks;
   const int a0 = a_blk * A_BLK, b0 = b_blk * B_BLK;
 
+  // several same-shaped layers in one grid (tg_wgrad_multi): the layer index is the slow part of blockIdx.x
+  int split = blockIdx.x;
+  const char* xbase = p.x;
+  const char* ybase = p.y;
+  float* sbase = p.slab;
+  if (p.jobs) {
+    const int job = blockIdx.x / p.nsplit;
+    split -= job * p.nsplit;
+    xbase = reinterpret_cast<const char*>(p.jobs[3 * job]);
+    ybase = reinterpret_cast<const char*>(p.jobs[3 * job + 1]);
+    sbase = reinterpret_cast<float*>(p.jobs[3 * job + 2]);
+  }
+
   const int tap0 = blockIdx.z * TPW;
+  // bias gradient = sum over pixels of Y: the Y tiles pass through this thread's registers anyway, and a thread always
+  // holds the same 16-byte channel piece (256 % YV == 0), so it keeps E running sums (one X block / tap group does it)
+  constexpr int E = 16 / TR::kBytes;
+  const bool ysum = p.ysum && a_blk == 0 && blockIdx.z == 0;
+  float bsum[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) bsum[e] = 0.f;
   f32x4 acc[TPW][BT];
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
@@ -80,7 +115,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     const int n = r / p.tiles_y;
     const int ty0 = tyb * p.th, tx0 = txb * tw;
     const int iy0 = ty0 * p.S + p.dymin, ix0 = tx0 * p.S + p.dxmin;
-    const char* xn = p.x + (size_t)n * p.XH * p.XW * xpix_bytes + (size_t)a0 * TR::kBytes;
+    const char* xn = xbase + (size_t)n * p.XH * p.XW * xpix_bytes + (size_t)a0 * TR::kBytes;
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
       const int i = tid + u * 256;
@@ -93,7 +128,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
           vx[u] = *reinterpret_cast<const u32x4*>(xn + ((size_t)iy * p.XW + ix) * xpix_bytes + s2 * 16);
       }
     }
-    const char* yn = p.y + (size_t)n * p.YH * p.YW * ypix_bytes + (size_t)b0 * TR::kBytes;
+    const char* yn = ybase + (size_t)n * p.YH * p.YW * ypix_bytes + (size_t)b0 * TR::kBytes;
 #pragma unroll
     for (int u = 0; u < UY; ++u) {
       const int i = tid + u * 256;
@@ -107,7 +142,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     }
   };
 
-  int tile = blockIdx.x;
+  int tile = split;
   if (tile < p.tiles_total) issue(tile);
   for (; tile < p.tiles_total; tile += p.nsplit) {
     __syncthreads();  // the previous tile's fragment reads are done
@@ -125,6 +160,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
       if (i < ny) {
         const int prow = i / YV, s2 = i - prow * YV;
         *reinterpret_cast<u32x4*>(lds_y + prow * YROW + s2 * 16) = vy[u];
+        if (ysum) {
+          float f[E];
+          unpack16<T>(vy[u], f);
+#pragma unroll
+          for (int e = 0; e < E; ++e) bsum[e] += f[e];
+        }
       }
     }
     __syncthreads();
@@ -186,8 +227,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     }
   }
 
-  // slab[split][t][a][b]; accumulator rows 4g+j are the X channel, column idx the Y channel
-  float* slab = p.slab + (size_t)blockIdx.x * NTAPS * p.Cx * p.Cy;
+  // slab[split][t][a][b] (+ [Cy] channel sums of Y when ysum); accumulator rows 4g+j are the X channel, column idx the Y channel
+  const size_t slab_sz = (size_t)NTAPS * p.Cx * p.Cy + (p.ysum ? p.Cy : 0);
+  float* slab = sbase + (size_t)split * slab_sz;
+  if (ysum) {  // combine the 256/YV threads that hold the same channel piece
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [256/YV][YV*E] ; LDS tiles are dead now
+    constexpr int CH = YV * E;                    // == B_BLK
+    const int s2 = tid % YV, r = tid / YV;
+#pragma unroll
+    for (int e = 0; e < E; ++e) red[r * CH + s2 * E + e] = bsum[e];
+    __syncthreads();
+    if (tid < CH) {
+      float t = 0.f;
+      for (int q = 0; q < 256 / YV; ++q) t += red[q * CH + tid];
+      slab[(size_t)NTAPS * p.Cx * p.Cy + b0 + tid] = t;
+    }
+  }
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
@@ -201,94 +257,86 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     }
 }
 
-// 256 threads = 32 consecutive output elements x 8 split lanes: every lane sums its share of the slabs with 4 independent
-// loads in flight, then the 8 partial sums are combined through LDS.  (A thread-per-element loop over up to 256 slabs
-// was a 28 us latency chain per layer.)
-__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ slab, int nsplit, int ntaps,
-                                                            int ca_p, int cb_p, int ca, int cb, float* __restrict__ grad,
-                                                            long long s_a, long long s_b,
-                                                            const int* __restrict__ slot_off, int accumulate) {
-  __shared__ float sh[8][33];
-  const long long total = (long long)ntaps * ca * cb;
-  const size_t slab_sz = (size_t)ntaps * ca_p * cb_p;
-  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  for (long long e0 = (long long)blockIdx.x * 32; e0 < total; e0 += (long long)gridDim.x * 32) {
-    const long long i = e0 + el;
-    float s = 0.f;
+// Fold of the per-split slabs into the PyTorch-layout gradient.  The fold is pure HBM streaming (nsplit x the weight
+// volume, fp32), so it is laid out for wide contiguous reads: a thread owns 4 consecutive slab elements (one 16-byte
+// load per slab), a wavefront therefore reads 1 KiB contiguous per slab, and the 4 wavefronts of a workgroup take every
+// 4th slab each with 4 independent loads in flight; the 4 partial sums meet in LDS.  (The first version read 128-byte
+// pieces - 32 elements x 8 split lanes - and reached 2.3 TB/s.)
+__device__ __forceinline__ void fold_job(const float* __restrict__ slab, float* __restrict__ grad, long long s_a,
+                                         long long s_b, int nsplit, int ntaps, int ca_p, int cb_p, int ca, int cb,
+                                         const int* __restrict__ slot_off, int accumulate, int blk, int nblk,
+                                         f32x4 (*sh)[64], float* __restrict__ bias_grad, size_t slab_sz) {
+  const int wunits = ntaps * ca_p * (cb_p / 4);  // float4 units of the weight part of one slab
+  const int units = wunits + (bias_grad ? cb_p / 4 : 0);  // + the channel sums of Y (bias gradient), always accumulated
+  const int col = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  for (int u0 = blk * 64; u0 < units; u0 += nblk * 64) {
+    const int u = u0 + col;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     int a = 0, b = 0, t = 0;
-    if (i < total) {
-      b = (int)(i % cb);
-      const long long r = i / cb;
-      a = (int)(r % ca);
-      t = (int)(r / ca);
-      const float* src = slab + ((size_t)t * ca_p + a) * cb_p + b;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      int k = sl;
-      for (; k + 24 < nsplit; k += 32) {
-        s0 += src[(size_t)k * slab_sz];
-        s1 += src[(size_t)(k + 8) * slab_sz];
-        s2 += src[(size_t)(k + 16) * slab_sz];
-        s3 += src[(size_t)(k + 24) * slab_sz];
-      }
-      for (; k < nsplit; k += 8) s0 += src[(size_t)k * slab_sz];
-      s = (s0 + s1) + (s2 + s3);
+    bool live = false;
+    const bool is_bias = u >= wunits;
+    if (u < units) {
+      b = (u % (cb_p / 4)) * 4;
+      const int r = u / (cb_p / 4);
+      a = r % ca_p;
+      t = r / ca_p;
+      live = is_bias ? b < cb : (a < ca && b < cb);  // padded rows / columns are never read
     }
-    sh[sl][el] = s;
+    if (live) {
+      const float* src = slab + (is_bias ? (size_t)ntaps * ca_p * cb_p + b : ((size_t)t * ca_p + a) * cb_p + b);
+      f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
+      int k = sl;
+      for (; k + 12 < nsplit; k += 16) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (size_t)k * slab_sz);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (size_t)(k + 4) * slab_sz);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (size_t)(k + 8) * slab_sz);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + (size_t)(k + 12) * slab_sz);
+        s += v0; s1 += v1; s2 += v2; s3 += v3;
+      }
+      for (; k < nsplit; k += 4) s += *reinterpret_cast<const f32x4*>(src + (size_t)k * slab_sz);
+      s = (s + s1) + (s2 + s3);
+    }
+    sh[sl][col] = s;
     __syncthreads();
-    if (sl == 0 && i < total) {
-      float tsum = 0.f;
+    if (sl == 0 && live) {
+      const f32x4 tot = (sh[0][col] + sh[1][col]) + (sh[2][col] + sh[3][col]);
+      if (is_bias) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) tsum += sh[q][el];
-      float* dst = grad + a * s_a + b * s_b + slot_off[t];
-      *dst = accumulate ? *dst + tsum : tsum;
+        for (int e = 0; e < 4; ++e)
+          if (b + e < cb) bias_grad[b + e] += tot[e];
+      } else {
+        float* dst = grad + a * s_a + (slot_off ? slot_off[t] : t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (b + e < cb) {
+            float* d = dst + (b + e) * s_b;
+            *d = accumulate ? *d + tot[e] : tot[e];
+          }
+      }
     }
     __syncthreads();
   }
 }
 
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ slab, int nsplit, int ntaps,
+                                                            int ca_p, int cb_p, int ca, int cb, float* __restrict__ grad,
+                                                            long long s_a, long long s_b,
+                                                            const int* __restrict__ slot_off, int accumulate,
+                                                            float* __restrict__ bias_grad, long long slab_stride) {
+  __shared__ f32x4 sh[4][64];
+  fold_job(slab, grad, s_a, s_b, nsplit, ntaps, ca_p, cb_p, ca, cb, slot_off, accumulate, blockIdx.x, gridDim.x, sh,
+           bias_grad, (size_t)slab_stride);
+}
+
 // All weight gradients of a network folded in ONE launch: blockIdx.y selects the job.
-// Job = 10 x int64: slab ptr, grad ptr, s_a, s_b, nsplit, ntaps, ca_p, cb_p, ca, cb  (slot t adds kernel offset t).
+// Job = 12 x int64: slab ptr, grad ptr, s_a, s_b, nsplit, ntaps, ca_p, cb_p, ca, cb, bias-grad ptr or 0, slab stride
+// in floats (slot t adds kernel offset t).
 __global__ __launch_bounds__(256) void wgrad_finalize_multi_kernel(const long long* __restrict__ jobs) {
-  __shared__ float sh[8][33];
-  const long long* j = jobs + 10 * blockIdx.y;
-  const float* slab = reinterpret_cast<const float*>(j[0]);
-  float* grad = reinterpret_cast<float*>(j[1]);
-  const long long s_a = j[2], s_b = j[3];
-  const int nsplit = (int)j[4], ntaps = (int)j[5], ca_p = (int)j[6], cb_p = (int)j[7], ca = (int)j[8], cb = (int)j[9];
-  const long long total = (long long)ntaps * ca * cb;
-  const size_t slab_sz = (size_t)ntaps * ca_p * cb_p;
-  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  for (long long e0 = (long long)blockIdx.x * 32; e0 < total; e0 += (long long)gridDim.x * 32) {
-    const long long i = e0 + el;
-    float s = 0.f;
-    int a = 0, b = 0, t = 0;
-    if (i < total) {
-      b = (int)(i % cb);
-      const long long r = i / cb;
-      a = (int)(r % ca);
-      t = (int)(r / ca);
-      const float* src = slab + ((size_t)t * ca_p + a) * cb_p + b;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      int k = sl;
-      for (; k + 24 < nsplit; k += 32) {
-        s0 += src[(size_t)k * slab_sz];
-        s1 += src[(size_t)(k + 8) * slab_sz];
-        s2 += src[(size_t)(k + 16) * slab_sz];
-        s3 += src[(size_t)(k + 24) * slab_sz];
-      }
-      for (; k < nsplit; k += 8) s0 += src[(size_t)k * slab_sz];
-      s = (s0 + s1) + (s2 + s3);
-    }
-    sh[sl][el] = s;
-    __syncthreads();
-    if (sl == 0 && i < total) {
-      float tsum = 0.f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) tsum += sh[q][el];
-      grad[a * s_a + b * s_b + t] += tsum;
-    }
-    __syncthreads();
-  }
+  __shared__ f32x4 sh[4][64];
+  const long long* j = jobs + 12 * blockIdx.y;
+  fold_job(reinterpret_cast<const float*>(j[0]), reinterpret_cast<float*>(j[1]), j[2], j[3], (int)j[4], (int)j[5],
+           (int)j[6], (int)j[7], (int)j[8], (int)j[9], nullptr, 1, blockIdx.x, gridDim.x, sh,
+           reinterpret_cast<float*>(j[10]), (size_t)j[11]);
 }
 
 struct WgCfg {
@@ -333,22 +381,40 @@ int pick_cfg(const tg_wgrad_desc* d, WgCfg* c) {  // returns config id
 
 extern "C" int64_t tg_wgrad_slab_floats(const tg_wgrad_desc* d) {
   if (!d || d->nsplit <= 0 || d->ntaps <= 0) return TG_E_BADARG;
-  return (int64_t)d->nsplit * d->ntaps * d->Cx * d->Cy;
+  return (int64_t)d->nsplit * ((int64_t)d->ntaps * d->Cx * d->Cy + (d->y_sum ? d->Cy : 0));
+}
+
+namespace {
+int wgrad_launch(const tg_wgrad_desc* d, const void* x, const void* y, float* slab, const int64_t* jobs, int njobs,
+                 void* stream);
 }
 
 extern "C" int tg_wgrad(const tg_wgrad_desc* d, const void* x, const void* y, float* slab, void* stream) {
   if (!d || !x || !y || !slab) return TG_E_BADARG;
+  if (!tg_aligned16(x) || !tg_aligned16(y) || !tg_aligned16(slab)) return TG_E_ALIGN;
+  return wgrad_launch(d, x, y, slab, nullptr, 1, stream);
+}
+
+extern "C" int tg_wgrad_multi(const tg_wgrad_desc* d, const int64_t* jobs_dev, int njobs, void* stream) {
+  if (!d || !jobs_dev || njobs <= 0) return TG_E_BADARG;
+  if ((long long)njobs * d->nsplit > 65535LL * 16) return TG_E_UNSUPPORTED;
+  return wgrad_launch(d, nullptr, nullptr, nullptr, jobs_dev, njobs, stream);
+}
+
+namespace {
+int wgrad_launch(const tg_wgrad_desc* d, const void* x, const void* y, float* slab, const int64_t* jobs, int njobs,
+                 void* stream) {
   if (d->dtype != TG_F32 && d->dtype != TG_BF16) return TG_E_BADARG;
   if (d->N <= 0 || d->XH <= 0 || d->XW <= 0 || d->YH <= 0 || d->YW <= 0 || d->S <= 0 || d->S > 2 || d->nsplit <= 0)
     return TG_E_BADARG;
   if (d->Cx % 32 || d->Cy % 32 || d->Cx <= 0 || d->Cy <= 0) return TG_E_ALIGN;
-  if (!tg_aligned16(x) || !tg_aligned16(y) || !tg_aligned16(slab)) return TG_E_ALIGN;
   WgCfg c;
   const int cfg = pick_cfg(d, &c);
   if (cfg < 0) return TG_E_UNSUPPORTED;
 
   WgradK k;
   k.x = (const char*)x; k.y = (const char*)y; k.slab = slab;
+  k.jobs = reinterpret_cast<const long long*>(jobs);
   k.N = d->N; k.XH = d->XH; k.XW = d->XW; k.Cx = d->Cx; k.YH = d->YH; k.YW = d->YW; k.Cy = d->Cy; k.S = d->S;
   k.ntaps = d->ntaps;
   int dymin = 127, dymax = -128, dxmin = 127, dxmax = -128;
@@ -371,6 +437,7 @@ extern "C" int tg_wgrad(const tg_wgrad_desc* d, const void* x, const void* y, fl
   if (tt > 0x7fffffffLL) return TG_E_UNSUPPORTED;
   k.tiles_total = (int)tt;
   k.nsplit = d->nsplit;
+  k.ysum = d->y_sum ? 1 : 0;
   k.b_blocks = d->Cy / c.b_blk;
   const int eb = d->dtype == TG_BF16 ? 2 : 4;
   const size_t lds = (size_t)tw * th * (c.b_blk * eb + 16) + (size_t)k.ih * k.iw * (c.a_blk * eb + 16);
@@ -382,7 +449,7 @@ extern "C" int tg_wgrad(const tg_wgrad_desc* d, const void* x, const void* y, fl
   }
   const int tpw = d->taps_per_wg > 0 ? d->taps_per_wg : d->ntaps;
   if (!((d->ntaps == 9 && (tpw == 9 || tpw == 3)) || (d->ntaps == 16 && (tpw == 16 || tpw == 4)))) return TG_E_UNSUPPORTED;
-  dim3 grid((unsigned)d->nsplit, (unsigned)((d->Cx / c.a_blk) * k.b_blocks), (unsigned)(d->ntaps / tpw));
+  dim3 grid((unsigned)(d->nsplit * njobs), (unsigned)((d->Cx / c.a_blk) * k.b_blocks), (unsigned)(d->ntaps / tpw));
   hipStream_t st = (hipStream_t)stream;
   const bool split = tpw != d->ntaps;
 #define TG_WG(T_, NT_, TP_, AW_, BT_) return launch_wgrad<T_, NT_, TP_, AW_, BT_>(k, grid, lds, st)
@@ -404,16 +471,20 @@ extern "C" int tg_wgrad(const tg_wgrad_desc* d, const void* x, const void* y, fl
 #undef TG_WG
   return TG_E_UNSUPPORTED;
 }
+}  // namespace
 
 extern "C" int tg_wgrad_finalize(const float* slab, int nsplit, int ntaps, int ca_p, int cb_p, int ca, int cb,
                                  float* grad, int64_t s_a, int64_t s_b, const int32_t* slot_off_dev, int accumulate,
-                                 void* stream) {
+                                 float* bias_grad, int64_t slab_stride, void* stream) {
   if (!slab || !grad || !slot_off_dev || nsplit <= 0 || ntaps <= 0 || ca <= 0 || cb <= 0 || ca > ca_p || cb > cb_p)
     return TG_E_BADARG;
-  const long long total = (long long)ntaps * ca * cb;
-  const int blocks = (int)std::min<long long>((total + 31) / 32, 4096);
+  if (cb_p % 4 || slab_stride % 4 || !tg_aligned16(slab)) return TG_E_ALIGN;
+  if (slab_stride < (int64_t)ntaps * ca_p * cb_p + (bias_grad ? cb_p : 0)) return TG_E_BADARG;
+  const long long units = (long long)ntaps * ca_p * (cb_p / 4) + (bias_grad ? cb_p / 4 : 0);
+  const int blocks = (int)std::min<long long>((units + 63) / 64, 4096);
   hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slab, nsplit, ntaps, ca_p,
-                     cb_p, ca, cb, grad, (long long)s_a, (long long)s_b, slot_off_dev, accumulate);
+                     cb_p, ca, cb, grad, (long long)s_a, (long long)s_b, slot_off_dev, accumulate, bias_grad,
+                     (long long)slab_stride);
   return tg_launch_status();
 }
 

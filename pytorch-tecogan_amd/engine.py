@@ -162,36 +162,99 @@ class Conv:
             return
         K.conv(d, dout, self.wb, out, res=res, mask=mask, stats=st)
 
-    def wgrad(self, x_in, dout, side=None):
+    def wgrad(self, x_in, dout, side=None, bias_sum=False):
         """accumulates dW into the flat gradient buffer (which the step zeroes first).  With `side` (a stream) the two
         launches go there after waiting for everything enqueued so far on the current stream: weight gradients are leaves
-        of the backward graph, so they can run beside the dgrad chain.  Every conv owns its slab (no sharing hazards)."""
+        of the backward graph, so they can run beside the dgrad chain.  Every conv owns its slab (no sharing hazards).
+        bias_sum: `dout` is the gradient w.r.t. this conv's output, so its per-channel sum (the bias gradient) is taken
+        from the Y tiles that pass through the kernel anyway (plain convs only: Y must be `dout`)."""
         x_is_in, S, taps, ca, cb, s_a, s_b = self.spec.wgrad_info()
+        if bias_sum and (not x_is_in or self.gbias is None):
+            raise L.TecoganHipError("bias_sum needs a conv with a bias whose wgrad Y operand is the output gradient")
         X, Y = (x_in, dout) if x_is_in else (dout, x_in)
         N, XH, XW, cx = X.shape
         _, YH, YW, cy = Y.shape
-        key = ("w", N, XH, XW, YH, YW)
+        key = ("w", N, XH, XW, YH, YW, bias_sum)
         ent = self._desc.get(key)
         if ent is None:
             nsplit, tpw = K.wgrad_plan(N, YH, YW, S, len(taps), cx, cy)
             if self.ws.frozen:
                 raise L.TecoganHipError("new wgrad shape after graph capture")
-            slab = torch.empty(nsplit * len(taps) * cx * cy, dtype=torch.float32, device=X.device)
-            ent = (K.make_wgrad_desc(self.tg, N, XH, XW, cx, YH, YW, cy, S, taps, nsplit, tpw), nsplit, slab)
+            stride = len(taps) * cx * cy + (cy if bias_sum else 0)
+            slab = torch.empty(nsplit * stride, dtype=torch.float32, device=X.device)
+            ent = (K.make_wgrad_desc(self.tg, N, XH, XW, cx, YH, YW, cy, S, taps, nsplit, tpw, y_sum=bias_sum), nsplit,
+                   slab, stride)
             self._desc[key] = ent
-        d, nsplit, slab = ent
-        self.fin_job = [slab.data_ptr(), self.gw.data_ptr(), s_a, s_b, nsplit, len(taps), cx, cy, ca, cb]
+        d, nsplit, slab, stride = ent
+        gb = self.gbias if bias_sum else None
+        self.fin_job = [slab.data_ptr(), self.gw.data_ptr(), s_a, s_b, nsplit, len(taps), cx, cy, ca, cb,
+                        gb.data_ptr() if bias_sum else 0, stride]
         if self.defer_finalize:  # the network folds every slab in one launch (Finalizer) after its backward pass
             K.wgrad(d, X, Y, slab)
             return
         if side is None:
             K.wgrad(d, X, Y, slab)
-            K.wgrad_finalize(slab, nsplit, len(taps), cx, cy, ca, cb, self.gw, s_a, s_b, self.slots, True)
+            K.wgrad_finalize(slab, nsplit, len(taps), cx, cy, ca, cb, self.gw, s_a, s_b, self.slots, True, gb)
             return
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             K.wgrad(d, X, Y, slab)
-            K.wgrad_finalize(slab, nsplit, len(taps), cx, cy, ca, cb, self.gw, s_a, s_b, self.slots, True)
+            K.wgrad_finalize(slab, nsplit, len(taps), cx, cy, ca, cb, self.gw, s_a, s_b, self.slots, True, gb)
+
+
+class WgradGroup:
+    """Weight gradients of several same-shaped layers in ONE launch (tg_wgrad_multi).  The layers' backward operands all
+    exist once the dgrad chain has passed them (every gradient tensor has its own buffer), so the launch is issued after
+    the chain: the grid is layers x splits, i.e. the chip is filled by cross-layer parallelism instead of a deep split of
+    the pixel dimension, and the fp32 slab volume (written here, read back by the fold) shrinks by the number of layers.
+    Needs the deferred fold (Finalizer)."""
+
+    def __init__(self):
+        self.items, self.cache = [], {}
+
+    def add(self, conv, x_in, dout, bias_sum=False):
+        self.items.append((conv, x_in, dout, bias_sum))
+
+    def launch(self):
+        items, self.items = self.items, []
+        if not items:
+            return
+        key = tuple((id(c), x.data_ptr(), y.data_ptr(), tuple(x.shape), tuple(y.shape), b) for c, x, y, b in items)
+        ent = self.cache.get(key)
+        if ent is None:
+            c0 = items[0][0]
+            x_is_in, S, taps, ca, cb, s_a, s_b = c0.spec.wgrad_info()
+            rows = []
+            any_bias = any(b for _, _, _, b in items)
+            for c, x_in, dout, b in items:
+                if c.spec.wgrad_info()[:3] != (x_is_in, S, taps) or (c.cin_p, c.cout_p) != (c0.cin_p, c0.cout_p) or \
+                        x_in.shape != items[0][1].shape or dout.shape != items[0][2].shape:
+                    raise L.TecoganHipError("WgradGroup needs layers of identical shape")
+                if b and (not x_is_in or c.gbias is None):
+                    raise L.TecoganHipError("bias_sum needs a conv with a bias whose wgrad Y operand is the output gradient")
+                if c.ws.frozen:
+                    raise L.TecoganHipError("new wgrad shape after graph capture")
+            X0, Y0 = (items[0][1], items[0][2]) if x_is_in else (items[0][2], items[0][1])
+            N, XH, XW, cx = X0.shape
+            _, YH, YW, cy = Y0.shape
+            blocks = K.wgrad_blocks(len(taps), cx, cy)
+            nsplit = max(1, min(K.wgrad_tiles(N, YH, YW, S), 256 // (len(items) * blocks)))
+            fin = []
+            stride = len(taps) * cx * cy + (cy if any_bias else 0)
+            for c, x_in, dout, b in items:
+                X, Y = (x_in, dout) if x_is_in else (dout, x_in)
+                slab = torch.empty(nsplit * stride, dtype=torch.float32, device=X.device)
+                _, _, _, ca, cb, s_a, s_b = c.spec.wgrad_info()
+                rows.append([X.data_ptr(), Y.data_ptr(), slab.data_ptr()])
+                fin.append((c, slab, [slab.data_ptr(), c.gw.data_ptr(), s_a, s_b, nsplit, len(taps), cx, cy, ca, cb,
+                                      c.gbias.data_ptr() if b else 0, stride]))
+            desc = K.make_wgrad_desc(c0.tg, N, XH, XW, cx, YH, YW, cy, S, taps, nsplit, 0, y_sum=any_bias)
+            ent = (desc, torch.tensor(rows, dtype=torch.int64, device=X0.device), fin)
+            self.cache[key] = ent
+        desc, jobs, fin = ent
+        for c, _, job in fin:
+            c.fin_job = job
+        K.wgrad_multi(desc, jobs, len(fin))
 
 
 class SideStreams:
@@ -359,6 +422,7 @@ class GeneratorEngine:
         self.shape = None
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
+        self.trunk_group = WgradGroup() if os.environ.get("TECOGAN_WGRAD_GROUPS", "1") != "0" else None
 
     def repack(self):
         self.repacker.run()
@@ -422,32 +486,39 @@ class GeneratorEngine:
         RELU = L.MASK_RELU
         sd = self.side
         self.cout.wgrad(a["u4"], g["dpre"], sd.next())                         # output bias grad: see TecoGANStep
-        self.cout.dgrad(g["dpre"], g["hr64"], mask=a["u4"], mask_mode=RELU, bias_grad_of=self.c6)
-        self.c6.wgrad(a["u3"], g["hr64"], sd.next())
+        # bias gradients of plain convs come out of their own wgrad launch (bias_sum): the output gradient is that
+        # launch's Y operand, so its channel sums cost a few VALU adds there instead of an atomics epilogue here
+        self.cout.dgrad(g["dpre"], g["hr64"], mask=a["u4"], mask_mode=RELU)
+        self.c6.wgrad(a["u3"], g["hr64"], sd.next(), bias_sum=True)
         self.c6.dgrad(g["hr64"], g["hr128"], mask=a["u3"], mask_mode=RELU, bias_grad_of=self.ct4)
         self.ct4.wgrad(a["u2"], g["hr128"], sd.next())
         self.ct4.dgrad(g["hr128"], g["m128a"])
         self.c32.wgrad(a["h2"], g["m128a"], sd.next())
-        self.c32.dgrad(g["m128a"], g["m128b"], mask=a["h2"], mask_mode=RELU, bias_grad_of=self.c30)
-        self.c30.wgrad(a["u1"], g["m128b"], sd.next())
+        self.c32.dgrad(g["m128a"], g["m128b"], mask=a["h2"], mask_mode=RELU)
+        self.c30.wgrad(a["u1"], g["m128b"], sd.next(), bias_sum=True)
         self.c30.dgrad(g["m128b"], g["m64a"])
         self.c22.wgrad(a["hh"], g["m64a"], sd.next())
-        self.c22.dgrad(g["m64a"], g["m64b"], mask=a["hh"], mask_mode=RELU, bias_grad_of=self.c20)
-        self.c20.wgrad(a["u0"], g["m64b"], sd.next())
+        self.c22.dgrad(g["m64a"], g["m64b"], mask=a["hh"], mask_mode=RELU)
+        self.c20.wgrad(a["u0"], g["m64b"], sd.next(), bias_sum=True)
         self.c20.dgrad(g["m64b"], g["m64c"], mask=a["u0"], mask_mode=RELU, bias_grad_of=self.ct0)
         self.ct0.wgrad(a["a"][self.nrb], g["m64c"], sd.next())
         dA, dH = g["dA"], g["dH"]
         self.ct0.dgrad(g["m64c"], dA[self.nrb])
+        grouped = self.finalizer is not None and self.trunk_group is not None
+        wg = (lambda c, x, y, b=False: self.trunk_group.add(c, x, y, b)) if grouped else \
+            (lambda c, x, y, b=False: c.wgrad(x, y, sd.next(), bias_sum=b))
         for i in range(self.nrb - 1, -1, -1):
             c1, c2 = self.rb[i]
-            c2.wgrad(a["h"][i], dA[i + 1], sd.next())
-            c2.dgrad(dA[i + 1], dH[i], mask=a["h"][i], mask_mode=RELU, bias_grad_of=c1)
-            c1.wgrad(a["a"][i], dH[i], sd.next())
+            wg(c2, a["h"][i], dA[i + 1])
+            c2.dgrad(dA[i + 1], dH[i], mask=a["h"][i], mask_mode=RELU)
+            wg(c1, a["a"][i], dH[i], True)
             if i > 0:
                 c1.dgrad(dH[i], dA[i], res=dA[i + 1])
-            else:  # a[0] = relu(conv0(in0)): fold its relu' and conv0's bias gradient into the same epilogue
-                c1.dgrad(dH[i], dA[i], res=dA[i + 1], mask=a["a"][0], mask_mode=RELU, bias_grad_of=self.conv0)
-        self.conv0.wgrad(a["in0"], dA[0], sd.next())
+            else:  # a[0] = relu(conv0(in0)): fold its relu' into the same epilogue
+                c1.dgrad(dH[i], dA[i], res=dA[i + 1], mask=a["a"][0], mask_mode=RELU)
+        wg(self.conv0, a["in0"], dA[0], True)
+        if grouped:
+            self.trunk_group.launch()  # 2*nrb+1 layers of one shape (64 -> 64 channels, 3x3, h x w): one grid
         sd.join()
         if self.finalizer is not None and s1 == NS:  # last (or only) sample range of the step
             self.finalizer.run()
@@ -584,6 +655,7 @@ class DiscriminatorEngine:
         self.shape = None
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
+        self.res_group = WgradGroup() if os.environ.get("TECOGAN_WGRAD_GROUPS", "1") != "0" else None
 
     def repack(self):
         self.repacker.run()
@@ -664,6 +736,9 @@ class DiscriminatorEngine:
         N = a["in"].shape[0]
         K.fc_head_bwd(a["n"][5], self.fc_w, self.dlogit, g["dn"][5], self.g_fc_w, self.g_fc_b, N, self.fc_hw, 3, 32)
         d_net = g["dn"][5]  # gradient w.r.t. the current stage's output
+        grouped = self.finalizer is not None and self.res_group is not None
+        wg = (lambda c, x, y, b=False: self.res_group.add(c, x, y, b)) if grouped else \
+            (lambda c, x, y, b=False: c.wgrad(x, y, sd.next(), bias_sum=b))
         for k in range(5, 0, -1):
             if k <= 3:
                 for j in range(self.nrb - 1, -1, -1):
@@ -672,11 +747,13 @@ class DiscriminatorEngine:
                     d_r, d_h = g["dr"][k][j], g["dh"][k][j]
                     d_in = g["dnet"][k][j - 1] if j > 0 else g["dn"][k]
                     bnj.backward(d_net, None, a["r"][k][j], d_r, L.ACT_NONE, groups)
-                    c2.wgrad(a["h"][k][j], d_r, sd.next())
-                    c2.dgrad(d_r, d_h, mask=a["h"][k][j], mask_mode=L.MASK_RELU, bias_grad_of=c1)
-                    c1.wgrad(net_in, d_h, sd.next())
+                    wg(c2, a["h"][k][j], d_r)
+                    c2.dgrad(d_r, d_h, mask=a["h"][k][j], mask_mode=L.MASK_RELU)
+                    wg(c1, net_in, d_h, True)
                     c1.dgrad(d_h, d_in, res=d_net)
                     d_net = d_in
+                if grouped:
+                    self.res_group.launch()  # the 2*nrb same-shaped residual convs of this stage in one grid
             conv, bn = self.blk[k]
             d_z = g["dz"][k]
             bn.backward(d_net, a["n"][k], a["z"][k], d_z, L.ACT_LRELU, groups)
@@ -687,8 +764,8 @@ class DiscriminatorEngine:
                 conv.dgrad(d_z, d_prev)
                 d_net = d_prev
             else:
-                conv.dgrad(d_z, self.g_c0, mask=a["c0"], mask_mode=L.MASK_LRELU, bias_grad_of=self.conv0)
-                self.conv0.wgrad(a["in"], self.g_c0, sd.next())
+                conv.dgrad(d_z, self.g_c0, mask=a["c0"], mask_mode=L.MASK_LRELU)
+                self.conv0.wgrad(a["in"], self.g_c0, sd.next(), bias_sum=True)
         if join:
             sd.join()
         if self.finalizer is not None:

@@ -181,9 +181,10 @@ def pack_weights(dtype_t, w, rows, K, s_row, s_k, nslots, slots, out=None):
     return out
 
 
-def make_wgrad_desc(dtype, N, XH, XW, cx_p, YH, YW, cy_p, S, taps, nsplit, taps_per_wg=0):
+def make_wgrad_desc(dtype, N, XH, XW, cx_p, YH, YW, cy_p, S, taps, nsplit, taps_per_wg=0, y_sum=False):
     d = L.WgradDesc()
     d.taps_per_wg = taps_per_wg
+    d.y_sum = 1 if y_sum else 0
     d.dtype, d.N, d.XH, d.XW, d.Cx, d.YH, d.YW, d.Cy, d.S = dtype, N, XH, XW, cx_p, YH, YW, cy_p, S
     d.ntaps, d.nsplit = len(taps), nsplit
     for t, (dy, dx) in enumerate(taps):
@@ -195,9 +196,20 @@ def wgrad(desc, x, y, slab):
     L.check(L.load().tg_wgrad(C.byref(desc), _ptr(x), _ptr(y), _ptr(slab), _stream()), "tg_wgrad")
 
 
-def wgrad_finalize(slab, nsplit, ntaps, ca_p, cb_p, ca, cb, grad, s_a, s_b, slots, accumulate):
+def wgrad_multi(desc, jobs, njobs):
+    L.check(L.load().tg_wgrad_multi(C.byref(desc), _ptr(jobs), njobs, _stream()), "tg_wgrad_multi")
+
+
+def wgrad_tiles(N, YH, YW, S):
+    tw, th = (16, 4) if S == 2 else ((32, 4) if YW > 16 else (16, 8))
+    return N * ((YW + tw - 1) // tw) * ((YH + th - 1) // th)
+
+
+def wgrad_finalize(slab, nsplit, ntaps, ca_p, cb_p, ca, cb, grad, s_a, s_b, slots, accumulate, bias_grad=None):
+    stride = ntaps * ca_p * cb_p + (cb_p if bias_grad is not None else 0)
     L.check(L.load().tg_wgrad_finalize(_ptr(slab), nsplit, ntaps, ca_p, cb_p, ca, cb, _ptr(grad), s_a, s_b,
-                                       _ptr(slots), int(accumulate), _stream()), "tg_wgrad_finalize")
+                                       _ptr(slots), int(accumulate), _ptr(bias_grad), stride, _stream()),
+            "tg_wgrad_finalize")
 
 
 def wgrad_nsplit(N, YH, YW, S, blocks=1):

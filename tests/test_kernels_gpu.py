@@ -222,6 +222,76 @@ def test_conv_wgrad(kind, cin, cout, N, H, W, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("kind,cin,cout,N,H,W,tpw", [("c3", 64, 64, 3, 32, 32, 0), ("c3", 64, 64, 3, 32, 32, 3),
+                                                      ("c3", 27, 64, 1, 40, 24, 0), ("c3", 64, 128, 2, 16, 16, 0),
+                                                      ("c3", 128, 64, 1, 64, 64, 0), ("c4s2", 64, 128, 2, 16, 16, 0)])
+def test_conv_wgrad_with_bias_sum(kind, cin, cout, N, H, W, tpw, dt):
+    """y_sum: the bias gradient (per-channel sum of the output gradient) rides in every slab behind the taps"""
+    spec = K.ConvSpec(kind, cin, cout)
+    OH, OW = spec.out_hw(H, W)
+    x = q(rnd((N, cin, H, W), 16), dt)
+    w = rnd(spec.weight_shape, 17, -0.1, 0.1).requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    dout = q(rnd((N, cout, OH, OW), 18), dt)
+    ref_conv(spec, x, w, b).backward(dout)
+    x_is_in, S, taps, ca, cb, s_a, s_b = spec.wgrad_info()
+    assert x_is_in
+    X, Y = K.to_nhwc(x.to(DEV), dt), K.to_nhwc(dout.to(DEV), dt)
+    nsplit = 7
+    desc = K.make_wgrad_desc(K.tg_dtype(dt), N, X.shape[1], X.shape[2], X.shape[3], Y.shape[1], Y.shape[2], Y.shape[3],
+                             S, taps, nsplit, tpw, y_sum=True)
+    nfl = L.load().tg_wgrad_slab_floats(__import__("ctypes").byref(desc))
+    assert nfl == nsplit * (len(taps) * X.shape[3] * Y.shape[3] + Y.shape[3])
+    slab = torch.full((nfl,), float("nan"), device=DEV)
+    K.wgrad(desc, X, Y, slab)
+    grad = torch.zeros(spec.weight_shape, device=DEV)
+    gb = torch.full((K.pad32(cout),), 2.0, device=DEV)
+    K.wgrad_finalize(slab, nsplit, len(taps), X.shape[3], Y.shape[3], ca, cb, grad, s_a, s_b,
+                     K.slot_table(len(taps), DEV), False, bias_grad=gb)
+    torch.cuda.synchronize()
+    scale = float(w.grad.abs().max())
+    torch.testing.assert_close(grad.cpu(), w.grad, rtol=1e-3 if dt == torch.float32 else 2e-2,
+                               atol=scale * (1e-5 if dt == torch.float32 else 1e-2))
+    torch.testing.assert_close(gb[:cout].cpu() - 2.0, b.grad, rtol=1e-4, atol=float(b.grad.abs().max()) * 1e-5 + 1e-4)
+    assert torch.all(gb[cout:] == 2.0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv_wgrad_multi_same_shape_layers(dt):
+    """tg_wgrad_multi: several same-shaped layers in one grid, some with bias sums, folded by tg_wgrad_finalize_multi"""
+    spec = K.ConvSpec("c3", 64, 64)
+    N, H, W, nl, nsplit = 3, 32, 32, 5, 4
+    x_is_in, S, taps, ca, cb, s_a, s_b = spec.wgrad_info()
+    xs = [q(rnd((N, 64, H, W), 60 + i), dt) for i in range(nl)]
+    ds = [q(rnd((N, 64, H, W), 70 + i), dt) for i in range(nl)]
+    Xs, Ys = [K.to_nhwc(t.to(DEV), dt) for t in xs], [K.to_nhwc(t.to(DEV), dt) for t in ds]
+    desc = K.make_wgrad_desc(K.tg_dtype(dt), N, H, W, 64, H, W, 64, S, taps, nsplit, 0, y_sum=True)
+    stride = len(taps) * 64 * 64 + 64
+    slabs = [torch.full((nsplit * stride,), float("nan"), device=DEV) for _ in range(nl)]
+    jobs = torch.tensor([[X.data_ptr(), Y.data_ptr(), sl.data_ptr()] for X, Y, sl in zip(Xs, Ys, slabs)],
+                        dtype=torch.int64, device=DEV)
+    K.wgrad_multi(desc, jobs, nl)
+    grads = [torch.zeros(spec.weight_shape, device=DEV) for _ in range(nl)]
+    gbs = [torch.zeros(64, device=DEV) for _ in range(nl)]
+    fin = torch.tensor([[sl.data_ptr(), g.data_ptr(), s_a, s_b, nsplit, len(taps), 64, 64, ca, cb,
+                         gb.data_ptr() if i % 2 == 0 else 0, stride]
+                        for i, (sl, g, gb) in enumerate(zip(slabs, grads, gbs))], dtype=torch.int64, device=DEV)
+    L.check(L.load().tg_wgrad_finalize_multi(fin.data_ptr(), nl, 16, None), "tg_wgrad_finalize_multi")
+    torch.cuda.synchronize()
+    for i in range(nl):
+        w = torch.zeros(spec.weight_shape, requires_grad=True)
+        b = torch.zeros(64, requires_grad=True)
+        F.conv2d(xs[i], w, b, 1, 1).backward(ds[i])
+        scale = float(w.grad.abs().max())
+        torch.testing.assert_close(grads[i].cpu(), w.grad, rtol=1e-3 if dt == torch.float32 else 2e-2,
+                                   atol=scale * (1e-5 if dt == torch.float32 else 1e-2))
+        if i % 2 == 0:
+            torch.testing.assert_close(gbs[i].cpu(), b.grad, rtol=1e-4, atol=1e-3)
+        else:
+            assert float(gbs[i].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("C_,act,skip", [(64, L.ACT_NONE, True), (128, L.ACT_LRELU, False), (32, L.ACT_LRELU, False)])
 def test_batchnorm_train_fwd_bwd(C_, act, skip, dt):
     N, H, W, G = 4, 8, 8, 2
