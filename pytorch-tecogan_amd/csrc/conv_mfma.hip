@@ -589,8 +589,11 @@ static int pick_tile(const tg_conv_desc* d) {
     const bool plain3x3 = d->ncls == 1 && d->S == 1 && d->OS == 1 && d->cls[0].ntaps == 9;
     if (d->Cout % 64) cfg = TG_TILE_32x128;
     else if (d->S > 1) cfg = (d->Cout % 128 == 0 && px >= 16384) ? TG_TILE_128x128 : (px >= 32768 ? TG_TILE_64x128 : TG_TILE_64x64);
-    else if (plain3x3 && px <= 16384) cfg = TG_TILE_32x64;                   // recurrent-pass and deep-D layers
-    else if (plain3x3) cfg = TG_TILE_64x256;                                 // best for every larger 3x3 launch measured
+    else if (plain3x3 && px < 16384) cfg = TG_TILE_32x64;                    // recurrent-pass and deep-D layers
+    else if (plain3x3 && px <= 16384 && d->Cin <= 64 && d->Cout <= 64) cfg = TG_TILE_32x64;  // 7.0 vs 7.6 us (64x64)
+    else if (plain3x3 && (px > 262144 || (d->Cin >= 128 && d->Cout >= 128 && px > 65536)))
+      cfg = TG_TILE_64x256;                                                  // 150 vs 214 us (c6 dgrad), 99 vs 105 us
+    else if (plain3x3) cfg = TG_TILE_64x128;                                 // tools/microbench.py tiles: 10-30 % faster
     else if (d->ncls == 4 && d->Cout % 128 == 0 && px >= 16384) cfg = TG_TILE_64x128;  // conv-transpose forward: 22.7 vs 27.2 us
     else if (d->Cout % 128 == 0 && px >= 16384) cfg = TG_TILE_128x128;
     else if (px >= 32768) cfg = TG_TILE_64x256;

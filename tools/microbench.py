@@ -100,6 +100,20 @@ def bench_wgrad(kind, cin, cout, N, H, W, dt, splits):
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     bf = torch.bfloat16
+    if what == "tiles":  # the launches the 64x128-vs-64x256 rule of pick_tile() decides
+        big = ["64x256", "64x128"]
+        bench_conv("c3", 128, 64, 4, 128, 128, "fwd", bf, big)
+        bench_conv("c3", 128, 64, 40, 128, 128, "dgrad", bf, big)
+        bench_conv("c3", 64, 3, 40, 128, 128, "dgrad", bf, big)
+        bench_conv("c3", 27, 64, 24, 128, 128, "fwd", bf, big)
+        bench_conv("c3", 64, 64, 24, 64, 64, "fwd", bf, big)
+        bench_conv("c3", 128, 128, 24, 32, 32, "fwd", bf, big)
+        bench_conv("c3", 64, 128, 40, 64, 64, "dgrad", bf, big)
+        bench_conv("c3", 64, 128, 4, 64, 64, "fwd", bf, big + ["32x64"])
+        bench_conv("c3", 128, 128, 4, 64, 64, "fwd", bf, big + ["32x64"])
+        bench_conv("c3", 64, 64, 4, 64, 64, "fwd", bf, big + ["32x64", "64x64"])
+        bench_conv("c3", 128, 128, 40, 64, 64, "dgrad", bf, big)
+        bench_conv("c3", 64, 64, 40, 64, 64, "dgrad", bf, big)
     if what in ("conv", "all"):
         small = ["64x64", "32x64", "32x128", "64x256"]
         bench_conv("c3", 64, 64, 4, 32, 32, "fwd", bf, small)
@@ -109,9 +123,9 @@ def main():
         bench_conv("c3", 64, 128, 4, 64, 64, "fwd", bf, ["64x64", "32x64", "128x128", "64x256"])
         bench_conv("c3", 128, 128, 4, 64, 64, "fwd", bf, ["64x64", "32x64", "128x128", "64x256"])
         bench_conv("ct", 128, 128, 4, 64, 64, "fwd", bf, ["64x64", "128x128", "64x256", "64x128"])
-        bench_conv("c3", 128, 64, 4, 128, 128, "fwd", bf, ["64x64", "32x64", "64x256"])
+        bench_conv("c3", 128, 64, 4, 128, 128, "fwd", bf, ["64x64", "32x64", "64x256", "64x128"])
         bench_conv("c3", 64, 3, 4, 128, 128, "fwd", bf, ["32x128", "32x64"])
-        big = ["64x64", "64x256", "128x128"]
+        big = ["64x64", "64x256", "128x128", "64x128"]
         bench_conv("c3", 64, 64, 40, 32, 32, "dgrad", bf, big)
         bench_conv("c3", 128, 128, 40, 64, 64, "dgrad", bf, big)
         bench_conv("c3", 128, 64, 40, 128, 128, "dgrad", bf, big)
