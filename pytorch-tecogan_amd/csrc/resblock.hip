@@ -1,0 +1,248 @@
+// One residual block of the generator trunk in ONE launch (bf16, 64 channels):
+//
+//     h   = relu(conv3x3(a, W1) + b1)          code/ops.py:45-54 (residual_block), code/models.py:66-69
+//     out = a + conv3x3(h, W2)
+//
+// The recurrent pass runs 16 such blocks per frame on 4 x 32x32 pixels: each conv is a ~6 us launch of which the MFMAs
+// are a few hundred nanoseconds - the rest is the launch boundary, the weight/activation load latency and the store.
+// Fusing the pair halves the boundaries and loads `a` once.  A workgroup owns an 8x8 output tile of one image:
+//   phase 1  stage the 12x12 input patch and W1 (73.7 KB, all taps) in LDS; start W2's global loads into registers
+//   phase 2  conv1 on the 10x10 halo region (7 MFMA pixel tiles), bias + relu, zero outside the image (conv2 pads h with
+//            zeros), h -> LDS (bf16, exactly what the unfused path would read back) and -> global (the backward pass
+//            needs it: relu mask and weight-gradient operand)
+//   phase 3  W2 registers -> the LDS region W1 occupied; conv2 on the 8x8 tile from the LDS copy of h; + a; store
+// MFMA operand roles, packed-weight layout and the 80-byte LDS rows are those of conv_mfma.hip.
+#include "common.h"
+
+namespace {
+
+constexpr int kRow = 80;                    // 64 data bytes (32 bf16 channels) + 16 pad
+constexpr int kInW = 12, kInPix = 144;      // input patch 12 x 12
+constexpr int kHW = 10, kHPix = 100;        // h region 10 x 10
+constexpr int kHRows = 112;                 // 7 MFMA pixel tiles
+constexpr int kLdsIn = 2 * kInPix * kRow;   // [chunk][pixel][80]
+constexpr int kLdsH = 2 * kHRows * kRow;
+constexpr int kLdsW = 2 * 9 * 64 * kRow;    // [chunk][tap][row][80]
+constexpr int kLdsTotal = kLdsIn + kLdsH + kLdsW;
+
+struct ResblockK {
+  const char* in;
+  const char* w1;
+  const float* b1;
+  const char* w2;
+  char* out_h;
+  char* out_a;
+  int N, H, W, tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ u32x4 pack8(const float* v) {
+  u32x4 t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    t[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+  return t;
+}
+
+__global__ __launch_bounds__(256) void resblock_fwd_kernel(const ResblockK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_in = smem;
+  char* lds_h = smem + kLdsIn;
+  char* lds_w = smem + kLdsIn + kLdsH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int idx = lane & 15, g = lane >> 4;
+  const int wc = wid & 1, wp = wid >> 1;  // wave = 32-channel half x pixel-tile half
+  int bx = blockIdx.x;
+  const int txb = bx % p.tiles_x;
+  bx /= p.tiles_x;
+  const int tyb = bx % p.tiles_y;
+  const int n = bx / p.tiles_y;
+  const int y0 = tyb * 8, x0 = txb * 8;
+  const char* in_n = p.in + (size_t)n * p.H * p.W * 128;
+
+  // ---- phase 1: every global load of the phase is issued before the first LDS store
+  u32x4 va[5];
+  int da[5];
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int i = tid + u * 256;
+    va[u] = u32x4{0u, 0u, 0u, 0u};
+    da[u] = -1;
+    if (i < 2 * kInPix * 4) {
+      const int s = i & 3, r = i >> 2;
+      const int cc = r >= kInPix ? 1 : 0, prow = r - cc * kInPix;
+      const int py = (prow * 171) >> 11, px = prow - py * kInW;  // prow / 12, exact for prow < 144
+      const int iy = y0 - 2 + py, ix = x0 - 2 + px;
+      da[u] = (cc * kInPix + prow) * kRow + s * 16;
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+        va[u] = *reinterpret_cast<const u32x4*>(in_n + ((size_t)iy * p.W + ix) * 128 + cc * 64 + s * 16);
+    }
+  }
+  // packed weights: [tap][chunk][64 rows][64 B]; one (tap, chunk) block is exactly 256 16-byte pieces
+  u32x4 vw[18];
+#pragma unroll
+  for (int u = 0; u < 18; ++u) vw[u] = *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)u * 256 + tid) * 16);
+  // this lane's bias (channels 32*wc + 8g .. +7), in flight under the staging
+  float bias[8];
+  {
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.b1 + 32 * wc + 8 * g);
+    const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.b1 + 32 * wc + 8 * g + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bias[j] = t0[j]; bias[4 + j] = t1[j]; }
+  }
+  auto store_w = [&]() {
+#pragma unroll
+    for (int u = 0; u < 18; ++u) {
+      const int tt = u >> 1, cc = u & 1;
+      *reinterpret_cast<u32x4*>(lds_w + ((cc * 9 + tt) * 64 + (tid >> 2)) * kRow + (tid & 3) * 16) = vw[u];
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < 5; ++u)
+    if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_in + da[u]) = va[u];
+  store_w();
+  __syncthreads();
+  // W2 travels in registers while conv1 computes
+#pragma unroll
+  for (int u = 0; u < 18; ++u) vw[u] = *reinterpret_cast<const u32x4*>(p.w2 + ((size_t)u * 256 + tid) * 16);
+
+  // ---- phase 2: conv1 over the 10x10 region.  Pixel tile t covers region pixels 16t .. 16t+15 (row-major, 10 wide)
+  const int wrow = ((wc * 2) * 16 + idx) * kRow + g * 16;  // this wave's two weight tiles: packed rows 32wc .. 32wc+31
+  {
+    const int nt = wp == 0 ? 4 : 3;  // tiles 0-3 / 4-6
+    int xb[4], hp_l[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      int hp = (wp * 4 + b) * 16 + idx;
+      hp_l[b] = hp;
+      hp = hp < kHPix ? hp : kHPix - 1;
+      const int hy = (hp * 205) >> 11, hx = hp - hy * kHW;  // hp / 10 for hp < 112
+      xb[b] = (hy * kInW + hx) * kRow + g * 16;
+    }
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+      for (int tt = 0; tt < 9; ++tt) {
+        const int toff = ((tt / 3) * kInW + (tt % 3)) * kRow;
+        const char* lw = lds_w + (cc * 9 + tt) * 64 * kRow + wrow;
+        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(lw);
+        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(lw + 16 * kRow);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (b < nt) {  // wave-uniform
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds_in + cc * kInPix * kRow + xb[b] + toff);
+            acc[0][b] = mma(w0, xf, acc[0][b]);
+            acc[1][b] = mma(w1, xf, acc[1][b]);
+          }
+        }
+      }
+    }
+    // lane (idx, g): region pixel hp_l[b], channels 32wc + 8g .. +7 = rows 4g..4g+3 of the wave's two tiles
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int hp = hp_l[b];
+      if (b < nt && hp < kHPix) {
+        const int hy = (hp * 205) >> 11, hx = hp - hy * kHW;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const bool inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[0][b][j] + bias[j];
+          v[4 + j] = acc[1][b][j] + bias[4 + j];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (inside && v[e] > 0.f) ? v[e] : 0.f;
+        const u32x4 pk = pack8(v);
+        *reinterpret_cast<u32x4*>(lds_h + (wc * kHRows + hp) * kRow + g * 16) = pk;
+        if (inside && hy >= 1 && hy <= 8 && hx >= 1 && hx <= 8)
+          *reinterpret_cast<u32x4*>(p.out_h + (((size_t)n * p.H + y) * p.W + x) * 128 + wc * 64 + g * 16) = pk;
+      }
+    }
+  }
+  __syncthreads();  // W1 reads done, h complete
+  store_w();
+  __syncthreads();
+
+  // ---- phase 3: conv2 on the 8x8 tile; pixel tile t = output rows 2t, 2t+1
+  {
+    int xb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int op = (wp * 2 + b) * 16 + idx;
+      xb[b] = ((op >> 3) * kHW + (op & 7)) * kRow + g * 16;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+      for (int tt = 0; tt < 9; ++tt) {
+        const int toff = ((tt / 3) * kHW + (tt % 3)) * kRow;
+        const char* lw = lds_w + (cc * 9 + tt) * 64 * kRow + wrow;
+        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(lw);
+        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(lw + 16 * kRow);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds_h + cc * kHRows * kRow + xb[b] + toff);
+          acc[0][b] = mma(w0, xf, acc[0][b]);
+          acc[1][b] = mma(w1, xf, acc[1][b]);
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int op = (wp * 2 + b) * 16 + idx;
+      const int oy = op >> 3, ox = op & 7;
+      const int y = y0 + oy, x = x0 + ox;
+      if (y < p.H && x < p.W) {
+        float r[8], v[8];
+        Vec<BF16>::load(lds_in + (wc * kInPix + (oy + 2) * kInW + ox + 2) * kRow + g * 16, r);  // the skip connection
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[0][b][j] + r[j];
+          v[4 + j] = acc[1][b][j] + r[4 + j];
+        }
+        *reinterpret_cast<u32x4*>(p.out_a + (((size_t)n * p.H + y) * p.W + x) * 128 + wc * 64 + g * 16) = pack8(v);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int tg_resblock_fwd(int dtype, const void* in, const void* w1_packed, const float* b1, const void* w2_packed,
+                               void* out_h, void* out_a, int N, int H, int W, int C, void* stream) {
+  if (!in || !w1_packed || !b1 || !w2_packed || !out_h || !out_a || N <= 0 || H <= 0 || W <= 0) return TG_E_BADARG;
+  if (dtype != TG_BF16 || C != 64) return TG_E_UNSUPPORTED;  // the trunk shape; anything else runs as two tg_conv launches
+  if (!tg_aligned16(in) || !tg_aligned16(w1_packed) || !tg_aligned16(w2_packed) || !tg_aligned16(out_h) ||
+      !tg_aligned16(out_a) || !tg_aligned16(b1))
+    return TG_E_ALIGN;
+  ResblockK k;
+  k.in = (const char*)in; k.w1 = (const char*)w1_packed; k.b1 = b1; k.w2 = (const char*)w2_packed;
+  k.out_h = (char*)out_h; k.out_a = (char*)out_a;
+  k.N = N; k.H = H; k.W = W;
+  k.tiles_x = (W + 7) / 8; k.tiles_y = (H + 7) / 8;
+  const long long blocks = (long long)k.tiles_x * k.tiles_y * N;
+  if (blocks > 0x7fffffffLL) return TG_E_UNSUPPORTED;
+  static bool attr_done = false;
+  if (!attr_done) {
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_fwd_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(resblock_fwd_kernel, dim3((unsigned)blocks), dim3(256), kLdsTotal, (hipStream_t)stream, k);
+  return tg_launch_status();
+}

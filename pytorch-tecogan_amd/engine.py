@@ -423,6 +423,7 @@ class GeneratorEngine:
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
         self.trunk_group = WgradGroup() if os.environ.get("TECOGAN_WGRAD_GROUPS", "1") != "0" else None
+        self.fused_rb = dtype_t == torch.bfloat16 and os.environ.get("TECOGAN_FUSED_RESBLOCK", "1") != "0"
 
     def repack(self):
         self.repacker.run()
@@ -446,6 +447,9 @@ class GeneratorEngine:
         sl = slice(s0, s0 + B)
         self.conv0.fwd(a["in0"][sl], a["a"][0][sl], act=L.ACT_RELU)
         for i, (c1, c2) in enumerate(self.rb):
+            if self.fused_rb:  # conv-relu-conv-skip in one launch (csrc/resblock.hip)
+                K.resblock_fwd(a["a"][i][sl], c1.wf, c1.bias, c2.wf, a["h"][i][sl], a["a"][i + 1][sl])
+                continue
             c1.fwd(a["a"][i][sl], a["h"][i][sl], act=L.ACT_RELU)
             c2.fwd(a["h"][i][sl], a["a"][i + 1][sl], res=a["a"][i][sl])
         self.ct0.fwd(a["a"][self.nrb][sl], a["u0"][sl], act=L.ACT_RELU)

@@ -257,6 +257,12 @@ def nhwc_to_nchw(src, dst, n_stride, N, C_, H, W):
             "tg_nhwc_to_nchw")
 
 
+def resblock_fwd(x, w1, b1, w2, out_h, out_a):
+    N, H, W, C_ = x.shape
+    L.check(L.load().tg_resblock_fwd(tg_dtype(x.dtype), _ptr(x), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(out_h), _ptr(out_a),
+                                     N, H, W, C_, _stream()), "tg_resblock_fwd")
+
+
 def maxpool2(src, dst):
     N, H, W, C_ = src.shape
     L.check(L.load().tg_maxpool2(tg_dtype(src.dtype), _ptr(src), _ptr(dst), N, H, W, C_, _stream()), "tg_maxpool2")

@@ -538,3 +538,40 @@ def test_fnet_resampling_kernels(N, H, W, C_, dt):
     lib = L.load()
     assert lib.tg_maxpool2(K.tg_dtype(dt), xd.data_ptr(), pooled.data_ptr(), N, 3, W, C_, None) == -1
     assert lib.tg_up2_bilinear(K.tg_dtype(dt), xd.data_ptr(), up.data_ptr(), N, H, W, 40, None) == -3
+
+
+@pytest.mark.parametrize("N,H,W", [(4, 32, 32), (1, 8, 8), (2, 20, 12), (1, 9, 17)])
+def test_fused_resblock_forward(N, H, W):
+    """tg_resblock_fwd == conv-relu-conv-skip of code/ops.py:45-54 as two tg_conv launches (bf16), and close to torch"""
+    dt = torch.bfloat16
+    spec = K.ConvSpec("c3", 64, 64)
+    x = q(rnd((N, 64, H, W), 80), dt)
+    w1, w2 = rnd(spec.weight_shape, 81, -0.05, 0.05), rnd(spec.weight_shape, 82, -0.05, 0.05)
+    b1 = rnd((64,), 83, -0.1, 0.1)
+    xd = K.to_nhwc(x.to(DEV), dt)
+    rows, Kd, s_row, s_k = spec.fwd_pack()
+    slots = K.slot_table(9, DEV)
+    wp1 = K.pack_weights(dt, w1.to(DEV), rows, Kd, s_row, s_k, 9, slots)
+    wp2 = K.pack_weights(dt, w2.to(DEV), rows, Kd, s_row, s_k, 9, slots)
+    bd = b1.to(DEV)
+    h_f = torch.full((N, H, W, 64), float("nan"), dtype=dt, device=DEV)
+    a_f = torch.full((N, H, W, 64), float("nan"), dtype=dt, device=DEV)
+    K.resblock_fwd(xd, wp1, bd, wp2, h_f, a_f)
+    # the same block as two launches
+    h_u, a_u = torch.empty_like(h_f), torch.empty_like(a_f)
+    d1 = K.make_conv_desc(spec.fwd_geom(), L.TG_BF16, N, H, W, 64, H, W, 64, act=L.ACT_RELU)
+    d2 = K.make_conv_desc(spec.fwd_geom(), L.TG_BF16, N, H, W, 64, H, W, 64)
+    K.conv(d1, xd, wp1, h_u, bias=bd)
+    K.conv(d2, h_u, wp2, a_u, res=xd)
+    torch.cuda.synchronize()
+    assert not torch.isnan(h_f.float()).any() and not torch.isnan(a_f.float()).any()
+    # same inputs, same bf16 rounding points; only the fp32 accumulation order may differ -> at most one bf16 ulp
+    torch.testing.assert_close(h_f.float(), h_u.float(), rtol=2 ** -7, atol=1e-3)
+    torch.testing.assert_close(a_f.float(), a_u.float(), rtol=2 ** -7, atol=2e-3)
+    assert float((h_f.float() != h_u.float()).float().mean()) < 0.02
+    ref_h = F.relu(F.conv2d(x, q(w1, dt), b1, 1, 1))
+    ref_a = x + F.conv2d(q(ref_h, dt), q(w2, dt), None, 1, 1)
+    torch.testing.assert_close(K.to_nchw(h_f, 64).cpu(), ref_h, **tol(dt))
+    torch.testing.assert_close(K.to_nchw(a_f, 64).cpu(), ref_a, **tol(dt))
+    assert L.load().tg_resblock_fwd(L.TG_F32, xd.data_ptr(), wp1.data_ptr(), bd.data_ptr(), wp2.data_ptr(),
+                                    h_f.data_ptr(), a_f.data_ptr(), N, H, W, 64, None) == -2
