@@ -109,6 +109,37 @@ def roofline_pass(st, dtype):
     def fl_wgrad(self, x_in, dout, *rest):
         return conv_flops(self.spec, x_in.shape[0], x_in.shape[1], x_in.shape[2])
 
+    # the fused residual-block launch (csrc/resblock.hip) and the grouped weight-gradient launch are not Conv methods
+    orig_rb, orig_group = K.resblock_fwd, E.WgradGroup.launch
+
+    def rb_timed(x, *a):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_rb(x, *a)
+        e1.record()
+        N, H, W, C_ = x.shape
+        recs.append(("resblock_fwd_kernel", 2 * 2.0 * N * H * W * 9 * C_ * C_, e0, e1))  # algorithmic: two 3x3 convs
+        replays.setdefault("resblock_fwd_kernel", []).append(lambda: orig_rb(x, *a))
+
+    def group_timed(self):
+        items = list(self.items)
+        if not items:
+            return orig_group(self)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_group(self)
+        e1.record()
+        fl = sum(conv_flops(c.spec, x.shape[0], x.shape[1], x.shape[2]) for c, x, _, _ in items)
+        lab = f"wgrad_kernel<{'BF16' if dtype == 'bf16' else 'F32'}, 9, 9, ..> (tg_wgrad_multi, {len(items)} layers)"
+        recs.append((lab, fl, e0, e1))
+
+        def again():
+            for it in items:
+                self.add(*it)
+            orig_group(self)
+        replays.setdefault(lab, []).append(again)
+
+    K.resblock_fwd, E.WgradGroup.launch = rb_timed, group_timed
     E.Conv.fwd = timed(lab_fwd, fl_fwd, orig_fwd)
     E.Conv.dgrad = timed(lab_dgrad, fl_dgrad, orig_dgrad)
     E.Conv.wgrad = timed(lambda self, *a: f"wgrad_kernel<{'BF16' if dtype == 'bf16' else 'F32'}, {self.spec.nslots}, ..> + "
@@ -126,6 +157,7 @@ def roofline_pass(st, dtype):
         torch.cuda.synchronize()
     finally:
         E.Conv.fwd, E.Conv.dgrad, E.Conv.wgrad = orig_fwd, orig_dgrad, orig_wgrad
+        K.resblock_fwd, E.WgradGroup.launch = orig_rb, orig_group
         st.sB, st.sC = side
         st.G.side.streams, st.D.side.streams = pools
     fam = {}

@@ -187,10 +187,11 @@ int tg_copy_blocks(const float* src, const int64_t* src_off_dev, float* dst, con
 
 /* ---- batch norm, training mode, eps/momentum as code/ops.py:75-77 -------------------------------------- */
 /* y = act(gamma*(z-mean)*invstd+beta) (+skip).  stats = [groups][2][C] sums from the producing conv.  Block 0 also
- * updates running_mean/var (group after group) and writes mean/invstd to save[groups][2][C]. */
+ * updates running_mean/var (group after group), adds `groups` to *num_batches_tracked (int64, may be null) and writes
+ * mean/invstd to save[groups][2][C]. */
 int tg_bn_apply(int dtype, const void* z, const float* stats, const float* gamma, const float* beta, const void* skip,
                 void* y, float* running_mean, float* running_var, float* save, int N, int HW, int C, int groups,
-                int act, float eps, float momentum, void* stream);
+                int act, float eps, float momentum, int64_t* num_batches_tracked, void* stream);
 /* red[groups][2][C] += (sum dyp, sum dyp*xhat) where dyp = dy * act'(yact). */
 int tg_bn_bwd_reduce(int dtype, const void* dy, const void* yact, const void* z, const float* save, float* red, int N,
                      int HW, int C, int groups, int act, void* stream);

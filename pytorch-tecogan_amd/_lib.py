@@ -65,7 +65,7 @@ _PROTOS = {
     "tg_warp_nchw": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "tg_gen_input": (_I, [_I, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _P]),
     "tg_d_assemble": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "tg_bn_apply": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
+    "tg_bn_apply": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
     "tg_bn_bwd_reduce": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "tg_bn_bwd_apply": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "tg_fc_head_fwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

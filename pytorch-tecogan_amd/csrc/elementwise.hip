@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ 
                                                       const char* __restrict__ skip, char* __restrict__ y,
                                                       float* __restrict__ rmean, float* __restrict__ rvar,
                                                       float* __restrict__ save, int N, int HW, int C, int groups,
-                                                      int act, float eps, float momentum) {
+                                                      int act, float eps, float momentum,
+                                                      long long* __restrict__ nbt) {
   using TR = ElemTraits<T>;
   constexpr int E = TR::kVec;
   const int vpp = C / E;
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ 
     }
     if (rmean) rmean[c] = rm;
     if (rvar) rvar[c] = rv;
+    if (nbt && c == 0) *nbt += groups;  // num_batches_tracked: one per forward call of the reference
   }
   const long long base = (long long)grp * npix;
   for (long long p = (long long)blockIdx.x * rows + prow; p < npix; p += (long long)gridDim.x * rows) {
@@ -417,13 +419,15 @@ inline bool bn_shape_ok(int dtype, int C) {
 
 extern "C" int tg_bn_apply(int dtype, const void* z, const float* stats, const float* gamma, const float* beta,
                            const void* skip, void* y, float* running_mean, float* running_var, float* save, int N,
-                           int HW, int C, int groups, int act, float eps, float momentum, void* stream) {
+                           int HW, int C, int groups, int act, float eps, float momentum, int64_t* num_batches_tracked,
+                           void* stream) {
   if (!z || !stats || !gamma || !beta || !y || !save || N <= 0 || HW <= 0 || groups <= 0 || N % groups) return TG_E_BADARG;
   if (!bn_shape_ok(dtype, C)) return TG_E_UNSUPPORTED;
   const int rows = 256 / (C / (dtype == TG_BF16 ? 8 : 4));
   dim3 grid(grid_for((long long)(N / groups) * HW, rows * 4, 1024), groups);
   TG_DISPATCH(dtype, bn_apply_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)z, stats, gamma, beta,
-              (const char*)skip, (char*)y, running_mean, running_var, save, N, HW, C, groups, act, eps, momentum);
+              (const char*)skip, (char*)y, running_mean, running_var, save, N, HW, C, groups, act, eps, momentum,
+              (long long*)num_batches_tracked);
   return tg_launch_status();
 }
 

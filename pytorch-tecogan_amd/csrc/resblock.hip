@@ -14,6 +14,20 @@
 // MFMA operand roles, packed-weight layout and the 80-byte LDS rows are those of conv_mfma.hip.
 #include "common.h"
 
+#ifdef TG_STAMP
+// Diagnostic build only (build.sh -DTG_STAMP): workgroup 0 records s_memtime at phase boundaries (tools/stamp_resblock.py)
+__device__ long long tg_rb_stamps[16];
+#define RB_STAMP(i)                                                                          \
+  do {                                                                                       \
+    if (blockIdx.x == 0 && threadIdx.x == 0) tg_rb_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+extern "C" int tg_debug_read_rb_stamps(long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_rb_stamps), sizeof(long long) * n);
+}
+#else
+#define RB_STAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int kRow = 80;                    // 64 data bytes (32 bf16 channels) + 16 pad
@@ -64,23 +78,24 @@ __global__ __launch_bounds__(256) void resblock_fwd_kernel(const ResblockK p) {
   const int y0 = tyb * 8, x0 = txb * 8;
   const char* in_n = p.in + (size_t)n * p.H * p.W * 128;
 
+  RB_STAMP(0);
   // ---- phase 1: every global load of the phase is issued before the first LDS store
+  // (the patch loads are unconditional from a clamped address and zeroed afterwards: a load under a divergent `if` makes
+  // the compiler wait for each one before issuing the next - five dependent round trips)
   u32x4 va[5];
   int da[5];
+  bool ok[5];
 #pragma unroll
   for (int u = 0; u < 5; ++u) {
-    const int i = tid + u * 256;
-    va[u] = u32x4{0u, 0u, 0u, 0u};
-    da[u] = -1;
-    if (i < 2 * kInPix * 4) {
-      const int s = i & 3, r = i >> 2;
-      const int cc = r >= kInPix ? 1 : 0, prow = r - cc * kInPix;
-      const int py = (prow * 171) >> 11, px = prow - py * kInW;  // prow / 12, exact for prow < 144
-      const int iy = y0 - 2 + py, ix = x0 - 2 + px;
-      da[u] = (cc * kInPix + prow) * kRow + s * 16;
-      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-        va[u] = *reinterpret_cast<const u32x4*>(in_n + ((size_t)iy * p.W + ix) * 128 + cc * 64 + s * 16);
-    }
+    const int i = min(tid + u * 256, 2 * kInPix * 4 - 1);
+    const int s = i & 3, r = i >> 2;
+    const int cc = r >= kInPix ? 1 : 0, prow = r - cc * kInPix;
+    const int py = (prow * 171) >> 11, px = prow - py * kInW;  // prow / 12, exact for prow < 144
+    const int iy = y0 - 2 + py, ix = x0 - 2 + px;
+    da[u] = (tid + u * 256 < 2 * kInPix * 4) ? (cc * kInPix + prow) * kRow + s * 16 : -1;
+    ok[u] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+    va[u] = *reinterpret_cast<const u32x4*>(in_n + ((size_t)cy * p.W + cx) * 128 + cc * 64 + s * 16);
   }
   // packed weights: [tap][chunk][64 rows][64 B]; one (tap, chunk) block is exactly 256 16-byte pieces
   u32x4 vw[18];
@@ -101,11 +116,14 @@ __global__ __launch_bounds__(256) void resblock_fwd_kernel(const ResblockK p) {
       *reinterpret_cast<u32x4*>(lds_w + ((cc * 9 + tt) * 64 + (tid >> 2)) * kRow + (tid & 3) * 16) = vw[u];
     }
   };
+  RB_STAMP(1);
 #pragma unroll
   for (int u = 0; u < 5; ++u)
-    if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_in + da[u]) = va[u];
+    if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_in + da[u]) = ok[u] ? va[u] : u32x4{0u, 0u, 0u, 0u};
   store_w();
+  RB_STAMP(2);
   __syncthreads();
+  RB_STAMP(3);
   // W2 travels in registers while conv1 computes
 #pragma unroll
   for (int u = 0; u < 18; ++u) vw[u] = *reinterpret_cast<const u32x4*>(p.w2 + ((size_t)u * 256 + tid) * 16);
@@ -128,24 +146,37 @@ __global__ __launch_bounds__(256) void resblock_fwd_kernel(const ResblockK p) {
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // 18 k-steps (chunk, tap); the fragments of step s+1 are read from LDS before the MFMAs of step s are issued - with
+    // one wave per SIMD nothing else hides the LDS latency
+    bf16x8 wf[3][2], xf[3][4];
+    auto frags1 = [&](int st, int buf) {
+      const int cc = st / 9, tt = st - cc * 9;
+      const int toff = ((tt / 3) * kInW + (tt % 3)) * kRow;
+      const char* lw = lds_w + (cc * 9 + tt) * 64 * kRow + wrow;
+      wf[buf][0] = *reinterpret_cast<const bf16x8*>(lw);
+      wf[buf][1] = *reinterpret_cast<const bf16x8*>(lw + 16 * kRow);
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
+      for (int b = 0; b < 4; ++b)
+        if (b < nt) xf[buf][b] = *reinterpret_cast<const bf16x8*>(lds_in + cc * kInPix * kRow + xb[b] + toff);
+    };
+    // (sched_barrier: without it the scheduler sinks every read back next to its MFMA to save registers)
+    frags1(0, 0);
+    frags1(1, 1);
 #pragma unroll
-      for (int tt = 0; tt < 9; ++tt) {
-        const int toff = ((tt / 3) * kInW + (tt % 3)) * kRow;
-        const char* lw = lds_w + (cc * 9 + tt) * 64 * kRow + wrow;
-        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(lw);
-        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(lw + 16 * kRow);
+    for (int st = 0; st < 18; ++st) {
+      const int cur = st % 3;
+      if (st + 2 < 18) frags1(st + 2, (st + 2) % 3);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          if (b < nt) {  // wave-uniform
-            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds_in + cc * kInPix * kRow + xb[b] + toff);
-            acc[0][b] = mma(w0, xf, acc[0][b]);
-            acc[1][b] = mma(w1, xf, acc[1][b]);
-          }
+      for (int b = 0; b < 4; ++b) {
+        if (b < nt) {  // wave-uniform
+          acc[0][b] = mma(wf[cur][0], xf[cur][b], acc[0][b]);
+          acc[1][b] = mma(wf[cur][1], xf[cur][b], acc[1][b]);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    RB_STAMP(4);
     // lane (idx, g): region pixel hp_l[b], channels 32wc + 8g .. +7 = rows 4g..4g+3 of the wave's two tiles
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -169,9 +200,12 @@ __global__ __launch_bounds__(256) void resblock_fwd_kernel(const ResblockK p) {
       }
     }
   }
+  RB_STAMP(5);
   __syncthreads();  // W1 reads done, h complete
+  RB_STAMP(6);
   store_w();
   __syncthreads();
+  RB_STAMP(7);
 
   // ---- phase 3: conv2 on the 8x8 tile; pixel tile t = output rows 2t, 2t+1
   {
@@ -186,22 +220,31 @@ __global__ __launch_bounds__(256) void resblock_fwd_kernel(const ResblockK p) {
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 wf[3][2], xf[3][2];
+    auto frags2 = [&](int st, int buf) {
+      const int cc = st / 9, tt = st - cc * 9;
+      const int toff = ((tt / 3) * kHW + (tt % 3)) * kRow;
+      const char* lw = lds_w + (cc * 9 + tt) * 64 * kRow + wrow;
+      wf[buf][0] = *reinterpret_cast<const bf16x8*>(lw);
+      wf[buf][1] = *reinterpret_cast<const bf16x8*>(lw + 16 * kRow);
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
+      for (int b = 0; b < 2; ++b) xf[buf][b] = *reinterpret_cast<const bf16x8*>(lds_h + cc * kHRows * kRow + xb[b] + toff);
+    };
+    frags2(0, 0);
+    frags2(1, 1);
 #pragma unroll
-      for (int tt = 0; tt < 9; ++tt) {
-        const int toff = ((tt / 3) * kHW + (tt % 3)) * kRow;
-        const char* lw = lds_w + (cc * 9 + tt) * 64 * kRow + wrow;
-        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(lw);
-        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(lw + 16 * kRow);
+    for (int st = 0; st < 18; ++st) {
+      const int cur = st % 3;
+      if (st + 2 < 18) frags2(st + 2, (st + 2) % 3);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds_h + cc * kHRows * kRow + xb[b] + toff);
-          acc[0][b] = mma(w0, xf, acc[0][b]);
-          acc[1][b] = mma(w1, xf, acc[1][b]);
-        }
+      for (int b = 0; b < 2; ++b) {
+        acc[0][b] = mma(wf[cur][0], xf[cur][b], acc[0][b]);
+        acc[1][b] = mma(wf[cur][1], xf[cur][b], acc[1][b]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    RB_STAMP(8);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int op = (wp * 2 + b) * 16 + idx;
@@ -219,6 +262,7 @@ __global__ __launch_bounds__(256) void resblock_fwd_kernel(const ResblockK p) {
       }
     }
   }
+  RB_STAMP(9);
 }
 
 }  // namespace

@@ -352,9 +352,8 @@ class BatchNorm:
         stats, save = (self.stats, self.save) if half is None else (self.stats[half], self.save[half])
         g = groups if half is None else 1
         K.bn_apply(z, stats, self.gamma, self.beta, y, save, N, H * W, C_, g, act, skip=skip,
-                   running_mean=self.rm if update else None, running_var=self.rv if update else None)
-        if update:
-            self.nbt += g
+                   running_mean=self.rm if update else None, running_var=self.rv if update else None,
+                   nbt=self.nbt if update else None)
 
     def backward(self, dy, yact, z, dz, act, groups):
         N, H, W, C_ = z.shape

@@ -325,10 +325,10 @@ def d_assemble(x, y, gen, tvel, dst, B, T, K, h, border, half=-1):
 
 
 def bn_apply(z, stats, gamma, beta, y, save, N, HW, C_, groups, act, skip=None, running_mean=None, running_var=None,
-             eps=1e-3, momentum=0.1):
+             eps=1e-3, momentum=0.1, nbt=None):
     L.check(L.load().tg_bn_apply(tg_dtype(z.dtype), _ptr(z), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(skip), _ptr(y),
                                  _ptr(running_mean), _ptr(running_var), _ptr(save), N, HW, C_, groups, act, eps,
-                                 momentum, _stream()), "tg_bn_apply")
+                                 momentum, _ptr(nbt), _stream()), "tg_bn_apply")
 
 
 def bn_bwd_reduce(dy, yact, z, save, red, N, HW, C_, groups, act):

@@ -325,8 +325,10 @@ def test_batchnorm_train_fwd_bwd(C_, act, skip, dt):
     save = torch.empty(G, 2, C_, device=DEV)
     rmd, rvd = torch.zeros(C_, device=DEV), torch.ones(C_, device=DEV)
     gd, bd = gamma.to(DEV), beta.to(DEV)
+    nbt = torch.full((), 5, dtype=torch.long, device=DEV)
     K.bn_apply(zd, stats, gd, bd, y, save, N, H * W, C_, G, act, skip=K.to_nhwc(sk.to(DEV), dt) if skip else None,
-               running_mean=rmd, running_var=rvd)
+               running_mean=rmd, running_var=rvd, nbt=nbt)
+    assert int(nbt) == 5 + G  # num_batches_tracked advances once per group (= per forward call of the reference)
     t = tol(dt)
     torch.testing.assert_close(K.to_nchw(y, C_).cpu(), ref_y, **t)
     torch.testing.assert_close(rmd.cpu(), rm, rtol=1e-4, atol=1e-5)

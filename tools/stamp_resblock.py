@@ -1,0 +1,27 @@
+"""Diagnostic: phase stamps of workgroup 0 of the fused residual-block launch (library built with build.sh -DTG_STAMP).
+Runs the 16-block trunk as the recurrent pass does (distinct weights/buffers per block) and prints the last block's stamps."""
+import ctypes, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import pytorch_tecogan_amd
+from pytorch_tecogan_amd import _lib as L, kernels as K
+lib = L.load()
+lib.tg_debug_read_rb_stamps.restype = ctypes.c_int
+lib.tg_debug_read_rb_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+dt = torch.bfloat16
+N, H, NB = 4, 32, 16
+spec = K.ConvSpec("c3", 64, 64)
+rows, Kd, s_row, s_k = spec.fwd_pack()
+slots = K.slot_table(9, "cuda")
+wps = [[K.pack_weights(dt, torch.randn(spec.weight_shape, device="cuda") * 0.03, rows, Kd, s_row, s_k, 9, slots) for _ in range(2)] for _ in range(NB)]
+bs = [torch.zeros(64, device="cuda") for _ in range(NB)]
+a = [torch.randn(N, H, H, 64, device="cuda").to(dt) for _ in range(NB + 1)]
+h = [torch.empty(N, H, H, 64, dtype=dt, device="cuda") for _ in range(NB)]
+names = ["issue loads", "wait+LDS stores", "barrier", "conv1 MFMA", "epilogue1", "barrier", "W2 store+barrier", "conv2 MFMA", "epilogue2"]
+for rep in range(4):
+    for i in range(NB):
+        K.resblock_fwd(a[i], wps[i][0], bs[i], wps[i][1], h[i], a[i + 1])
+    torch.cuda.synchronize()
+    buf = (ctypes.c_longlong * 16)()
+    lib.tg_debug_read_rb_stamps(buf, 16)
+    t = list(buf)
+    print(" | ".join(f"{n} {t[i+1]-t[i]}" for i, n in enumerate(names)), "| total", t[9] - t[0], "ticks of 10 ns")
