@@ -3,15 +3,20 @@
 //     h   = relu(conv3x3(a, W1) + b1)          code/ops.py:45-54 (residual_block), code/models.py:66-69
 //     out = a + conv3x3(h, W2)
 //
-// The recurrent pass runs 16 such blocks per frame on 4 x 32x32 pixels: each conv is a ~6 us launch of which the MFMAs
-// are a few hundred nanoseconds - the rest is the launch boundary, the weight/activation load latency and the store.
-// Fusing the pair halves the boundaries and loads `a` once.  A workgroup owns an 8x8 output tile of one image:
-//   phase 1  stage the 12x12 input patch and W1 (73.7 KB, all taps) in LDS; start W2's global loads into registers
+// The recurrent pass runs 16 such blocks per frame on 4 x 32x32 pixels: as two launches each conv is ~6 us of which the
+// MFMAs are a few hundred nanoseconds - the rest is the launch boundary, load latency and stores.  Fusing the pair halves
+// the boundaries and loads `a` once.  A workgroup owns an 8x8 output tile of one image; wave w owns output channels of MFMA
+// row tile w (16 packed rows) for EVERY pixel tile, so
+//   * the weights never touch LDS: each lane loads exactly the A-fragments it will feed to the MFMAs (18 x 16 B per conv,
+//     1 KiB contiguous per wave-load) straight from the packed global image, in k-step order, a few steps ahead of their
+//     use, and the k-loops wait for them one step at a time (vmcnt) - the weight stream runs underneath the MFMAs;
+//   * LDS holds only the 12x12 input patch and the 10x10 h region (48 KB), in conflict-free swizzled rows (below).
+//   phase 1  patch loads and the head of the weight stream issued; patch -> LDS
 //   phase 2  conv1 on the 10x10 halo region (7 MFMA pixel tiles), bias + relu, zero outside the image (conv2 pads h with
 //            zeros), h -> LDS (bf16, exactly what the unfused path would read back) and -> global (the backward pass
 //            needs it: relu mask and weight-gradient operand)
-//   phase 3  W2 registers -> the LDS region W1 occupied; conv2 on the 8x8 tile from the LDS copy of h; + a; store
-// MFMA operand roles and the packed-weight layout are those of conv_mfma.hip; the LDS images are swizzled (below).
+//   phase 3  conv2 on the 8x8 tile from the LDS copy of h; + a (from the LDS patch); store
+// MFMA operand roles and the packed-weight layout are those of conv_mfma.hip.
 #include "common.h"
 
 #ifdef TG_STAMP
@@ -34,8 +39,8 @@ namespace {
 // index XOR-swizzled by bit 2 of the row: piece' = piece ^ 2*((row >> 2) & 1).  ds_read_b128 services a wave in four fixed
 // groups of 16 lanes ({0-3,12-15,20-27}, ...; MI355X_MICROARCH.md, LDS), each group needs 16 distinct 16-byte slots mod
 // 256 B.  With this swizzle, a patch pitch of 18 rows for the 12-wide input patch and 16 for the 10-wide h region, every
-// fragment read of both convolutions (all taps, all pixel tiles) and of the weights is conflict-free; the 80-byte padded
-// rows of conv_mfma.hip cost 2x on the weight reads and 2.6-3x on these pixel patterns (exhaustive count, tools/lds_layout.py).
+// fragment read of both convolutions (all taps, all pixel tiles) is conflict-free; the 80-byte padded rows of conv_mfma.hip
+// cost 2.6-3x on these pixel patterns (exhaustive count, tools/lds_layout.py).
 constexpr int kRow = 64;
 constexpr int kInW = 12, kInPix = 144;      // input patch 12 x 12 pixels ...
 constexpr int kInP = 18, kInRows = 12 * kInP;  // ... stored with a pitch of 18 rows
@@ -43,8 +48,7 @@ constexpr int kHW = 10, kHPix = 100;        // h region 10 x 10 ...
 constexpr int kHP = 16, kHRows = 10 * kHP;  // ... stored with a pitch of 16 rows
 constexpr int kLdsIn = 2 * kInRows * kRow;  // [chunk][row][64]
 constexpr int kLdsH = 2 * kHRows * kRow;
-constexpr int kLdsW = 2 * 9 * 64 * kRow;    // [chunk][tap][row][64]
-constexpr int kLdsTotal = kLdsIn + kLdsH + kLdsW;
+constexpr int kLdsTotal = kLdsIn + kLdsH;
 
 // byte offset of 16-byte piece `piece` of row `row` inside an image
 __device__ __forceinline__ int lds_off(int row, int piece) { return row * kRow + ((piece ^ ((row >> 1) & 2)) << 4); }
@@ -71,16 +75,17 @@ __device__ __forceinline__ u32x4 pack8(const float* v) {
   return t;
 }
 
+// LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the weight stream and the h stores
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(256) void resblock_fwd_kernel(const ResblockK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_in = smem;
   char* lds_h = smem + kLdsIn;
-  char* lds_w = smem + kLdsIn + kLdsH;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform on purpose: keeps wc / wp in SGPRs
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = MFMA row tile (wave-uniform on purpose)
   const int idx = lane & 15, g = lane >> 4;
-  const int wc = wid & 1, wp = wid >> 1;  // wave = 32-channel half x pixel-tile half
   int bx = blockIdx.x;
   const int txb = bx % p.tiles_x;
   bx /= p.tiles_x;
@@ -90,9 +95,8 @@ __global__ __launch_bounds__(256) void resblock_fwd_kernel(const ResblockK p) {
   const char* in_n = p.in + (size_t)n * p.H * p.W * 128;
 
   RB_STAMP(0);
-  // ---- phase 1: every global load of the phase is issued before the first LDS store
-  // (the patch loads are unconditional from a clamped address and zeroed afterwards: a load under a divergent `if` makes
-  // the compiler wait for each one before issuing the next - five dependent round trips)
+  // ---- phase 1.  Patch loads are unconditional from a clamped address and zeroed afterwards: a load under a divergent
+  // `if` makes the compiler wait for each one before issuing the next.
   u32x4 va[5];
   int da[5];
   bool ok[5];
@@ -108,167 +112,144 @@ __global__ __launch_bounds__(256) void resblock_fwd_kernel(const ResblockK p) {
     const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
     va[u] = *reinterpret_cast<const u32x4*>(in_n + ((size_t)cy * p.W + cx) * 128 + cc * 64 + s * 16);
   }
-  // packed weights: [tap][chunk][64 rows][64 B]; one (tap, chunk) block is exactly 256 16-byte pieces
-  u32x4 vw[18];
-#pragma unroll
-  for (int u = 0; u < 18; ++u) vw[u] = *reinterpret_cast<const u32x4*>(p.w1 + ((size_t)u * 256 + tid) * 16);
-  // this lane's bias (channels 32*wc + 8g .. +7), in flight under the staging
-  float bias[8];
-  {
-    const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.b1 + 32 * wc + 8 * g);
-    const f32x4 t1 = *reinterpret_cast<const f32x4*>(p.b1 + 32 * wc + 8 * g + 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { bias[j] = t0[j]; bias[4 + j] = t1[j]; }
-  }
-  auto store_w = [&]() {
-#pragma unroll
-    for (int u = 0; u < 18; ++u) {
-      const int tt = u >> 1, cc = u & 1;
-      *reinterpret_cast<u32x4*>(lds_w + (cc * 9 + tt) * 64 * kRow + lds_off(tid >> 2, tid & 3)) = vw[u];
-    }
+  // A-fragments of this wave's row tile, in k-step order st = chunk*9 + tap.  Packed image: [tap][chunk][64 rows][64 B];
+  // lane (idx, g) needs bytes 16g..16g+15 of row 16w + idx.  The 36 fragment loads (W1 then W2) form one stream that is
+  // issued kAhead steps ahead of its use: a CU accepts ~33 B/clk of vector loads (measured: the 41 loads of this kernel
+  // issued back to back block the wave for 5000 cycles), so issuing everything up front serialises load and compute,
+  // while one load per k-step lets every issue stall overlap the previous step's MFMAs.
+  const int wlane = ((w * 16 + idx) * 64 + g * 16);
+  bf16x8 wfr[36];
+  auto issue_w = [&](int k) {  // k < 18: W1 step k; else W2 step k-18 (compile-time after unrolling)
+    const int st = k < 18 ? k : k - 18;
+    const char* base = k < 18 ? p.w1 : p.w2;
+    wfr[k] = *reinterpret_cast<const bf16x8*>(base + (size_t)((st % 9) * 2 + st / 9) * 4096 + wlane);
   };
+  constexpr int kAhead = 8;
+#pragma unroll
+  for (int k = 0; k < kAhead; ++k) issue_w(k);
+  // lane (idx, g) of row tile w ends up with channels ch0 .. ch0+3 of pixel idx (row_to_channel<BF16> of common.h)
+  const int chunk = w >> 1, half = w & 1;
+  const int ch0 = 32 * chunk + 8 * g + 4 * half;
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(p.b1 + ch0);
   RB_STAMP(1);
+
+  // fragment addresses of conv1 (7 pixel tiles x 9 taps), computed while the loads are in flight.  Pixel tile t covers
+  // region pixels 16t .. 16t+15 (row-major, 10 wide); tile 6 is partial: its spare lanes read a clamped pixel.
+  int xa[7][9];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    int hp = t * 16 + idx;
+    hp = hp < kHPix ? hp : kHPix - 1;
+    const int hy = (hp * 205) >> 11, hx = hp - hy * kHW;  // hp / 10
+#pragma unroll
+    for (int tt = 0; tt < 9; ++tt) xa[t][tt] = lds_off((hy + tt / 3) * kInP + hx + tt % 3, g);
+  }
 #pragma unroll
   for (int u = 0; u < 5; ++u)
     if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_in + da[u]) = ok[u] ? va[u] : u32x4{0u, 0u, 0u, 0u};
-  store_w();
   RB_STAMP(2);
-  __syncthreads();
+  lds_barrier();
   RB_STAMP(3);
-  // W2 travels in registers while conv1 computes
-#pragma unroll
-  for (int u = 0; u < 18; ++u) vw[u] = *reinterpret_cast<const u32x4*>(p.w2 + ((size_t)u * 256 + tid) * 16);
 
-  // ---- phase 2: conv1 over the 10x10 region.  Pixel tile t covers region pixels 16t .. 16t+15 (row-major, 10 wide)
-  // this wave's two weight tiles: packed rows 32wc .. 32wc+31 (row bit 2 == idx bit 2 in both tiles)
-  const int wrow = (wc * 2) * 16 * kRow + lds_off(idx, g);
+  // ---- phase 2: conv1.  Fragments of k-step st+2 are read from LDS before the MFMAs of step st are issued (one wave per
+  // SIMD: nothing else hides the LDS latency; sched_barrier keeps the scheduler from sinking the reads back).
   {
-    // tiles 0-3 / 4-7; tile 7 does not exist (and tile 6 is partial): those lanes read a clamped pixel and their results are
-    // dropped - cheaper than a branch around two of the eight MFMAs of every k-step
-    int xa[4][9], hp_l[4];  // LDS byte offset of every (pixel tile, tap) fragment of this lane: no address math in the k-loop
+    f32x4 acc[7];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      int hp = (wp * 4 + b) * 16 + idx;
-      hp_l[b] = hp;
-      hp = hp < kHPix ? hp : kHPix - 1;
-      const int hy = (hp * 205) >> 11, hx = hp - hy * kHW;  // hp / 10 for hp < 128
-#pragma unroll
-      for (int tt = 0; tt < 9; ++tt) xa[b][tt] = lds_off((hy + tt / 3) * kInP + hx + tt % 3, g);
-    }
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // 18 k-steps (chunk, tap); the fragments of step s+1 are read from LDS before the MFMAs of step s are issued - with
-    // one wave per SIMD nothing else hides the LDS latency
-    bf16x8 wf[3][2], xf[3][4];
-    auto frags1 = [&](int st, int buf) {
+    for (int t = 0; t < 7; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[3][7];
+    auto frags = [&](int st, int buf) {
       const int cc = st / 9, tt = st - cc * 9;
-      const char* lw = lds_w + (cc * 9 + tt) * 64 * kRow + wrow;
-      wf[buf][0] = *reinterpret_cast<const bf16x8*>(lw);
-      wf[buf][1] = *reinterpret_cast<const bf16x8*>(lw + 16 * kRow);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) xf[buf][b] = *reinterpret_cast<const bf16x8*>(lds_in + cc * kInRows * kRow + xa[b][tt]);
+      for (int t = 0; t < 7; ++t) xf[buf][t] = *reinterpret_cast<const bf16x8*>(lds_in + cc * kInRows * kRow + xa[t][tt]);
     };
-    // (sched_barrier: without it the scheduler sinks every read back next to its MFMA to save registers)
-    frags1(0, 0);
-    frags1(1, 1);
+    frags(0, 0);
+    frags(1, 1);
 #pragma unroll
     for (int st = 0; st < 18; ++st) {
-      const int cur = st % 3;
-      if (st + 2 < 18) frags1(st + 2, (st + 2) % 3);
+      if (st + 2 < 18) frags(st + 2, (st + 2) % 3);
+      issue_w(st + kAhead);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        acc[0][b] = mma(wf[cur][0], xf[cur][b], acc[0][b]);
-        acc[1][b] = mma(wf[cur][1], xf[cur][b], acc[1][b]);
-      }
+      for (int t = 0; t < 7; ++t) acc[t] = mma(wfr[st], xf[st % 3][t], acc[t]);
       __builtin_amdgcn_sched_barrier(0);
     }
     RB_STAMP(4);
-    // lane (idx, g): region pixel hp_l[b], channels 32wc + 8g .. +7 = rows 4g..4g+3 of the wave's two tiles
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int hp = hp_l[b];
+    for (int t = 0; t < 7; ++t) {
+      const int hp = t * 16 + idx;
       if (hp < kHPix) {
         const int hy = (hp * 205) >> 11, hx = hp - hy * kHW;
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         const bool inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
-        float v[8];
+        float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          v[j] = acc[0][b][j] + bias[j];
-          v[4 + j] = acc[1][b][j] + bias[4 + j];
+          v[j] = acc[t][j] + bias[j];
+          v[j] = (inside && v[j] > 0.f) ? v[j] : 0.f;
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (inside && v[e] > 0.f) ? v[e] : 0.f;
-        const u32x4 pk = pack8(v);
-        *reinterpret_cast<u32x4*>(lds_h + wc * kHRows * kRow + lds_off(hy * kHP + hx, g)) = pk;
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+        pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+        *reinterpret_cast<uint2*>(lds_h + chunk * kHRows * kRow + lds_off(hy * kHP + hx, g) + half * 8) = pk;
         if (inside && hy >= 1 && hy <= 8 && hx >= 1 && hx <= 8)
-          *reinterpret_cast<u32x4*>(p.out_h + (((size_t)n * p.H + y) * p.W + x) * 128 + wc * 64 + g * 16) = pk;
+          *reinterpret_cast<uint2*>(p.out_h + (((size_t)n * p.H + y) * p.W + x) * 128 + ch0 * 2) = pk;
       }
     }
   }
   RB_STAMP(5);
-  __syncthreads();  // W1 reads done, h complete
+  lds_barrier();  // h complete
   RB_STAMP(6);
-  store_w();
-  __syncthreads();
-  RB_STAMP(7);
 
   // ---- phase 3: conv2 on the 8x8 tile; pixel tile t = output rows 2t, 2t+1
   {
-    int xa[2][9];
+    int xb[4][9];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int op = (wp * 2 + b) * 16 + idx;
+    for (int t = 0; t < 4; ++t) {
+      const int op = t * 16 + idx;
 #pragma unroll
-      for (int tt = 0; tt < 9; ++tt) xa[b][tt] = lds_off(((op >> 3) + tt / 3) * kHP + (op & 7) + tt % 3, g);
+      for (int tt = 0; tt < 9; ++tt) xb[t][tt] = lds_off(((op >> 3) + tt / 3) * kHP + (op & 7) + tt % 3, g);
     }
-    f32x4 acc[2][2];
+    f32x4 acc[4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 wf[3][2], xf[3][2];
-    auto frags2 = [&](int st, int buf) {
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[3][4];
+    auto frags = [&](int st, int buf) {
       const int cc = st / 9, tt = st - cc * 9;
-      const char* lw = lds_w + (cc * 9 + tt) * 64 * kRow + wrow;
-      wf[buf][0] = *reinterpret_cast<const bf16x8*>(lw);
-      wf[buf][1] = *reinterpret_cast<const bf16x8*>(lw + 16 * kRow);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) xf[buf][b] = *reinterpret_cast<const bf16x8*>(lds_h + cc * kHRows * kRow + xa[b][tt]);
+      for (int t = 0; t < 4; ++t) xf[buf][t] = *reinterpret_cast<const bf16x8*>(lds_h + cc * kHRows * kRow + xb[t][tt]);
     };
-    frags2(0, 0);
-    frags2(1, 1);
+    frags(0, 0);
+    frags(1, 1);
+    RB_STAMP(7);
 #pragma unroll
     for (int st = 0; st < 18; ++st) {
-      const int cur = st % 3;
-      if (st + 2 < 18) frags2(st + 2, (st + 2) % 3);
+      if (st + 2 < 18) frags(st + 2, (st + 2) % 3);
+      if (18 + st + kAhead < 36) issue_w(18 + st + kAhead);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        acc[0][b] = mma(wf[cur][0], xf[cur][b], acc[0][b]);
-        acc[1][b] = mma(wf[cur][1], xf[cur][b], acc[1][b]);
-      }
+      for (int t = 0; t < 4; ++t) acc[t] = mma(wfr[18 + st], xf[st % 3][t], acc[t]);
       __builtin_amdgcn_sched_barrier(0);
     }
     RB_STAMP(8);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int op = (wp * 2 + b) * 16 + idx;
+    for (int t = 0; t < 4; ++t) {
+      const int op = t * 16 + idx;
       const int oy = op >> 3, ox = op & 7;
       const int y = y0 + oy, x = x0 + ox;
       if (y < p.H && x < p.W) {
-        float r[8], v[8];
-        Vec<BF16>::load(lds_in + wc * kInRows * kRow + lds_off((oy + 2) * kInP + ox + 2, g), r);  // the skip connection
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = acc[0][b][j] + r[j];
-          v[4 + j] = acc[1][b][j] + r[4 + j];
-        }
-        *reinterpret_cast<u32x4*>(p.out_a + (((size_t)n * p.H + y) * p.W + x) * 128 + wc * 64 + g * 16) = pack8(v);
+        // the skip connection comes from the LDS patch
+        const uint2 rr = *reinterpret_cast<const uint2*>(lds_in + chunk * kInRows * kRow +
+                                                         lds_off((oy + 2) * kInP + ox + 2, g) + half * 8);
+        float v[4];
+        v[0] = acc[t][0] + __uint_as_float(rr.x << 16);
+        v[1] = acc[t][1] + __uint_as_float(rr.x & 0xffff0000u);
+        v[2] = acc[t][2] + __uint_as_float(rr.y << 16);
+        v[3] = acc[t][3] + __uint_as_float(rr.y & 0xffff0000u);
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+        pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+        *reinterpret_cast<uint2*>(p.out_a + (((size_t)n * p.H + y) * p.W + x) * 128 + ch0 * 2) = pk;
       }
     }
   }

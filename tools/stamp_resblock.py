@@ -16,7 +16,7 @@ wps = [[K.pack_weights(dt, torch.randn(spec.weight_shape, device="cuda") * 0.03,
 bs = [torch.zeros(64, device="cuda") for _ in range(NB)]
 a = [torch.randn(N, H, H, 64, device="cuda").to(dt) for _ in range(NB + 1)]
 h = [torch.empty(N, H, H, 64, dtype=dt, device="cuda") for _ in range(NB)]
-names = ["issue loads", "wait+LDS stores", "barrier", "conv1 MFMA", "epilogue1", "barrier", "W2 store+barrier", "conv2 MFMA", "epilogue2"]
+names = ["issue loads", "addr+wait+LDS stores", "barrier", "conv1 MFMA", "epilogue1", "barrier", "conv2 prologue", "conv2 MFMA", "epilogue2"]
 for rep in range(4):
     for i in range(NB):
         K.resblock_fwd(a[i], wps[i][0], bs[i], wps[i][1], h[i], a[i + 1])
