@@ -112,14 +112,14 @@ def roofline_pass(st, dtype):
     # the fused residual-block launch (csrc/resblock.hip) and the grouped weight-gradient launch are not Conv methods
     orig_rb, orig_group = K.resblock_fwd, E.WgradGroup.launch
 
-    def rb_timed(x, *a):
+    def rb_timed(x, *a, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        orig_rb(x, *a)
+        orig_rb(x, *a, **kw)
         e1.record()
         N, H, W, C_ = x.shape
         recs.append(("resblock_fwd_kernel", 2 * 2.0 * N * H * W * 9 * C_ * C_, e0, e1))  # algorithmic: two 3x3 convs
-        replays.setdefault("resblock_fwd_kernel", []).append(lambda: orig_rb(x, *a))
+        replays.setdefault("resblock_fwd_kernel", []).append(lambda: orig_rb(x, *a, **kw))
 
     def group_timed(self):
         items = list(self.items)

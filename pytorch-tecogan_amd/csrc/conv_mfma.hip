@@ -35,7 +35,15 @@ extern "C" int tg_debug_read_stamps(long long* out, int n) {
 
 namespace {
 
-constexpr int kRowBytes = 80;  // 64 data bytes + 16 pad: keeps ds_read_b128 fragment reads at most 2-way conflicted
+constexpr int kRowBytes = 80;  // generic path: 64 data bytes + 16 pad, ds_read_b128 fragment reads at most 2-way conflicted
+// STD3 path: unpadded 64-byte rows whose 16-byte piece index is XOR-ed with 2*(bit 2 of the row), patch pitch 24 rows.
+// ds_read_b128 serves a wave in four fixed groups of 16 lanes ({0-3,12-15,20-27}, ...: MI355X_MICROARCH.md, LDS); with
+// this swizzle 16 lanes on 16 consecutive rows - at any base row, i.e. for every tap - hit 16 distinct 16-byte slots, so
+// every fragment read takes the minimum 4 LDS cycles instead of 8 (tools/lds_layout.py counts them exhaustively).  The
+// pitch of 24 (a multiple of 8) keeps bit 2 of a row independent of the tap's row offset, so the three column taps need
+// three precomputed lane addresses and everything else is an immediate offset.
+constexpr int kSwzRow = 64, kSwzPitch = 24;
+__device__ __forceinline__ int swz_off(int row, int piece) { return row * kSwzRow + ((piece ^ ((row >> 1) & 2)) << 4); }
 
 // All fields are 32-bit on purpose: the struct lives in the kernarg segment and is indexed by blockIdx.z / the tap index;
 // with 8/16-bit members hipcc lowers every such access to a VECTOR global_load_ubyte/ushort + v_readfirstlane (a ~600-cycle
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_a = smem;
-  char* lds_w = smem + (size_t)p.cg * p.a_rows_max * kRowBytes;
+  char* lds_w = smem + (size_t)p.cg * p.a_rows_max * (STD3 ? kSwzRow : kRowBytes);
 
   const ConvClassK& cl = p.cls[blockIdx.z];
   const int tid = threadIdx.x;
@@ -179,17 +187,19 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
   // small tiles: the whole K of a 64-channel 3x3 layer in flight at once; big tiles: one 3x3 chunk (pipelined kernel) or
   // fewer blocks in the generic kernel, whose 128-channel tiles otherwise lose occupancy to the staging registers
   constexpr int UW = (CT * PT <= 4) ? 18 : ((STD3 || PPT == 1) ? 9 : 5);
-  const int a_stride = p.a_rows_max * kRowBytes;  // LDS bytes of one chunk's activation patch
+  const int a_stride = p.a_rows_max * (STD3 ? kSwzRow : kRowBytes);  // LDS bytes of one chunk's activation patch
   const float inv_iw = 1.0f / (float)cl.iw, inv_prow = 1.0f / (float)prow_n;
   if constexpr (STD3) {
     // ---- 3x3 fast path, software-pipelined over chunk groups: the global loads of group i+1 are issued right after
     // group i has been written to LDS and stay in flight (in registers) while the MFMAs of group i run.  The host
     // guarantees that one group fits one issue: cg*prow_n*4 <= 256*UA pieces and cg*9 <= UW weight blocks.
-    const int pitch = cl.iw * kRowBytes;
-    int xbase[PT];
+    constexpr int pitch = kSwzPitch * kSwzRow;
+    int xbase[PT][3];  // lane address of pixel (row wp*PT+b, column idx + c) of the patch, c = column tap
 #pragma unroll
-    for (int b = 0; b < PT; ++b) xbase[b] = (wp * PT + b) * pitch + idx * kRowBytes + g * 16;
-    const int wbase = (wc * CT * 16 + idx) * kRowBytes + g * 16;
+    for (int b = 0; b < PT; ++b)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xbase[b][c] = swz_off((wp * PT + b) * kSwzPitch + idx + c, g);
+    const int wbase = swz_off(wc * CT * 16 + idx, g);  // + multiples of 16 rows: bit 2 unchanged
     u32x4 va[UA];
     int da[UA];
     u32x4 vw[UW][PPT];
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
           const int cc = (int)(((float)r + 0.5f) * inv_prow), prow = r - cc * prow_n;
           const int py = (int)(((float)prow + 0.5f) * inv_iw), px = prow - py * cl.iw;
           const int iy = iy0 + py, ix = ix0 + px;
-          da[u] = cc * a_stride + prow * kRowBytes + s * 16;
+          da[u] = cc * a_stride + swz_off(py * kSwzPitch + px, s);
           if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
             va[u] = *reinterpret_cast<const u32x4*>(in_n + ((size_t)iy * p.IW + ix) * in_pix_bytes +
                                                     (size_t)(c0 + cc) * 64 + s * 16);
@@ -231,12 +241,12 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
 #pragma unroll
       for (int u = 0; u < UW; ++u) {
         if (u < cn * 9) {
-          char* dstw = lds_w + u * CO_TILE * kRowBytes;  // [cc][tt] with tg == 9
+          char* dstw = lds_w + u * CO_TILE * kSwzRow;  // [cc][tt] with tg == 9
 #pragma unroll
           for (int k = 0; k < PPT; ++k) {
             const int piece = tid + k * 256;
             if (PIECES % 256 == 0 || piece < PIECES)
-              *reinterpret_cast<u32x4*>(dstw + (piece >> 2) * kRowBytes + (piece & 3) * 16) = vw[u][k];
+              *reinterpret_cast<u32x4*>(dstw + swz_off(piece >> 2, piece & 3)) = vw[u][k];
           }
         }
       }
@@ -254,17 +264,18 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
       if (c1 < p.nchunks) issue(c1, min(p.cg, p.nchunks - c1));
       for (int cc = 0; cc < cn; ++cc) {
         const char* la = lds_a + cc * a_stride;
-        const char* lw = lds_w + cc * 9 * CO_TILE * kRowBytes + wbase;
+        const char* lw = lds_w + cc * 9 * CO_TILE * kSwzRow + wbase;
+        // spatial offsets in compile-time order (so every pixel read is register + immediate); the input-gradient launch
+        // pairs offset `so` with weight slot 8 - so instead (taps mirrored)
 #pragma unroll
-        for (int tt = 0; tt < 9; ++tt) {
-          const int r = p.flip ? 2 - tt / 3 : tt / 3, c = p.flip ? 2 - tt % 3 : tt % 3;
-          const int toff = r * pitch + c * kRowBytes;
+        for (int so = 0; so < 9; ++so) {
+          const int tt = p.flip ? 8 - so : so;
           Frag wf[CT];
 #pragma unroll
-          for (int a = 0; a < CT; ++a) wf[a] = *reinterpret_cast<const Frag*>(lw + (tt * CO_TILE + a * 16) * kRowBytes);
+          for (int a = 0; a < CT; ++a) wf[a] = *reinterpret_cast<const Frag*>(lw + (tt * CO_TILE + a * 16) * kSwzRow);
 #pragma unroll
           for (int b = 0; b < PT; ++b) {
-            const Frag xf = *reinterpret_cast<const Frag*>(la + xbase[b] + toff);
+            const Frag xf = *reinterpret_cast<const Frag*>(la + xbase[b][so % 3] + (so / 3) * pitch);
 #pragma unroll
             for (int a = 0; a < CT; ++a) acc[a][b] = Mma<T>::run(wf[a], xf, acc[a][b]);
           }
@@ -663,8 +674,8 @@ static int prepare_conv(const tg_conv_desc* d, const void* in, const void* w_pac
     max_owc = std::max(max_owc, (d->OW - s.oox + d->OS - 1) / d->OS);
   }
   k.a_rows_max = max_rows;
-  const size_t a_bytes = (size_t)max_rows * kRowBytes;
-  const size_t w_tap = (size_t)tc.co_tile * kRowBytes;
+  size_t a_bytes = (size_t)max_rows * kRowBytes;
+  size_t w_tap = (size_t)tc.co_tile * kRowBytes;
   k.tiles_x = (max_owc + 15) / 16;
   k.tiles_y = (max_ohc + tc.th - 1) / tc.th;
   auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
@@ -690,18 +701,33 @@ static int prepare_conv(const tg_conv_desc* d, const void* in, const void* w_pac
   // measured (profiles/r01_*_microbench*.log): the pipelined kernel wins up to ~1000 workgroups (latency-bound launches);
   // beyond that two co-resident workgroups of the plain kernel hide latency better than one pipelined workgroup per CU
   const bool pattern = (pat_fwd || pat_bwd) && (wgs <= 1024 || (k.nchunks >= 4 && wgs <= 2048));
+  const bool std3_ok = pattern && max_taps == 9 && max_rows * 4 <= 256 * 6;
+  if (std3_ok) {  // the pipelined 3x3 kernel keeps its LDS images in swizzled 64-byte rows, patch pitch kSwzPitch
+    a_bytes = (size_t)k.cls[0].ih * kSwzPitch * kSwzRow;
+    w_tap = (size_t)tc.co_tile * kSwzRow;
+  }
   // LDS budget: small grids (<= 2 workgroups per CU anyway) and the software-pipelined 3x3 kernel (it hides its own load
   // latency) may use almost all 160 KB; the generic kernel on big grids keeps two workgroups per CU.
   const size_t budget = (wgs <= 512 || pattern) ? 150 * 1024 : 72 * 1024;
-  int tg = max_taps;
-  while (tg > 1 && a_bytes + tg * w_tap > budget) --tg;
-  int cg = 1;
-  if (tg == max_taps)
-    while (cg < k.nchunks && (size_t)(cg + 1) * (a_bytes + tg * w_tap) <= budget) ++cg;
+  int tg = 0, cg = 0;
+  auto plan = [&]() {
+    tg = max_taps;
+    while (tg > 1 && a_bytes + tg * w_tap > budget) --tg;
+    cg = 1;
+    if (tg == max_taps)
+      while (cg < k.nchunks && (size_t)(cg + 1) * (a_bytes + tg * w_tap) <= budget) ++cg;
+  };
+  plan();
+  if (std3_ok && tg != 9) {  // cannot happen with the tile configurations above; stay correct if one is added
+    a_bytes = (size_t)max_rows * kRowBytes;
+    w_tap = (size_t)tc.co_tile * kRowBytes;
+    plan();
+  }
   k.std3 = 0;
   k.flip = 0;
-  if (pattern && tg == 9 && max_rows * 4 <= 256 * 6) {
+  if (std3_ok && tg == 9) {
     k.std3 = 1;
+    k.a_rows_max = k.cls[0].ih * kSwzPitch;
     k.flip = (!pat_fwd && pat_bwd) ? 1 : 0;
     // one chunk group must fit one issue phase of the pipelined kernel: UA = 6 pieces, UW = 18 / 9 weight blocks per thread
     const bool small_cfg = (cfg == TG_TILE_64x64 || cfg == TG_TILE_32x128 || cfg == TG_TILE_32x64);

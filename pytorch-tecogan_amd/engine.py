@@ -447,7 +447,8 @@ class GeneratorEngine:
         self.conv0.fwd(a["in0"][sl], a["a"][0][sl], act=L.ACT_RELU)
         for i, (c1, c2) in enumerate(self.rb):
             if self.fused_rb:  # conv-relu-conv-skip in one launch (csrc/resblock.hip)
-                K.resblock_fwd(a["a"][i][sl], c1.wf, c1.bias, c2.wf, a["h"][i][sl], a["a"][i + 1][sl])
+                nxt = (self.rb[i + 1][0].wf, self.rb[i + 1][1].wf) if i + 1 < self.nrb else None
+                K.resblock_fwd(a["a"][i][sl], c1.wf, c1.bias, c2.wf, a["h"][i][sl], a["a"][i + 1][sl], next_w=nxt)
                 continue
             c1.fwd(a["a"][i][sl], a["h"][i][sl], act=L.ACT_RELU)
             c2.fwd(a["h"][i][sl], a["a"][i + 1][sl], res=a["a"][i][sl])

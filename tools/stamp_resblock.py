@@ -19,9 +19,10 @@ h = [torch.empty(N, H, H, 64, dtype=dt, device="cuda") for _ in range(NB)]
 names = ["issue loads", "addr+wait+LDS stores", "barrier", "conv1 MFMA", "epilogue1", "barrier", "conv2 prologue", "conv2 MFMA", "epilogue2"]
 for rep in range(4):
     for i in range(NB):
-        K.resblock_fwd(a[i], wps[i][0], bs[i], wps[i][1], h[i], a[i + 1])
+        K.resblock_fwd(a[i], wps[i][0], bs[i], wps[i][1], h[i], a[i + 1], next_w=(wps[i + 1] if i + 1 < NB and os.environ.get('RB_PREFETCH', '1') == '1' else None))
     torch.cuda.synchronize()
     buf = (ctypes.c_longlong * 16)()
     lib.tg_debug_read_rb_stamps(buf, 16)
     t = list(buf)
-    print(" | ".join(f"{n} {t[i+1]-t[i]}" for i, n in enumerate(names)), "| total", t[9] - t[0], "ticks of 10 ns")
+    print(" | ".join(f"{n} {t[i+1]-t[i]}" for i, n in enumerate(names)), "| total", t[9] - t[0], "ticks;",
+          f"epilogue1 = exchange writes {t[10]-t[4]} + barrier {t[11]-t[10]} + finalise {t[5]-t[11]}")
