@@ -7,7 +7,7 @@ lib = L.load()
 lib.tg_debug_read_stamps.restype = ctypes.c_int
 lib.tg_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 dt = torch.bfloat16
-for (kind, cin, cout, N, H, tile) in (("c3",64,64,4,32,2), ("c3",64,64,4,32,5), ("ct",64,64,4,32,2), ("c3",128,64,4,128,1)):
+for (kind, cin, cout, N, H, tile) in (("c3",64,64,4,32,5), ("c3",64,64,40,32,6), ("c3",64,64,40,32,1), ("c3",128,128,24,32,6), ("c3",128,64,4,128,6)):
     spec = K.ConvSpec(kind, cin, cout)
     OH, OW = spec.out_hw(H, H)
     x = torch.randn(N, H, H, K.pad32(cin), device="cuda").to(dt)
@@ -21,5 +21,5 @@ for (kind, cin, cout, N, H, tile) in (("c3",64,64,4,32,2), ("c3",64,64,4,32,5), 
     buf = (ctypes.c_longlong * 8)()
     lib.tg_debug_read_stamps(buf, 8)
     t = list(buf)
-    names = ["start->issued", "A stores", "W stores", "barrier", "compute", "epilogue"]
-    print(kind, cin, cout, N, H, "tile", tile, " | ".join(f"{n} {t[i+1]-t[i]}" for i, n in enumerate(names)), "| total ticks", t[6]-t[0], "(100 MHz ticks => x10 ns)")
+    print(kind, cin, cout, N, H, "tile", tile, f"| issue+wait {t[1]-t[0]} | LDS stores {t[3]-t[1]} | barrier {t[4]-t[3]} | k-loop {t[5]-t[4]} | "
+          f"epilogue {t[6]-t[5]} | total {t[6]-t[0]} cycles (pipelined 3x3 path; last chunk group)")
