@@ -453,8 +453,11 @@ class GeneratorEngine:
             c1.fwd(a["a"][i][sl], a["h"][i][sl], act=L.ACT_RELU)
             c2.fwd(a["h"][i][sl], a["a"][i + 1][sl], res=a["a"][i][sl])
         self.ct0.fwd(a["a"][self.nrb][sl], a["u0"][sl], act=L.ACT_RELU)
-        self.c20.fwd(a["u0"][sl], a["hh"][sl], act=L.ACT_RELU)
-        self.c22.fwd(a["hh"][sl], a["u1"][sl])
+        if self.fused_rb:  # conv_trans.2 is conv-relu-conv without a skip: the same fused launch
+            K.resblock_fwd(a["u0"][sl], self.c20.wf, self.c20.bias, self.c22.wf, a["hh"][sl], a["u1"][sl], skip=False)
+        else:
+            self.c20.fwd(a["u0"][sl], a["hh"][sl], act=L.ACT_RELU)
+            self.c22.fwd(a["hh"][sl], a["u1"][sl])
         self.c30.fwd(a["u1"][sl], a["h2"][sl], act=L.ACT_RELU)
         self.c32.fwd(a["h2"][sl], a["u2"][sl])
         self.ct4.fwd(a["u2"][sl], a["u3"][sl], act=L.ACT_RELU)

@@ -257,12 +257,12 @@ def nhwc_to_nchw(src, dst, n_stride, N, C_, H, W):
             "tg_nhwc_to_nchw")
 
 
-def resblock_fwd(x, w1, b1, w2, out_h, out_a, next_w=None):
-    """next_w: (w1, w2) packed weights of the block launched next (L2 prefetch hint) or None"""
+def resblock_fwd(x, w1, b1, w2, out_h, out_a, next_w=None, skip=True):
+    """next_w: (w1, w2) packed weights of the block launched next (L2 prefetch hint) or None; skip=False: conv-relu-conv"""
     N, H, W, C_ = x.shape
     n1, n2 = next_w if next_w is not None else (None, None)
     L.check(L.load().tg_resblock_fwd(tg_dtype(x.dtype), _ptr(x), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(out_h), _ptr(out_a),
-                                     N, H, W, C_, _ptr(n1), _ptr(n2), _stream()), "tg_resblock_fwd")
+                                     N, H, W, C_, int(skip), _ptr(n1), _ptr(n2), _stream()), "tg_resblock_fwd")
 
 
 def maxpool2(src, dst):

@@ -576,7 +576,13 @@ def test_fused_resblock_forward(N, H, W):
     torch.testing.assert_close(K.to_nchw(h_f, 64).cpu(), ref_h, **tol(dt))
     torch.testing.assert_close(K.to_nchw(a_f, 64).cpu(), ref_a, **tol(dt))
     assert L.load().tg_resblock_fwd(L.TG_F32, xd.data_ptr(), wp1.data_ptr(), bd.data_ptr(), wp2.data_ptr(),
-                                    h_f.data_ptr(), a_f.data_ptr(), N, H, W, 64, None, None, None) == -2
+                                    h_f.data_ptr(), a_f.data_ptr(), N, H, W, 64, 1, None, None, None) == -2
+    # add_skip = 0: conv-relu-conv (conv_trans.2 of the generator)
+    a_n = torch.empty_like(a_f)
+    K.resblock_fwd(xd, wp1, bd, wp2, h_p := torch.empty_like(h_f), a_n, skip=False)
+    torch.cuda.synchronize()
+    assert torch.equal(h_p, h_f)
+    torch.testing.assert_close(K.to_nchw(a_n, 64).cpu(), ref_a - x, **tol(dt))
     # the L2 prefetch hint for the next block must not change anything
     h_p, a_p = torch.empty_like(h_f), torch.empty_like(a_f)
     K.resblock_fwd(xd, wp1, bd, wp2, h_p, a_p, next_w=(wp2, wp1))
