@@ -110,16 +110,18 @@ def roofline_pass(st, dtype):
         return conv_flops(self.spec, x_in.shape[0], x_in.shape[1], x_in.shape[2])
 
     # the fused residual-block launch (csrc/resblock.hip) and the grouped weight-gradient launch are not Conv methods
-    orig_rb, orig_group = K.resblock_fwd, E.WgradGroup.launch
+    orig_rb, orig_rbb, orig_group = K.resblock_fwd, K.resblock_bwd, E.WgradGroup.launch
 
-    def rb_timed(x, *a, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        orig_rb(x, *a, **kw)
-        e1.record()
-        N, H, W, C_ = x.shape
-        recs.append(("resblock_fwd_kernel", 2 * 2.0 * N * H * W * 9 * C_ * C_, e0, e1))  # algorithmic: two 3x3 convs
-        replays.setdefault("resblock_fwd_kernel", []).append(lambda: orig_rb(x, *a, **kw))
+    def rb_wrap(orig, label):
+        def rb_timed(x, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(x, *a, **kw)
+            e1.record()
+            N, H, W, C_ = x.shape
+            recs.append((label, 2 * 2.0 * N * H * W * 9 * C_ * C_, e0, e1))  # algorithmic: two 3x3 convs
+            replays.setdefault(label, []).append(lambda: orig(x, *a, **kw))
+        return rb_timed
 
     def group_timed(self):
         items = list(self.items)
@@ -139,7 +141,8 @@ def roofline_pass(st, dtype):
             orig_group(self)
         replays.setdefault(lab, []).append(again)
 
-    K.resblock_fwd, E.WgradGroup.launch = rb_timed, group_timed
+    K.resblock_fwd, K.resblock_bwd = rb_wrap(orig_rb, "resblock_kernel<false>"), rb_wrap(orig_rbb, "resblock_kernel<true>")
+    E.WgradGroup.launch = group_timed
     E.Conv.fwd = timed(lab_fwd, fl_fwd, orig_fwd)
     E.Conv.dgrad = timed(lab_dgrad, fl_dgrad, orig_dgrad)
     E.Conv.wgrad = timed(lambda self, *a: f"wgrad_kernel<{'BF16' if dtype == 'bf16' else 'F32'}, {self.spec.nslots}, ..> + "
@@ -157,7 +160,7 @@ def roofline_pass(st, dtype):
         torch.cuda.synchronize()
     finally:
         E.Conv.fwd, E.Conv.dgrad, E.Conv.wgrad = orig_fwd, orig_dgrad, orig_wgrad
-        K.resblock_fwd, E.WgradGroup.launch = orig_rb, orig_group
+        K.resblock_fwd, K.resblock_bwd, E.WgradGroup.launch = orig_rb, orig_rbb, orig_group
         st.sB, st.sC = side
         st.G.side.streams, st.D.side.streams = pools
     fam = {}

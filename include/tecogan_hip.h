@@ -151,6 +151,14 @@ int tg_resblock_fwd(int dtype, const void* in, const void* w1_packed, const floa
                     void* out_a, int N, int H, int W, int C, int add_skip, const void* next_w1_packed,
                     const void* next_w2_packed, void* stream);
 
+/* Input-gradient of the same block in ONE launch (aten::convolution_backward x2 + threshold_backward, code/train.py:336):
+ * out_dh = (h > 0) * conv3x3^T(dout, w2), out_din = dout + conv3x3^T(out_dh, w1); w*_dgrad_packed are the role-swapped
+ * ("dgrad") packings of tg_pack_conv_weights; h is the forward pass's out_h.  out_dh is the Y operand of the first conv's
+ * weight gradient (and, summed per channel, its bias gradient).  next_*: L2 prefetch hint as in tg_resblock_fwd. */
+int tg_resblock_bwd(int dtype, const void* dout, const void* w2_dgrad_packed, const void* h, const void* w1_dgrad_packed,
+                    void* out_dh, void* out_din, int N, int H, int W, int C, const void* next_wa_packed,
+                    const void* next_wb_packed, void* stream);
+
 /* ---- layout converters ------------------------------------------------------------------------------- */
 /* NCHW fp32 (strided samples) -> NHWC `dtype` with zero channel padding. */
 int tg_nchw_to_nhwc(int dtype, const float* src, int64_t src_n_stride, void* dst, int N, int C, int Cp, int H, int W,

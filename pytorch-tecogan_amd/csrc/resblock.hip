@@ -71,6 +71,7 @@ struct ResblockK {
   const char* pf2;
   int N, H, W, tiles_x, tiles_y;
   int skip;  // 1: out_a = in + conv2(h) (residual block); 0: out_a = conv2(h) (the conv-relu-conv pair of conv_trans.2)
+  const char* hmask;  // BWD: the block's saved forward activation h (relu mask of the first stage)
 };
 
 __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
@@ -98,7 +99,13 @@ __device__ __forceinline__ uint2 pack4(const float* v) {
   return pk;
 }
 
-__global__ __launch_bounds__(512) void resblock_fwd_kernel(const ResblockK p) {
+// BWD = the input-gradient of the same block, which has the same shape:
+//     dH = relu'(h) * conv3x3^T(dOut, W2),   dIn = dOut + conv3x3^T(dH, W1)          (autograd of code/ops.py:45-54)
+// i.e. stage 1 = transposed conv with the role-swapped packing of W2 (taps mirrored: weight slot 8 - t goes with spatial
+// offset t), bias + relu replaced by the mask h > 0; stage 2 = transposed conv with W1, skip = dOut.  dH is stored like h
+// (the weight-gradient launch of the first conv reads it; its channel sums are that conv's bias gradient).
+template <bool BWD>
+__global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_in = smem;
   char* lds_h = smem + kLdsIn;
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(512) void resblock_fwd_kernel(const ResblockK p) {
   bf16x8 wfr[18];
   auto issue_w = [&](int k) {  // compile-time k after unrolling
     const char* base = k < 9 ? p.w1 : p.w2;
-    wfr[k] = *reinterpret_cast<const bf16x8*>(base + (size_t)(k % 9) * 8192 + wlane);
+    wfr[k] = *reinterpret_cast<const bf16x8*>(base + (size_t)(BWD ? 8 - k % 9 : k % 9) * 8192 + wlane);
   };
   constexpr int kAhead = 9;  // all of W1 up front (the registers exist anyway), W2 one load per conv1 step
 #pragma unroll
@@ -148,7 +155,19 @@ __global__ __launch_bounds__(512) void resblock_fwd_kernel(const ResblockK p) {
   // lane (idx, g) of row tile w ends up with channels ch0 .. ch0+3 of pixel idx (row_to_channel<BF16> of common.h)
   const int chunk = w >> 1, half = w & 1;
   const int ch0 = 32 * chunk + 8 * g + 4 * half;
-  const f32x4 bias = *reinterpret_cast<const f32x4*>(p.b1 + ch0);
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (!BWD) bias = *reinterpret_cast<const f32x4*>(p.b1 + ch0);
+  // BWD: the relu mask of the (up to four) region tiles this wave finalises - 8 bytes per lane and tile, fetched now
+  uint2 hm[4];
+  if constexpr (BWD) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int hp = min((kc ? 4 + j : j) * 16 + idx, kHPix - 1);
+      const int hy = (hp * 205) >> 11, hx = hp - hy * kHW;
+      const int y = min(max(y0 - 1 + hy, 0), p.H - 1), x = min(max(x0 - 1 + hx, 0), p.W - 1);  // clamped: unused outside
+      hm[j] = *reinterpret_cast<const uint2*>(p.hmask + (((size_t)n * p.H + y) * p.W + x) * 128 + ch0 * 2);
+    }
+  }
   RB_STAMP(1);
 
   // fragment offsets of conv1 (7 pixel tiles x 9 taps) inside one chunk image, computed while the loads are in flight.
@@ -215,7 +234,13 @@ __global__ __launch_bounds__(512) void resblock_fwd_kernel(const ResblockK p) {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[e] = fmaxf(acc[t][e] + other[e] + bias[e], 0.f);
+            if constexpr (BWD) {
+              const unsigned word = (e < 2) ? hm[j].x : hm[j].y;
+              const float hv = __uint_as_float((e & 1) ? (word & 0xffff0000u) : (word << 16));
+              v[e] = hv > 0.f ? acc[t][e] + other[e] : 0.f;
+            } else {
+              v[e] = fmaxf(acc[t][e] + other[e] + bias[e], 0.f);
+            }
             v[e] = inside ? v[e] : 0.f;
           }
           const uint2 pk = pack4(v);
@@ -311,6 +336,32 @@ __global__ __launch_bounds__(512) void resblock_fwd_kernel(const ResblockK p) {
 
 }  // namespace
 
+namespace {
+int resblock_launch(bool bwd, const void* in, const void* wa, const float* b1, const void* wb2, const void* hmask, void* out_h,
+                    void* out_a, int N, int H, int W, int add_skip, const void* next_w1, const void* next_w2, void* stream) {
+  ResblockK k;
+  k.in = (const char*)in; k.w1 = (const char*)wa; k.b1 = b1; k.w2 = (const char*)wb2;
+  k.out_h = (char*)out_h; k.out_a = (char*)out_a; k.hmask = (const char*)hmask;
+  k.pf1 = (next_w1 && next_w2) ? (const char*)next_w1 : nullptr;
+  k.pf2 = (const char*)next_w2;
+  k.N = N; k.H = H; k.W = W; k.skip = add_skip ? 1 : 0;
+  k.tiles_x = (W + 7) / 8; k.tiles_y = (H + 7) / 8;
+  const long long blocks = (long long)k.tiles_x * k.tiles_y * N;
+  if (blocks > 0x7fffffffLL) return TG_E_UNSUPPORTED;
+  static bool attr_done = false;
+  if (!attr_done) {
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal));
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal));
+    attr_done = true;
+  }
+  if (bwd) hipLaunchKernelGGL(resblock_kernel<true>, dim3((unsigned)blocks), dim3(512), kLdsTotal, (hipStream_t)stream, k);
+  else hipLaunchKernelGGL(resblock_kernel<false>, dim3((unsigned)blocks), dim3(512), kLdsTotal, (hipStream_t)stream, k);
+  return tg_launch_status();
+}
+}  // namespace
+
 extern "C" int tg_resblock_fwd(int dtype, const void* in, const void* w1_packed, const float* b1, const void* w2_packed,
                                void* out_h, void* out_a, int N, int H, int W, int C, int add_skip,
                                const void* next_w1_packed, const void* next_w2_packed, void* stream) {
@@ -319,21 +370,19 @@ extern "C" int tg_resblock_fwd(int dtype, const void* in, const void* w1_packed,
   if (!tg_aligned16(in) || !tg_aligned16(w1_packed) || !tg_aligned16(w2_packed) || !tg_aligned16(out_h) ||
       !tg_aligned16(out_a) || !tg_aligned16(b1))
     return TG_E_ALIGN;
-  ResblockK k;
-  k.in = (const char*)in; k.w1 = (const char*)w1_packed; k.b1 = b1; k.w2 = (const char*)w2_packed;
-  k.out_h = (char*)out_h; k.out_a = (char*)out_a;
-  k.pf1 = (next_w1_packed && next_w2_packed) ? (const char*)next_w1_packed : nullptr;
-  k.pf2 = (const char*)next_w2_packed;
-  k.N = N; k.H = H; k.W = W; k.skip = add_skip ? 1 : 0;
-  k.tiles_x = (W + 7) / 8; k.tiles_y = (H + 7) / 8;
-  const long long blocks = (long long)k.tiles_x * k.tiles_y * N;
-  if (blocks > 0x7fffffffLL) return TG_E_UNSUPPORTED;
-  static bool attr_done = false;
-  if (!attr_done) {
-    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_fwd_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(resblock_fwd_kernel, dim3((unsigned)blocks), dim3(512), kLdsTotal, (hipStream_t)stream, k);
-  return tg_launch_status();
+  return resblock_launch(false, in, w1_packed, b1, w2_packed, nullptr, out_h, out_a, N, H, W, add_skip, next_w1_packed,
+                         next_w2_packed, stream);
+}
+
+extern "C" int tg_resblock_bwd(int dtype, const void* dout, const void* w2_dgrad_packed, const void* h, const void* w1_dgrad_packed,
+                               void* out_dh, void* out_din, int N, int H, int W, int C, const void* next_wa_packed,
+                               const void* next_wb_packed, void* stream) {
+  if (!dout || !w2_dgrad_packed || !h || !w1_dgrad_packed || !out_dh || !out_din || N <= 0 || H <= 0 || W <= 0)
+    return TG_E_BADARG;
+  if (dtype != TG_BF16 || C != 64) return TG_E_UNSUPPORTED;
+  if (!tg_aligned16(dout) || !tg_aligned16(w2_dgrad_packed) || !tg_aligned16(w1_dgrad_packed) || !tg_aligned16(out_dh) ||
+      !tg_aligned16(out_din) || !tg_aligned16(h))
+    return TG_E_ALIGN;
+  return resblock_launch(true, dout, w2_dgrad_packed, nullptr, w1_dgrad_packed, h, out_dh, out_din, N, H, W, 1, next_wa_packed,
+                         next_wb_packed, stream);
 }

@@ -423,6 +423,10 @@ class GeneratorEngine:
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
         self.trunk_group = WgradGroup() if os.environ.get("TECOGAN_WGRAD_GROUPS", "1") != "0" else None
         self.fused_rb = dtype_t == torch.bfloat16 and os.environ.get("TECOGAN_FUSED_RESBLOCK", "1") != "0"
+        # the fused input-gradient launch (tg_resblock_bwd) is numerically identical and was measured EQUAL in time on the
+        # batched backward (15 x 28.2 us vs 30 x 14.9 us at 40 samples: 640 workgroups each re-read 147 KB of weights), so
+        # it stays an option
+        self.fused_rb_bwd = self.fused_rb and os.environ.get("TECOGAN_FUSED_RESBLOCK_BWD", "0") == "1"
 
     def repack(self):
         self.repacker.run()
@@ -517,6 +521,11 @@ class GeneratorEngine:
         for i in range(self.nrb - 1, -1, -1):
             c1, c2 = self.rb[i]
             wg(c2, a["h"][i], dA[i + 1])
+            if self.fused_rb_bwd and i > 0:  # both input-gradients of the block in one launch (csrc/resblock.hip, BWD)
+                nxt = (self.rb[i - 1][1].wb, self.rb[i - 1][0].wb) if i > 1 else None
+                K.resblock_bwd(dA[i + 1], c2.wb, a["h"][i], c1.wb, dH[i], dA[i], next_w=nxt)
+                wg(c1, a["a"][i], dH[i], True)
+                continue
             c2.dgrad(dA[i + 1], dH[i], mask=a["h"][i], mask_mode=RELU)
             wg(c1, a["a"][i], dH[i], True)
             if i > 0:

@@ -265,6 +265,14 @@ def resblock_fwd(x, w1, b1, w2, out_h, out_a, next_w=None, skip=True):
                                      N, H, W, C_, int(skip), _ptr(n1), _ptr(n2), _stream()), "tg_resblock_fwd")
 
 
+def resblock_bwd(dout, w2b, h, w1b, out_dh, out_din, next_w=None):
+    """input-gradient of conv-relu-conv-skip in one launch; w*b = dgrad packings, h = saved forward activation"""
+    N, H, W, C_ = dout.shape
+    n1, n2 = next_w if next_w is not None else (None, None)
+    L.check(L.load().tg_resblock_bwd(tg_dtype(dout.dtype), _ptr(dout), _ptr(w2b), _ptr(h), _ptr(w1b), _ptr(out_dh),
+                                     _ptr(out_din), N, H, W, C_, _ptr(n1), _ptr(n2), _stream()), "tg_resblock_bwd")
+
+
 def maxpool2(src, dst):
     N, H, W, C_ = src.shape
     L.check(L.load().tg_maxpool2(tg_dtype(src.dtype), _ptr(src), _ptr(dst), N, H, W, C_, _stream()), "tg_maxpool2")

@@ -588,3 +588,35 @@ def test_fused_resblock_forward(N, H, W):
     K.resblock_fwd(xd, wp1, bd, wp2, h_p, a_p, next_w=(wp2, wp1))
     torch.cuda.synchronize()
     assert torch.equal(h_p, h_f) and torch.equal(a_p, a_f)
+
+
+@pytest.mark.parametrize("N,H,W", [(5, 32, 32), (1, 8, 8), (2, 20, 12)])
+def test_fused_resblock_backward(N, H, W):
+    """tg_resblock_bwd == the two masked input-gradient launches of the block, and close to torch autograd"""
+    dt = torch.bfloat16
+    spec = K.ConvSpec("c3", 64, 64)
+    dout = q(rnd((N, 64, H, W), 90), dt)
+    hfw = q(rnd((N, 64, H, W), 91).clamp_min(0.0), dt)  # a relu output: about half zeros
+    w1, w2 = rnd(spec.weight_shape, 92, -0.05, 0.05), rnd(spec.weight_shape, 93, -0.05, 0.05)
+    dd, hd = K.to_nhwc(dout.to(DEV), dt), K.to_nhwc(hfw.to(DEV), dt)
+    rows, Kd, s_row, s_k = spec.dgrad_pack()
+    slots = K.slot_table(9, DEV)
+    wb1 = K.pack_weights(dt, w1.to(DEV), rows, Kd, s_row, s_k, 9, slots)
+    wb2 = K.pack_weights(dt, w2.to(DEV), rows, Kd, s_row, s_k, 9, slots)
+    dh_f = torch.full((N, H, W, 64), float("nan"), dtype=dt, device=DEV)
+    da_f = torch.full((N, H, W, 64), float("nan"), dtype=dt, device=DEV)
+    K.resblock_bwd(dd, wb2, hd, wb1, dh_f, da_f)
+    dh_u, da_u = torch.empty_like(dh_f), torch.empty_like(da_f)
+    d2 = K.make_conv_desc(spec.dgrad_geom(), L.TG_BF16, N, H, W, 64, H, W, 64, mask_mode=L.MASK_RELU)
+    d1 = K.make_conv_desc(spec.dgrad_geom(), L.TG_BF16, N, H, W, 64, H, W, 64)
+    K.conv(d2, dd, wb2, dh_u, mask=hd)
+    K.conv(d1, dh_u, wb1, da_u, res=dd)
+    torch.cuda.synchronize()
+    assert not torch.isnan(dh_f.float()).any() and not torch.isnan(da_f.float()).any()
+    torch.testing.assert_close(dh_f.float(), dh_u.float(), rtol=2 ** -7, atol=1e-3)
+    torch.testing.assert_close(da_f.float(), da_u.float(), rtol=2 ** -7, atol=2e-3)
+    # torch: out = a + conv(relu(pre), w2) with relu(pre) == hfw  =>  d pre = (hfw > 0) * conv_T(dout, w2); da = dout + conv_T(d pre, w1)
+    dpre = torch.nn.grad.conv2d_input((N, 64, H, W), q(w2, dt), dout, padding=1) * (hfw > 0)
+    da = dout + torch.nn.grad.conv2d_input((N, 64, H, W), q(w1, dt), q(dpre, dt), padding=1)
+    torch.testing.assert_close(K.to_nchw(dh_f, 64).cpu(), dpre, **tol(dt))
+    torch.testing.assert_close(K.to_nchw(da_f, 64).cpu(), da, **tol(dt))
