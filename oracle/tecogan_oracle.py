@@ -303,10 +303,15 @@ def fnet_forward(p, x):
 # --------------------------------------------------------------------------------------------
 # the step
 # --------------------------------------------------------------------------------------------
-def pseudo_flow(x):
-    """code/train.py:71-77.  x: (B,T,3,h,h) -> (B,T-1,2,4h,4h), values in [0,4]."""
+def pseudo_flow(x, fnet_params=None):
+    """code/train.py:71-77.  x: (B,T,3,h,h) -> (B,T-1,2,4h,4h), values in [0,4].
+    fnet_params (NOT reference behaviour, opt-in, parity unpinned): the flow estimator the reference
+    defines but never calls replaces the raw LR frame at code/train.py:74, i.e. gen_flow_lr = f_net(Frame_t_pre)."""
     B, T, C, h, w = x.shape
-    f = up4(x[:, :-1].reshape(B * (T - 1), C, h, w) * 4.0)
+    prev = x[:, :-1].reshape(B * (T - 1), C, h, w)
+    if fnet_params is not None:
+        return up4(fnet_forward(fnet_params, prev).detach() * 4.0).reshape(B, T - 1, 2, 4 * h, 4 * w)
+    f = up4(prev * 4.0)
     return f[:, 0:2].reshape(B, T - 1, 2, 4 * h, 4 * w)
 
 
@@ -426,7 +431,7 @@ def tecogan_forward(gp, dp, dbufs, x, y, args, global_step, counter1=0.0, counte
     B = x.shape[0]
     h = args.crop_size
     H = 4 * h
-    flow = pseudo_flow(x)
+    flow = pseudo_flow(x, getattr(args, "tg_fnet_params", None))
     lr_prev = x[:, :-1].reshape(B * (T - 1), 3, h, h)
     lr_next = x[:, 1:].reshape(B * (T - 1), 3, h, h)
     lr_warp = warp(lr_prev, x[:, 1:, 0:2].reshape(B * (T - 1), h, h, 2))

@@ -29,7 +29,7 @@ def _i64(vals, device):
     return torch.tensor(vals, dtype=torch.int64, device=device)
 
 
-def build_tables(B, T, h, K, pingpang=False):
+def build_tables(B, T, h, K, pingpang=False, fnet_flow=False):
     """Element-offset tables that drive tg_up4_planes / tg_copy_blocks / tg_warp_nchw (pure host logic, unit-tested on CPU).
     x is (B,T,3,h,h), flow (B,T-1,2,H,H), T_vel (B*3K,H,H,2) == blocks of 2*H*H floats."""
     H = 4 * h
@@ -38,11 +38,12 @@ def build_tables(B, T, h, K, pingpang=False):
     xo = lambda b, t, c=0: ((b * T + t) * 3 + c) * hh
     out = {}
     # pseudo-flow planes: x[b,t,c] (t<T-1, c<2) -> flow[b,t,c]   (code/train.py:71-77)
+    # (fnet_flow: the planes come from the f_net output of all B*T frames, 2 channels per frame)
     src, dst = [], []
     for b in range(B):
         for t in range(T - 1):
             for c in range(2):
-                src.append(xo(b, t, c))
+                src.append(((b * T + t) * 2 + c) * hh if fnet_flow else xo(b, t, c))
                 dst.append(((b * (T - 1) + t) * 2 + c) * HH)
     out["flow_src"], out["flow_dst"] = src, dst
     # LR warp (logged loss only): img x[b,t], grid block = x[b,t+1,0:2], reference x[b,t+1]  (code/train.py:78-84,247-249)
@@ -143,7 +144,13 @@ class TecoGANStep:
 
     # ----------------------------------------------------------------------------------------------------------
     def _tables(self):
-        t = build_tables(self.B, self.T, self.h, self.K, self.pingpang)
+        # opt-in (not reference behaviour): args.tg_fnet = an f_net module -> flow = up4(4 * f_net(previous LR frame))
+        fn = getattr(self.args, "tg_fnet", None)
+        self.F = fn.engine(self.G.dt) if fn is not None else None
+        if self.F is not None:
+            self.F.alloc(self.B * self.T, self.h, self.h)
+            self.fx = torch.empty(self.B * self.T, 2, self.h, self.h, dtype=torch.float32, device=self.dev)
+        t = build_tables(self.B, self.T, self.h, self.K, self.pingpang, fnet_flow=self.F is not None)
         dev = self.dev
         self.flow_src, self.flow_dst, self.n_flow = _i64(t["flow_src"], dev), _i64(t["flow_dst"], dev), len(t["flow_src"])
         self.lrw_img, self.lrw_grid = _i64(t["lrw_img"], dev), _i64(t["lrw_grid"], dev)
@@ -193,7 +200,12 @@ class TecoGANStep:
         D.arena.zero()
         G.flat.g.zero_()
         D.flat.g.zero_()
-        K.up4_planes(self.x, self.flow_src, self.flow, self.flow_dst, self.n_flow, h, h, pre=4.0)
+        if self.F is not None:  # the estimator sees every LR frame (the last frame of a sequence is computed but unused)
+            K.nchw_to_nhwc(self.x, 3 * hh, self.F.act["in"], B * T, 3, h, h)
+            self.F.forward(self.fx)
+            K.up4_planes(self.fx, self.flow_src, self.flow, self.flow_dst, self.n_flow, h, h, pre=4.0)
+        else:
+            K.up4_planes(self.x, self.flow_src, self.flow, self.flow_dst, self.n_flow, h, h, pre=4.0)
         K.warp_nchw(self.x, self.lrw_img, self.x, self.lrw_grid, B * (T - 1), 3, h, h, h, h, False, sq_ref=self.x,
                     sq_off=self.lrw_grid, loss_acc=self.acc[1:2])
         K.copy_blocks(self.flow, self.tv_csrc, self.tvel, self.tv_cdst, self.n_tvc, 2 * HH)

@@ -48,7 +48,7 @@ def get_step(generator_F, discriminator_F, B, T, h, args, device, dtype_t=None, 
     if use_graph is None:
         use_graph = os.environ.get("TECOGAN_GRAPH", "1") != "0"
     Ge, De = generator_F.engine(dtype_t), discriminator_F.engine(dtype_t)
-    key = (id(Ge), id(De), B, T, h, use_graph, bool(getattr(args, "pingpang", False)))
+    key = (id(Ge), id(De), B, T, h, use_graph, bool(getattr(args, "pingpang", False)), id(getattr(args, "tg_fnet", None)))
     st = _STEPS.get(key)
     if st is None:
         pg, world = parallel.dist_info()

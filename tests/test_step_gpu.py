@@ -221,6 +221,32 @@ def test_step_extension_config4_shape_vs_oracle(monkeypatch):
     assert float(og.state[next(iter(G.parameters()))]["step"]) == 1.0
 
 
+def test_step_with_fnet_flow_option_vs_oracle(monkeypatch):
+    """opt-in, NOT reference behaviour (the reference defines f_net but never calls it): args.tg_fnet = an f_net module makes
+    the flow up4(4 * f_net(previous LR frame)) instead of the raw-frame pseudo-flow; the oracle states the same option."""
+    monkeypatch.setenv("TECOGAN_GRAPH", "0")
+    args, G, D, og, od, gp, dp = build(8, "fp32")
+    fp = orc.init_params(orc.fnet_param_shapes(), 308)
+    Fn = models.f_net(args)
+    Fn.load_state_dict(fp)
+    args.tg_fnet = Fn.cuda()
+    x, y = synth(1, 10, 32, 8)
+    torch.set_num_threads(max(1, os.cpu_count() // 2))
+    oargs = orc.default_args()
+    oargs.tg_fnet_params = fp
+    f = orc.tecogan_forward(gp, dp, orc.init_bn_buffers(dp), x, y, oargs, 0)
+    f_plain = orc.tecogan_forward(gp, dp, orc.init_bn_buffers(dp), x, y, orc.default_args(), 0)
+    out = train.FRVSR_Train(x.cuda(), y.cuda(), args, D, G, 0, 0.0, 0.0, og, od)
+    got = np.array([float(v) for v in out.update_list])
+    exp = np.array([float(v) for v in f["update_list"]])
+    np.testing.assert_allclose(got, exp, rtol=2e-3, atol=1e-5)
+    # f_net values are ~1e0..1e1 grid units: a last-bit difference moves a bilinear sample, so gen matches to 1e-3, and the
+    # option must actually change the result
+    assert rel(out.gen_output.cpu(), f["gen"]) < 2e-3
+    # the option really replaces the flow (a random-init generator's output is almost flat, so the frames barely move)
+    assert rel(f_plain["flow"], f["flow"]) > 0.5
+
+
 def test_step_fp32_three_steps_teacher_forced(golden_dir, monkeypatch):
     """three consecutive steps; the oracle is re-synchronised to the HIP weights before every compared step."""
     monkeypatch.setenv("TECOGAN_GRAPH", "0")

@@ -100,6 +100,20 @@ def bench_wgrad(kind, cin, cout, N, H, W, dt, splits):
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     bf = torch.bfloat16
+    if what == "small":  # the deep discriminator layers (a few thousand output pixels): pure latency
+        t = ["64x64", "32x128", "32x64", "64x128"]
+        for N in (12, 24):
+            bench_conv("c4s2", 128, 128, N, 32, 32, "fwd", bf, t)
+            bench_conv("c4s2", 128, 64, N, 16, 16, "fwd", bf, t)
+            bench_conv("c4s2", 64, 3, N, 8, 8, "fwd", bf, ["32x128", "32x64"])
+            bench_conv("c3", 128, 128, N, 16, 16, "fwd", bf, t)
+        bench_conv("c4s2", 128, 128, 24, 32, 32, "dgrad", bf, t)
+        bench_conv("c4s2", 128, 64, 24, 16, 16, "dgrad", bf, t)
+        bench_conv("c4s2", 64, 3, 24, 8, 8, "dgrad", bf, t)
+        bench_conv("c3", 128, 128, 24, 16, 16, "dgrad", bf, t)
+        bench_conv("c4s2", 64, 128, 24, 64, 64, "fwd", bf, t + ["128x128"])
+        bench_conv("c4s2", 64, 128, 24, 64, 64, "dgrad", bf, t + ["128x128"])
+        return
     if what == "tiles":  # the launches the 64x128-vs-64x256 rule of pick_tile() decides
         big = ["64x256", "64x128"]
         bench_conv("c3", 128, 64, 4, 128, 128, "fwd", bf, big)
