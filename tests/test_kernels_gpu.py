@@ -383,6 +383,35 @@ def test_warp_golden_boundary_and_corner_indices(golden_dir):
         assert torch.equal(corner.cpu(), exp), "warp corner indices must be bit-exact"
 
 
+def test_warp_and_up4_vs_c_restatement():
+    """HIP index arithmetic vs the independent plain-C restatement (oracle/warp_ref.c): corner indices and the x4
+    bilinear upsample bit for bit, on pseudo-flow-like data"""
+    import warp_ref as W
+    rng = np.random.default_rng(31)
+    B, h, H = 2, 32, 128
+    x = rng.random((B, 2, h, h), dtype=np.float32)
+    src = torch.from_numpy(x).to(DEV)
+    dst = torch.empty(B, 2, H, H, device=DEV)
+    so = (torch.arange(B * 2, dtype=torch.int64) * h * h).to(DEV)
+    do = (torch.arange(B * 2, dtype=torch.int64) * H * H).to(DEV)
+    K.up4_planes(src, so, dst, do, B * 2, h, h, pre=4.0)
+    flow = dst.cpu().numpy()
+    for b in range(B):
+        for c in range(2):
+            assert np.array_equal(flow[b, c], W.up4(x[b, c], pre=4.0))
+    img = rng.random((B, 3, H, H), dtype=np.float32)
+    out = torch.empty(B, 3, H, H, device=DEV)
+    corner = torch.empty(B, H, H, 2, dtype=torch.int32, device=DEV)
+    io = (torch.arange(B, dtype=torch.int64) * 3 * H * H).to(DEV)
+    go = (torch.arange(B, dtype=torch.int64) * 2 * H * H).to(DEV)
+    K.warp_nchw(torch.from_numpy(img).to(DEV), io, dst, go, B, 3, H, H, H, H, 1, out=out, corner=corner)
+    for b in range(B):
+        grid = flow[b].reshape(H, H, 2)  # the reference REINTERPRETS the (2,H,W) block as (H,W,2) (code/train.py:96)
+        c, _ = W.corners(grid, H, H, half_grid=True)
+        assert np.array_equal(corner[b].cpu().numpy(), c)
+        np.testing.assert_allclose(out[b].cpu().numpy(), W.warp(img[b], grid, half_grid=True), rtol=0, atol=3e-7)
+
+
 def test_warp_random_vs_oracle_hr():
     B, H = 3, 128
     img = rnd((B, 3, H, H), 25, 0, 1)

@@ -38,6 +38,36 @@ def test_warp_boundary_grid(units):
     assert np.array_equal(orc.warp(img, orc.fp16_round(grid)).numpy(), units["warp_out_f16grid"])
 
 
+def test_c_restatement_of_the_bit_exact_arithmetic(units):
+    """oracle/warp_ref.c (plain C, -ffp-contract=off) == the reference's fixtures and torch, bit for bit, for the x4
+    bilinear upsample and the grid-sample corner indices; sampled values to the last bits"""
+    import warp_ref as W
+    assert np.array_equal(W.up4(units["up4_in"][0, 0]), units["up4_out"][0, 0])
+    rng = np.random.default_rng(5)
+    pl = rng.random((32, 32), dtype=np.float32)
+    ref = orc.up4(torch.from_numpy(pl)[None, None] * 4.0)[0, 0].numpy()
+    assert np.array_equal(W.up4(pl, pre=4.0), ref)
+    assert np.array_equal(W.up4(pl, pre=4.0, post_a=2.0, post_b=-1.0), ref * 2.0 - 1.0)
+    img, grid = units["warp_img"], units["warp_grid"]
+    for half, key in ((False, "warp_out_f32grid"), (True, "warp_out_f16grid")):
+        for n in range(2):
+            np.testing.assert_allclose(W.warp(img[n], grid[n], half), units[key][n], rtol=0, atol=1e-7)
+    # corner indices on pseudo-flow-like grids (values in [0, 4], fp16-rounded): against torch's own arithmetic
+    g = rng.uniform(0.0, 4.0, size=(64, 64, 2)).astype(np.float32)
+    gt = torch.from_numpy(g).half().float()
+    ix, iy = ((gt[..., 0] + 1) * 128 - 1) / 2, ((gt[..., 1] + 1) * 128 - 1) / 2
+    exp = torch.stack([torch.floor(ix).clamp(-2, 129), torch.floor(iy).clamp(-2, 129)], dim=-1).int().numpy()
+    c, _ = W.corners(g, 128, 128, half_grid=True)
+    assert np.array_equal(c, exp)
+    # the C fp16 rounding (no _Float16 dependency) == torch .half() incl. subnormals and ties
+    v = np.concatenate([rng.standard_normal(4096).astype(np.float32) * 3, np.float32([0, 1e-8, 6e-8, 3e-5, 65504, 1.00048828125])])
+    gg = np.stack([v, -v], axis=-1)
+    c2, _ = W.corners(gg, 7, 5, half_grid=True)
+    t = torch.from_numpy(gg).half().float()
+    e2 = torch.stack([torch.floor(((t[..., 0] + 1) * 5 - 1) / 2).clamp(-2, 6), torch.floor(((t[..., 1] + 1) * 7 - 1) / 2).clamp(-2, 8)], -1)
+    assert np.array_equal(c2, e2.int().numpy())
+
+
 def test_pack_is_pixel_unshuffle(units):
     assert np.array_equal(orc.pixel_unshuffle4(torch.from_numpy(units["pack_in"])).numpy(), units["pack_out"])
 
