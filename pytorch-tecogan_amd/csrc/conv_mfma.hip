@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
         __syncthreads();  // previous fragment reads are done before LDS is overwritten
         const int total_a = (t0 == 0) ? cn * prow_n * 4 : 0;
         const int nq = cn * tn;
-        int a_done = 0, q_done = 0;
+        int a_done = 0, q_done = 0, q_cc = 0, q_tt = 0;
         while (a_done < total_a || q_done < nq) {
           u32x4 va[UA];
           int da[UA];
@@ -313,12 +313,18 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
                                                         (size_t)(c0 + cc) * 64 + s * 16);
             }
           }
-          // weights: for one (chunk, tap) the CO_TILE packed rows are contiguous in global memory: a plain block copy
+          // weights: for one (chunk, tap) the CO_TILE packed rows are contiguous in global memory: a plain block copy.
+          // (chunk, tap) of block qq = q_done + u is carried as two wave-uniform counters: `qq / tn` by a runtime tn is a
+          // ~50-instruction emulated division per block - in VALU - and that address arithmetic, not the loads, was the
+          // bulk of the ~2000 instructions a staging phase of the stride-2 launches executed (in-kernel stamps:
+          // 12500 cycles per phase).
+          int w_cc = q_cc, w_tt = q_tt;
   #pragma unroll
           for (int u = 0; u < UW; ++u) {
             const int qq = q_done + u;  // wave-uniform
             if (qq < nq) {
-              const int cc = qq / tn, tt = qq - cc * tn;
+              const int cc = w_cc, tt = w_tt;
+              if (++w_tt == tn) { w_tt = 0; ++w_cc; }
               const int slot = cl.widx[t0 + tt];
               const char* src = p.w + (((size_t)slot * p.nchunks + c0 + cc) * p.Cout + co_base) * 64;
   #pragma unroll
@@ -334,11 +340,14 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
           for (int u = 0; u < UA; ++u)
             if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_a + da[u]) = va[u];
           TG_STAMP_AT(2);
+          w_cc = q_cc;
+          w_tt = q_tt;
   #pragma unroll
           for (int u = 0; u < UW; ++u) {
             const int qq = q_done + u;
             if (qq < nq) {
-              const int cc = qq / tn, tt = qq - cc * tn;
+              const int cc = w_cc, tt = w_tt;
+              if (++w_tt == tn) { w_tt = 0; ++w_cc; }
               char* dstw = lds_w + (cc * p.tg + tt) * CO_TILE * kRowBytes;
   #pragma unroll
               for (int k = 0; k < PPT; ++k) {
@@ -350,6 +359,8 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
           }
           a_done += 256 * UA;
           q_done += UW;
+          q_cc = w_cc;  // (w_cc, w_tt) now describe block q_done
+          q_tt = w_tt;
           TG_STAMP_AT(3);
         }
         __syncthreads();

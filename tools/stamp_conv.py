@@ -7,7 +7,7 @@ lib = L.load()
 lib.tg_debug_read_stamps.restype = ctypes.c_int
 lib.tg_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 dt = torch.bfloat16
-for (kind, cin, cout, N, H, tile) in (("c3",64,64,4,32,5), ("c3",64,64,40,32,6), ("c3",64,64,40,32,1), ("c3",128,128,24,32,6), ("c3",128,64,4,128,6)):
+for (kind, cin, cout, N, H, tile) in (("c3",64,64,4,32,5), ("c3",64,64,40,32,6), ("ct",128,128,4,64,6), ("c4s2",128,64,12,16,2), ("c4s2",128,128,12,32,2), ("c4s2",64,64,12,128,1)):
     spec = K.ConvSpec(kind, cin, cout)
     OH, OW = spec.out_hw(H, H)
     x = torch.randn(N, H, H, K.pad32(cin), device="cuda").to(dt)
@@ -22,4 +22,4 @@ for (kind, cin, cout, N, H, tile) in (("c3",64,64,4,32,5), ("c3",64,64,40,32,6),
     lib.tg_debug_read_stamps(buf, 8)
     t = list(buf)
     print(kind, cin, cout, N, H, "tile", tile, f"| issue+wait {t[1]-t[0]} | LDS stores {t[3]-t[1]} | barrier {t[4]-t[3]} | k-loop {t[5]-t[4]} | "
-          f"epilogue {t[6]-t[5]} | total {t[6]-t[0]} cycles (pipelined 3x3 path; last chunk group)")
+          f"epilogue {t[6]-t[5]} | total {t[6]-t[0]} cycles (last stage only for issue/stores/barrier)")
