@@ -367,21 +367,25 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
         TG_STAMP_AT(4);
 
         {
+          // lane-invariant parts of the fragment addresses; the tap offset comes from the kernarg tap list (scalar loads
+          // the compiler can issue several taps ahead) - the LDS tap table cost a dependent ds_read per tap, which with one
+          // wave per SIMD was ~250 cycles per tap for 64 cycles of MFMA
+          int xrow[PT];
+#pragma unroll
+          for (int b = 0; b < PT; ++b) xrow[b] = ((wp * PT + b) * cl.iw + idx) * p.S * kRowBytes + g * 16;
+          const int wrow = (wc * CT * 16 + idx) * kRowBytes + g * 16;
           for (int cc = 0; cc < cn; ++cc) {
             const char* la = lds_a + cc * a_stride;
-  #pragma unroll 2
+  #pragma unroll 4
             for (int tt = 0; tt < tn; ++tt) {
-              const int toff = tap_off[t0 + tt];  // LDS table: ((dy-dymin)*iw + dx-dxmin) * row bytes
-              const char* lw = lds_w + (cc * p.tg + tt) * CO_TILE * kRowBytes;
+              const int toff = ((cl.dy[t0 + tt] - cl.dymin) * cl.iw + (cl.dx[t0 + tt] - cl.dxmin)) * kRowBytes;
+              const char* lw = lds_w + (cc * p.tg + tt) * CO_TILE * kRowBytes + wrow;
               Frag wf[CT];
   #pragma unroll
-              for (int a = 0; a < CT; ++a)
-                wf[a] = *reinterpret_cast<const Frag*>(lw + ((wc * CT + a) * 16 + idx) * kRowBytes + g * 16);
+              for (int a = 0; a < CT; ++a) wf[a] = *reinterpret_cast<const Frag*>(lw + a * 16 * kRowBytes);
   #pragma unroll
               for (int b = 0; b < PT; ++b) {
-                const int ty = wp * PT + b;
-                const int prow = (ty * cl.iw + idx) * p.S;
-                const Frag xf = *reinterpret_cast<const Frag*>(la + prow * kRowBytes + toff + g * 16);
+                const Frag xf = *reinterpret_cast<const Frag*>(la + xrow[b] + toff);
   #pragma unroll
                 for (int a = 0; a < CT; ++a) acc[a][b] = Mma<T>::run(wf[a], xf, acc[a][b]);
               }
