@@ -649,3 +649,65 @@ def test_fused_resblock_backward(N, H, W):
     da = dout + torch.nn.grad.conv2d_input((N, 64, H, W), q(w1, dt), q(dpre, dt), padding=1)
     torch.testing.assert_close(K.to_nchw(dh_f, 64).cpu(), dpre, **tol(dt))
     torch.testing.assert_close(K.to_nchw(da_f, 64).cpu(), da, **tol(dt))
+
+
+def _random_conv_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        kind = str(rng.choice(["c3", "c3", "c4s2", "ct"]))
+        cin = int(rng.choice([3, 27, 32, 51, 64, 96, 128]))
+        cout = int(rng.choice([3, 32, 64, 96, 128]))
+        N = int(rng.integers(1, 4))
+        if kind == "c4s2":
+            H, W = 2 * int(rng.integers(1, 13)), 2 * int(rng.integers(1, 13))  # even sizes (k4 s2 p1)
+        else:
+            H, W = int(rng.integers(1, 25)), int(rng.integers(1, 25))
+        cases.append((kind, cin, cout, N, H, W))
+    return cases
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("kind,cin,cout,N,H,W", _random_conv_cases(16, 2026))
+def test_conv_random_shapes_fwd_dgrad_wgrad(kind, cin, cout, N, H, W, dt):
+    """ragged / tiny / odd shapes (1-pixel images, widths that are not multiples of 16, channel counts that need padding):
+    forward, input-gradient and weight-gradient of the three conv kinds against torch"""
+    spec = K.ConvSpec(kind, cin, cout)
+    OH, OW = spec.out_hw(H, W)
+    x = q(rnd((N, cin, H, W), 100), dt).requires_grad_(True)
+    w = q(rnd(spec.weight_shape, 101, -0.1, 0.1), dt).requires_grad_(True)
+    dout = q(rnd((N, cout, OH, OW), 102), dt)
+    ref = ref_conv(spec, x, w, None)
+    ref.backward(dout)
+    t = tol(dt)
+    out, _, _ = hip_conv_fwd(spec, x.detach(), w.detach(), dt)
+    torch.testing.assert_close(out, ref.detach(), **t)
+    # input gradient
+    dd = K.to_nhwc(dout.to(DEV), dt)
+    rows, Kd, s_row, s_k = spec.dgrad_pack()
+    wb = K.pack_weights(dt, w.detach().to(DEV).contiguous(), rows, Kd, s_row, s_k, spec.nslots, K.slot_table(spec.nslots, DEV))
+    dx = torch.empty(N, H, W, K.pad32(cin), dtype=dt, device=DEV)
+    d = K.make_conv_desc(spec.dgrad_geom(), K.tg_dtype(dt), N, OH, OW, K.pad32(cout), H, W, K.pad32(cin))
+    K.conv(d, dd, wb, dx)
+    scale = float(x.grad.abs().max()) + 1e-6
+    torch.testing.assert_close(K.to_nchw(dx, cin).cpu(), x.grad, rtol=t["rtol"], atol=t["atol"] * max(1.0, scale))
+    # weight gradient
+    x_is_in, S, taps, ca, cb, s_a, s_b = spec.wgrad_info()
+    xd = K.to_nhwc(x.detach().to(DEV), dt)
+    X, Y = (xd, dd) if x_is_in else (dd, xd)
+    nsplit = 3
+    desc = K.make_wgrad_desc(K.tg_dtype(dt), N, X.shape[1], X.shape[2], X.shape[3], Y.shape[1], Y.shape[2], Y.shape[3],
+                             S, taps, nsplit)
+    slab = torch.empty(L.load().tg_wgrad_slab_floats(__import__("ctypes").byref(desc)), device=DEV)
+    if X.shape[3] % 64 and Y.shape[3] % 64:
+        # neither operand has a 64-channel block (e.g. 27 -> 3): no layer of the path has that shape and no kernel is
+        # instantiated for it; the ABI must say so instead of launching
+        assert L.load().tg_wgrad(__import__("ctypes").byref(desc), X.data_ptr(), Y.data_ptr(), slab.data_ptr(), None) == -2
+        return
+    K.wgrad(desc, X, Y, slab)
+    gw = torch.zeros(spec.weight_shape, device=DEV)
+    K.wgrad_finalize(slab, nsplit, len(taps), X.shape[3], Y.shape[3], ca, cb, gw, s_a, s_b, K.slot_table(len(taps), DEV), False)
+    torch.cuda.synchronize()
+    wscale = float(w.grad.abs().max()) + 1e-6
+    torch.testing.assert_close(gw.cpu(), w.grad, rtol=1e-3 if dt == torch.float32 else 2e-2,
+                               atol=wscale * (1e-5 if dt == torch.float32 else 1e-2))
