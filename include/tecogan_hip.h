@@ -106,6 +106,13 @@ int tg_conv_pick_tile(const tg_conv_desc* d);
 int tg_conv(const tg_conv_desc* d, const void* in, const void* w_packed, const float* bias, const void* res,
             const void* mask, void* out, float* stats, void* stream);
 
+/* Conv-transpose k3 s2 p1 op1 forward (code/ops.py:45-54 conv2_tran; code/models.py:72,74) as ONE sub-pixel launch: a
+ * workgroup computes all four output classes of its input tile from one staged patch (tg_conv runs the classes as four sets
+ * of workgroups).  in [N][IH][IW][Cin] -> out [N][2IH][2IW][Cout], w_packed = the 9-slot forward packing, epilogue
+ * +bias, act in {NONE, RELU, LRELU}.  TG_E_UNSUPPORTED unless Cout % 64 == 0 (use tg_conv then). */
+int tg_convt_fwd(int dtype, const void* in, const void* w_packed, const float* bias, void* out, int N, int IH, int IW,
+                 int Cin, int Cout, int act, void* stream);
+
 /* Weight gradient: slab[split][t][a][b] = sum over the split's pixels of X[n, y*S+dy[t], x*S+dx[t]][a] * Y[n,y,x][b].
  * (aten::convolution_backward weight path, code/train.py:336,340.) */
 typedef struct {

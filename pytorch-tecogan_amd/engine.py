@@ -77,6 +77,9 @@ class Workspace:
         return self.slab
 
 
+_SUBPIX_CT = os.environ.get("TECOGAN_SUBPIX_CT", "1") != "0"
+
+
 class Conv:
     """One conv / conv-transpose layer of the reference: packed weights + forward / dgrad / wgrad launches."""
 
@@ -111,6 +114,11 @@ class Conv:
         """x [N,H,W,cin_p] -> out [N,OH,OW,cout_p]; nchw=(buffer, elem_offset, n_stride, c_real) for the fp32 NCHW store."""
         N, H, W, _ = x.shape
         OH, OW = self.spec.out_hw(H, W)
+        if self.spec.kind == "ct" and self.cout_p % 64 == 0 and res is None and stats is None and nchw is None and \
+                act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and self.tile == L.TILE_AUTO and _SUBPIX_CT:
+            self.last_desc = None  # one sub-pixel launch for all four classes (csrc/convt_mfma.hip)
+            K.convt_fwd(x, self.wf, self.bias, out, act)
+            return
         key = ("f", N, H, W, act, res is not None, stats is not None, groups, nchw is not None and nchw[2:])
         ent = self._desc.get(key)
         if ent is None:

@@ -265,6 +265,13 @@ def resblock_fwd(x, w1, b1, w2, out_h, out_a, next_w=None, skip=True):
                                      N, H, W, C_, int(skip), _ptr(n1), _ptr(n2), _stream()), "tg_resblock_fwd")
 
 
+def convt_fwd(x, w_packed, bias, out, act=L.ACT_NONE):
+    """conv-transpose k3 s2 forward, all four sub-pixel classes per workgroup; x [N,H,W,Cin] -> out [N,2H,2W,Cout]"""
+    N, H, W, cin = x.shape
+    L.check(L.load().tg_convt_fwd(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), N, H, W, cin,
+                                  out.shape[3], act, _stream()), "tg_convt_fwd")
+
+
 def resblock_bwd(dout, w2b, h, w1b, out_dh, out_din, next_w=None):
     """input-gradient of conv-relu-conv-skip in one launch; w*b = dgrad packings, h = saved forward activation"""
     N, H, W, C_ = dout.shape

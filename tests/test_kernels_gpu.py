@@ -711,3 +711,30 @@ def test_conv_random_shapes_fwd_dgrad_wgrad(kind, cin, cout, N, H, W, dt):
     wscale = float(w.grad.abs().max()) + 1e-6
     torch.testing.assert_close(gw.cpu(), w.grad, rtol=1e-3 if dt == torch.float32 else 2e-2,
                                atol=wscale * (1e-5 if dt == torch.float32 else 1e-2))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cin,cout,N,H,W,act", [(64, 64, 2, 32, 32, L.ACT_RELU), (128, 128, 1, 16, 16, L.ACT_RELU),
+                                                (64, 128, 2, 9, 21, L.ACT_NONE), (51, 64, 1, 1, 1, L.ACT_LRELU),
+                                                (128, 64, 3, 7, 40, L.ACT_RELU)])
+def test_convt_subpixel_forward(cin, cout, N, H, W, act, dt):
+    """tg_convt_fwd (all four sub-pixel classes per workgroup) == F.conv_transpose2d(k3, s2, p1, op1) and == tg_conv"""
+    spec = K.ConvSpec("ct", cin, cout)
+    x = q(rnd((N, cin, H, W), 110), dt)
+    w = q(rnd(spec.weight_shape, 111, -0.1, 0.1), dt)
+    b = rnd((cout,), 112)
+    ref = ref_conv(spec, x, w, b)
+    ref = F.relu(ref) if act == L.ACT_RELU else (F.leaky_relu(ref, 0.2) if act == L.ACT_LRELU else ref)
+    xd = K.to_nhwc(x.to(DEV), dt)
+    rows, Kd, s_row, s_k = spec.fwd_pack()
+    wp = K.pack_weights(dt, w.to(DEV).contiguous(), rows, Kd, s_row, s_k, 9, K.slot_table(9, DEV))
+    bd = torch.zeros(K.pad32(cout), device=DEV)
+    bd[:cout] = b.to(DEV)
+    out = torch.full((N, 2 * H, 2 * W, K.pad32(cout)), float("nan"), dtype=dt, device=DEV)
+    K.convt_fwd(xd, wp, bd, out, act)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(K.to_nchw(out, cout).cpu(), ref, **tol(dt))
+    via_classes, _, _ = hip_conv_fwd(spec, x, w, dt, bias=b, act=act)
+    torch.testing.assert_close(K.to_nchw(out, cout).cpu(), via_classes, rtol=2 ** -7, atol=1e-3)
+    assert L.load().tg_convt_fwd(K.tg_dtype(dt), xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), N, H, W,
+                                 K.pad32(cin), 32, act, None) == -2
