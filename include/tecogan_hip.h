@@ -113,6 +113,13 @@ int tg_conv(const tg_conv_desc* d, const void* in, const void* w_packed, const f
 int tg_convt_fwd(int dtype, const void* in, const void* w_packed, const float* bias, void* out, int N, int IH, int IW,
                  int Cin, int Cout, int act, void* stream);
 
+/* 4x4 stride-2 padding-1 conv forward (the discriminator's down-sampling convs, code/models.py:90-94) with compile-time
+ * taps and pipelined chunk staging; in [N][IH][IW][Cin] (IH, IW even) -> out [N][IH/2][IW/2][Cout]; w_packed = the 16-slot
+ * forward packing; bias may be null; stats (may be null) = [stats_groups][2][Cout] per-channel sum / sum of squares of the
+ * stored output, ACCUMULATED (zero it first).  TG_E_UNSUPPORTED unless Cout % 64 == 0 (use tg_conv then). */
+int tg_conv4s2_fwd(int dtype, const void* in, const void* w_packed, const float* bias, void* out, float* stats,
+                   int stats_groups, int N, int IH, int IW, int Cin, int Cout, void* stream);
+
 /* Weight gradient: slab[split][t][a][b] = sum over the split's pixels of X[n, y*S+dy[t], x*S+dx[t]][a] * Y[n,y,x][b].
  * (aten::convolution_backward weight path, code/train.py:336,340.) */
 typedef struct {

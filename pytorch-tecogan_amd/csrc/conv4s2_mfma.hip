@@ -1,0 +1,257 @@
+// 4x4 stride-2 padding-1 convolution forward (the discriminator's down-sampling convs, code/models.py:90-94) on MFMA:
+//
+//   out[y][x][co] = sum_{ky,kx in 0..3} in[2y-1+ky][2x-1+kx][ci] * W[ky*4+kx][co][ci]     (+bias) and per-channel
+//   sum / sum of squares of the stored output (the BatchNorm batch statistics of the layer that follows).
+//
+// tg_conv runs this shape through its generic tap-table path, where in-kernel stamps showed ~8600 cycles of staging and ~4300
+// cycles of k-loop per 32-channel stage for 1000 cycles of MFMA (per-load address arithmetic, a dependent LDS table read per
+// tap, no overlap between stages): 26-48 us per launch whatever the layer size.  This kernel is the 3x3 pipelined path's
+// structure for the 16-tap stride-2 pattern: compile-time taps (every pixel-fragment read is one lane register + an immediate),
+// the next chunk's global loads in flight during the current chunk's 128 MFMAs per wave, weights in swizzled conflict-free
+// 64-byte rows.  The input patch keeps 80-byte rows: for lanes 2 pixels apart that padding IS conflict-free
+// (tools/lds_layout.py).  A workgroup owns 8 x 16 output pixels x 64 channels.
+#include "common.h"
+
+namespace {
+
+constexpr int kWRow = 64;                  // weights: unpadded rows, piece index XOR 2*(bit 2 of row)
+__device__ __forceinline__ int swz(int row, int piece) { return row * kWRow + ((piece ^ ((row >> 1) & 2)) << 4); }
+constexpr int kARow = 80;                  // patch rows: 64 data bytes + 16 pad
+constexpr int CT = 4, PT = 2, WP = 4, TH = PT * WP, CO_TILE = 16 * CT;
+constexpr int IH_P = 2 * TH + 2, IW_P = 2 * 16 + 2;  // 18 x 34 input pixels
+constexpr int kPatchBytes = IH_P * IW_P * kARow;      // 48,960
+constexpr int kWBytes = 16 * CO_TILE * kWRow;         // 65,536
+constexpr int kLds = kPatchBytes + kWBytes;
+
+struct C4K {
+  const char* in;
+  const char* w;
+  const float* bias;
+  char* out;
+  float* stats;
+  int N, IH, IW, Cin, OH, OW, Cout, tiles_x, tiles_y, nchunks, stats_groups;
+};
+
+template <typename T> struct MmaT;
+template <> struct MmaT<BF16> {
+  using Frag = bf16x8;
+  __device__ __forceinline__ static f32x4 run(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct MmaT<F32> {
+  using Frag = f32x4;
+  __device__ __forceinline__ static f32x4 run(Frag a, Frag b, f32x4 c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], c, 0, 0, 0);
+    return c;
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv4s2_fwd_kernel(const C4K p) {
+  using TR = ElemTraits<T>;
+  using Frag = typename MmaT<T>::Frag;
+  constexpr int E = TR::kVec;
+  constexpr int NG = (TR::kBytes == 2) ? CT / 2 : CT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_a = smem;
+  char* lds_w = smem + kPatchBytes;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wp = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int idx = lane & 15, g = lane >> 4;
+  int bx = blockIdx.x;
+  const int txb = bx % p.tiles_x;
+  bx /= p.tiles_x;
+  const int tyb = bx % p.tiles_y;
+  const int n = bx / p.tiles_y;
+  const int ty0 = tyb * TH, tx0 = txb * 16;
+  const int iy0 = 2 * ty0 - 1, ix0 = 2 * tx0 - 1;
+  const int co_base = blockIdx.y * CO_TILE;
+  const size_t in_pix = (size_t)p.Cin * TR::kBytes;
+  const char* in_n = p.in + (size_t)n * p.IH * p.IW * in_pix;
+
+  float bias_r[NG][E];
+#pragma unroll
+  for (int a = 0; a < NG; ++a) {
+    const int ch0 = (TR::kBytes == 2) ? co_base + 2 * a * 16 + 8 * g : co_base + a * 16 + 4 * g;
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) t = *reinterpret_cast<const f32x4*>(p.bias + ch0 + e);
+      bias_r[a][e] = t[0]; bias_r[a][e + 1] = t[1]; bias_r[a][e + 2] = t[2]; bias_r[a][e + 3] = t[3];
+    }
+  }
+
+  f32x4 acc[CT][PT];
+#pragma unroll
+  for (int a = 0; a < CT; ++a)
+#pragma unroll
+    for (int b = 0; b < PT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // patch: 18 x 34 pixels x 4 pieces = 2448 pieces -> 10 per thread; weights: 16 blocks of 256 pieces -> 16 per thread
+  constexpr int UA = 10, NPIECE = IH_P * IW_P * 4;
+  u32x4 va[UA], vw[16];
+  int da[UA];
+  bool ok[UA];
+  auto issue = [&](int c0) {
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const int i = min(tid + u * 256, NPIECE - 1);
+      const int s = i & 3, prow = i >> 2;
+      const int py = (prow * 241) >> 13, px = prow - py * IW_P;  // prow / 34, exact for prow < 612
+      const int iy = iy0 + py, ix = ix0 + px;
+      da[u] = (tid + u * 256 < NPIECE) ? prow * kARow + s * 16 : -1;
+      ok[u] = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+      const int cy = min(max(iy, 0), p.IH - 1), cx = min(max(ix, 0), p.IW - 1);  // clamped load, zeroed at the store
+      va[u] = *reinterpret_cast<const u32x4*>(in_n + ((size_t)cy * p.IW + cx) * in_pix + (size_t)c0 * 64 + s * 16);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t)  // packed weights [slot][chunk][Cout rows][64 B]: 64 consecutive rows = 256 pieces
+      vw[t] = *reinterpret_cast<const u32x4*>(p.w + (((size_t)t * p.nchunks + c0) * p.Cout + co_base) * 64 + tid * 16);
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int u = 0; u < UA; ++u)
+      if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_a + da[u]) = ok[u] ? va[u] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t = 0; t < 16; ++t) *reinterpret_cast<u32x4*>(lds_w + t * CO_TILE * kWRow + swz(tid >> 2, tid & 3)) = vw[t];
+  };
+
+  int xb[PT];  // lane address of input pixel (2*(wp*PT+b), 2*idx) of the patch = tap (0,0) of output pixel (b, idx)
+#pragma unroll
+  for (int b = 0; b < PT; ++b) xb[b] = ((wp * PT + b) * 2 * IW_P + 2 * idx) * kARow + g * 16;
+  const int wbase = swz(idx, g);
+
+  issue(0);
+  for (int c0 = 0; c0 < p.nchunks; ++c0) {
+    __syncthreads();  // the previous chunk's fragment reads are done
+    store();
+    __syncthreads();
+    if (c0 + 1 < p.nchunks) issue(c0 + 1);  // in flight during the MFMAs below
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int toff = ((t >> 2) * IW_P + (t & 3)) * kARow;  // compile-time after unrolling
+      Frag wf[CT];
+#pragma unroll
+      for (int a = 0; a < CT; ++a) wf[a] = *reinterpret_cast<const Frag*>(lds_w + (t * CO_TILE + a * 16) * kWRow + wbase);
+#pragma unroll
+      for (int b = 0; b < PT; ++b) {
+        const Frag xf = *reinterpret_cast<const Frag*>(lds_a + xb[b] + toff);
+#pragma unroll
+        for (int a = 0; a < CT; ++a) acc[a][b] = MmaT<T>::run(wf[a], xf, acc[a][b]);
+      }
+    }
+  }
+
+  // epilogue: +bias, store, per-channel statistics of what was stored
+  float s1[NG][E], s2[NG][E];
+#pragma unroll
+  for (int a = 0; a < NG; ++a)
+#pragma unroll
+    for (int e = 0; e < E; ++e) s1[a][e] = s2[a][e] = 0.f;
+#pragma unroll
+  for (int b = 0; b < PT; ++b) {
+    const int oy = ty0 + wp * PT + b, ox = tx0 + idx;
+    const bool valid = oy < p.OH && ox < p.OW;
+    const size_t pix = ((size_t)n * p.OH + oy) * p.OW + ox;
+#pragma unroll
+    for (int a = 0; a < NG; ++a) {
+      float v[E];
+      int ch0;
+      if constexpr (TR::kBytes == 2) {
+        ch0 = co_base + 2 * a * 16 + 8 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[2 * a][b][j];
+          v[4 + j] = acc[2 * a + 1][b][j];
+        }
+      } else {
+        ch0 = co_base + a * 16 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j];
+      }
+      if (valid) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] += bias_r[a][e];
+        Vec<T>::store(p.out + (pix * p.Cout + ch0) * TR::kBytes, v);
+        if (p.stats) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            s1[a][e] += v[e];
+            s2[a][e] += v[e] * v[e];
+          }
+        }
+      }
+    }
+  }
+  if (p.stats) {  // uniform
+#pragma unroll
+    for (int a = 0; a < NG; ++a)
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          s1[a][e] += __shfl_xor(s1[a][e], m);
+          s2[a][e] += __shfl_xor(s2[a][e], m);
+        }
+      }
+    __syncthreads();  // all fragment reads finished: LDS becomes the cross-wave reduction scratch
+    float* red = reinterpret_cast<float*>(smem);  // [WP][2][CO_TILE]
+    if (idx == 0) {
+#pragma unroll
+      for (int a = 0; a < NG; ++a) {
+        const int cl0 = (TR::kBytes == 2) ? 2 * a * 16 + 8 * g : a * 16 + 4 * g;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          red[(wp * 2 + 0) * CO_TILE + cl0 + e] = s1[a][e];
+          red[(wp * 2 + 1) * CO_TILE + cl0 + e] = s2[a][e];
+        }
+      }
+    }
+    __syncthreads();
+    const int grp = n / (p.N / p.stats_groups);
+    if (tid < 2 * CO_TILE) {
+      const int which = tid / CO_TILE, chn = tid - which * CO_TILE;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WP; ++w) s += red[(w * 2 + which) * CO_TILE + chn];
+      atomicAdd(p.stats + ((size_t)grp * 2 + which) * p.Cout + co_base + chn, s);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int tg_conv4s2_fwd(int dtype, const void* in, const void* w_packed, const float* bias, void* out, float* stats,
+                              int stats_groups, int N, int IH, int IW, int Cin, int Cout, void* stream) {
+  if (!in || !w_packed || !out || N <= 0 || IH <= 0 || IW <= 0 || Cin <= 0 || Cout <= 0) return TG_E_BADARG;
+  if (dtype != TG_BF16 && dtype != TG_F32) return TG_E_BADARG;
+  if ((IH & 1) || (IW & 1)) return TG_E_UNSUPPORTED;
+  if (stats && (stats_groups <= 0 || N % stats_groups)) return TG_E_BADARG;
+  if (Cin % 32 || Cout % 32) return TG_E_ALIGN;
+  if (Cout % CO_TILE) return TG_E_UNSUPPORTED;  // run tg_conv instead
+  if (!tg_aligned16(in) || !tg_aligned16(w_packed) || !tg_aligned16(out) || (bias && !tg_aligned16(bias))) return TG_E_ALIGN;
+  C4K k;
+  k.in = (const char*)in; k.w = (const char*)w_packed; k.bias = bias; k.out = (char*)out; k.stats = stats;
+  k.N = N; k.IH = IH; k.IW = IW; k.Cin = Cin; k.OH = IH / 2; k.OW = IW / 2; k.Cout = Cout;
+  k.stats_groups = stats ? stats_groups : 1;
+  k.nchunks = Cin / (dtype == TG_BF16 ? 32 : 16);
+  k.tiles_x = (k.OW + 15) / 16; k.tiles_y = (k.OH + TH - 1) / TH;
+  const long long gx = (long long)k.tiles_x * k.tiles_y * N;
+  if (gx > 0x7fffffffLL) return TG_E_UNSUPPORTED;
+  dim3 grid((unsigned)gx, (unsigned)(Cout / CO_TILE));
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr_done = false;
+  if (!attr_done) {
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv4s2_fwd_kernel<BF16>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv4s2_fwd_kernel<F32>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    attr_done = true;
+  }
+  if (dtype == TG_BF16) hipLaunchKernelGGL(conv4s2_fwd_kernel<BF16>, grid, dim3(256), kLds, st, k);
+  else hipLaunchKernelGGL(conv4s2_fwd_kernel<F32>, grid, dim3(256), kLds, st, k);
+  return tg_launch_status();
+}

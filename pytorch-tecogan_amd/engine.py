@@ -78,6 +78,7 @@ class Workspace:
 
 
 _SUBPIX_CT = os.environ.get("TECOGAN_SUBPIX_CT", "1") != "0"
+_FAST_C4S2 = os.environ.get("TECOGAN_FAST_C4S2", "1") != "0"
 
 
 class Conv:
@@ -115,9 +116,18 @@ class Conv:
         N, H, W, _ = x.shape
         OH, OW = self.spec.out_hw(H, W)
         if self.spec.kind == "ct" and self.cout_p % 64 == 0 and res is None and stats is None and nchw is None and \
-                act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and self.tile == L.TILE_AUTO and _SUBPIX_CT:
-            self.last_desc = None  # one sub-pixel launch for all four classes (csrc/convt_mfma.hip)
+                act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and self.tile == L.TILE_AUTO and _SUBPIX_CT and \
+                N * ((H + 7) // 8) * ((W + 15) // 16) * (self.cout_p // 64) >= 128:
+            # one sub-pixel launch for all four classes (csrc/convt_mfma.hip).  Measured (tools/mb_convt.py): 128->128 on
+            # 4x64x64 14.4 vs 24.5 us; with only 32 workgroups (64->64 on 4x32x32) the four-class launch wins, 6.9 vs 9.8 us
+            self.last_desc = None
             K.convt_fwd(x, self.wf, self.bias, out, act)
+            return
+        if self.spec.kind == "c4s2" and self.cout_p % 64 == 0 and res is None and nchw is None and act == L.ACT_NONE and \
+                self.tile == L.TILE_AUTO and _FAST_C4S2 and H % 2 == 0 and W % 2 == 0 and \
+                (stats is None or K.stats_replicas_for(N * OH * OW) == 1):
+            self.last_desc = "c4s2"  # compile-time-tap stride-2 kernel (csrc/conv4s2_mfma.hip)
+            K.conv4s2_fwd(x, self.wf, self.bias, out, stats, groups)
             return
         key = ("f", N, H, W, act, res is not None, stats is not None, groups, nchw is not None and nchw[2:])
         ent = self._desc.get(key)

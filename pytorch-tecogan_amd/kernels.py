@@ -265,6 +265,13 @@ def resblock_fwd(x, w1, b1, w2, out_h, out_a, next_w=None, skip=True):
                                      N, H, W, C_, int(skip), _ptr(n1), _ptr(n2), _stream()), "tg_resblock_fwd")
 
 
+def conv4s2_fwd(x, w_packed, bias, out, stats=None, groups=1):
+    """conv k4 s2 p1 forward with compile-time taps; stats [groups][2][Cout] accumulated"""
+    N, H, W, cin = x.shape
+    L.check(L.load().tg_conv4s2_fwd(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(stats),
+                                    groups, N, H, W, cin, out.shape[3], _stream()), "tg_conv4s2_fwd")
+
+
 def convt_fwd(x, w_packed, bias, out, act=L.ACT_NONE):
     """conv-transpose k3 s2 forward, all four sub-pixel classes per workgroup; x [N,H,W,Cin] -> out [N,2H,2W,Cout]"""
     N, H, W, cin = x.shape

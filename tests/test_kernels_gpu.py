@@ -738,3 +738,33 @@ def test_convt_subpixel_forward(cin, cout, N, H, W, act, dt):
     torch.testing.assert_close(K.to_nchw(out, cout).cpu(), via_classes, rtol=2 ** -7, atol=1e-3)
     assert L.load().tg_convt_fwd(K.tg_dtype(dt), xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), N, H, W,
                                  K.pad32(cin), 32, act, None) == -2
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cin,cout,N,H,W,G", [(64, 64, 4, 32, 32, 2), (64, 128, 2, 16, 16, 1), (128, 128, 2, 8, 8, 2),
+                                              (128, 64, 3, 16, 16, 1), (27, 64, 1, 2, 2, 1), (64, 64, 2, 20, 44, 1)])
+def test_conv4s2_fast_forward_with_stats(cin, cout, N, H, W, G, dt):
+    """tg_conv4s2_fwd == F.conv2d(k4, s2, p1) (+ per-group sum / sum of squares of the stored output)"""
+    spec = K.ConvSpec("c4s2", cin, cout)
+    x = q(rnd((N, cin, H, W), 120), dt)
+    w = q(rnd(spec.weight_shape, 121, -0.1, 0.1), dt)
+    ref = ref_conv(spec, x, w, None)
+    xd = K.to_nhwc(x.to(DEV), dt)
+    rows, Kd, s_row, s_k = spec.fwd_pack()
+    wp = K.pack_weights(dt, w.to(DEV).contiguous(), rows, Kd, s_row, s_k, 16, K.slot_table(16, DEV))
+    out = torch.full((N, H // 2, W // 2, K.pad32(cout)), float("nan"), dtype=dt, device=DEV)
+    stats = torch.zeros(G, 2, K.pad32(cout), device=DEV)
+    K.conv4s2_fwd(xd, wp, None, out, stats, G)
+    torch.cuda.synchronize()
+    got = K.to_nchw(out, cout).cpu()
+    torch.testing.assert_close(got, ref, **tol(dt))
+    n = N // G
+    for g in range(G):
+        r = got[g * n:(g + 1) * n].double()  # statistics are of what was STORED (bf16-rounded values feed the BN apply)
+        f32 = dt == torch.float32
+        torch.testing.assert_close(stats[g, 0, :cout].cpu().double(), r.sum(dim=(0, 2, 3)), rtol=1e-4 if f32 else 2e-2,
+                                   atol=1e-3 if f32 else 0.5)
+        torch.testing.assert_close(stats[g, 1, :cout].cpu().double(), (r * r).sum(dim=(0, 2, 3)), rtol=1e-4 if f32 else 2e-2,
+                                   atol=1e-3 if f32 else 0.5)
+    assert L.load().tg_conv4s2_fwd(K.tg_dtype(dt), xd.data_ptr(), wp.data_ptr(), None, out.data_ptr(), None, 1, N, H, W,
+                                   K.pad32(cin), 32, None) == -2
