@@ -69,8 +69,8 @@ def kernel_name(conv, dtype):
     from pytorch_tecogan_amd import _lib as L
     if conv.last_desc is None:  # the sub-pixel conv-transpose launch (csrc/convt_mfma.hip)
         return f"convt_fwd_kernel<{'BF16' if dtype == 'bf16' else 'F32'}>"
-    if conv.last_desc == "c4s2":  # csrc/conv4s2_mfma.hip
-        return f"conv4s2_fwd_kernel<{'BF16' if dtype == 'bf16' else 'F32'}>"
+    if conv.last_desc in ("c4s2", "ctd"):  # csrc/conv4s2_mfma.hip
+        return f"conv_s2_gather_kernel<{'BF16' if dtype == 'bf16' else 'F32'}, {4 if conv.last_desc == 'c4s2' else 3}>"
     plan = L.load().tg_conv_pick_tile(ctypes.byref(conv.last_desc))
     t = "BF16" if dtype == "bf16" else "F32"
     return f"conv_gather_kernel<{t}, {TILE_PARAMS[plan & 255]}, {'true' if plan >> 8 else 'false'}>"

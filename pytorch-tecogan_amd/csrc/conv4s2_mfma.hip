@@ -18,10 +18,15 @@ constexpr int kWRow = 64;                  // weights: unpadded rows, piece inde
 __device__ __forceinline__ int swz(int row, int piece) { return row * kWRow + ((piece ^ ((row >> 1) & 2)) << 4); }
 constexpr int kARow = 80;                  // patch rows: 64 data bytes + 16 pad
 constexpr int CT = 4, PT = 2, WP = 4, TH = PT * WP, CO_TILE = 16 * CT;
-constexpr int IH_P = 2 * TH + 2, IW_P = 2 * 16 + 2;  // 18 x 34 input pixels
-constexpr int kPatchBytes = IH_P * IW_P * kARow;      // 48,960
-constexpr int kWBytes = 16 * CO_TILE * kWRow;         // 65,536
-constexpr int kLds = kPatchBytes + kWBytes;
+// KS = 4: the 4x4 stride-2 forward.  KS = 3: the same gather with a 3x3 window (taps dy,dx in -1..1) - that is the
+// input-gradient of the conv-transpose layers (code/ops.py:45-54, autograd), with the role-swapped weight packing.
+template <int KS> struct Geo {
+  static constexpr int NT = KS * KS;
+  static constexpr int IH_P = 2 * TH + KS - 2, IW_P = 2 * 16 + KS - 2;  // 18 x 34 (KS = 4) / 17 x 33 input pixels
+  static constexpr int kPatchBytes = IH_P * IW_P * kARow;
+  static constexpr int kWBytes = NT * CO_TILE * kWRow;
+  static constexpr int kLds = kPatchBytes + kWBytes;
+};
 
 struct C4K {
   const char* in;
@@ -48,8 +53,9 @@ template <> struct MmaT<F32> {
   }
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void conv4s2_fwd_kernel(const C4K p) {
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void conv_s2_gather_kernel(const C4K p) {
+  constexpr int NT = Geo<KS>::NT, IH_P = Geo<KS>::IH_P, IW_P = Geo<KS>::IW_P, kPatchBytes = Geo<KS>::kPatchBytes;
   using TR = ElemTraits<T>;
   using Frag = typename MmaT<T>::Frag;
   constexpr int E = TR::kVec;
@@ -90,9 +96,10 @@ __global__ __launch_bounds__(256) void conv4s2_fwd_kernel(const C4K p) {
 #pragma unroll
     for (int b = 0; b < PT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // patch: 18 x 34 pixels x 4 pieces = 2448 pieces -> 10 per thread; weights: 16 blocks of 256 pieces -> 16 per thread
-  constexpr int UA = 10, NPIECE = IH_P * IW_P * 4;
-  u32x4 va[UA], vw[16];
+  // patch: 18 x 34 pixels x 4 pieces = 2448 pieces -> 10 per thread (KS = 4); weights: NT blocks of 256 pieces -> NT per thread
+  constexpr int NPIECE = IH_P * IW_P * 4, UA = (NPIECE + 255) / 256;
+  constexpr int kDivMul = (65536 + IW_P - 1) / IW_P;  // prow / IW_P == (prow * kDivMul) >> 16, exact for prow < 612 (IW_P 33, 34)
+  u32x4 va[UA], vw[NT];
   int da[UA];
   bool ok[UA];
   auto issue = [&](int c0) {
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(256) void conv4s2_fwd_kernel(const C4K p) {
     for (int u = 0; u < UA; ++u) {
       const int i = min(tid + u * 256, NPIECE - 1);
       const int s = i & 3, prow = i >> 2;
-      const int py = (prow * 241) >> 13, px = prow - py * IW_P;  // prow / 34, exact for prow < 612
+      const int py = (prow * kDivMul) >> 16, px = prow - py * IW_P;
       const int iy = iy0 + py, ix = ix0 + px;
       da[u] = (tid + u * 256 < NPIECE) ? prow * kARow + s * 16 : -1;
       ok[u] = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(256) void conv4s2_fwd_kernel(const C4K p) {
       va[u] = *reinterpret_cast<const u32x4*>(in_n + ((size_t)cy * p.IW + cx) * in_pix + (size_t)c0 * 64 + s * 16);
     }
 #pragma unroll
-    for (int t = 0; t < 16; ++t)  // packed weights [slot][chunk][Cout rows][64 B]: 64 consecutive rows = 256 pieces
+    for (int t = 0; t < NT; ++t)  // packed weights [slot][chunk][Cout rows][64 B]: 64 consecutive rows = 256 pieces
       vw[t] = *reinterpret_cast<const u32x4*>(p.w + (((size_t)t * p.nchunks + c0) * p.Cout + co_base) * 64 + tid * 16);
   };
   auto store = [&]() {
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(256) void conv4s2_fwd_kernel(const C4K p) {
     for (int u = 0; u < UA; ++u)
       if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_a + da[u]) = ok[u] ? va[u] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int t = 0; t < 16; ++t) *reinterpret_cast<u32x4*>(lds_w + t * CO_TILE * kWRow + swz(tid >> 2, tid & 3)) = vw[t];
+    for (int t = 0; t < NT; ++t) *reinterpret_cast<u32x4*>(lds_w + t * CO_TILE * kWRow + swz(tid >> 2, tid & 3)) = vw[t];
   };
 
   int xb[PT];  // lane address of input pixel (2*(wp*PT+b), 2*idx) of the patch = tap (0,0) of output pixel (b, idx)
@@ -131,8 +138,8 @@ __global__ __launch_bounds__(256) void conv4s2_fwd_kernel(const C4K p) {
     __syncthreads();
     if (c0 + 1 < p.nchunks) issue(c0 + 1);  // in flight during the MFMAs below
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int toff = ((t >> 2) * IW_P + (t & 3)) * kARow;  // compile-time after unrolling
+    for (int t = 0; t < NT; ++t) {
+      const int toff = ((t / KS) * IW_P + (t % KS)) * kARow;  // compile-time after unrolling
       Frag wf[CT];
 #pragma unroll
       for (int a = 0; a < CT; ++a) wf[a] = *reinterpret_cast<const Frag*>(lds_w + (t * CO_TILE + a * 16) * kWRow + wbase);
@@ -224,15 +231,10 @@ __global__ __launch_bounds__(256) void conv4s2_fwd_kernel(const C4K p) {
 
 }  // namespace
 
-extern "C" int tg_conv4s2_fwd(int dtype, const void* in, const void* w_packed, const float* bias, void* out, float* stats,
-                              int stats_groups, int N, int IH, int IW, int Cin, int Cout, void* stream) {
-  if (!in || !w_packed || !out || N <= 0 || IH <= 0 || IW <= 0 || Cin <= 0 || Cout <= 0) return TG_E_BADARG;
-  if (dtype != TG_BF16 && dtype != TG_F32) return TG_E_BADARG;
-  if ((IH & 1) || (IW & 1)) return TG_E_UNSUPPORTED;
-  if (stats && (stats_groups <= 0 || N % stats_groups)) return TG_E_BADARG;
-  if (Cin % 32 || Cout % 32) return TG_E_ALIGN;
-  if (Cout % CO_TILE) return TG_E_UNSUPPORTED;  // run tg_conv instead
-  if (!tg_aligned16(in) || !tg_aligned16(w_packed) || !tg_aligned16(out) || (bias && !tg_aligned16(bias))) return TG_E_ALIGN;
+namespace {
+template <int KS>
+int launch_s2(int dtype, const void* in, const void* w_packed, const float* bias, void* out, float* stats, int stats_groups,
+              int N, int IH, int IW, int Cin, int Cout, void* stream) {
   C4K k;
   k.in = (const char*)in; k.w = (const char*)w_packed; k.bias = bias; k.out = (char*)out; k.stats = stats;
   k.N = N; k.IH = IH; k.IW = IW; k.Cin = Cin; k.OH = IH / 2; k.OW = IW / 2; k.Cout = Cout;
@@ -243,15 +245,44 @@ extern "C" int tg_conv4s2_fwd(int dtype, const void* in, const void* w_packed, c
   if (gx > 0x7fffffffLL) return TG_E_UNSUPPORTED;
   dim3 grid((unsigned)gx, (unsigned)(Cout / CO_TILE));
   hipStream_t st = (hipStream_t)stream;
+  constexpr int lds = Geo<KS>::kLds;
   static bool attr_done = false;
   if (!attr_done) {
-    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv4s2_fwd_kernel<BF16>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv4s2_fwd_kernel<F32>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2_gather_kernel<BF16, KS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2_gather_kernel<F32, KS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  if (dtype == TG_BF16) hipLaunchKernelGGL(conv4s2_fwd_kernel<BF16>, grid, dim3(256), kLds, st, k);
-  else hipLaunchKernelGGL(conv4s2_fwd_kernel<F32>, grid, dim3(256), kLds, st, k);
+  if (dtype == TG_BF16) hipLaunchKernelGGL((conv_s2_gather_kernel<BF16, KS>), grid, dim3(256), lds, st, k);
+  else hipLaunchKernelGGL((conv_s2_gather_kernel<F32, KS>), grid, dim3(256), lds, st, k);
   return tg_launch_status();
+}
+
+int check_s2(int dtype, const void* in, const void* w_packed, const float* bias, void* out, int N, int IH, int IW, int Cin,
+             int Cout) {
+  if (!in || !w_packed || !out || N <= 0 || IH <= 0 || IW <= 0 || Cin <= 0 || Cout <= 0) return TG_E_BADARG;
+  if (dtype != TG_BF16 && dtype != TG_F32) return TG_E_BADARG;
+  if ((IH & 1) || (IW & 1)) return TG_E_UNSUPPORTED;
+  if (Cin % 32 || Cout % 32) return TG_E_ALIGN;
+  if (Cout % CO_TILE) return TG_E_UNSUPPORTED;  // run tg_conv instead
+  if (!tg_aligned16(in) || !tg_aligned16(w_packed) || !tg_aligned16(out) || (bias && !tg_aligned16(bias))) return TG_E_ALIGN;
+  return TG_OK;
+}
+}  // namespace
+
+extern "C" int tg_conv4s2_fwd(int dtype, const void* in, const void* w_packed, const float* bias, void* out, float* stats,
+                              int stats_groups, int N, int IH, int IW, int Cin, int Cout, void* stream) {
+  const int rc = check_s2(dtype, in, w_packed, bias, out, N, IH, IW, Cin, Cout);
+  if (rc != TG_OK) return rc;
+  if (stats && (stats_groups <= 0 || N % stats_groups)) return TG_E_BADARG;
+  return launch_s2<4>(dtype, in, w_packed, bias, out, stats, stats_groups, N, IH, IW, Cin, Cout, stream);
+}
+
+extern "C" int tg_convt_dgrad(int dtype, const void* dout, const void* w_dgrad_packed, void* din, int N, int OH, int OW,
+                              int Cout, int Cin, void* stream) {
+  // din[y][x][ci] = sum_{dy,dx in -1..1} dout[2y+dy][2x+dx][co] * W[slot][ci][co]: the 3x3-window stride-2 gather
+  const int rc = check_s2(dtype, dout, w_dgrad_packed, nullptr, din, N, OH, OW, Cout, Cin);
+  if (rc != TG_OK) return rc;
+  return launch_s2<3>(dtype, dout, w_dgrad_packed, nullptr, din, nullptr, 1, N, OH, OW, Cout, Cin, stream);
 }

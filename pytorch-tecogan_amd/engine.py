@@ -160,6 +160,11 @@ class Conv:
         gradient is the per-channel sum of `out` (accumulated straight into its grad slot)."""
         N, OH, OW, _ = dout.shape
         _, H, W, _ = out.shape
+        if self.spec.kind == "ct" and self.cin_p % 64 == 0 and mask is None and res is None and bias_grad_of is None and \
+                _FAST_C4S2 and OH == 2 * H and OW == 2 * W:
+            self.last_desc = "ctd"  # 3x3-window stride-2 gather (csrc/conv4s2_mfma.hip, KS = 3)
+            K.convt_dgrad(dout, self.wb, out)
+            return
         st = bias_grad_of.gbias if bias_grad_of is not None else None
         key = ("d", N, OH, OW, mask_mode, res is not None, st is not None)
         ent = self._desc.get(key)

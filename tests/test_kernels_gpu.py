@@ -768,3 +768,23 @@ def test_conv4s2_fast_forward_with_stats(cin, cout, N, H, W, G, dt):
                                    atol=1e-3 if f32 else 0.5)
     assert L.load().tg_conv4s2_fwd(K.tg_dtype(dt), xd.data_ptr(), wp.data_ptr(), None, out.data_ptr(), None, 1, N, H, W,
                                    K.pad32(cin), 32, None) == -2
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cin,cout,N,H,W", [(64, 64, 2, 16, 16), (128, 128, 1, 8, 12), (64, 128, 2, 5, 9), (128, 64, 1, 1, 1)])
+def test_convt_input_gradient_fast_path(cin, cout, N, H, W, dt):
+    """tg_convt_dgrad (3x3-window stride-2 gather) == autograd of F.conv_transpose2d(k3, s2, p1, op1) w.r.t. its input"""
+    spec = K.ConvSpec("ct", cin, cout)
+    x = q(rnd((N, cin, H, W), 130), dt).requires_grad_(True)
+    w = q(rnd(spec.weight_shape, 131, -0.1, 0.1), dt)
+    dout = q(rnd((N, cout, 2 * H, 2 * W), 132), dt)
+    ref_conv(spec, x, w, None).backward(dout)
+    dd = K.to_nhwc(dout.to(DEV), dt)
+    rows, Kd, s_row, s_k = spec.dgrad_pack()
+    wb = K.pack_weights(dt, w.to(DEV).contiguous(), rows, Kd, s_row, s_k, 9, K.slot_table(9, DEV))
+    dx = torch.full((N, H, W, K.pad32(cin)), float("nan"), dtype=dt, device=DEV)
+    K.convt_dgrad(dd, wb, dx)
+    torch.cuda.synchronize()
+    t = tol(dt)
+    scale = float(x.grad.abs().max()) + 1e-6
+    torch.testing.assert_close(K.to_nchw(dx, cin).cpu(), x.grad, rtol=t["rtol"], atol=t["atol"] * max(1.0, scale))
