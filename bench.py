@@ -67,8 +67,8 @@ def kernel_name(conv, dtype):
     """the rocprofv3 kernel name of the launch `conv` just made (template parameters from the C library's launch plan)"""
     import ctypes
     from pytorch_tecogan_amd import _lib as L
-    if conv.last_desc is None:  # the sub-pixel conv-transpose launch (csrc/convt_mfma.hip)
-        return f"convt_fwd_kernel<{'BF16' if dtype == 'bf16' else 'F32'}>"
+    if conv.last_desc is None or conv.last_desc == "c4d":  # the sub-pixel launches (csrc/convt_mfma.hip)
+        return f"subpixel_kernel<{'BF16' if dtype == 'bf16' else 'F32'}, {0 if conv.last_desc is None else 1}>"
     if conv.last_desc in ("c4s2", "ctd"):  # csrc/conv4s2_mfma.hip
         return f"conv_s2_gather_kernel<{'BF16' if dtype == 'bf16' else 'F32'}, {4 if conv.last_desc == 'c4s2' else 3}>"
     plan = L.load().tg_conv_pick_tile(ctypes.byref(conv.last_desc))

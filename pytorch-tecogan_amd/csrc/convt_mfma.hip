@@ -19,15 +19,30 @@ constexpr int kRow = 64, kPitch = 24;  // unpadded 64-byte rows, piece index XOR
 __device__ __forceinline__ int swz(int row, int piece) { return row * kRow + ((piece ^ ((row >> 1) & 2)) << 4); }
 
 constexpr int CT = 4, PT = 2, WP = 4, TH = PT * WP, CO_TILE = 16 * CT;  // 64 channels x (8 rows x 16 px)
-constexpr int kPatchRows = (TH + 1) * kPitch;
-constexpr int kPatchBytes = kPatchRows * kRow;          // one chunk
-constexpr int kWBytes = 9 * CO_TILE * kRow;             // one chunk: 9 slots x 64 rows
-constexpr int kLds = kPatchBytes + kWBytes;
-
-// (class, tap) pairs in kernel-slot order: slot s -> class, dy, dx
-__device__ constexpr int kCls[9] = {3, 2, 3, 1, 0, 1, 3, 2, 3};
-__device__ constexpr int kDy[9] = {1, 1, 1, 0, 0, 0, 0, 0, 0};
-__device__ constexpr int kDx[9] = {1, 0, 0, 1, 0, 0, 1, 0, 0};
+// Sub-pixel patterns: (class, tap) pair s uses weight slot s, window position (dy, dx) relative to the window origin.
+//   PAT 0  conv-transpose k3 s2 p1 op1 forward: window 2x2 at origin (0,0), 9 pairs (table in the header comment)
+//   PAT 1  input-gradient of the 4x4 stride-2 conv (code/models.py:90-94, autograd): window 3x3 at origin (-1,-1), 16 pairs:
+//            (0,0): (0,0,5) (0,-1,7) (-1,0,13) (-1,-1,15)      (0,1): (0,1,4) (0,0,6) (-1,1,12) (-1,0,14)
+//            (1,0): (1,0,1) (1,-1,3) (0,0,9)  (0,-1,11)        (1,1): (1,1,0) (1,0,2) (0,1,8)   (0,0,10)
+template <int PAT> struct Pat;
+template <> struct Pat<0> {
+  static constexpr int NT = 9, WIN = 2, ORG = 0;
+  static constexpr int cls[9] = {3, 2, 3, 1, 0, 1, 3, 2, 3};
+  static constexpr int dy[9] = {1, 1, 1, 0, 0, 0, 0, 0, 0};
+  static constexpr int dx[9] = {1, 0, 0, 1, 0, 0, 1, 0, 0};
+};
+template <> struct Pat<1> {
+  static constexpr int NT = 16, WIN = 3, ORG = -1;
+  static constexpr int cls[16] = {3, 2, 3, 2, 1, 0, 1, 0, 3, 2, 3, 2, 1, 0, 1, 0};
+  static constexpr int dy[16] = {2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0};   // window row = tap dy + 1
+  static constexpr int dx[16] = {2, 1, 1, 0, 2, 1, 1, 0, 2, 1, 1, 0, 2, 1, 1, 0};
+};
+template <int PAT> struct PGeo {
+  static constexpr int IH_P = TH + Pat<PAT>::WIN - 1, IW_P = 16 + Pat<PAT>::WIN - 1;
+  static constexpr int kPatchBytes = IH_P * kPitch * kRow;            // one chunk
+  static constexpr int kWBytes = Pat<PAT>::NT * CO_TILE * kRow;       // one chunk: NT slots x 64 rows
+  static constexpr int kLds = kPatchBytes + kWBytes;
+};
 
 struct ConvtK {
   const char* in;
@@ -53,8 +68,11 @@ template <> struct MmaT<F32> {
   }
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void convt_fwd_kernel(const ConvtK p) {
+template <typename T, int PAT>
+__global__ __launch_bounds__(256) void subpixel_kernel(const ConvtK p) {
+  using P = Pat<PAT>;
+  constexpr int NT = P::NT, WIN = P::WIN, ORG = P::ORG, IH_P = PGeo<PAT>::IH_P, IW_P = PGeo<PAT>::IW_P;
+  constexpr int kPatchBytes = PGeo<PAT>::kPatchBytes;
   using TR = ElemTraits<T>;
   using Frag = typename MmaT<T>::Frag;
   constexpr int E = TR::kVec;
@@ -96,9 +114,10 @@ __global__ __launch_bounds__(256) void convt_fwd_kernel(const ConvtK p) {
 #pragma unroll
       for (int b = 0; b < PT; ++b) acc[c][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // patch: (TH+1) x 17 pixels x 4 pieces = 612 pieces -> 3 per thread; weights: 9 blocks of 256 pieces -> 9 per thread
-  constexpr int UA = 3, IW_P = 17, NPIECE = (TH + 1) * IW_P * 4;
-  u32x4 va[UA], vw[9];
+  // patch: IH_P x IW_P pixels x 4 pieces (612 for the 9 x 17 patch) -> 3 per thread; weights: NT blocks of 256 pieces
+  constexpr int NPIECE = IH_P * IW_P * 4, UA = (NPIECE + 255) / 256;
+  constexpr int kDivMul = (65536 + IW_P - 1) / IW_P;  // prow / IW_P == (prow * kDivMul) >> 16 (exact for prow < 256)
+  u32x4 va[UA], vw[NT];
   int da[UA];
   bool ok[UA];
   auto issue = [&](int c0) {
@@ -106,15 +125,15 @@ __global__ __launch_bounds__(256) void convt_fwd_kernel(const ConvtK p) {
     for (int u = 0; u < UA; ++u) {
       const int i = min(tid + u * 256, NPIECE - 1);
       const int s = i & 3, prow = i >> 2;
-      const int py = (prow * 241) >> 12, px = prow - py * IW_P;  // prow / 17, exact for prow < 153
-      const int iy = ty0 + py, ix = tx0 + px;
+      const int py = (prow * kDivMul) >> 16, px = prow - py * IW_P;
+      const int iy = ty0 + ORG + py, ix = tx0 + ORG + px;
       da[u] = (tid + u * 256 < NPIECE) ? swz(py * kPitch + px, s) : -1;
-      ok[u] = iy < p.IH && ix < p.IW;
-      const int cy = min(iy, p.IH - 1), cx = min(ix, p.IW - 1);  // unconditional load from a clamped address, zeroed later
+      ok[u] = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+      const int cy = min(max(iy, 0), p.IH - 1), cx = min(max(ix, 0), p.IW - 1);  // clamped load, zeroed at the store
       va[u] = *reinterpret_cast<const u32x4*>(in_n + ((size_t)cy * p.IW + cx) * in_pix + (size_t)c0 * 64 + s * 16);
     }
 #pragma unroll
-    for (int s9 = 0; s9 < 9; ++s9)  // packed weights [slot][chunk][Cout rows][64 B]: 64 consecutive rows = 256 pieces
+    for (int s9 = 0; s9 < NT; ++s9)  // packed weights [slot][chunk][Cout rows][64 B]: 64 consecutive rows = 256 pieces
       vw[s9] = *reinterpret_cast<const u32x4*>(p.w + (((size_t)s9 * p.nchunks + c0) * p.Cout + co_base) * 64 + tid * 16);
   };
   auto store = [&]() {
@@ -122,15 +141,15 @@ __global__ __launch_bounds__(256) void convt_fwd_kernel(const ConvtK p) {
     for (int u = 0; u < UA; ++u)
       if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_a + da[u]) = ok[u] ? va[u] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int s9 = 0; s9 < 9; ++s9) *reinterpret_cast<u32x4*>(lds_w + s9 * CO_TILE * kRow + swz(tid >> 2, tid & 3)) = vw[s9];
+    for (int s9 = 0; s9 < NT; ++s9) *reinterpret_cast<u32x4*>(lds_w + s9 * CO_TILE * kRow + swz(tid >> 2, tid & 3)) = vw[s9];
   };
 
   // lane addresses: pixel (row wp*PT+b [+dy], column idx [+dx]); the pitch of 24 keeps bit 2 of the row independent of dy
-  int xb[PT][2];
+  int xb[PT][WIN];
 #pragma unroll
   for (int b = 0; b < PT; ++b)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) xb[b][c] = swz((wp * PT + b) * kPitch + idx + c, g);
+    for (int c = 0; c < WIN; ++c) xb[b][c] = swz((wp * PT + b) * kPitch + idx + c, g);
   const int wbase = swz(idx, g);  // + multiples of 16 rows
 
   issue(0);
@@ -139,16 +158,16 @@ __global__ __launch_bounds__(256) void convt_fwd_kernel(const ConvtK p) {
     store();
     __syncthreads();
     if (c0 + 1 < p.nchunks) issue(c0 + 1);  // in flight during the MFMAs below
-    Frag xf[2][2][PT];
+    Frag xf[WIN][WIN][PT];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < WIN; ++r)
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int c = 0; c < WIN; ++c)
 #pragma unroll
         for (int b = 0; b < PT; ++b)
           xf[r][c][b] = *reinterpret_cast<const Frag*>(lds_a + xb[b][c] + r * kPitch * kRow);
 #pragma unroll
-    for (int s9 = 0; s9 < 9; ++s9) {
+    for (int s9 = 0; s9 < NT; ++s9) {
       Frag wf[CT];
 #pragma unroll
       for (int a = 0; a < CT; ++a) wf[a] = *reinterpret_cast<const Frag*>(lds_w + (s9 * CO_TILE + a * 16) * kRow + wbase);
@@ -156,7 +175,7 @@ __global__ __launch_bounds__(256) void convt_fwd_kernel(const ConvtK p) {
       for (int b = 0; b < PT; ++b)
 #pragma unroll
         for (int a = 0; a < CT; ++a)
-          acc[kCls[s9]][a][b] = MmaT<T>::run(wf[a], xf[kDy[s9]][kDx[s9]][b], acc[kCls[s9]][a][b]);
+          acc[P::cls[s9]][a][b] = MmaT<T>::run(wf[a], xf[P::dy[s9]][P::dx[s9]][b], acc[P::cls[s9]][a][b]);
     }
   }
 
@@ -200,14 +219,10 @@ __global__ __launch_bounds__(256) void convt_fwd_kernel(const ConvtK p) {
 
 }  // namespace
 
-extern "C" int tg_convt_fwd(int dtype, const void* in, const void* w_packed, const float* bias, void* out, int N, int IH,
-                            int IW, int Cin, int Cout, int act, void* stream) {
-  if (!in || !w_packed || !out || N <= 0 || IH <= 0 || IW <= 0 || Cin <= 0 || Cout <= 0) return TG_E_BADARG;
-  if (dtype != TG_BF16 && dtype != TG_F32) return TG_E_BADARG;
-  if (act != TG_ACT_NONE && act != TG_ACT_RELU && act != TG_ACT_LRELU) return TG_E_UNSUPPORTED;
-  if (Cin % 32 || Cout % 32) return TG_E_ALIGN;
-  if (Cout % CO_TILE) return TG_E_UNSUPPORTED;  // run tg_conv with the four-class descriptor instead
-  if (!tg_aligned16(in) || !tg_aligned16(w_packed) || !tg_aligned16(out) || (bias && !tg_aligned16(bias))) return TG_E_ALIGN;
+namespace {
+template <int PAT>
+int launch_subpixel(int dtype, const void* in, const void* w_packed, const float* bias, void* out, int N, int IH, int IW,
+                    int Cin, int Cout, int act, void* stream) {
   ConvtK k;
   k.in = (const char*)in; k.w = (const char*)w_packed; k.bias = bias; k.out = (char*)out;
   k.N = N; k.IH = IH; k.IW = IW; k.Cin = Cin; k.Cout = Cout; k.act = act;
@@ -217,15 +232,41 @@ extern "C" int tg_convt_fwd(int dtype, const void* in, const void* w_packed, con
   if (gx > 0x7fffffffLL) return TG_E_UNSUPPORTED;
   dim3 grid((unsigned)gx, (unsigned)(Cout / CO_TILE));
   hipStream_t st = (hipStream_t)stream;
+  constexpr int lds = PGeo<PAT>::kLds;
   static bool attr_done = false;
   if (!attr_done) {
-    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(convt_fwd_kernel<BF16>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(convt_fwd_kernel<F32>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(subpixel_kernel<BF16, PAT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(subpixel_kernel<F32, PAT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  if (dtype == TG_BF16) hipLaunchKernelGGL(convt_fwd_kernel<BF16>, grid, dim3(256), kLds, st, k);
-  else hipLaunchKernelGGL(convt_fwd_kernel<F32>, grid, dim3(256), kLds, st, k);
+  if (dtype == TG_BF16) hipLaunchKernelGGL((subpixel_kernel<BF16, PAT>), grid, dim3(256), lds, st, k);
+  else hipLaunchKernelGGL((subpixel_kernel<F32, PAT>), grid, dim3(256), lds, st, k);
   return tg_launch_status();
+}
+
+int check_subpixel(int dtype, const void* in, const void* w_packed, const float* bias, void* out, int N, int IH, int IW,
+                   int Cin, int Cout, int act) {
+  if (!in || !w_packed || !out || N <= 0 || IH <= 0 || IW <= 0 || Cin <= 0 || Cout <= 0) return TG_E_BADARG;
+  if (dtype != TG_BF16 && dtype != TG_F32) return TG_E_BADARG;
+  if (act != TG_ACT_NONE && act != TG_ACT_RELU && act != TG_ACT_LRELU) return TG_E_UNSUPPORTED;
+  if (Cin % 32 || Cout % 32) return TG_E_ALIGN;
+  if (Cout % CO_TILE) return TG_E_UNSUPPORTED;  // run tg_conv with the four-class descriptor instead
+  if (!tg_aligned16(in) || !tg_aligned16(w_packed) || !tg_aligned16(out) || (bias && !tg_aligned16(bias))) return TG_E_ALIGN;
+  return TG_OK;
+}
+}  // namespace
+
+extern "C" int tg_convt_fwd(int dtype, const void* in, const void* w_packed, const float* bias, void* out, int N, int IH,
+                            int IW, int Cin, int Cout, int act, void* stream) {
+  const int rc = check_subpixel(dtype, in, w_packed, bias, out, N, IH, IW, Cin, Cout, act);
+  return rc != TG_OK ? rc : launch_subpixel<0>(dtype, in, w_packed, bias, out, N, IH, IW, Cin, Cout, act, stream);
+}
+
+extern "C" int tg_conv4s2_dgrad(int dtype, const void* dout, const void* w_dgrad_packed, void* din, int N, int OH, int OW,
+                                int Cout, int Cin, void* stream) {
+  // dout [N][OH][OW][Cout] -> din [N][2OH][2OW][Cin]: the four sub-pixel classes of the 4x4 stride-2 conv's input-gradient
+  const int rc = check_subpixel(dtype, dout, w_dgrad_packed, nullptr, din, N, OH, OW, Cout, Cin, TG_ACT_NONE);
+  return rc != TG_OK ? rc : launch_subpixel<1>(dtype, dout, w_dgrad_packed, nullptr, din, N, OH, OW, Cout, Cin, TG_ACT_NONE, stream);
 }

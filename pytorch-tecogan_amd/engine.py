@@ -165,6 +165,11 @@ class Conv:
             self.last_desc = "ctd"  # 3x3-window stride-2 gather (csrc/conv4s2_mfma.hip, KS = 3)
             K.convt_dgrad(dout, self.wb, out)
             return
+        if self.spec.kind == "c4s2" and self.cin_p % 64 == 0 and mask is None and res is None and bias_grad_of is None and \
+                _FAST_C4S2 and H == 2 * OH and W == 2 * OW and N * ((OH + 7) // 8) * ((OW + 15) // 16) * (self.cin_p // 64) >= 64:
+            self.last_desc = "c4d"  # four-class sub-pixel launch (csrc/convt_mfma.hip, PAT 1)
+            K.conv4s2_dgrad(dout, self.wb, out)
+            return
         st = bias_grad_of.gbias if bias_grad_of is not None else None
         key = ("d", N, OH, OW, mask_mode, res is not None, st is not None)
         ent = self._desc.get(key)

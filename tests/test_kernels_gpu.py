@@ -788,3 +788,23 @@ def test_convt_input_gradient_fast_path(cin, cout, N, H, W, dt):
     t = tol(dt)
     scale = float(x.grad.abs().max()) + 1e-6
     torch.testing.assert_close(K.to_nchw(dx, cin).cpu(), x.grad, rtol=t["rtol"], atol=t["atol"] * max(1.0, scale))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cin,cout,N,H,W", [(64, 64, 2, 32, 32), (64, 128, 1, 16, 16), (128, 128, 2, 8, 8), (128, 64, 1, 2, 6)])
+def test_conv4s2_input_gradient_subpixel(cin, cout, N, H, W, dt):
+    """tg_conv4s2_dgrad (four sub-pixel classes, 16 slots, one launch) == autograd of F.conv2d(k4, s2, p1) w.r.t. its input"""
+    spec = K.ConvSpec("c4s2", cin, cout)
+    x = q(rnd((N, cin, H, W), 140), dt).requires_grad_(True)
+    w = q(rnd(spec.weight_shape, 141, -0.1, 0.1), dt)
+    dout = q(rnd((N, cout, H // 2, W // 2), 142), dt)
+    ref_conv(spec, x, w, None).backward(dout)
+    dd = K.to_nhwc(dout.to(DEV), dt)
+    rows, Kd, s_row, s_k = spec.dgrad_pack()
+    wb = K.pack_weights(dt, w.to(DEV).contiguous(), rows, Kd, s_row, s_k, 16, K.slot_table(16, DEV))
+    dx = torch.full((N, H, W, K.pad32(cin)), float("nan"), dtype=dt, device=DEV)
+    K.conv4s2_dgrad(dd, wb, dx)
+    torch.cuda.synchronize()
+    t = tol(dt)
+    scale = float(x.grad.abs().max()) + 1e-6
+    torch.testing.assert_close(K.to_nchw(dx, cin).cpu(), x.grad, rtol=t["rtol"], atol=t["atol"] * max(1.0, scale))
