@@ -149,7 +149,10 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
     const char* base = k < 9 ? p.w1 : p.w2;
     wfr[k] = *reinterpret_cast<const bf16x8*>(base + (size_t)(BWD ? 8 - k % 9 : k % 9) * 8192 + wlane);
   };
-  constexpr int kAhead = 9;  // all of W1 up front (the registers exist anyway), W2 one load per conv1 step
+#ifndef RB_AHEAD
+#define RB_AHEAD 9
+#endif
+  constexpr int kAhead = RB_AHEAD;  // all of W1 up front (the registers exist anyway), W2 one load per conv1 step
 #pragma unroll
   for (int k = 0; k < kAhead; ++k) issue_w(k);
   // lane (idx, g) of row tile w ends up with channels ch0 .. ch0+3 of pixel idx (row_to_channel<BF16> of common.h)
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
 #pragma unroll
     for (int tt = 0; tt < 9; ++tt) {
       if (tt + 1 < 9) frags(tt + 1, (tt + 1) & 1);
-      issue_w(tt + kAhead);
+      if (tt + kAhead < 18) issue_w(tt + kAhead);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 7; ++t) acc[t] = mma(wfr[tt], xf[tt & 1][t], acc[t]);
