@@ -122,9 +122,10 @@ int tg_conv4s2_fwd(int dtype, const void* in, const void* w_packed, const float*
 
 /* Input-gradient of the 4x4 stride-2 convs (autograd of code/models.py:90-94) as one four-class sub-pixel launch (the
  * tg_convt_fwd kernel with a 3x3 window and 16 (class, tap) pairs): dout [N][OH][OW][Cout] -> din [N][2OH][2OW][Cin];
- * w_dgrad_packed = the role-swapped 16-slot packing.  TG_E_UNSUPPORTED unless Cin % 64 == 0 (use tg_conv then). */
+ * w_dgrad_packed = the role-swapped 16-slot packing; mask (may be null) [N][2OH][2OW][Cin] = saved activation of the layer
+ * below, the result is multiplied by act'(mask) (TG_MASK_*).  TG_E_UNSUPPORTED unless Cin % 64 == 0 (use tg_conv then). */
 int tg_conv4s2_dgrad(int dtype, const void* dout, const void* w_dgrad_packed, void* din, int N, int OH, int OW, int Cout,
-                     int Cin, void* stream);
+                     int Cin, const void* mask, int mask_mode, void* stream);
 
 /* Input-gradient of the conv-transpose layers (autograd of code/ops.py:45-54) with the same kernel structure (3x3-window
  * stride-2 gather): dout [N][OH][OW][Cout] (OH, OW even) -> din [N][OH/2][OW/2][Cin]; w_dgrad_packed = the role-swapped

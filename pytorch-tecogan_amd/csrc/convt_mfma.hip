@@ -49,7 +49,8 @@ struct ConvtK {
   const char* w;
   const float* bias;
   char* out;
-  int N, IH, IW, Cin, Cout, tiles_x, tiles_y, nchunks, act;
+  const char* mask;  // optional: multiply by act'(mask) (the saved activation of the layer below), TG_MASK_*
+  int N, IH, IW, Cin, Cout, tiles_x, tiles_y, nchunks, act, mask_mode;
 };
 
 template <typename T> struct MmaT;
@@ -210,6 +211,13 @@ __global__ __launch_bounds__(256) void subpixel_kernel(const ConvtK p) {
             if (p.act == TG_ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
             else if (p.act == TG_ACT_LRELU) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
           }
+          if (p.mask_mode != TG_MASK_NONE) {
+            float m[E];
+            Vec<T>::load(p.mask + (pix * p.Cout + ch0) * TR::kBytes, m);
+            const float neg = p.mask_mode == TG_MASK_LRELU ? 0.2f : 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] *= (m[e] > 0.f ? 1.f : neg);
+          }
           Vec<T>::store(p.out + (pix * p.Cout + ch0) * TR::kBytes, v);
         }
       }
@@ -222,9 +230,10 @@ __global__ __launch_bounds__(256) void subpixel_kernel(const ConvtK p) {
 namespace {
 template <int PAT>
 int launch_subpixel(int dtype, const void* in, const void* w_packed, const float* bias, void* out, int N, int IH, int IW,
-                    int Cin, int Cout, int act, void* stream) {
+                    int Cin, int Cout, int act, void* stream, const void* mask = nullptr, int mask_mode = TG_MASK_NONE) {
   ConvtK k;
   k.in = (const char*)in; k.w = (const char*)w_packed; k.bias = bias; k.out = (char*)out;
+  k.mask = (const char*)mask; k.mask_mode = mask ? mask_mode : TG_MASK_NONE;
   k.N = N; k.IH = IH; k.IW = IW; k.Cin = Cin; k.Cout = Cout; k.act = act;
   k.nchunks = Cin / (dtype == TG_BF16 ? 32 : 16);
   k.tiles_x = (IW + 15) / 16; k.tiles_y = (IH + TH - 1) / TH;
@@ -265,8 +274,11 @@ extern "C" int tg_convt_fwd(int dtype, const void* in, const void* w_packed, con
 }
 
 extern "C" int tg_conv4s2_dgrad(int dtype, const void* dout, const void* w_dgrad_packed, void* din, int N, int OH, int OW,
-                                int Cout, int Cin, void* stream) {
+                                int Cout, int Cin, const void* mask, int mask_mode, void* stream) {
   // dout [N][OH][OW][Cout] -> din [N][2OH][2OW][Cin]: the four sub-pixel classes of the 4x4 stride-2 conv's input-gradient
   const int rc = check_subpixel(dtype, dout, w_dgrad_packed, nullptr, din, N, OH, OW, Cout, Cin, TG_ACT_NONE);
-  return rc != TG_OK ? rc : launch_subpixel<1>(dtype, dout, w_dgrad_packed, nullptr, din, N, OH, OW, Cout, Cin, TG_ACT_NONE, stream);
+  if (rc != TG_OK) return rc;
+  if (mask && (mask_mode < TG_MASK_NONE || mask_mode > TG_MASK_LRELU || !tg_aligned16(mask))) return TG_E_BADARG;
+  return launch_subpixel<1>(dtype, dout, w_dgrad_packed, nullptr, din, N, OH, OW, Cout, Cin, TG_ACT_NONE, stream, mask,
+                            mask_mode);
 }

@@ -272,11 +272,12 @@ def conv4s2_fwd(x, w_packed, bias, out, stats=None, groups=1):
                                     groups, N, H, W, cin, out.shape[3], _stream()), "tg_conv4s2_fwd")
 
 
-def conv4s2_dgrad(dout, wb_packed, din):
-    """input-gradient of conv k4 s2 p1: dout [N,OH,OW,Cout] -> din [N,2OH,2OW,Cin] (four sub-pixel classes in one launch)"""
+def conv4s2_dgrad(dout, wb_packed, din, mask=None, mask_mode=L.MASK_NONE):
+    """input-gradient of conv k4 s2 p1: dout [N,OH,OW,Cout] -> din [N,2OH,2OW,Cin] (four sub-pixel classes in one launch),
+    optionally times act'(mask)"""
     N, OH, OW, cout = dout.shape
     L.check(L.load().tg_conv4s2_dgrad(tg_dtype(dout.dtype), _ptr(dout), _ptr(wb_packed), _ptr(din), N, OH, OW, cout,
-                                      din.shape[3], _stream()), "tg_conv4s2_dgrad")
+                                      din.shape[3], _ptr(mask), mask_mode, _stream()), "tg_conv4s2_dgrad")
 
 
 def convt_dgrad(dout, wb_packed, din):

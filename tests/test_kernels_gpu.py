@@ -808,3 +808,9 @@ def test_conv4s2_input_gradient_subpixel(cin, cout, N, H, W, dt):
     t = tol(dt)
     scale = float(x.grad.abs().max()) + 1e-6
     torch.testing.assert_close(K.to_nchw(dx, cin).cpu(), x.grad, rtol=t["rtol"], atol=t["atol"] * max(1.0, scale))
+    # with the LeakyReLU mask of the layer below (the discriminator's first conv)
+    act_below = q(rnd((N, cin, H, W), 143), dt)
+    K.conv4s2_dgrad(dd, wb, dx, mask=K.to_nhwc(act_below.to(DEV), dt), mask_mode=L.MASK_LRELU)
+    torch.cuda.synchronize()
+    exp = x.grad * torch.where(act_below > 0, 1.0, 0.2)
+    torch.testing.assert_close(K.to_nchw(dx, cin).cpu(), exp, rtol=t["rtol"], atol=t["atol"] * max(1.0, scale))
