@@ -17,7 +17,8 @@ namespace {
 constexpr int kWRow = 64;                  // weights: unpadded rows, piece index XOR 2*(bit 2 of row)
 __device__ __forceinline__ int swz(int row, int piece) { return row * kWRow + ((piece ^ ((row >> 1) & 2)) << 4); }
 constexpr int kARow = 80;                  // patch rows: 64 data bytes + 16 pad
-constexpr int CT = 4, PT = 2, WP = 4, TH = PT * WP, CO_TILE = 16 * CT;
+// 8 waves (two per SIMD - the staging loads of one overlap the MFMAs of its partner): WC = 2 channel halves x WP = 4 row pairs
+constexpr int CT = 2, WC = 2, PT = 2, WP = 4, TH = PT * WP, CO_TILE = 16 * CT * WC, NTHR = 64 * WC * WP;
 // KS = 4: the 4x4 stride-2 forward.  KS = 3: the same gather with a 3x3 window (taps dy,dx in -1..1) - that is the
 // input-gradient of the conv-transpose layers (code/ops.py:45-54, autograd), with the role-swapped weight packing.
 template <int KS> struct Geo {
@@ -54,7 +55,7 @@ template <> struct MmaT<F32> {
 };
 
 template <typename T, int KS>
-__global__ __launch_bounds__(256) void conv_s2_gather_kernel(const C4K p) {
+__global__ __launch_bounds__(NTHR) void conv_s2_gather_kernel(const C4K p) {
   constexpr int NT = Geo<KS>::NT, IH_P = Geo<KS>::IH_P, IW_P = Geo<KS>::IW_P, kPatchBytes = Geo<KS>::kPatchBytes;
   using TR = ElemTraits<T>;
   using Frag = typename MmaT<T>::Frag;
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256) void conv_s2_gather_kernel(const C4K p) {
   char* lds_w = smem + kPatchBytes;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wp = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wid % WC, wp = wid / WC;
   const int idx = lane & 15, g = lane >> 4;
   int bx = blockIdx.x;
   const int txb = bx % p.tiles_x;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void conv_s2_gather_kernel(const C4K p) {
   float bias_r[NG][E];
 #pragma unroll
   for (int a = 0; a < NG; ++a) {
-    const int ch0 = (TR::kBytes == 2) ? co_base + 2 * a * 16 + 8 * g : co_base + a * 16 + 4 * g;
+    const int ch0 = (TR::kBytes == 2) ? co_base + (wc * CT + 2 * a) * 16 + 8 * g : co_base + (wc * CT + a) * 16 + 4 * g;
 #pragma unroll
     for (int e = 0; e < E; e += 4) {
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
@@ -97,39 +99,45 @@ __global__ __launch_bounds__(256) void conv_s2_gather_kernel(const C4K p) {
     for (int b = 0; b < PT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // patch: 18 x 34 pixels x 4 pieces = 2448 pieces -> 10 per thread (KS = 4); weights: NT blocks of 256 pieces -> NT per thread
-  constexpr int NPIECE = IH_P * IW_P * 4, UA = (NPIECE + 255) / 256;
+  constexpr int NPIECE = IH_P * IW_P * 4, UA = (NPIECE + NTHR - 1) / NTHR;
+  constexpr int WPIECES = CO_TILE * 4, UW = (NT * WPIECES + NTHR - 1) / NTHR;  // weight pieces of one chunk, per thread
   constexpr int kDivMul = (65536 + IW_P - 1) / IW_P;  // prow / IW_P == (prow * kDivMul) >> 16, exact for prow < 612 (IW_P 33, 34)
-  u32x4 va[UA], vw[NT];
+  u32x4 va[UA], vw[UW];
   int da[UA];
   bool ok[UA];
   auto issue = [&](int c0) {
 #pragma unroll
     for (int u = 0; u < UA; ++u) {
-      const int i = min(tid + u * 256, NPIECE - 1);
+      const int i = min(tid + u * NTHR, NPIECE - 1);
       const int s = i & 3, prow = i >> 2;
       const int py = (prow * kDivMul) >> 16, px = prow - py * IW_P;
       const int iy = iy0 + py, ix = ix0 + px;
-      da[u] = (tid + u * 256 < NPIECE) ? prow * kARow + s * 16 : -1;
+      da[u] = (tid + u * NTHR < NPIECE) ? prow * kARow + s * 16 : -1;
       ok[u] = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
       const int cy = min(max(iy, 0), p.IH - 1), cx = min(max(ix, 0), p.IW - 1);  // clamped load, zeroed at the store
       va[u] = *reinterpret_cast<const u32x4*>(in_n + ((size_t)cy * p.IW + cx) * in_pix + (size_t)c0 * 64 + s * 16);
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t)  // packed weights [slot][chunk][Cout rows][64 B]: 64 consecutive rows = 256 pieces
-      vw[t] = *reinterpret_cast<const u32x4*>(p.w + (((size_t)t * p.nchunks + c0) * p.Cout + co_base) * 64 + tid * 16);
+    for (int k = 0; k < UW; ++k) {  // packed weights [slot][chunk][Cout rows][64 B]: CO_TILE consecutive rows per slot
+      const int i = min(tid + k * NTHR, NT * WPIECES - 1), t = i / WPIECES, piece = i - t * WPIECES;
+      vw[k] = *reinterpret_cast<const u32x4*>(p.w + (((size_t)t * p.nchunks + c0) * p.Cout + co_base) * 64 + piece * 16);
+    }
   };
   auto store = [&]() {
 #pragma unroll
     for (int u = 0; u < UA; ++u)
       if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_a + da[u]) = ok[u] ? va[u] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int t = 0; t < NT; ++t) *reinterpret_cast<u32x4*>(lds_w + t * CO_TILE * kWRow + swz(tid >> 2, tid & 3)) = vw[t];
+    for (int k = 0; k < UW; ++k) {
+      const int i = tid + k * NTHR, t = i / WPIECES, piece = i - t * WPIECES;
+      if (i < NT * WPIECES) *reinterpret_cast<u32x4*>(lds_w + t * CO_TILE * kWRow + swz(piece >> 2, piece & 3)) = vw[k];
+    }
   };
 
   int xb[PT];  // lane address of input pixel (2*(wp*PT+b), 2*idx) of the patch = tap (0,0) of output pixel (b, idx)
 #pragma unroll
   for (int b = 0; b < PT; ++b) xb[b] = ((wp * PT + b) * 2 * IW_P + 2 * idx) * kARow + g * 16;
-  const int wbase = swz(idx, g);
+  const int wbase = wc * CT * 16 * kWRow + swz(idx, g);  // + multiples of 16 rows: bit 2 unchanged
 
   issue(0);
   for (int c0 = 0; c0 < p.nchunks; ++c0) {
@@ -168,14 +176,14 @@ __global__ __launch_bounds__(256) void conv_s2_gather_kernel(const C4K p) {
       float v[E];
       int ch0;
       if constexpr (TR::kBytes == 2) {
-        ch0 = co_base + 2 * a * 16 + 8 * g;
+        ch0 = co_base + (wc * CT + 2 * a) * 16 + 8 * g;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           v[j] = acc[2 * a][b][j];
           v[4 + j] = acc[2 * a + 1][b][j];
         }
       } else {
-        ch0 = co_base + a * 16 + 4 * g;
+        ch0 = co_base + (wc * CT + a) * 16 + 4 * g;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[a][b][j];
       }
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(256) void conv_s2_gather_kernel(const C4K p) {
     if (idx == 0) {
 #pragma unroll
       for (int a = 0; a < NG; ++a) {
-        const int cl0 = (TR::kBytes == 2) ? 2 * a * 16 + 8 * g : a * 16 + 4 * g;
+        const int cl0 = (TR::kBytes == 2) ? (wc * CT + 2 * a) * 16 + 8 * g : (wc * CT + a) * 16 + 4 * g;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           red[(wp * 2 + 0) * CO_TILE + cl0 + e] = s1[a][e];
@@ -254,8 +262,8 @@ int launch_s2(int dtype, const void* in, const void* w_packed, const float* bias
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  if (dtype == TG_BF16) hipLaunchKernelGGL((conv_s2_gather_kernel<BF16, KS>), grid, dim3(256), lds, st, k);
-  else hipLaunchKernelGGL((conv_s2_gather_kernel<F32, KS>), grid, dim3(256), lds, st, k);
+  if (dtype == TG_BF16) hipLaunchKernelGGL((conv_s2_gather_kernel<BF16, KS>), grid, dim3(NTHR), lds, st, k);
+  else hipLaunchKernelGGL((conv_s2_gather_kernel<F32, KS>), grid, dim3(NTHR), lds, st, k);
   return tg_launch_status();
 }
 
