@@ -18,7 +18,8 @@ namespace {
 constexpr int kRow = 64, kPitch = 24;  // unpadded 64-byte rows, piece index XOR 2*(bit 2 of row); patch pitch 24 rows
 __device__ __forceinline__ int swz(int row, int piece) { return row * kRow + ((piece ^ ((row >> 1) & 2)) << 4); }
 
-constexpr int CT = 4, PT = 2, WP = 4, TH = PT * WP, CO_TILE = 16 * CT;  // 64 channels x (8 rows x 16 px)
+// 8 waves (two per SIMD - the staging loads of one overlap the MFMAs of its partner): WC = 2 channel halves x WP = 4 row pairs
+constexpr int CT = 2, WC = 2, PT = 2, WP = 4, TH = PT * WP, CO_TILE = 16 * CT * WC, NTHR = 64 * WC * WP;  // 64 ch x (8 x 16 px)
 // Sub-pixel patterns: (class, tap) pair s uses weight slot s, window position (dy, dx) relative to the window origin.
 //   PAT 0  conv-transpose k3 s2 p1 op1 forward: window 2x2 at origin (0,0), 9 pairs (table in the header comment)
 //   PAT 1  input-gradient of the 4x4 stride-2 conv (code/models.py:90-94, autograd): window 3x3 at origin (-1,-1), 16 pairs:
@@ -70,7 +71,7 @@ template <> struct MmaT<F32> {
 };
 
 template <typename T, int PAT>
-__global__ __launch_bounds__(256) void subpixel_kernel(const ConvtK p) {
+__global__ __launch_bounds__(NTHR) void subpixel_kernel(const ConvtK p) {
   using P = Pat<PAT>;
   constexpr int NT = P::NT, WIN = P::WIN, ORG = P::ORG, IH_P = PGeo<PAT>::IH_P, IW_P = PGeo<PAT>::IW_P;
   constexpr int kPatchBytes = PGeo<PAT>::kPatchBytes;
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(256) void subpixel_kernel(const ConvtK p) {
   char* lds_w = smem + kPatchBytes;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wp = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wid % WC, wp = wid / WC;
   const int idx = lane & 15, g = lane >> 4;
   int bx = blockIdx.x;
   const int txb = bx % p.tiles_x;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void subpixel_kernel(const ConvtK p) {
   float bias_r[NG][E];
 #pragma unroll
   for (int a = 0; a < NG; ++a) {
-    const int ch0 = (TR::kBytes == 2) ? co_base + 2 * a * 16 + 8 * g : co_base + a * 16 + 4 * g;
+    const int ch0 = (TR::kBytes == 2) ? co_base + (wc * CT + 2 * a) * 16 + 8 * g : co_base + (wc * CT + a) * 16 + 4 * g;
 #pragma unroll
     for (int e = 0; e < E; e += 4) {
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
@@ -116,33 +118,39 @@ __global__ __launch_bounds__(256) void subpixel_kernel(const ConvtK p) {
       for (int b = 0; b < PT; ++b) acc[c][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // patch: IH_P x IW_P pixels x 4 pieces (612 for the 9 x 17 patch) -> 3 per thread; weights: NT blocks of 256 pieces
-  constexpr int NPIECE = IH_P * IW_P * 4, UA = (NPIECE + 255) / 256;
+  constexpr int NPIECE = IH_P * IW_P * 4, UA = (NPIECE + NTHR - 1) / NTHR;
+  constexpr int WPIECES = CO_TILE * 4, UW = (NT * WPIECES + NTHR - 1) / NTHR;  // weight pieces of one chunk, per thread
   constexpr int kDivMul = (65536 + IW_P - 1) / IW_P;  // prow / IW_P == (prow * kDivMul) >> 16 (exact for prow < 256)
-  u32x4 va[UA], vw[NT];
+  u32x4 va[UA], vw[UW];
   int da[UA];
   bool ok[UA];
   auto issue = [&](int c0) {
 #pragma unroll
     for (int u = 0; u < UA; ++u) {
-      const int i = min(tid + u * 256, NPIECE - 1);
+      const int i = min(tid + u * NTHR, NPIECE - 1);
       const int s = i & 3, prow = i >> 2;
       const int py = (prow * kDivMul) >> 16, px = prow - py * IW_P;
       const int iy = ty0 + ORG + py, ix = tx0 + ORG + px;
-      da[u] = (tid + u * 256 < NPIECE) ? swz(py * kPitch + px, s) : -1;
+      da[u] = (tid + u * NTHR < NPIECE) ? swz(py * kPitch + px, s) : -1;
       ok[u] = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
       const int cy = min(max(iy, 0), p.IH - 1), cx = min(max(ix, 0), p.IW - 1);  // clamped load, zeroed at the store
       va[u] = *reinterpret_cast<const u32x4*>(in_n + ((size_t)cy * p.IW + cx) * in_pix + (size_t)c0 * 64 + s * 16);
     }
 #pragma unroll
-    for (int s9 = 0; s9 < NT; ++s9)  // packed weights [slot][chunk][Cout rows][64 B]: 64 consecutive rows = 256 pieces
-      vw[s9] = *reinterpret_cast<const u32x4*>(p.w + (((size_t)s9 * p.nchunks + c0) * p.Cout + co_base) * 64 + tid * 16);
+    for (int k = 0; k < UW; ++k) {  // packed weights [slot][chunk][Cout rows][64 B]: CO_TILE consecutive rows per slot
+      const int i = min(tid + k * NTHR, NT * WPIECES - 1), s9 = i / WPIECES, piece = i - s9 * WPIECES;
+      vw[k] = *reinterpret_cast<const u32x4*>(p.w + (((size_t)s9 * p.nchunks + c0) * p.Cout + co_base) * 64 + piece * 16);
+    }
   };
   auto store = [&]() {
 #pragma unroll
     for (int u = 0; u < UA; ++u)
       if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_a + da[u]) = ok[u] ? va[u] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int s9 = 0; s9 < NT; ++s9) *reinterpret_cast<u32x4*>(lds_w + s9 * CO_TILE * kRow + swz(tid >> 2, tid & 3)) = vw[s9];
+    for (int k = 0; k < UW; ++k) {
+      const int i = tid + k * NTHR, s9 = i / WPIECES, piece = i - s9 * WPIECES;
+      if (i < NT * WPIECES) *reinterpret_cast<u32x4*>(lds_w + s9 * CO_TILE * kRow + swz(piece >> 2, piece & 3)) = vw[k];
+    }
   };
 
   // lane addresses: pixel (row wp*PT+b [+dy], column idx [+dx]); the pitch of 24 keeps bit 2 of the row independent of dy
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(256) void subpixel_kernel(const ConvtK p) {
   for (int b = 0; b < PT; ++b)
 #pragma unroll
     for (int c = 0; c < WIN; ++c) xb[b][c] = swz((wp * PT + b) * kPitch + idx + c, g);
-  const int wbase = swz(idx, g);  // + multiples of 16 rows
+  const int wbase = wc * CT * 16 * kRow + swz(idx, g);  // + multiples of 16 rows: bit 2 unchanged
 
   issue(0);
   for (int c0 = 0; c0 < p.nchunks; ++c0) {
@@ -194,14 +202,14 @@ __global__ __launch_bounds__(256) void subpixel_kernel(const ConvtK p) {
           float v[E];
           int ch0;
           if constexpr (TR::kBytes == 2) {
-            ch0 = co_base + 2 * a * 16 + 8 * g;
+            ch0 = co_base + (wc * CT + 2 * a) * 16 + 8 * g;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               v[j] = acc[c][2 * a][b][j];
               v[4 + j] = acc[c][2 * a + 1][b][j];
             }
           } else {
-            ch0 = co_base + a * 16 + 4 * g;
+            ch0 = co_base + (wc * CT + a) * 16 + 4 * g;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = acc[c][a][b][j];
           }
@@ -250,8 +258,8 @@ int launch_subpixel(int dtype, const void* in, const void* w_packed, const float
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  if (dtype == TG_BF16) hipLaunchKernelGGL((subpixel_kernel<BF16, PAT>), grid, dim3(256), lds, st, k);
-  else hipLaunchKernelGGL((subpixel_kernel<F32, PAT>), grid, dim3(256), lds, st, k);
+  if (dtype == TG_BF16) hipLaunchKernelGGL((subpixel_kernel<BF16, PAT>), grid, dim3(NTHR), lds, st, k);
+  else hipLaunchKernelGGL((subpixel_kernel<F32, PAT>), grid, dim3(NTHR), lds, st, k);
   return tg_launch_status();
 }
 

@@ -165,13 +165,13 @@ class Conv:
             self.last_desc = "ctd"  # 3x3-window stride-2 gather (csrc/conv4s2_mfma.hip, KS = 3)
             K.convt_dgrad(dout, self.wb, out)
             return
-        if self.spec.kind == "c4s2" and self.cin_p % 64 == 0 and mask is None and res is None and bias_grad_of is None and \
+        if self.spec.kind == "c4s2" and self.cin_p % 64 == 0 and res is None and bias_grad_of is None and \
                 _FAST_C4S2 and H == 2 * OH and W == 2 * OW and N * ((OH + 7) // 8) * ((OW + 15) // 16) * (self.cin_p // 64) >= 64:
             # four-class sub-pixel launch (csrc/convt_mfma.hip, PAT 1).  Measured (tools/mb_c4s2_dgrad.py, 24 samples):
-            # 64->128 @64x64 18.3 vs 29.0 us, 128->128 @32x32 17.7 vs 19.1; the masked 64->64 @128x128 launch (43.5 vs 49.9)
-            # and launches of fewer than 64 workgroups (7.0 vs 12.8) stay on tg_conv
+            # 64->128 @64x64 15.3 vs 29.0 us, 128->128 @32x32 14.6 vs 19.1, masked 64->64 @128x128 38.1 vs 45.3; launches of
+            # fewer than 64 workgroups (9.8 vs 7.0) stay on tg_conv
             self.last_desc = "c4d"
-            K.conv4s2_dgrad(dout, self.wb, out)
+            K.conv4s2_dgrad(dout, self.wb, out, mask, mask_mode if mask is not None else L.MASK_NONE)
             return
         st = bias_grad_of.gbias if bias_grad_of is not None else None
         key = ("d", N, OH, OW, mask_mode, res is not None, st is not None)
