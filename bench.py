@@ -60,7 +60,8 @@ def conv_flops(spec, N, H, W):
     return 2.0 * N * H * W * 9 * spec.cin * spec.cout  # conv-transpose: every input pixel meets all 9 taps
 
 
-TILE_PARAMS = {1: "4, 4, 1, 4", 2: "2, 2, 2, 2", 3: "4, 4, 2, 2", 4: "2, 2, 1, 4", 5: "2, 1, 1, 4", 6: "4, 2, 1, 4"}
+TILE_PARAMS = {1: "4, 4, 1, 4", 2: "2, 2, 2, 2", 3: "4, 4, 2, 2", 4: "2, 2, 1, 4", 5: "2, 1, 1, 4", 6: "4, 2, 1, 4",
+               7: "2, 2, 2, 4"}
 
 
 def kernel_name(conv, dtype):

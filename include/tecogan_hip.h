@@ -76,7 +76,9 @@ typedef struct {
 } tg_conv_desc;
 
 enum { TG_TILE_AUTO = 0, TG_TILE_64x256 = 1, TG_TILE_64x64 = 2, TG_TILE_128x128 = 3, TG_TILE_32x128 = 4,
-       TG_TILE_32x64 = 5, TG_TILE_64x128 = 6 };  /* <output channels>x<pixels> per workgroup */
+       TG_TILE_32x64 = 5, TG_TILE_64x128 = 6,
+       TG_TILE_64x128_8W = 7 /* 64x128 with 8 waves (two per SIMD); plain 3x3 launches only, else runs as 64x128 */ };
+/* <output channels>x<pixels> per workgroup */
 
 int tg_abi_version(void);
 const char* tg_error_string(int code);

@@ -108,14 +108,18 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // reads in flight; the generic path (tap table per class) pays a dependent table lookup per k-step and is kept for the
 // stride-2 / sub-pixel launches.
 template <typename T, int CT, int PT, int WC, int WP, bool STD3>
-__global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
+__global__ __launch_bounds__(64 * WC * WP) void conv_gather_kernel(const ConvK p) {
+  // NTHR = 512 (pipelined 3x3 path only): two waves per SIMD from ONE workgroup, for launches that cannot give a CU two
+  // workgroups (<= 256 workgroups): one wave's staging-load issue (~120 cycles per 1-KiB load) overlaps its partner's MFMAs
+  constexpr int NTHR = 64 * WC * WP;
+  static_assert(NTHR == 256 || (NTHR == 512 && STD3), "8-wave workgroups exist for the pipelined 3x3 path");
   using TR = ElemTraits<T>;
   using Frag = typename Mma<T>::Frag;
   constexpr int CO_TILE = 16 * CT * WC;
   constexpr int TH = PT * WP;
   constexpr int E = TR::kVec;                              // channels per 16-byte epilogue vector
   constexpr int NG = (TR::kBytes == 2) ? CT / 2 : CT;      // epilogue vectors per px-tile per lane
-  static_assert(WC * WP == 4, "4 waves per workgroup");
+  static_assert(WC * WP == 4 || WC * WP == 8, "4 or 8 waves per workgroup");
   static_assert(TR::kBytes == 4 || CT % 2 == 0, "bf16 pairs co-tiles");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,9 +188,13 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
   // UA activation pieces and UW (chunk,tap) weight blocks per thread are loaded in ONE issue phase before any LDS store.
   constexpr int UA = 6;
   constexpr int PIECES = CO_TILE * 4, PPT = (PIECES + 255) / 256;
+  // 512 threads and 256-piece weight blocks: the two 256-thread halves take alternate blocks (half = wave-uniform)
+  constexpr bool HALVES = NTHR == 512;
+  static_assert(!HALVES || PIECES == 256, "8-wave configs use 64-channel tiles");
+  const int half = HALVES ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;
   // small tiles: the whole K of a 64-channel 3x3 layer in flight at once; big tiles: one 3x3 chunk (pipelined kernel) or
   // fewer blocks in the generic kernel, whose 128-channel tiles otherwise lose occupancy to the staging registers
-  constexpr int UW = (CT * PT <= 4) ? 18 : ((STD3 || PPT == 1) ? 9 : 5);
+  constexpr int UW = (64 * WC * WP == 512) ? 9 : ((CT * PT <= 4) ? 18 : ((STD3 || PPT == 1) ? 9 : 5));
   const int a_stride = p.a_rows_max * (STD3 ? kSwzRow : kRowBytes);  // LDS bytes of one chunk's activation patch
   const float inv_iw = 1.0f / (float)cl.iw, inv_prow = 1.0f / (float)prow_n;
   if constexpr (STD3) {
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
       const int total_a = cn * prow_n * 4;
 #pragma unroll
       for (int u = 0; u < UA; ++u) {
-        const int i = tid + u * 256;
+        const int i = tid + u * NTHR;
         va[u] = u32x4{0u, 0u, 0u, 0u};
         da[u] = -1;
         if (i < total_a) {
@@ -223,12 +231,13 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
       }
 #pragma unroll
       for (int u = 0; u < UW; ++u) {
-        if (u < cn * 9) {  // wave-uniform; (chunk, tap) split is compile-time, slot == tap
-          const int cc = u / 9, tt = u - cc * 9;
+        const int blk = HALVES ? 2 * u + half : u;  // (chunk, tap) block: compile-time unless the halves alternate
+        if (blk < cn * 9) {  // wave-uniform; slot == tap
+          const int cc = blk / 9, tt = blk - cc * 9;
           const char* src = p.w + (((size_t)tt * p.nchunks + c0 + cc) * p.Cout + co_base) * 64;
 #pragma unroll
           for (int k = 0; k < PPT; ++k) {
-            const int piece = tid + k * 256;
+            const int piece = (HALVES ? (tid & 255) : tid) + k * 256;
             if (PIECES % 256 == 0 || piece < PIECES) vw[u][k] = *reinterpret_cast<const u32x4*>(src + piece * 16);
           }
         }
@@ -240,11 +249,12 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
         if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_a + da[u]) = va[u];
 #pragma unroll
       for (int u = 0; u < UW; ++u) {
-        if (u < cn * 9) {
-          char* dstw = lds_w + u * CO_TILE * kSwzRow;  // [cc][tt] with tg == 9
+        const int blk = HALVES ? 2 * u + half : u;
+        if (blk < cn * 9) {
+          char* dstw = lds_w + blk * CO_TILE * kSwzRow;  // [cc][tt] with tg == 9
 #pragma unroll
           for (int k = 0; k < PPT; ++k) {
-            const int piece = tid + k * 256;
+            const int piece = (HALVES ? (tid & 255) : tid) + k * 256;
             if (PIECES % 256 == 0 || piece < PIECES)
               *reinterpret_cast<u32x4*>(dstw + swz_off(piece >> 2, piece & 3)) = vw[u][k];
           }
@@ -493,7 +503,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(const ConvK p) {
     }
     __syncthreads();
     const int grp = n / (p.N / p.stats_groups);
-    for (int i = tid; i < p.stats_mode * CO_TILE; i += 256) {
+    for (int i = tid; i < p.stats_mode * CO_TILE; i += NTHR) {
       const int which = i / CO_TILE, chn = i - which * CO_TILE;
       float s = 0.f;
 #pragma unroll
@@ -542,7 +552,7 @@ int launch_conv_impl(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
                                      160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k);
+  hipLaunchKernelGGL(fn, grid, dim3(64 * WC * WP), lds, st, k);
   return tg_launch_status();
 }
 
@@ -561,6 +571,8 @@ int dispatch_conv(int cfg, const ConvK& k, dim3 grid, size_t lds, hipStream_t st
     case TG_TILE_32x128: return launch_conv<T, 2, 2, 1, 4>(k, grid, lds, st);
     case TG_TILE_32x64: return launch_conv<T, 2, 1, 1, 4>(k, grid, lds, st);
     case TG_TILE_64x128: return launch_conv<T, 4, 2, 1, 4>(k, grid, lds, st);
+    case TG_TILE_64x128_8W:  // pipelined 3x3 path only (prepare_conv falls back to 64x128 otherwise)
+      return k.std3 ? launch_conv_impl<T, 2, 2, 2, 4, true>(k, grid, lds, st) : TG_E_UNSUPPORTED;
   }
   return TG_E_UNSUPPORTED;
 }
@@ -573,6 +585,7 @@ TileCfg tile_cfg(int cfg) {
     case TG_TILE_32x128: return {32, 8};
     case TG_TILE_32x64: return {32, 4};
     case TG_TILE_64x128: return {64, 8};
+    case TG_TILE_64x128_8W: return {64, 8};
   }
   return {0, 0};
 }
@@ -619,7 +632,13 @@ static int pick_tile(const tg_conv_desc* d) {
     else if (plain3x3 && px <= 16384 && d->Cin <= 64 && d->Cout <= 64) cfg = TG_TILE_32x64;  // 7.0 vs 7.6 us (64x64)
     else if (plain3x3 && (px > 262144 || (d->Cin >= 128 && d->Cout >= 128 && px > 65536)))
       cfg = TG_TILE_64x256;                                                  // 150 vs 214 us (c6 dgrad), 99 vs 105 us
-    else if (plain3x3) cfg = TG_TILE_64x128;                                 // tools/microbench.py tiles: 10-30 % faster
+    else if (plain3x3) {
+      cfg = TG_TILE_64x128;                                                  // tools/microbench.py tiles: 10-30 % faster
+      // <= 256 workgroups: every CU gets at most one, so take two waves per SIMD from the workgroup itself
+      // (tools/microbench.py w8: 9.8 -> 8.6, 13.5 -> 11.6 us at 256 workgroups; slower on larger grids, which co-schedule)
+      const long long wgs = (long long)d->N * ((d->OH + 7) / 8) * ((d->OW + 15) / 16) * (d->Cout / 64);
+      if (wgs <= 256) cfg = TG_TILE_64x128_8W;
+    }
     else if (d->ncls == 4 && d->Cout % 128 == 0 && px >= 16384) cfg = TG_TILE_64x128;  // conv-transpose forward: 22.7 vs 27.2 us
     else if (d->Cout % 128 == 0 && px >= 16384) cfg = TG_TILE_128x128;
     else if (px >= 32768) cfg = TG_TILE_64x256;
@@ -651,7 +670,7 @@ static int prepare_conv(const tg_conv_desc* d, const void* in, const void* w_pac
   if (d->out_mode != TG_OUT_NHWC && d->out_mode != TG_OUT_NCHW_F32) return TG_E_BADARG;
   if (d->out_mode == TG_OUT_NCHW_F32 && (res || d->mask_mode)) return TG_E_UNSUPPORTED;
 
-  const int cfg = pick_tile(d);
+  int cfg = pick_tile(d);
   const TileCfg tc = tile_cfg(cfg);
   if (!tc.co_tile || d->Cout % tc.co_tile) return TG_E_UNSUPPORTED;
 
@@ -745,10 +764,11 @@ static int prepare_conv(const tg_conv_desc* d, const void* in, const void* w_pac
     k.a_rows_max = k.cls[0].ih * kSwzPitch;
     k.flip = (!pat_fwd && pat_bwd) ? 1 : 0;
     // one chunk group must fit one issue phase of the pipelined kernel: UA = 6 pieces, UW = 18 / 9 weight blocks per thread
-    const bool small_cfg = (cfg == TG_TILE_64x64 || cfg == TG_TILE_32x128 || cfg == TG_TILE_32x64);
+    const bool small_cfg = (cfg == TG_TILE_64x64 || cfg == TG_TILE_32x128 || cfg == TG_TILE_32x64 || cfg == TG_TILE_64x128_8W);
     const int uw = small_cfg ? 18 : 9;
     while (cg > 1 && (cg * max_rows * 4 > 256 * 6 || cg * 9 > uw)) --cg;
   }
+  if (cfg == TG_TILE_64x128_8W && !k.std3) cfg = TG_TILE_64x128;  // same tile geometry, 4 waves, generic path
   size_t lds = (size_t)cg * (a_bytes + tg * w_tap);
   k.tap_table_off = (int)lds;
   lds += TG_MAX_TAPS * sizeof(int);

@@ -16,7 +16,7 @@ from pytorch_tecogan_amd import kernels as K  # noqa: E402
 DEV = "cuda:0"
 REP = 40
 TILES = {"auto": L.TILE_AUTO, "64x256": L.TILE_64x256, "64x64": L.TILE_64x64, "128x128": L.TILE_128x128,
-         "32x128": L.TILE_32x128, "32x64": 5, "64x128": 6}
+         "32x128": L.TILE_32x128, "32x64": 5, "64x128": 6, "64x128w8": 7}
 
 
 def time_graph(fn, reps=REP, iters=20):
@@ -113,6 +113,21 @@ def main():
         bench_conv("c3", 128, 128, 24, 16, 16, "dgrad", bf, t)
         bench_conv("c4s2", 64, 128, 24, 64, 64, "fwd", bf, t + ["128x128"])
         bench_conv("c4s2", 64, 128, 24, 64, 64, "dgrad", bf, t + ["128x128"])
+        return
+    if what == "w8":  # 64x128 tile: 4 waves vs 8 waves (two per SIMD from one workgroup)
+        t = ["64x128", "64x128w8", "32x64"]
+        bench_conv("c3", 64, 128, 4, 64, 64, "fwd", bf, t)
+        bench_conv("c3", 128, 128, 4, 64, 64, "fwd", bf, t)
+        bench_conv("c3", 128, 64, 4, 128, 128, "fwd", bf, t)
+        bench_conv("c3", 64, 64, 4, 64, 64, "fwd", bf, t)
+        bench_conv("c3", 51, 64, 4, 32, 32, "fwd", bf, t)
+        bench_conv("c3", 64, 64, 12, 64, 64, "fwd", bf, t)
+        bench_conv("c3", 128, 128, 12, 32, 32, "fwd", bf, t)
+        bench_conv("c3", 128, 128, 12, 16, 16, "fwd", bf, t)
+        bench_conv("c3", 64, 64, 40, 32, 32, "dgrad", bf, t)
+        bench_conv("c3", 64, 64, 40, 64, 64, "dgrad", bf, t)
+        bench_conv("c3", 64, 128, 40, 64, 64, "dgrad", bf, t)
+        bench_conv("c3", 128, 128, 24, 32, 32, "dgrad", bf, t)
         return
     if what == "tiles":  # the launches the 64x128-vs-64x256 rule of pick_tile() decides
         big = ["64x256", "64x128"]
