@@ -48,10 +48,13 @@ template <> __device__ __forceinline__ void unpack16<F32>(const u32x4& v, float*
 // TPW = taps per workgroup (blockIdx.z selects the tap group).  With TPW == NTAPS a workgroup owns every tap (best when it
 // walks many pixel tiles); TPW = 3 (4 for 4x4) cuts the fp32 slab each workgroup writes - and the fold reads back - by
 // NTAPS/TPW for the same number of workgroups: small layers were bound by exactly that traffic (256 x 147 KB per layer).
-template <typename T, int NTAPS, int TPW, int AW, int BT>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
+// NW = waves per workgroup.  8 (two per SIMD): each wave holds half the accumulators (72 for 9 taps), so the tile-staging
+// loads of one wave (~120 cycles of issue each) overlap its partner's MFMAs instead of serialising with them.
+template <typename T, int NTAPS, int TPW, int AW, int BT, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void wgrad_kernel(const WgradK p) {
   using TR = ElemTraits<T>;
-  constexpr int BW = 4 / AW;
+  constexpr int NTHR = 64 * NW;
+  constexpr int BW = NW / AW;
   constexpr int A_BLK = 16 * AW, B_BLK = 16 * BT * BW;
   constexpr int XROW = A_BLK * TR::kBytes + 16, YROW = B_BLK * TR::kBytes + 16;
   constexpr int XV = A_BLK * TR::kBytes / 16, YV = B_BLK * TR::kBytes / 16;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
 
   const int tap0 = blockIdx.z * TPW;
   // bias gradient = sum over pixels of Y: the Y tiles pass through this thread's registers anyway, and a thread always
-  // holds the same 16-byte channel piece (256 % YV == 0), so it keeps E running sums (one X block / tap group does it)
+  // holds the same 16-byte channel piece (NTHR % YV == 0), so it keeps E running sums (one X block / tap group does it)
   constexpr int E = 16 / TR::kBytes;
   const bool ysum = p.ysum && a_blk == 0 && blockIdx.z == 0;
   float bsum[E];
@@ -101,8 +104,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
   // Software pipeline over this workgroup's pixel tiles: the global loads of tile i+1 are issued (into registers) right
   // after tile i has been written to LDS and stay in flight while the MFMAs of tile i run.  The kernel runs one
   // workgroup per CU (its accumulators fill the register file), so no other workgroup would hide that latency.
-  constexpr int UX = (TR::kBytes == 2) ? 11 : 22;  // 16-byte pieces per thread: X patch up to 10x34 pixels x A_BLK channels
-  constexpr int UY = (TR::kBytes == 2) ? 4 : 8;    //                            Y tile 128 pixels x B_BLK channels
+  constexpr int UX = ((TR::kBytes == 2) ? 11 : 22) * 4 / NW + (NW == 8 ? 1 : 0);  // 16-byte pieces per thread: X patch up to 10x34 pixels x A_BLK channels
+  constexpr int UY = ((TR::kBytes == 2) ? 4 : 8) * 4 / NW;                           //                            Y tile 128 pixels x B_BLK channels
   u32x4 vx[UX], vy[UY];
   const float inv_iw = 1.0f / (float)p.iw;
   const int nx = prow_n * XV, ny = ypix * YV;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     const char* xn = xbase + (size_t)n * p.XH * p.XW * xpix_bytes + (size_t)a0 * TR::kBytes;
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
-      const int i = tid + u * 256;
+      const int i = tid + u * NTHR;
       vx[u] = u32x4{0u, 0u, 0u, 0u};
       if (i < nx) {
         const int prow = i / XV, s2 = i - prow * XV;  // XV is a power of two
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     const char* yn = ybase + (size_t)n * p.YH * p.YW * ypix_bytes + (size_t)b0 * TR::kBytes;
 #pragma unroll
     for (int u = 0; u < UY; ++u) {
-      const int i = tid + u * 256;
+      const int i = tid + u * NTHR;
       vy[u] = u32x4{0u, 0u, 0u, 0u};
       if (i < ny) {
         const int prow = i / YV, s2 = i - prow * YV;
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     __syncthreads();  // the previous tile's fragment reads are done
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
-      const int i = tid + u * 256;
+      const int i = tid + u * NTHR;
       if (i < nx) {
         const int prow = i / XV, s2 = i - prow * XV;
         *reinterpret_cast<u32x4*>(lds_x + prow * XROW + s2 * 16) = vx[u];
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     }
 #pragma unroll
     for (int u = 0; u < UY; ++u) {
-      const int i = tid + u * 256;
+      const int i = tid + u * NTHR;
       if (i < ny) {
         const int prow = i / YV, s2 = i - prow * YV;
         *reinterpret_cast<u32x4*>(lds_y + prow * YROW + s2 * 16) = vy[u];
@@ -230,9 +233,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
   // slab[split][t][a][b] (+ [Cy] channel sums of Y when ysum); accumulator rows 4g+j are the X channel, column idx the Y channel
   const size_t slab_sz = (size_t)NTAPS * p.Cx * p.Cy + (p.ysum ? p.Cy : 0);
   float* slab = sbase + (size_t)split * slab_sz;
-  if (ysum) {  // combine the 256/YV threads that hold the same channel piece
+  if (ysum) {  // combine the NTHR/YV threads that hold the same channel piece
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [256/YV][YV*E] ; LDS tiles are dead now
+    float* red = reinterpret_cast<float*>(smem);  // [NTHR/YV][YV*E] ; LDS tiles are dead now
     constexpr int CH = YV * E;                    // == B_BLK
     const int s2 = tid % YV, r = tid / YV;
 #pragma unroll
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK p) {
     __syncthreads();
     if (tid < CH) {
       float t = 0.f;
-      for (int q = 0; q < 256 / YV; ++q) t += red[q * CH + tid];
+      for (int q = 0; q < NTHR / YV; ++q) t += red[q * CH + tid];
       slab[(size_t)NTAPS * p.Cx * p.Cy + b0 + tid] = t;
     }
   }
@@ -343,16 +346,16 @@ struct WgCfg {
   int a_blk, b_blk;
 };
 
-template <typename T, int NTAPS, int TPW, int AW, int BT>
+template <typename T, int NTAPS, int TPW, int AW, int BT, int NW = 4>
 int launch_wgrad(const WgradK& k, dim3 grid, size_t lds, hipStream_t st) {
-  auto fn = wgrad_kernel<T, NTAPS, TPW, AW, BT>;
+  auto fn = wgrad_kernel<T, NTAPS, TPW, AW, BT, NW>;
   static bool attr_done = false;
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, k);
+  hipLaunchKernelGGL(fn, grid, dim3(64 * NW), lds, st, k);
   return tg_launch_status();
 }
 
@@ -455,7 +458,9 @@ int wgrad_launch(const tg_wgrad_desc* d, const void* x, const void* y, float* sl
 #define TG_WG(T_, NT_, TP_, AW_, BT_) return launch_wgrad<T_, NT_, TP_, AW_, BT_>(k, grid, lds, st)
   if (d->dtype == TG_BF16) {
     switch (cfg) {
-      case 0: if (split) TG_WG(BF16, 9, 3, 4, 4); else TG_WG(BF16, 9, 9, 4, 4);
+      case 0:
+        if (split) TG_WG(BF16, 9, 3, 4, 4);
+        else return launch_wgrad<BF16, 9, 9, 4, 2, 8>(k, grid, lds, st);  // 8 waves: 2-11 % faster (tools/microbench.py wgrad)
       case 1: if (split) TG_WG(BF16, 9, 3, 2, 2); else TG_WG(BF16, 9, 9, 2, 2);
       case 2: if (split) TG_WG(BF16, 9, 3, 4, 2); else TG_WG(BF16, 9, 9, 4, 2);
       case 3: if (split) TG_WG(BF16, 16, 4, 4, 2); else TG_WG(BF16, 16, 16, 4, 2);
