@@ -56,7 +56,12 @@ __global__ __launch_bounds__(64 * NW) void wgrad_kernel(const WgradK p) {
   constexpr int NTHR = 64 * NW;
   constexpr int BW = NW / AW;
   constexpr int A_BLK = 16 * AW, B_BLK = 16 * BT * BW;
-  constexpr int XROW = A_BLK * TR::kBytes + 16, YROW = B_BLK * TR::kBytes + 16;
+  // bf16 rows are padded to an ODD number of 32-byte segments (128 + 32, 64 + 32): a 32-lane group of ds_read_b64_tr_b16
+  // reads 32 contiguous bytes of each of 8 consecutive pixel rows (k = 4g + q below), and 8 consecutive multiples of an odd
+  // segment count are 8 distinct segments of the 256-byte bank window -> conflict-free at any base row / tap shift.
+  // (With +16-byte padding and k = 8g + q the rows r and r+8 overlapped by half a segment: 2-way conflicts.)
+  constexpr int PADB = (TR::kBytes == 2) ? 32 : 16;
+  constexpr int XROW = A_BLK * TR::kBytes + PADB, YROW = B_BLK * TR::kBytes + PADB;
   constexpr int XV = A_BLK * TR::kBytes / 16, YV = B_BLK * TR::kBytes / 16;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_kernel(const WgradK p) {
       if constexpr (TR::kBytes == 2) {
         // lane (q,pp) of each 16-lane group supplies row q, columns 4pp..4pp+3 of a 4-pixel x 16-channel block
         const int q = idx >> 2, pp = idx & 3;
-        const int k_lo = k0 + 8 * g + q, k_hi = k_lo + 4;
+        const int k_lo = k0 + 4 * g + q, k_hi = k_lo + 16;  // any bijection lane -> k works if X and Y use the same one
         bf16x8 bf[BT];
 #pragma unroll
         for (int b = 0; b < BT; ++b) {
@@ -443,7 +448,8 @@ int wgrad_launch(const tg_wgrad_desc* d, const void* x, const void* y, float* sl
   k.ysum = d->y_sum ? 1 : 0;
   k.b_blocks = d->Cy / c.b_blk;
   const int eb = d->dtype == TG_BF16 ? 2 : 4;
-  const size_t lds = (size_t)tw * th * (c.b_blk * eb + 16) + (size_t)k.ih * k.iw * (c.a_blk * eb + 16);
+  const int padb = d->dtype == TG_BF16 ? 32 : 16;  // row padding of the kernel (PADB)
+  const size_t lds = (size_t)tw * th * (c.b_blk * eb + padb) + (size_t)k.ih * k.iw * (c.a_blk * eb + padb);
   if (lds > 160 * 1024) return TG_E_UNSUPPORTED;
   {  // register staging capacity of the kernel (UX / UY pieces per thread)
     const int xv = c.a_blk * eb / 16, yv = c.b_blk * eb / 16;
