@@ -468,8 +468,8 @@ int wgrad_launch(const tg_wgrad_desc* d, const void* x, const void* y, float* sl
         if (split) TG_WG(BF16, 9, 3, 4, 4);
         else return launch_wgrad<BF16, 9, 9, 4, 2, 8>(k, grid, lds, st);  // 8 waves: 2-11 % faster (tools/microbench.py wgrad)
       case 1: if (split) TG_WG(BF16, 9, 3, 2, 2); else TG_WG(BF16, 9, 9, 2, 2);
-      case 2: if (split) TG_WG(BF16, 9, 3, 4, 2); else TG_WG(BF16, 9, 9, 4, 2);
-      case 3: if (split) TG_WG(BF16, 16, 4, 4, 2); else TG_WG(BF16, 16, 16, 4, 2);
+      case 2: if (split) TG_WG(BF16, 9, 3, 4, 2); else return launch_wgrad<BF16, 9, 9, 4, 1, 8>(k, grid, lds, st);
+      case 3: if (split) TG_WG(BF16, 16, 4, 4, 2); else return launch_wgrad<BF16, 16, 16, 4, 1, 8>(k, grid, lds, st);
     }
   } else {
     switch (cfg) {
