@@ -69,7 +69,6 @@ struct ConvK {
   int act, mask_mode, stats_mode, stats_groups, stats_replicas, out_mode, c_real;
   long long out_n_stride;
   int a_rows_max;
-  int tap_table_off;  // LDS byte offset of the per-class tap offset table (generic path)
   int flip;           // STD3: taps mirrored (input-gradient launch)
   int std3;           // host-side: launch the compile-time 3x3 variant
   ConvClassK cls[TG_MAX_CLASSES];
@@ -156,9 +155,6 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gather_kernel(const ConvK p
   const int iy0 = ty0 * p.S + cl.dymin, ix0 = tx0 * p.S + cl.dxmin;
   const int prow_n = cl.ih * cl.iw;
   const int ntaps = cl.ntaps;
-  int* tap_off = reinterpret_cast<int*>(smem + p.tap_table_off);
-  if (!STD3 && tid < ntaps)
-    tap_off[tid] = ((cl.dy[tid] - cl.dymin) * cl.iw + (cl.dx[tid] - cl.dxmin)) * kRowBytes;  // visible after the first barrier
 
   f32x4 acc[CT][PT];
 #pragma unroll
@@ -770,8 +766,6 @@ static int prepare_conv(const tg_conv_desc* d, const void* in, const void* w_pac
   }
   if (cfg == TG_TILE_64x128_8W && !k.std3) cfg = TG_TILE_64x128;  // same tile geometry, 4 waves, generic path
   size_t lds = (size_t)cg * (a_bytes + tg * w_tap);
-  k.tap_table_off = (int)lds;
-  lds += TG_MAX_TAPS * sizeof(int);
   if (lds > 160 * 1024) return TG_E_UNSUPPORTED;
   lds = std::max<size_t>(lds, 4 * 2 * tc.co_tile * sizeof(float));  // stats scratch
   k.tg = tg;
