@@ -77,7 +77,7 @@ typedef struct {
 
 enum { TG_TILE_AUTO = 0, TG_TILE_64x256 = 1, TG_TILE_64x64 = 2, TG_TILE_128x128 = 3, TG_TILE_32x128 = 4,
        TG_TILE_32x64 = 5, TG_TILE_64x128 = 6,
-       TG_TILE_64x128_8W = 7 /* 64x128 with 8 waves (two per SIMD); plain 3x3 launches only, else runs as 64x128 */ };
+       TG_TILE_64x128_8W = 7, TG_TILE_64x64_8W = 8 /* 8 waves (two per SIMD); plain 3x3 launches only, else the 4-wave tile */ };
 /* <output channels>x<pixels> per workgroup */
 
 int tg_abi_version(void);

@@ -16,7 +16,7 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_TANH24 = 0, 1, 2, 3, 4
 MASK_NONE, MASK_RELU, MASK_LRELU = 0, 1, 2
 OUT_NHWC, OUT_NCHW_F32 = 0, 1
 TILE_AUTO, TILE_64x256, TILE_64x64, TILE_128x128, TILE_32x128 = 0, 1, 2, 3, 4
-TILE_32x64, TILE_64x128, TILE_64x128_8W = 5, 6, 7
+TILE_32x64, TILE_64x128, TILE_64x128_8W, TILE_64x64_8W = 5, 6, 7, 8
 MAX_TAPS, MAX_CLASSES = 16, 4
 
 

@@ -569,6 +569,8 @@ int dispatch_conv(int cfg, const ConvK& k, dim3 grid, size_t lds, hipStream_t st
     case TG_TILE_64x128: return launch_conv<T, 4, 2, 1, 4>(k, grid, lds, st);
     case TG_TILE_64x128_8W:  // pipelined 3x3 path only (prepare_conv falls back to 64x128 otherwise)
       return k.std3 ? launch_conv_impl<T, 2, 2, 2, 4, true>(k, grid, lds, st) : TG_E_UNSUPPORTED;
+    case TG_TILE_64x64_8W:
+      return k.std3 ? launch_conv_impl<T, 2, 1, 2, 4, true>(k, grid, lds, st) : TG_E_UNSUPPORTED;
   }
   return TG_E_UNSUPPORTED;
 }
@@ -582,6 +584,7 @@ TileCfg tile_cfg(int cfg) {
     case TG_TILE_32x64: return {32, 4};
     case TG_TILE_64x128: return {64, 8};
     case TG_TILE_64x128_8W: return {64, 8};
+    case TG_TILE_64x64_8W: return {64, 4};
   }
   return {0, 0};
 }
@@ -760,11 +763,13 @@ static int prepare_conv(const tg_conv_desc* d, const void* in, const void* w_pac
     k.a_rows_max = k.cls[0].ih * kSwzPitch;
     k.flip = (!pat_fwd && pat_bwd) ? 1 : 0;
     // one chunk group must fit one issue phase of the pipelined kernel: UA = 6 pieces, UW = 18 / 9 weight blocks per thread
-    const bool small_cfg = (cfg == TG_TILE_64x64 || cfg == TG_TILE_32x128 || cfg == TG_TILE_32x64 || cfg == TG_TILE_64x128_8W);
+    const bool small_cfg = (cfg == TG_TILE_64x64 || cfg == TG_TILE_32x128 || cfg == TG_TILE_32x64 || cfg == TG_TILE_64x128_8W ||
+                            cfg == TG_TILE_64x64_8W);
     const int uw = small_cfg ? 18 : 9;
     while (cg > 1 && (cg * max_rows * 4 > 256 * 6 || cg * 9 > uw)) --cg;
   }
   if (cfg == TG_TILE_64x128_8W && !k.std3) cfg = TG_TILE_64x128;  // same tile geometry, 4 waves, generic path
+  if (cfg == TG_TILE_64x64_8W && !k.std3) cfg = TG_TILE_64x64;
   size_t lds = (size_t)cg * (a_bytes + tg * w_tap);
   if (lds > 160 * 1024) return TG_E_UNSUPPORTED;
   lds = std::max<size_t>(lds, 4 * 2 * tc.co_tile * sizeof(float));  // stats scratch

@@ -101,7 +101,7 @@ def test_conv_forward(kind, cin, cout, N, H, W, dt):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("tile", [L.TILE_64x256, L.TILE_64x64, L.TILE_128x128, L.TILE_32x128, L.TILE_32x64, L.TILE_64x128,
-                                  L.TILE_64x128_8W])
+                                  L.TILE_64x128_8W, L.TILE_64x64_8W])
 def test_conv_tile_configs(tile, dt):
     cout = 128 if tile == L.TILE_128x128 else (32 if tile == L.TILE_32x128 else 64)
     spec = K.ConvSpec("c3", 64, cout)

@@ -16,7 +16,7 @@ from pytorch_tecogan_amd import kernels as K  # noqa: E402
 DEV = "cuda:0"
 REP = 40
 TILES = {"auto": L.TILE_AUTO, "64x256": L.TILE_64x256, "64x64": L.TILE_64x64, "128x128": L.TILE_128x128,
-         "32x128": L.TILE_32x128, "32x64": 5, "64x128": 6, "64x128w8": 7}
+         "32x128": L.TILE_32x128, "32x64": 5, "64x128": 6, "64x128w8": 7, "64x64w8": 8}
 
 
 def time_graph(fn, reps=REP, iters=20):
@@ -113,6 +113,15 @@ def main():
         bench_conv("c3", 128, 128, 24, 16, 16, "dgrad", bf, t)
         bench_conv("c4s2", 64, 128, 24, 64, 64, "fwd", bf, t + ["128x128"])
         bench_conv("c4s2", 64, 128, 24, 64, 64, "dgrad", bf, t + ["128x128"])
+        return
+    if what == "w8s":  # small launches: 32x64 (4 waves) vs 64x64 with 8 waves
+        t = ["32x64", "64x64w8", "64x64", "64x128w8"]
+        bench_conv("c3", 51, 64, 4, 32, 32, "fwd", bf, t)
+        bench_conv("c3", 64, 64, 4, 32, 32, "fwd", bf, t)
+        bench_conv("c3", 128, 128, 12, 16, 16, "fwd", bf, t)
+        bench_conv("c3", 128, 128, 24, 16, 16, "dgrad", bf, t)
+        bench_conv("c3", 128, 128, 12, 32, 32, "fwd", bf, t)
+        bench_conv("c3", 64, 128, 4, 64, 64, "fwd", bf, t)
         return
     if what == "w8":  # 64x128 tile: 4 waves vs 8 waves (two per SIMD from one workgroup)
         t = ["64x128", "64x128w8", "32x64"]
