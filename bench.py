@@ -152,13 +152,10 @@ def roofline_pass(st, dtype):
     E.Conv.dgrad = timed(lab_dgrad, fl_dgrad, orig_dgrad)
     E.Conv.wgrad = timed(lambda self, *a: f"wgrad_kernel<{'BF16' if dtype == 'bf16' else 'F32'}, {self.spec.nslots}, ..> + "
                          "wgrad_finalize_kernel", fl_wgrad, orig_wgrad)
-    side = (st.sB, st.sC)
-    st.sB = st.sC = torch.cuda.current_stream()  # serialise the fork/join schedule: isolated per-launch durations
-    pools = (st.G.side.streams, st.D.side.streams)
-    st.G.side.streams, st.D.side.streams = [], []
     try:
         # park the GPU behind a ~60 ms spin kernel so that the host enqueues the whole eager step ahead of it: the event
-        # pairs then bracket back-to-back kernel executions, not host launch gaps (eager launches are host-bound here)
+        # pairs then bracket back-to-back kernel executions, not host launch gaps (eager launches are host-bound here).
+        # _forward_backward runs both lanes of the step on ONE stream, in dependency order: isolated launch durations.
         torch.cuda.synchronize()
         torch.cuda._sleep(int(0.06 * 2.0e9))
         st._forward_backward(True)
@@ -166,8 +163,6 @@ def roofline_pass(st, dtype):
     finally:
         E.Conv.fwd, E.Conv.dgrad, E.Conv.wgrad = orig_fwd, orig_dgrad, orig_wgrad
         K.resblock_fwd, K.resblock_bwd, E.WgradGroup.launch = orig_rb, orig_rbb, orig_group
-        st.sB, st.sC = side
-        st.G.side.streams, st.D.side.streams = pools
     fam = {}
     for label, fl, e0, e1 in recs:
         d = fam.setdefault(label, dict(launches=0, flops=0.0, ms=0.0))

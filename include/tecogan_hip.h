@@ -108,6 +108,16 @@ int tg_conv_pick_tile(const tg_conv_desc* d);
 int tg_conv(const tg_conv_desc* d, const void* in, const void* w_packed, const float* bias, const void* res,
             const void* mask, void* out, float* stats, void* stream);
 
+/* The same 3x3 stride-1 convolution (flip = 0: forward, taps dy = t/3-1, dx = t%3-1; flip = 1: input-gradient, taps mirrored,
+ * w_packed = the role-swapped packing) for DENSE launches: persistent workgroups that keep their weights in registers and
+ * walk pixel tiles of 8x16 with a double-buffered LDS patch (csrc/conv3_rw.hip).  bf16, Cin in {64, 128}, Cout % 64 == 0,
+ * else TG_E_UNSUPPORTED (use tg_conv).  Epilogue as tg_conv: +bias, +res, act (NONE/RELU/LRELU), *act'(mask), NHWC store,
+ * stats (may be null; stats_mode 1: per-channel sums, 2: sums and sums of squares; [stats_groups][2][Cout], ACCUMULATED).
+ * max_workgroups: 0 = one per CU (256); the grid is min(tiles, max_workgroups / (Cout/64)) x Cout/64. */
+int tg_conv3x3_rw(int dtype, const void* in, const void* w_packed, const float* bias, const void* res, const void* mask,
+                  void* out, float* stats, int N, int H, int W, int Cin, int Cout, int flip, int act, int mask_mode,
+                  int stats_mode, int stats_groups, int max_workgroups, void* stream);
+
 /* Conv-transpose k3 s2 p1 op1 forward (code/ops.py:45-54 conv2_tran; code/models.py:72,74) as ONE sub-pixel launch: a
  * workgroup computes all four output classes of its input tile from one staged patch (tg_conv runs the classes as four sets
  * of workgroups).  in [N][IH][IW][Cin] -> out [N][2IH][2IW][Cout], w_packed = the 9-slot forward packing, epilogue
@@ -262,6 +272,11 @@ int tg_content_loss(int dtype, const float* gen, const float* y, void* dpre, flo
 int tg_loss_finalize(const float* prob, const float* acc, float* scalars, float* dlogit, int tb, const float* cfg,
                      void* stream);
 
+/* d(logit) of the REAL half only: dlogit[n] = -(1/tb) * pr*(1-pr)/(pr+eps), n < tb (the real-half term of t_discrim_loss,
+ * code/train.py:304-307; eps = cfg[6]).  Lets the real half's D backward start before the fake half exists;
+ * tg_loss_finalize later writes the same values again. */
+int tg_dlogit_real(const float* prob, float* dlogit, int tb, const float* cfg, void* stream);
+
 /* dst[i] (+)= sum_r src[r*stride + i], i < n: folds the replicated per-channel statistics of tg_conv. */
 int tg_reduce_replicas(const float* src, int replicas, int stride, int n, float* dst, int accumulate, void* stream);
 
@@ -269,6 +284,13 @@ int tg_reduce_replicas(const float* src, int replicas, int stride, int n, float*
 /* hyper_dev (device floats): lr, beta1, beta2, eps, 1-beta1^t, 1-beta2^t, grad_scale - in memory so that a captured
  * hipGraph picks up each step's values. */
 int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, void* stream);
+
+/* ---- step schedule support (no reference counterpart: the reference runs everything on one CUDA stream) ------- */
+/* Creates a stream confined to every CU except the first `reserve_cus` CU-mask bits (hipExtStreamCreateWithCUMask; 64 bits
+ * = 8 CUs on each of the 8 XCDs of an MI355X).  The dense lane of the step runs there, so that the generator chain's
+ * 64-workgroup launches on an ordinary stream always find idle CUs.  *stream_out is a hipStream_t. */
+int tg_stream_create_cumask(int reserve_cus, void** stream_out);
+int tg_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

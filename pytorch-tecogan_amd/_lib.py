@@ -51,6 +51,7 @@ _PROTOS = {
     "tg_pack_conv_weights_multi": (_I, [_I, _P, _I, _I, _P]),
     "tg_conv_pick_tile": (_I, [C.POINTER(ConvDesc)]),
     "tg_conv": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "tg_conv3x3_rw": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "tg_wgrad_slab_floats": (_L, [C.POINTER(WgradDesc)]),
     "tg_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P]),
     "tg_wgrad_multi": (_I, [C.POINTER(WgradDesc), _P, _I, _P]),
@@ -80,8 +81,11 @@ _PROTOS = {
     "tg_absdiff_nchw": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
     "tg_content_loss": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _I, _F, _P]),
     "tg_loss_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P]),
+    "tg_dlogit_real": (_I, [_P, _P, _I, _P, _P]),
     "tg_reduce_replicas": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "tg_adam": (_I, [_P, _P, _P, _P, _L, _P, _P]),
+    "tg_stream_create_cumask": (_I, [_I, C.POINTER(C.c_void_p)]),
+    "tg_stream_destroy": (_I, [_P]),
 }
 
 EXPORTED = tuple(_PROTOS.keys())

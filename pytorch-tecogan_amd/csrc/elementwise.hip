@@ -509,6 +509,22 @@ extern "C" int tg_loss_finalize(const float* prob, const float* acc, float* scal
   return tg_launch_status();
 }
 
+namespace {
+__global__ void dlogit_real_kernel(const float* __restrict__ prob, float* __restrict__ dlogit, int tb,
+                                   const float* __restrict__ cfg) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= tb) return;
+  const float eps = cfg[6], inv = 1.f / (float)tb, pr = prob[n];
+  dlogit[n] = -inv * (1.f / (pr + eps)) * pr * (1.f - pr);  // same expression as loss_finalize_kernel
+}
+}  // namespace
+
+extern "C" int tg_dlogit_real(const float* prob, float* dlogit, int tb, const float* cfg, void* stream) {
+  if (!prob || !dlogit || !cfg || tb <= 0) return TG_E_BADARG;
+  hipLaunchKernelGGL(dlogit_real_kernel, dim3((tb + 63) / 64), dim3(64), 0, (hipStream_t)stream, prob, dlogit, tb, cfg);
+  return tg_launch_status();
+}
+
 extern "C" int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, void* stream) {
   if (!p || !g || !m || !v || !hyper_dev || n <= 0) return TG_E_BADARG;
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,

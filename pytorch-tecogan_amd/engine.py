@@ -129,6 +129,11 @@ class Conv:
             self.last_desc = "c4s2"  # compile-time-tap stride-2 kernel (csrc/conv4s2_mfma.hip)
             K.conv4s2_fwd(x, self.wf, self.bias, out, stats, groups)
             return
+        if self.spec.kind == "c3" and nchw is None and self.tile == L.TILE_AUTO and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) \
+                and K.rw_eligible(self.dt, self.cin_p, self.cout_p, N * H * W):
+            self.last_desc = "rw"  # persistent register-weights kernel (csrc/conv3_rw.hip)
+            K.conv3x3_rw(x, self.wf, out, False, bias=self.bias, res=res, act=act, stats=stats, stats_mode=2, groups=groups)
+            return
         key = ("f", N, H, W, act, res is not None, stats is not None, groups, nchw is not None and nchw[2:])
         ent = self._desc.get(key)
         if ent is None:
@@ -174,6 +179,10 @@ class Conv:
             K.conv4s2_dgrad(dout, self.wb, out, mask, mask_mode if mask is not None else L.MASK_NONE)
             return
         st = bias_grad_of.gbias if bias_grad_of is not None else None
+        if self.spec.kind == "c3" and self.tile == L.TILE_AUTO and K.rw_eligible(self.dt, self.cout_p, self.cin_p, N * H * W):
+            self.last_desc = "rw"  # the input-gradient of a 3x3 conv is the same conv with mirrored taps
+            K.conv3x3_rw(dout, self.wb, out, True, res=res, mask=mask, mask_mode=mask_mode, stats=st, stats_mode=1)
+            return
         key = ("d", N, OH, OW, mask_mode, res is not None, st is not None)
         ent = self._desc.get(key)
         if ent is None:
@@ -193,10 +202,9 @@ class Conv:
             return
         K.conv(d, dout, self.wb, out, res=res, mask=mask, stats=st)
 
-    def wgrad(self, x_in, dout, side=None, bias_sum=False):
-        """accumulates dW into the flat gradient buffer (which the step zeroes first).  With `side` (a stream) the two
-        launches go there after waiting for everything enqueued so far on the current stream: weight gradients are leaves
-        of the backward graph, so they can run beside the dgrad chain.  Every conv owns its slab (no sharing hazards).
+    def wgrad(self, x_in, dout, bias_sum=False):
+        """accumulates dW into the flat gradient buffer (which the step zeroes first): one launch writes per-split fp32
+        slabs, the fold adds them into the PyTorch-layout gradient (per conv, or once per network: Finalizer).
         bias_sum: `dout` is the gradient w.r.t. this conv's output, so its per-channel sum (the bias gradient) is taken
         from the Y tiles that pass through the kernel anyway (plain convs only: Y must be `dout`)."""
         x_is_in, S, taps, ca, cb, s_a, s_b = self.spec.wgrad_info()
@@ -220,16 +228,8 @@ class Conv:
         gb = self.gbias if bias_sum else None
         self.fin_job = [slab.data_ptr(), self.gw.data_ptr(), s_a, s_b, nsplit, len(taps), cx, cy, ca, cb,
                         gb.data_ptr() if bias_sum else 0, stride]
-        if self.defer_finalize:  # the network folds every slab in one launch (Finalizer) after its backward pass
-            K.wgrad(d, X, Y, slab)
-            return
-        if side is None:
-            K.wgrad(d, X, Y, slab)
-            K.wgrad_finalize(slab, nsplit, len(taps), cx, cy, ca, cb, self.gw, s_a, s_b, self.slots, True, gb)
-            return
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            K.wgrad(d, X, Y, slab)
+        K.wgrad(d, X, Y, slab)
+        if not self.defer_finalize:  # otherwise the network folds every slab in one launch after its backward pass
             K.wgrad_finalize(slab, nsplit, len(taps), cx, cy, ca, cb, self.gw, s_a, s_b, self.slots, True, gb)
 
 
@@ -288,35 +288,6 @@ class WgradGroup:
         K.wgrad_multi(desc, jobs, len(fin))
 
 
-class SideStreams:
-    """round-robin pool of streams for the backward graph's leaf work (weight gradients).  Measured on MI355X at config 2:
-    9.42 ms/step with 0 side streams, 10.85 / 10.63 / 11.00 ms with 1 / 2 / 3 - the one-workgroup-per-CU wgrad launches and
-    the dgrad launches slow each other down more than they overlap - so the default pool is EMPTY (TECOGAN_WGRAD_STREAMS)."""
-
-    def __init__(self, device, n=2):
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(n)] if device.type == "cuda" and n > 0 else []
-        self.i = 0
-
-    def next(self):
-        if not self.streams:
-            return None
-        s = self.streams[self.i % len(self.streams)]
-        self.i += 1
-        return s
-
-    def prefork(self, origin):
-        """make every side stream part of the capture by forking it from the ORIGIN stream first.  HIP stream capture
-        (ROCm 7.0 / this PyTorch) segfaults when a non-origin captured stream waits on a side stream; forks from any
-        stream are fine as long as all joins go into the origin (tools/capture_probe.py)."""
-        for s in self.streams:
-            s.wait_stream(origin)
-
-    def join(self, into=None):
-        into = into or torch.cuda.current_stream()
-        for s in self.streams:
-            into.wait_stream(s)
-
-
 class Repacker:
     """fp32 master weights -> packed compute copies (forward + dgrad) of every conv of a network in one launch."""
 
@@ -337,9 +308,8 @@ class Repacker:
 
 
 def _defer_finalize():
-    """one fold launch per network needs every slab to survive until the end of the backward pass and the fold to run after
-    all weight-gradient launches: not compatible with side-stream wgrads."""
-    return os.environ.get("TECOGAN_DEFER_FINALIZE", "1") != "0" and int(os.environ.get("TECOGAN_WGRAD_STREAMS", "0")) == 0
+    """one fold launch per network (every slab survives until the end of the backward pass) instead of one per conv"""
+    return os.environ.get("TECOGAN_DEFER_FINALIZE", "1") != "0"
 
 
 class Finalizer:
@@ -347,7 +317,7 @@ class Finalizer:
     of one ~9 us launch per conv).  The job table is rebuilt only when a conv's launch shape changed."""
 
     def __init__(self, convs, device):
-        self.convs, self.dev, self.key, self.jobs = convs, device, None, None
+        self.convs, self.dev, self.tables = convs, device, {}
         for c in convs:
             c.defer_finalize = True
 
@@ -356,12 +326,15 @@ class Finalizer:
             c.defer_finalize = False
 
     def run(self):
+        """folds the slabs of the launches issued since the previous run (a network whose backward pass runs in two
+        parts - the discriminator's real and fake halves - folds after each part; every distinct job set keeps its own
+        device table, so nothing is rebuilt under graph capture)"""
         jobs = [c.fin_job for c in self.convs if c.fin_job is not None]
         key = tuple(tuple(j) for j in jobs)
-        if key != self.key:
-            self.jobs = torch.tensor(jobs, dtype=torch.int64, device=self.dev)
-            self.key = key
-        L.check(L.load().tg_wgrad_finalize_multi(self.jobs.data_ptr(), len(jobs), 64,
+        table = self.tables.get(key)
+        if table is None:
+            table = self.tables[key] = torch.tensor(jobs, dtype=torch.int64, device=self.dev)
+        L.check(L.load().tg_wgrad_finalize_multi(table.data_ptr(), len(jobs), 64,
                                                  torch.cuda.current_stream().cuda_stream), "tg_wgrad_finalize_multi")
 
 
@@ -386,11 +359,13 @@ class BatchNorm:
                    running_mean=self.rm if update else None, running_var=self.rv if update else None,
                    nbt=self.nbt if update else None)
 
-    def backward(self, dy, yact, z, dz, act, groups):
+    def backward(self, dy, yact, z, dz, act, groups, half=None):
+        """half=g: the tensors hold only group g of 2 (see apply); that group's saved statistics / reduction slots are used"""
         N, H, W, C_ = z.shape
-        K.bn_bwd_reduce(dy, yact, z, self.save, self.red, N, H * W, C_, groups, act)
-        K.bn_bwd_apply(dy, yact, z, self.save, self.red, self.gamma, dz, self.dgamma, self.dbeta, N, H * W, C_, groups,
-                       act)
+        save, red = (self.save, self.red) if half is None else (self.save[half], self.red[half])
+        g = groups if half is None else 1
+        K.bn_bwd_reduce(dy, yact, z, save, red, N, H * W, C_, g, act)
+        K.bn_bwd_apply(dy, yact, z, save, red, self.gamma, dz, self.dgamma, self.dbeta, N, H * W, C_, g, act)
 
 
 class Arena:
@@ -500,9 +475,8 @@ class GeneratorEngine:
         self.cout.fwd(a["u4"][sl], None, act=L.ACT_SIGMOID, nchw=(out_buf, out_off, out_n_stride, self.out_ch))
 
     def _alloc_grad(self, chunk=None):
-        """gradient scratch for a backward chunk of `chunk` samples (default: all).  Every gradient tensor has its own
-        buffer: the weight-gradient launches run on side streams and may still be reading a buffer long after the dgrad
-        chain has moved on, so nothing is recycled within a step."""
+        """gradient scratch for a backward pass over `chunk` samples (default: all).  Every gradient tensor has its own
+        buffer: the grouped weight-gradient launch at the end of the pass reads all of them."""
         NS, h, w = self.shape
         NC = chunk or NS
         dev, dt = self.flat.device, self.dt
@@ -511,13 +485,11 @@ class GeneratorEngine:
                      "m128a": e(2 * h, 2 * w, 128), "m128b": e(2 * h, 2 * w, 128), "m64a": e(2 * h, 2 * w, 64),
                      "m64b": e(2 * h, 2 * w, 64), "m64c": e(2 * h, 2 * w, 64),
                      "dA": [e(h, w, 64) for _ in range(self.nrb + 1)], "dH": [e(h, w, 64) for _ in range(self.nrb)]}
-        self.side = SideStreams(dev, int(os.environ.get("TECOGAN_WGRAD_STREAMS", "0")))
 
     def backward(self, s0=0, s1=None, dpre=None):
         """consumes grad['dpre'][:s1-s0] (d loss / d pre-sigmoid of samples [s0,s1)) and ACCUMULATES every weight/bias
         gradient.  The T passes are independent in backward (inputs are detached, code/train.py:90,108), so any
-        sample range may be processed as one batch; ranges must not run concurrently (they add into the same grads).
-        The dgrad chain runs on the current stream, the weight gradients on the side streams."""
+        sample range may be processed as one batch; ranges must not run concurrently (they add into the same grads)."""
         NS = self.shape[0]
         s1 = NS if s1 is None else s1
         n = s1 - s0
@@ -526,29 +498,28 @@ class GeneratorEngine:
         if dpre is not None:
             g["dpre"] = dpre
         RELU = L.MASK_RELU
-        sd = self.side
-        self.cout.wgrad(a["u4"], g["dpre"], sd.next())                         # output bias grad: see TecoGANStep
+        self.cout.wgrad(a["u4"], g["dpre"])                         # output bias grad: see TecoGANStep
         # bias gradients of plain convs come out of their own wgrad launch (bias_sum): the output gradient is that
         # launch's Y operand, so its channel sums cost a few VALU adds there instead of an atomics epilogue here
         self.cout.dgrad(g["dpre"], g["hr64"], mask=a["u4"], mask_mode=RELU)
-        self.c6.wgrad(a["u3"], g["hr64"], sd.next(), bias_sum=True)
+        self.c6.wgrad(a["u3"], g["hr64"], bias_sum=True)
         self.c6.dgrad(g["hr64"], g["hr128"], mask=a["u3"], mask_mode=RELU, bias_grad_of=self.ct4)
-        self.ct4.wgrad(a["u2"], g["hr128"], sd.next())
+        self.ct4.wgrad(a["u2"], g["hr128"])
         self.ct4.dgrad(g["hr128"], g["m128a"])
-        self.c32.wgrad(a["h2"], g["m128a"], sd.next())
+        self.c32.wgrad(a["h2"], g["m128a"])
         self.c32.dgrad(g["m128a"], g["m128b"], mask=a["h2"], mask_mode=RELU)
-        self.c30.wgrad(a["u1"], g["m128b"], sd.next(), bias_sum=True)
+        self.c30.wgrad(a["u1"], g["m128b"], bias_sum=True)
         self.c30.dgrad(g["m128b"], g["m64a"])
-        self.c22.wgrad(a["hh"], g["m64a"], sd.next())
+        self.c22.wgrad(a["hh"], g["m64a"])
         self.c22.dgrad(g["m64a"], g["m64b"], mask=a["hh"], mask_mode=RELU)
-        self.c20.wgrad(a["u0"], g["m64b"], sd.next(), bias_sum=True)
+        self.c20.wgrad(a["u0"], g["m64b"], bias_sum=True)
         self.c20.dgrad(g["m64b"], g["m64c"], mask=a["u0"], mask_mode=RELU, bias_grad_of=self.ct0)
-        self.ct0.wgrad(a["a"][self.nrb], g["m64c"], sd.next())
+        self.ct0.wgrad(a["a"][self.nrb], g["m64c"])
         dA, dH = g["dA"], g["dH"]
         self.ct0.dgrad(g["m64c"], dA[self.nrb])
         grouped = self.finalizer is not None and self.trunk_group is not None
         wg = (lambda c, x, y, b=False: self.trunk_group.add(c, x, y, b)) if grouped else \
-            (lambda c, x, y, b=False: c.wgrad(x, y, sd.next(), bias_sum=b))
+            (lambda c, x, y, b=False: c.wgrad(x, y, bias_sum=b))
         for i in range(self.nrb - 1, -1, -1):
             c1, c2 = self.rb[i]
             wg(c2, a["h"][i], dA[i + 1])
@@ -566,7 +537,6 @@ class GeneratorEngine:
         wg(self.conv0, a["in0"], dA[0], True)
         if grouped:
             self.trunk_group.launch()  # 2*nrb+1 layers of one shape (64 -> 64 channels, 3x3, h x w): one grid
-        sd.join()
         if self.finalizer is not None and s1 == NS:  # last (or only) sample range of the step
             self.finalizer.run()
 
@@ -739,7 +709,6 @@ class DiscriminatorEngine:
         self.gbuf = g
         self.g_c0 = e(H, 64)
         self.dlogit = torch.empty(N, device=dev)
-        self.side = SideStreams(dev, int(os.environ.get("TECOGAN_WGRAD_STREAMS", "0")))
 
     def stage_out(self, k):
         return self.act["net"][k][self.nrb - 1] if (k <= 3 and self.nrb > 0) else self.act["n"][k]
@@ -776,16 +745,27 @@ class DiscriminatorEngine:
             prev = net
         K.fc_head_fwd(v(a["n"][5]), self.fc_w, self.fc_b, self.prob[sl], sl.stop - sl.start, self.fc_hw, 3, 32)
 
-    def backward(self, groups=2, join=True):
-        """consumes self.dlogit; accumulates all D gradients.  dgrad / BN-backward chain on the current stream, weight
-        gradients on the side streams (join=False: the caller joins self.side into the capture's origin stream)."""
-        a, g, sd = self.act, self.gbuf, self.side
-        N = a["in"].shape[0]
-        K.fc_head_bwd(a["n"][5], self.fc_w, self.dlogit, g["dn"][5], self.g_fc_w, self.g_fc_b, N, self.fc_hw, 3, 32)
+    def backward(self, groups=2, half=None):
+        """consumes self.dlogit; accumulates all D gradients (everything on the current stream).
+        half=0/1: only the real / fake half of the 2-group batch (the loss is a mean of per-half terms and BN statistics
+        are per half, code/train.py:199-203,304-307, so the halves are independent in backward): the real half's backward
+        can run before the generator has produced the frames the fake half needs."""
+        N = self.act["in"].shape[0]
+        if half is None:
+            sl = slice(0, N)
+        else:
+            sl = slice(half * (N // 2), (half + 1) * (N // 2))
+        cut = lambda v: ({k: cut(x) for k, x in v.items()} if isinstance(v, dict) else
+                         [x[sl] for x in v] if isinstance(v, list) else v[sl])
+        a, g = cut(self.act), cut(self.gbuf)
+        n = sl.stop - sl.start
+        K.fc_head_bwd(a["n"][5], self.fc_w, self.dlogit[sl], g["dn"][5], self.g_fc_w, self.g_fc_b, n, self.fc_hw, 3, 32)
         d_net = g["dn"][5]  # gradient w.r.t. the current stage's output
         grouped = self.finalizer is not None and self.res_group is not None
         wg = (lambda c, x, y, b=False: self.res_group.add(c, x, y, b)) if grouped else \
-            (lambda c, x, y, b=False: c.wgrad(x, y, sd.next(), bias_sum=b))
+            (lambda c, x, y, b=False: c.wgrad(x, y, bias_sum=b))
+        stage_out = lambda k: a["net"][k][self.nrb - 1] if (k <= 3 and self.nrb > 0) else a["n"][k]
+        g_c0 = self.g_c0[sl]
         for k in range(5, 0, -1):
             if k <= 3:
                 for j in range(self.nrb - 1, -1, -1):
@@ -793,7 +773,7 @@ class DiscriminatorEngine:
                     net_in = a["net"][k][j - 1] if j > 0 else a["n"][k]
                     d_r, d_h = g["dr"][k][j], g["dh"][k][j]
                     d_in = g["dnet"][k][j - 1] if j > 0 else g["dn"][k]
-                    bnj.backward(d_net, None, a["r"][k][j], d_r, L.ACT_NONE, groups)
+                    bnj.backward(d_net, None, a["r"][k][j], d_r, L.ACT_NONE, groups, half=half)
                     wg(c2, a["h"][k][j], d_r)
                     c2.dgrad(d_r, d_h, mask=a["h"][k][j], mask_mode=L.MASK_RELU)
                     wg(c1, net_in, d_h, True)
@@ -803,17 +783,15 @@ class DiscriminatorEngine:
                     self.res_group.launch()  # the 2*nrb same-shaped residual convs of this stage in one grid
             conv, bn = self.blk[k]
             d_z = g["dz"][k]
-            bn.backward(d_net, a["n"][k], a["z"][k], d_z, L.ACT_LRELU, groups)
-            prev = self.stage_out(k - 1) if k > 1 else a["c0"]
-            conv.wgrad(prev, d_z, sd.next())
+            bn.backward(d_net, a["n"][k], a["z"][k], d_z, L.ACT_LRELU, groups, half=half)
+            prev = stage_out(k - 1) if k > 1 else a["c0"]
+            conv.wgrad(prev, d_z)
             if k > 1:
                 d_prev = g["dnet"][k - 1][self.nrb - 1] if (k - 1 <= 3 and self.nrb > 0) else g["dn"][k - 1]
                 conv.dgrad(d_z, d_prev)
                 d_net = d_prev
             else:
-                conv.dgrad(d_z, self.g_c0, mask=a["c0"], mask_mode=L.MASK_LRELU)
-                self.conv0.wgrad(a["in"], self.g_c0, sd.next(), bias_sum=True)
-        if join:
-            sd.join()
+                conv.dgrad(d_z, g_c0, mask=a["c0"], mask_mode=L.MASK_LRELU)
+                self.conv0.wgrad(a["in"], g_c0, bias_sum=True)
         if self.finalizer is not None:
             self.finalizer.run()

@@ -4,6 +4,8 @@ import ctypes as C
 from dataclasses import dataclass, field
 from typing import List, Tuple
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -19,6 +21,10 @@ def tg_dtype(dt):
     if dt == torch.float32:
         return L.TG_F32
     raise L.TecoganHipError(f"unsupported element type {dt}")
+
+
+_RW = os.environ.get("TECOGAN_RW", "0") != "0"  # routing switched on once the step tests have run with it
+_RW_MINPIX = int(os.environ.get("TECOGAN_RW_MINPIX", "8192"))
 
 
 def _stream():
@@ -165,6 +171,23 @@ def reduce_replicas(src, replicas, stride, n, dst, accumulate=True):
 def conv(desc, x, w_packed, out, bias=None, res=None, mask=None, stats=None):
     L.check(L.load().tg_conv(C.byref(desc), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(res), _ptr(mask), _ptr(out),
                              _ptr(stats), _stream()), "tg_conv")
+
+
+def conv3x3_rw(x, w_packed, out, flip=False, bias=None, res=None, mask=None, mask_mode=L.MASK_NONE, act=L.ACT_NONE,
+               stats=None, stats_mode=2, groups=1, max_workgroups=0):
+    """3x3 stride-1 conv / input-gradient through the persistent register-weights kernel (csrc/conv3_rw.hip):
+    x [N,H,W,Cin] -> out [N,H,W,Cout], bf16, Cin in {64,128}, Cout % 64 == 0"""
+    N, H, W, cin = x.shape
+    L.check(L.load().tg_conv3x3_rw(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(res), _ptr(mask), _ptr(out),
+                                   _ptr(stats), N, H, W, cin, out.shape[3], int(flip), act,
+                                   mask_mode if mask is not None else L.MASK_NONE, stats_mode, groups, max_workgroups,
+                                   _stream()), "tg_conv3x3_rw")
+
+
+def rw_eligible(dtype_t, cin_p, cout_p, npix):
+    """launch shapes the register-weights kernel takes (TECOGAN_RW=0 switches it off; TECOGAN_RW_MINPIX: smallest
+    N*H*W routed to it)"""
+    return _RW and dtype_t == torch.bfloat16 and cin_p in (64, 128) and cout_p % 64 == 0 and npix >= _RW_MINPIX
 
 
 def slot_table(n, device):
@@ -400,6 +423,10 @@ def content_loss(gen, y, dpre, acc, B, T, H, W, gscale, t0=0, t1=None, pp_T=0, p
     dt = tg_dtype(dpre.dtype) if dpre is not None else L.TG_F32
     L.check(L.load().tg_content_loss(dt, _ptr(gen), _ptr(y), _ptr(dpre), _ptr(acc), B, T, H, W, gscale, t0,
                                      T if t1 is None else t1, pp_T, pp_coef, _stream()), "tg_content_loss")
+
+
+def dlogit_real(prob, dlogit, tb, cfg):
+    L.check(L.load().tg_dlogit_real(_ptr(prob), _ptr(dlogit), tb, _ptr(cfg), _stream()), "tg_dlogit_real")
 
 
 def loss_finalize(prob, acc, scalars, dlogit, tb, cfg):

@@ -8,7 +8,8 @@ buffers - which is what makes it hipGraph-capturable - plus the generator-only r
   * reported gen_loss = content + 2*ratio*t_adv + layer_sum*dt_ratio (aliased tensor), gradient of G = content only;
   * BN running statistics updated twice per step (real pass, then fake pass).
 Data parallel: sequences are sharded over ranks; the flat G and D gradient buffers are all-reduced over RCCL, the G
-all-reduce overlapping the D backward pass."""
+all-reduce issued behind the G backward so that it runs while the fake half of the D backward is still in flight
+(TecoGANStep._run_lanes)."""
 import os
 
 import torch
@@ -81,7 +82,36 @@ def build_tables(B, T, h, K, pingpang=False, fnet_flow=False):
     return out
 
 
+def lane_stream(device, reserve_cus):
+    """stream of the dense lane: confined to every CU except the first `reserve_cus` mask bits (tg_stream_create_cumask),
+    or an ordinary stream when reserve_cus == 0"""
+    if reserve_cus <= 0:
+        return torch.cuda.Stream(device=device)
+    import ctypes
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        L.check(L.load().tg_stream_create_cumask(int(reserve_cus), ctypes.byref(h)), "tg_stream_create_cumask")
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
 class TecoGANStep:
+    """The step as two LANES of launches (each a linear sequence, so each is one hipGraph replayed on its own stream):
+
+        lane A (current stream): prep (zeroing, pseudo-flow, T_vel) | generator chain, T passes | G backward (T*B samples)
+        lane B (stream sB)     :          D input (real), D forward + backward of the REAL half | D input (fake), D forward,
+                                          layer losses, loss scalars, D backward of the FAKE half
+        update (lane A)        : [data parallel: all-reduce G grads after lane A, D grads after lane B] 2 x Adam, repack
+
+    The chain is 420 dependent launches of 64-256 workgroups; what slows it down when dense work shares the chip is
+    QUEUEING: its launches need CUs with free LDS, and a dense launch holds every CU with workgroups that run for tens of
+    microseconds.  Stream priorities do nothing on MI355X and a CU mask does not survive inside one forked graph capture
+    (profiles/r02_a_overlap_probe_priority_cumask.log), hence one graph per lane; lane B's stream can be masked off the
+    first TECOGAN_CU_RESERVE CUs so that the chain's residual-block launches (64 workgroups) always start at once (default 0:
+    with the real kernels the dense lane loses more on 192 CUs than the chain gains, profiles/r02_b_lane_matrix.log).
+    The real half of the discriminator does not depend on the generator at all (code/train.py:160-185,199-203,304-307:
+    separate BN statistics, loss = mean of per-half terms), so its forward AND backward run beside the chain; only the
+    fake half is left for the time after the chain, beside the G backward."""
+
     def __init__(self, G, D, B, T, h, args, device, use_graph=False, process_group=None, world_size=1):
         """G: GeneratorEngine, D: DiscriminatorEngine (already bound to flat parameter buffers on `device`)."""
         if not getattr(args, "Dt_mergeDs", True):
@@ -119,23 +149,20 @@ class TecoGANStep:
         self.ring = torch.zeros(256, 32, dtype=torch.float32).pin_memory()
         self.ring_i = 0
         G.alloc(T * B, h, h)
-        # Frame-chunked G backward overlapping the rest of the chain was measured SLOWER (13.8 / 14.8 / 16.8 ms per step at
-        # 1 / 2 / 5 chunks): the dense backward launches hold every CU's LDS, so the chain's latency-critical launches
-        # queue behind them.  Default: one chunk, after the chain.
-        nchunk = max(1, min(T, int(os.environ.get("TECOGAN_GBWD_CHUNKS", "1"))))
-        bounds = [round(i * T / nchunk) for i in range(nchunk + 1)]
-        self.chunks = [(bounds[i], bounds[i + 1]) for i in range(nchunk)]
-        cmax = max(t1 - t0 for t0, t1 in self.chunks) * B
-        G._alloc_grad(cmax)
-        if nchunk > 1:
-            G.side.streams = []  # chunked backward runs on a forked stream: no nested joins under capture
-            if G.finalizer is not None:  # every chunk reuses the slabs: fold per conv
-                G.finalizer.disable()
-                G.finalizer = None
-        # one d(pre-sigmoid) buffer per chunk: chunk i+1's loss kernel must not overwrite what chunk i's backward reads
-        self.dpre = [torch.empty((t1 - t0) * B, H, H, 32, dtype=G.dt, device=device) for t0, t1 in self.chunks]
-        self.sB, self.sC = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
-        self.dreal_early = os.environ.get("TECOGAN_DREAL_EARLY", "1") != "0"
+        G._alloc_grad()
+        self.dpre = torch.empty(T * B, H, H, 32, dtype=G.dt, device=device)
+        # TECOGAN_LANES=0: the whole forward/backward as ONE forked capture (lane B's stream is then an ordinary one:
+        # a CU mask is lost inside a forked graph)
+        self.lanes = os.environ.get("TECOGAN_LANES", "1") != "0"
+        # measured (tools/lane_matrix.sh, profiles/r02_b_lane_matrix.log): reserving CUs for the chain does not pay - the dense
+        # lane loses more on 192 CUs than the chain gains - so the default is an unmasked lane B
+        self.reserve = int(os.environ.get("TECOGAN_CU_RESERVE", "0")) if self.lanes else 0
+        # hipExtStreamCreateWithCUMask makes a BLOCKING stream: it serialises against the legacy default stream.  Lane A
+        # therefore runs on a stream of its own as well (the caller's stream only brackets the step)
+        self.sA = torch.cuda.Stream(device=device)
+        self.sB = lane_stream(device, self.reserve)
+        self.dreal_bwd_early = os.environ.get("TECOGAN_DREAL_BWD", "1") != "0"
+        self.ev = {k: torch.cuda.Event() for k in ("prep", "chain", "d")}
         D.alloc(2 * self.tb, H)
         self._tables()
         self.graphs = None
@@ -181,21 +208,13 @@ class TecoGANStep:
         slot.copy_(torch.tensor(c, dtype=torch.float32))
         self.params_dev.copy_(slot, non_blocking=True)
 
-    # ----------------------------------------------------------------------------------------------------------
-    def _forward_backward(self, include_d_backward, parts=None):
-        """Everything up to (and including) the backward passes, as a fork/join over three streams so that the serial
-        generator chain (<= 64 workgroups per launch at B=4) shares the chip with independent dense work:
-            main : pseudo-flow, T_vel | G pass 0 .. T-1 (each: warp+pack, 41 convs) | content loss per frame chunk
-            sB   : D input (real) -> D forward (real half)  ...............| D input (fake) -> D forward (fake half)
-                   -> layer losses -> loss scalars, d(logit) -> [D backward when single-GPU]
-            sC   : G backward of frame chunk 0 (while the chain is still producing chunk 1), then chunk 1, ...
-        Captured in a hipGraph the fork/join become graph edges."""
+    # ---------------------------------------------------------------------------------------------------------- pieces
+    # Each piece is a linear launch sequence on the CURRENT stream (no forks inside), so it can be captured as one graph
+    # and replayed on whatever stream its lane uses.
+    def _prep(self):
+        """zero the accumulators / gradient buffers; pseudo-flow, LR warp loss (logged only) and T_vel"""
         G, D, B, T, h, H = self.G, self.D, self.B, self.T, self.h, self.H
         hh, HH = h * h, H * H
-        main, sB, sC = torch.cuda.current_stream(), self.sB, self.sC
-        on = (lambda name: True) if parts is None else (lambda name: name in parts)  # tools/step_breakdown.py only
-        G.side.prefork(main)
-        D.side.prefork(main)
         self.acc.zero_()
         D.arena.zero()
         G.flat.g.zero_()
@@ -211,18 +230,25 @@ class TecoGANStep:
         K.copy_blocks(self.flow, self.tv_csrc, self.tvel, self.tv_cdst, self.n_tvc, 2 * HH)
         if self.n_tvb:
             K.up4_planes(self.x, self.tv_bsrc, self.tvel, self.tv_bdst, self.n_tvb, h, h, pre=4.0, post_a=2.0, post_b=-1.0)
-        tb = self.tb
-        pp_T = self.T_in if self.pingpang else 0
-        pp_coef = (2.0 * self.args.pp_scaling / (B * (self.T_in - 1) * 3 * H * H)) if (self.pingpang and self.args.pp_scaling > 0) else 0.0
-        early = self.dreal_early
-        sB.wait_stream(main)
-        with torch.cuda.stream(sB):
-            if on("dreal") and early:
-                K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"][:tb], B, T, self.K, h, self.border, half=0)
-                K.nhwc_to_nchw(D.act["in"][:tb], self.target, 27 * HH, tb, 27, H, H)
-                D.forward(update_stats=True, half=0)
-        ci = 0
-        for t in range(T if on("chain") else 0):
+
+    def _d_real(self, backward=None):
+        """real half of the discriminator: input assembly, forward (BN statistics of this half, first running-stat
+        update) and - independent of the generator - its backward pass"""
+        D, B, T, h, H, tb = self.D, self.B, self.T, self.h, self.H, self.tb
+        backward = self.dreal_bwd_early if backward is None else backward
+        K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"][:tb], B, T, self.K, h, self.border, half=0)
+        K.nhwc_to_nchw(D.act["in"][:tb], self.target, 27 * H * H, tb, 27, H, H)
+        D.forward(update_stats=True, half=0)
+        if backward:
+            K.dlogit_real(D.prob, D.dlogit, tb, self.cfg)
+            D.backward(groups=2, half=0)
+
+    def _chain(self):
+        """the T recurrent generator passes (each: warp + pack, conv0, residual trunk, up-sampling stage), then the content
+        loss and d(loss)/d(pre-sigmoid) of all frames"""
+        G, B, T, h, H = self.G, self.B, self.T, self.h, self.H
+        hh, HH = h * h, H * H
+        for t in range(T):
             dst = G.act["in0"][t * B:(t + 1) * B]
             if t == 0:
                 K.gen_input(self.x, 0, T * 3 * hh, None, 0, 0, None, 0, 0, dst, B, h, h)
@@ -230,42 +256,33 @@ class TecoGANStep:
                 K.gen_input(self.x, t * 3 * hh, T * 3 * hh, self.gen, (t - 1) * 3 * HH, T * 3 * HH, self.flow,
                             (t - 1) * 2 * HH, (T - 1) * 2 * HH, dst, B, h, h)
             G.forward(t * B, B, self.gen, t * 3 * HH, T * 3 * HH)
-            if t + 1 == self.chunks[ci][1] and on("gbwd"):
-                t0, t1 = self.chunks[ci]
-                K.content_loss(self.gen, self.y, self.dpre[ci], self.acc, B, T, H, H, 1.0 / (B * T * 3 * H), t0, t1, pp_T,
-                               pp_coef)
-                if len(self.chunks) > 1:  # experimental frame-chunked backward beside the chain (measured slower)
-                    sC.wait_stream(main)
-                    with torch.cuda.stream(sC):
-                        G.backward(t0 * B, t1 * B, dpre=self.dpre[ci])
-                ci += 1
-        sB.wait_stream(main)  # all frames generated, content-loss sum complete
-        if len(self.chunks) == 1 and on("gbwd") and on("chain"):
-            # the chain is over, so the main (origin) stream carries the G backward's dgrad chain; its weight gradients
-            # fan out to G.side and join back into main
-            G.backward(0, T * B, dpre=self.dpre[0])
-        with torch.cuda.stream(sB):
-            if on("dfake") and early:
-                K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"][tb:], B, T, self.K, h, self.border, half=1)
-                D.forward(update_stats=True, half=1)
-            elif on("dfake"):  # both halves as ONE batch of 2*tb samples (BN statistics per half), after the chain
-                K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"], B, T, self.K, h, self.border, half=-1)
-                K.nhwc_to_nchw(D.act["in"][:tb], self.target, 27 * HH, tb, 27, H, H)
-                D.forward(groups=2, update_stats=True)
-            if self.args.D_LAYERLOSS and on("dfake"):
-                for i, l in enumerate(D.layers()):
-                    n = tb * l.shape[1] * l.shape[2]
-                    K.absdiff_sum(l[:tb], l[tb:], self.acc, 2 + i, n, l.shape[3], l.shape[3])
-            K.loss_finalize(D.prob, self.acc, self.scalars, D.dlogit, tb, self.cfg)
-            if include_d_backward and on("dbwd"):
-                D.backward(groups=2, join=False)
-        main.wait_stream(sB)
-        main.wait_stream(sC)
-        D.side.join(main)
+        pp_T = self.T_in if self.pingpang else 0
+        pp_coef = (2.0 * self.args.pp_scaling / (B * (self.T_in - 1) * 3 * H * H)) if (self.pingpang and self.args.pp_scaling > 0) else 0.0
+        K.content_loss(self.gen, self.y, self.dpre, self.acc, B, T, H, H, 1.0 / (B * T * 3 * H), 0, T, pp_T, pp_coef)
+
+    def _g_backward(self):
+        """G backward for all T*B samples as ONE batch (the passes are independent in backward: every generator input is
+        detached, code/train.py:90,108); the output bias gradient comes from the content-loss kernel's channel sums"""
+        G = self.G
+        G.backward(0, self.T * self.B, dpre=self.dpre)
         G.cout.gbias[:3] += self.acc[8:11]
 
-    def _d_backward(self):
-        self.D.backward(groups=2)
+    def _d_fake(self, backward=True):
+        """fake half: input assembly from the generated frames, forward, layer losses, every loss scalar and d(logit),
+        then the backward pass of the fake half (or of both halves when the real half has not run its own yet)"""
+        D, B, T, h, tb = self.D, self.B, self.T, self.h, self.tb
+        K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"][tb:], B, T, self.K, h, self.border, half=1)
+        D.forward(update_stats=True, half=1)
+        if self.args.D_LAYERLOSS:
+            for i, l in enumerate(D.layers()):
+                n = tb * l.shape[1] * l.shape[2]
+                K.absdiff_sum(l[:tb], l[tb:], self.acc, 2 + i, n, l.shape[3], l.shape[3])
+        K.loss_finalize(D.prob, self.acc, self.scalars, D.dlogit, tb, self.cfg)
+        if backward:
+            if self.dreal_bwd_early:
+                D.backward(groups=2, half=1)
+            else:
+                D.backward(groups=2)
 
     def _update(self):
         G, D = self.G, self.D
@@ -274,45 +291,96 @@ class TecoGANStep:
         G.repack()
         D.repack()
 
+    PIECES = ("prep", "d_real", "chain", "d_fake", "g_bwd", "update")
+
+    def _piece_fns(self):
+        return {"prep": self._prep, "d_real": self._d_real, "chain": self._chain, "d_fake": self._d_fake,
+                "g_bwd": self._g_backward, "update": self._update}
+
+    def _forward_backward(self, include_d_backward=True):
+        """everything up to the update on the CURRENT stream alone, in dependency order (serial; tools and bench.py's
+        per-launch roofline pass use this)"""
+        self._prep()
+        self._d_real()
+        self._chain()
+        self._d_fake(backward=include_d_backward)
+        self._g_backward()
+
+    # ---------------------------------------------------------------------------------------------------------- schedule
     def _allreduce(self, buf):
         if self.pg is not None and os.environ.get("TECOGAN_FORCE_DP_SEGMENTS", "0") == "1":
-            import torch.distributed as dist  # test hook: exercise the RCCL call path even with one rank
+            import torch.distributed as dist  # test hook: exercise the collective's call path even with one rank
             return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         return parallel.allreduce_sum_async(buf, self.pg, self.world)
 
-    def _segments(self):
-        """[forward + both backward passes | update].  Data parallel: both flat gradient buffers are all-reduced (RCCL, async,
-        concurrently) between the two segments.  A three-segment variant that overlapped the G all-reduce with a separate
-        D-backward segment was measured 0.9 ms/step slower on one GPU (it gives up the G-backward / D-backward overlap to hide
-        a 7 MB all-reduce of ~0.1 ms), so it is not used."""
-        return [lambda: self._forward_backward(True), None, self._update]
-
-    def _run(self, segs):
-        segs[0]()
+    def _run_lanes(self, fn):
+        """fn: piece name -> callable (the eager pieces or their graphs' replay).  Cross-lane dependencies are events
+        recorded between the pieces; the collectives of data-parallel mode are issued where their inputs become final: the
+        G all-reduce behind lane A's G backward - it then runs while lane B is still in the fake half's backward - and the
+        D all-reduce behind lane B.  Work.wait() of the RCCL backend makes the current STREAM wait (no host block)."""
+        main, sB, ev = torch.cuda.current_stream(), self.sB, self.ev
+        fn["prep"]()
+        ev["prep"].record(main)
+        sB.wait_event(ev["prep"])
+        with torch.cuda.stream(sB):
+            fn["d_real"]()
+        fn["chain"]()
+        ev["chain"].record(main)
+        sB.wait_event(ev["chain"])
+        with torch.cuda.stream(sB):
+            fn["d_fake"]()
+        fn["g_bwd"]()
         w1 = self._allreduce(self.G.flat.g)
-        if segs[1] is not None:
-            segs[1]()
+        with torch.cuda.stream(sB):
+            w2 = self._allreduce(self.D.flat.g)
+            ev["d"].record(sB)
+        main.wait_event(ev["d"])
+        for w in (w1, w2):
+            if w is not None:
+                w.wait()
+        fn["update"]()
+
+    def _fork_join(self):
+        """TECOGAN_LANES=0: the same schedule as ONE capturable fork/join (all joins go into the origin stream: HIP stream
+        capture segfaults when a non-origin captured stream joins a side stream, tools/capture_probe.py)"""
+        main, sB = torch.cuda.current_stream(), self.sB
+        self._prep()
+        sB.wait_stream(main)
+        with torch.cuda.stream(sB):
+            self._d_real()
+        self._chain()
+        sB.wait_stream(main)
+        with torch.cuda.stream(sB):
+            self._d_fake()
+        self._g_backward()
+        main.wait_stream(sB)
+
+    def _run_single(self, fwd_bwd, update):
+        fwd_bwd()
+        w1 = self._allreduce(self.G.flat.g)
         w2 = self._allreduce(self.D.flat.g)
         for w in (w1, w2):
             if w is not None:
                 w.wait()
-        segs[2]()
+        update()
 
     def _capture(self):
         pool = torch.cuda.graph_pool_handle()
         self.G.ws.frozen = self.D.ws.frozen = True
-        graphs = []
-        for fn in self._segments():
-            if fn is None:
-                graphs.append(None)
-                continue
+
+        def cap(fn, stream=None):
             g = torch.cuda.CUDAGraph()
             # thread_local: the RCCL watchdog thread polls its work events (hipEventQuery) while this thread captures;
             # under the default global mode that aborts with hipErrorStreamCaptureUnsupported
-            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, pool=pool, stream=stream, capture_error_mode="thread_local"):
                 fn()
-            graphs.append(g.replay)
-        self.graphs = graphs
+            return g.replay
+
+        if self.lanes:
+            fns = self._piece_fns()
+            self.graphs = {k: cap(fns[k], self.sB if k in ("d_real", "d_fake") else None) for k in self.PIECES}
+        else:
+            self.graphs = (cap(self._fork_join), cap(self._update))
 
     # ----------------------------------------------------------------------------------------------------------
     def run(self, x, y, global_step, lr_g, lr_d, betas_g=(0.9, 0.999), betas_d=(0.9, 0.999), eps_g=1e-8, eps_d=1e-8):
@@ -327,16 +395,22 @@ class TecoGANStep:
             self.x[:, Ti:].copy_(torch.flip(x, dims=[1])[:, 1:])
             self.y[:, Ti:].copy_(torch.flip(y, dims=[1])[:, 1:])
         self._host_params(global_step + 1, lr_g, lr_d, betas_g, betas_d, eps_g, eps_d)
-        if self.use_graph:
-            if self.graphs is None:
-                self._run(self._segments())   # warm-up: one-time attribute setup, workspace growth
-                self.adam_t = [self.adam_t[0] + 1, self.adam_t[1] + 1]
+        eager = (lambda: self._run_lanes(self._piece_fns())) if self.lanes else \
+            (lambda: self._run_single(self._fork_join, self._update))
+        caller = torch.cuda.current_stream()
+        self.sA.wait_stream(caller)
+        with torch.cuda.stream(self.sA):
+            if self.use_graph and self.graphs is None:
+                eager()   # warm-up: one-time attribute setup, workspace growth, job tables
                 torch.cuda.synchronize()
                 self._capture()
-                return
-            self._run(self.graphs)
-        else:
-            self._run(self._segments())
+            elif self.use_graph and self.lanes:
+                self._run_lanes(self.graphs)
+            elif self.use_graph:
+                self._run_single(*self.graphs)
+            else:
+                eager()
+        caller.wait_stream(self.sA)
         self.adam_t = [self.adam_t[0] + 1, self.adam_t[1] + 1]
 
 

@@ -33,7 +33,6 @@ def wrap(op, fn):
     return w
 o = (E.Conv.fwd, E.Conv.dgrad, E.Conv.wgrad)
 E.Conv.fwd, E.Conv.dgrad, E.Conv.wgrad = wrap("fwd", o[0]), wrap("dgrad", o[1]), wrap("wgrad+fin", o[2])
-side = (st.sB, st.sC); st.sB = st.sC = torch.cuda.current_stream()
 torch.cuda.synchronize(); torch.cuda._sleep(int(0.08 * 2.0e9))
 st._forward_backward(True); torch.cuda.synchronize()
 E.Conv.fwd, E.Conv.dgrad, E.Conv.wgrad = o

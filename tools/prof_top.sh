@@ -1,7 +1,8 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/prof_top.sh <tag> [bench args]   -> gpurun_out/prof_<tag>/ + top kernels
+set -euo pipefail
 tag=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT unset)}"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o $tag -- python3 bench.py "$@" > gpurun_out/prof_$tag.log 2>&1
 python3 - "$tag" <<'PY'
 import csv, glob, sys
