@@ -4,7 +4,8 @@ bf16 compute / fp32 master weights, full G + pseudo-flow/warp + D + losses + two
   python bench.py --gpus N --steps K --warmup W          (N>1: launched once per rank by torch.distributed.run)
 
 Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline      the dominant kernel family, timed live with events around every one of its launches in one eager step
+  roofline      the dominant kernel family (every family of one eager step is replayed inside one event bracket), the
+                per-family table, and `hbm_kernels`: the HBM-bound kernels as GB/s of algorithmic bytes
   cpu_baseline  the CPU oracle (PyTorch-CPU fp32 restatement of the reference) timed on this box's host cores
 """
 import argparse
@@ -33,7 +34,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
 
 
@@ -72,117 +73,115 @@ def kernel_name(conv, dtype):
         return f"subpixel_kernel<{'BF16' if dtype == 'bf16' else 'F32'}, {0 if conv.last_desc is None else 1}>"
     if conv.last_desc in ("c4s2", "ctd"):  # csrc/conv4s2_mfma.hip
         return f"conv_s2_gather_kernel<{'BF16' if dtype == 'bf16' else 'F32'}, {4 if conv.last_desc == 'c4s2' else 3}>"
+    if conv.last_desc == "rw":  # csrc/conv3_rw.hip (NCH = input channels / 32; statistics variant not distinguished)
+        return f"conv3_rw_kernel<{conv.last_rw_nch}, ..>"
     plan = L.load().tg_conv_pick_tile(ctypes.byref(conv.last_desc))
     t = "BF16" if dtype == "bf16" else "F32"
     return f"conv_gather_kernel<{t}, {TILE_PARAMS[plan & 255]}, {'true' if plan >> 8 else 'false'}>"
 
 
 def roofline_pass(st, dtype):
-    """One eager step with a start/stop event pair around every MFMA launch; returns the per-family table."""
+    """One eager step (both lanes on ONE stream, in dependency order) with every MFMA launch and every HBM-bound launch
+    recorded; then each family is replayed back to back inside ONE event bracket (GPU parked first, so the bracket holds
+    kernel executions, not host launch gaps) - the per-launch average that rocprofv3 --kernel-trace reports for the same
+    kernel.  Returns (mfma families, hbm families): {label: launches, work (flops | bytes), ms}."""
     from pytorch_tecogan_amd import engine as E
     from pytorch_tecogan_amd import kernels as K
-    recs, replays = [], {}
-    orig_fwd, orig_dgrad, orig_wgrad = E.Conv.fwd, E.Conv.dgrad, E.Conv.wgrad
+    recs, replays = {}, {}
+    saved = []
 
-    def timed(label_fn, flops_fn, fn):
-        def wrapper(self, *a, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            r = fn(self, *a, **kw)
-            e1.record()
-            lab = label_fn(self, *a)  # label AFTER the call: needs last_desc
-            recs.append((lab, flops_fn(self, *a), e0, e1))
-            replays.setdefault(lab, []).append(lambda: fn(self, *a, **kw))
+    def record(label, work, call, kind):
+        d = recs.setdefault(label, dict(launches=0, work=0.0, kind=kind))
+        d["launches"] += 1
+        d["work"] += work
+        replays.setdefault(label, []).append(call)
+
+    def wrap(obj, name, label_fn, work_fn, kind):
+        orig = getattr(obj, name)
+        saved.append((obj, name, orig))
+
+        def wrapper(*a, **kw):
+            r = orig(*a, **kw)
+            record(label_fn(*a, **kw), work_fn(*a, **kw), lambda: orig(*a, **kw), kind)  # label AFTER the call (last_desc)
             return r
-        return wrapper
+        setattr(obj, name, wrapper)
 
-    def in_shape_fwd(self, x, *a):
-        return x.shape[0], x.shape[1], x.shape[2]
+    T16 = "BF16" if dtype == "bf16" else "F32"
+    es = 2 if dtype == "bf16" else 4
+    nb = lambda *ts: float(sum(t.numel() * t.element_size() for t in ts if t is not None))  # noqa: E731
 
-    def lab_fwd(self, x, *a):
-        return kernel_name(self, dtype)
-
-    def lab_dgrad(self, dout, out, *a):
-        return kernel_name(self, dtype)
-
-    def fl_fwd(self, x, *a):
-        return conv_flops(self.spec, *in_shape_fwd(self, x))
-
-    def fl_dgrad(self, dout, out, *a):
-        return conv_flops(self.spec, out.shape[0], out.shape[1], out.shape[2])
-
-    def fl_wgrad(self, x_in, dout, *rest):
-        return conv_flops(self.spec, x_in.shape[0], x_in.shape[1], x_in.shape[2])
-
-    # the fused residual-block launch (csrc/resblock.hip) and the grouped weight-gradient launch are not Conv methods
-    orig_rb, orig_rbb, orig_group = K.resblock_fwd, K.resblock_bwd, E.WgradGroup.launch
-
-    def rb_wrap(orig, label):
-        def rb_timed(x, *a, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig(x, *a, **kw)
-            e1.record()
-            N, H, W, C_ = x.shape
-            recs.append((label, 2 * 2.0 * N * H * W * 9 * C_ * C_, e0, e1))  # algorithmic: two 3x3 convs
-            replays.setdefault(label, []).append(lambda: orig(x, *a, **kw))
-        return rb_timed
+    # ---- MFMA launches
+    wrap(E.Conv, "fwd", lambda self, x, *a, **k: kernel_name(self, dtype),
+         lambda self, x, *a, **k: conv_flops(self.spec, x.shape[0], x.shape[1], x.shape[2]), "mfma")
+    wrap(E.Conv, "dgrad", lambda self, dout, out, *a, **k: kernel_name(self, dtype),
+         lambda self, dout, out, *a, **k: conv_flops(self.spec, out.shape[0], out.shape[1], out.shape[2]), "mfma")
+    wrap(E.Conv, "wgrad", lambda self, *a, **k: f"wgrad_kernel<{T16}, {self.spec.nslots}, ..>",
+         lambda self, x_in, dout, *a, **k: conv_flops(self.spec, x_in.shape[0], x_in.shape[1], x_in.shape[2]), "mfma")
+    rb_fl = lambda x, *a, **k: 2 * 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * 9 * x.shape[3] * x.shape[3]  # noqa: E731
+    wrap(K, "resblock_fwd", lambda *a, **k: "resblock_kernel<false>", rb_fl, "mfma")
+    wrap(K, "resblock_bwd", lambda *a, **k: "resblock_kernel<true>", rb_fl, "mfma")
+    orig_group = E.WgradGroup.launch
+    saved.append((E.WgradGroup, "launch", orig_group))
 
     def group_timed(self):
         items = list(self.items)
-        if not items:
-            return orig_group(self)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
         orig_group(self)
-        e1.record()
+        if not items:
+            return
         fl = sum(conv_flops(c.spec, x.shape[0], x.shape[1], x.shape[2]) for c, x, _, _ in items)
-        lab = f"wgrad_kernel<{'BF16' if dtype == 'bf16' else 'F32'}, 9, 9, ..> (tg_wgrad_multi, {len(items)} layers)"
-        recs.append((lab, fl, e0, e1))
 
         def again():
             for it in items:
                 self.add(*it)
             orig_group(self)
-        replays.setdefault(lab, []).append(again)
-
-    K.resblock_fwd, K.resblock_bwd = rb_wrap(orig_rb, "resblock_kernel<false>"), rb_wrap(orig_rbb, "resblock_kernel<true>")
+        record(f"wgrad_kernel<{T16}, 9, 9, ..> (tg_wgrad_multi, {len(items)} layers)", fl, again, "mfma")
     E.WgradGroup.launch = group_timed
-    E.Conv.fwd = timed(lab_fwd, fl_fwd, orig_fwd)
-    E.Conv.dgrad = timed(lab_dgrad, fl_dgrad, orig_dgrad)
-    E.Conv.wgrad = timed(lambda self, *a: f"wgrad_kernel<{'BF16' if dtype == 'bf16' else 'F32'}, {self.spec.nslots}, ..> + "
-                         "wgrad_finalize_kernel", fl_wgrad, orig_wgrad)
+
+    # ---- HBM-bound launches: algorithmic bytes = every tensor the op must read + write once
+    wrap(K, "bn_apply", lambda *a, **k: f"bn_apply_kernel<{T16}>",
+         lambda z, stats, gamma, beta, y, *a, skip=None, **k: nb(z, y, skip), "hbm")
+    wrap(K, "bn_bwd_reduce", lambda *a, **k: f"bn_bwd_reduce_kernel<{T16}>",
+         lambda dy, yact, z, *a, **k: nb(dy, z, yact), "hbm")
+    wrap(K, "bn_bwd_apply", lambda *a, **k: f"bn_bwd_apply_kernel<{T16}>",
+         lambda dy, yact, z, save, red, gamma, dz, *a, **k: nb(dy, z, yact, dz), "hbm")
+    wrap(K, "adam", lambda *a, **k: "adam_kernel", lambda p, *a, **k: 28.0 * p.numel(), "hbm")  # p,g,m,v read; p,m,v written
+    wrap(K, "gen_input", lambda *a, **k: f"gen_input_kernel<{T16}>",
+         lambda lr, lo, ls, prev, po, ps, grid, go, gs, dst, B, h, w: nb(dst) + 4.0 * B * h * w * (3 + (16 * 5 if prev is not None else 0)),
+         "hbm")  # reads: LR frame, previous HR frame (3 ch) and the flow (2 ch) at 16 HR pixels per LR pixel
+    wrap(K, "d_assemble", lambda *a, **k: f"d_assemble_kernel<{T16}>",
+         lambda x, y, gen, tvel, dst, B, T, Kk, h, border, half=-1: nb(dst) + 4.0 * dst.shape[0] * 16 * h * h * (9 + 9 + 6) + 4.0 * dst.shape[0] * 9 * h * h,
+         "hbm")  # reads: 9 target ch + 9 warped-source ch + 3 x 2 velocity ch per HR pixel, 9 LR ch
+    wrap(K, "content_loss", lambda *a, **k: f"content_loss_kernel<{T16}>",
+         lambda gen, y, dpre, *a, **k: nb(gen, y, dpre), "hbm")
+    wrap(K, "up4_planes", lambda *a, **k: "up4_planes_kernel",
+         lambda src, so, dst, do, n, h, w, **k: 4.0 * n * h * w * 17, "hbm")
+    wrap(K, "absdiff_sum", lambda *a, **k: f"absdiff_sum_kernel<{T16}>", lambda a_, b_, *r, **k: nb(a_, b_), "hbm")
+
+    def fold_bytes(self):
+        jobs = [c.fin_job for c in self.convs if c.fin_job is not None]
+        return float(sum(j[4] * j[11] * 4 + j[5] * j[8] * j[9] * 4 for j in jobs))  # slabs read + gradient written
+    wrap(E.Finalizer, "run", lambda self: "wgrad_finalize_multi_kernel", fold_bytes, "hbm")
     try:
-        # park the GPU behind a ~60 ms spin kernel so that the host enqueues the whole eager step ahead of it: the event
-        # pairs then bracket back-to-back kernel executions, not host launch gaps (eager launches are host-bound here).
-        # _forward_backward runs both lanes of the step on ONE stream, in dependency order: isolated launch durations.
         torch.cuda.synchronize()
-        torch.cuda._sleep(int(0.06 * 2.0e9))
         st._forward_backward(True)
+        st._update()
         torch.cuda.synchronize()
     finally:
-        E.Conv.fwd, E.Conv.dgrad, E.Conv.wgrad = orig_fwd, orig_dgrad, orig_wgrad
-        K.resblock_fwd, K.resblock_bwd, E.WgradGroup.launch = orig_rb, orig_rbb, orig_group
-    fam = {}
-    for label, fl, e0, e1 in recs:
-        d = fam.setdefault(label, dict(launches=0, flops=0.0, ms=0.0))
-        d["launches"] += 1
-        d["flops"] += fl
-        d["ms"] += e0.elapsed_time(e1)
-    # An event pair costs several microseconds of its own, which matters for the ~7 us recurrent-pass launches.  The
-    # dominant family is therefore re-timed as ONE bracket around all of its launches (same arguments, back to back,
-    # GPU parked first): that is the average duration rocprofv3 --kernel-trace reports, plus the inter-kernel gap.
-    dom = max(fam, key=lambda k: fam[k]["ms"])
-    torch.cuda.synchronize()
-    torch.cuda._sleep(int(0.03 * 2.0e9))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for call in replays[dom]:
-        call()
-    e1.record()
-    torch.cuda.synchronize()
-    fam[dom]["ms_bracketed_once"] = e0.elapsed_time(e1)
-    return fam
+        for obj, name, orig in saved:
+            setattr(obj, name, orig)
+    for label, calls in replays.items():
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(0.008 * 2.0e9))  # park the GPU: the host enqueues the whole family ahead of it
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for call in calls:
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        recs[label]["ms"] = e0.elapsed_time(e1)
+    mf = {k: v for k, v in recs.items() if v["kind"] == "mfma"}
+    hb = {k: v for k, v in recs.items() if v["kind"] == "hbm"}
+    return mf, hb
 
 
 def usable_cores():
@@ -201,15 +200,15 @@ def usable_cores():
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are separate
     runs of this same command; they cannot be collected live).  gfx950 correction: FETCH_SIZE counts 64 B per 128-B request."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    try:
-        tab = json.load(open(path))["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None, None
-    ent = tab.get(kernel)
-    if not ent:
-        return None, None
-    return int(ent["hbm_bytes_per_launch"]), "profiles/r01_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, not live)"
+    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        try:
+            tab = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        ent = tab.get(kernel)
+        if ent:
+            return ent, f"profiles/{name} (rocprofv3 --pmc, separate passes of this same command; not live)"
+    return None, None
 
 
 def cpu_baseline(B, n_steps):
@@ -308,24 +307,34 @@ def main():
                "final_losses": {"gen_loss": round(gen_loss, 5), "d_loss": round(d_loss, 5)}}
         if not a.no_roofline:
             st = next(iter(TR._STEPS.values()))
-            log("roofline pass (events around every MFMA launch of one eager step)")
-            fam = roofline_pass(st, a.dtype)
+            log("roofline pass (one eager step recorded, every kernel family replayed inside one event bracket)")
+            fam, hbm = roofline_pass(st, a.dtype)
             dom = max(fam, key=lambda k: fam[k]["ms"])
             d = fam[dom]
-            dom_ms = d.get("ms_bracketed_once", d["ms"])
-            ach = d["flops"] / (dom_ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic(dom)
+            ach = d["work"] / (d["ms"] * 1e-3) / 1e12
+            pmc, pmc_src = pmc_traffic(dom)
+
+            def busy(label):  # MFMA-pipe busy share of the kernel's SQ busy cycles, from the committed counter passes
+                e, _ = pmc_traffic(label)
+                return e.get("mfma_busy_pct") if e else None
             res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
                                "peak": MFMA_PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
-                               "frac": round(ach / MFMA_PEAK_TFLOPS[a.dtype], 5), "traffic": traffic,
-                               "traffic_source": traffic_src,
+                               "frac": round(ach / MFMA_PEAK_TFLOPS[a.dtype], 5),
+                               "traffic": int(pmc["hbm_bytes_per_launch"]) if pmc else None,
+                               "traffic_source": pmc_src, "mfma_busy_pct": busy(dom),
                                "launches_per_step": d["launches"],
-                               "avg_launch_us": round(dom_ms * 1e3 / d["launches"], 2),
-                               "avg_launch_us_with_event_pair_per_launch": round(d["ms"] * 1e3 / d["launches"], 2),
-                               "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3),
+                               "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+                               "avg_launch_gflop": round(d["work"] / d["launches"] / 1e9, 3),
                                "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
-                                            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}}
+                                                "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                                "mfma_busy_pct": busy(k)}
+                                            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
+                               # the HBM-bound kernels of the step (reported separately, as GB/s of algorithmic bytes)
+                               "hbm_kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                                   "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
+                                                   "GBps": round(v["work"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                                   "frac_of_8TBps": round(v["work"] / (v["ms"] * 1e-3) / 8e12, 4)}
+                                               for k, v in sorted(hbm.items(), key=lambda kv: -kv[1]["ms"])}}
         if not a.no_cpu_baseline:
             log(f"cpu baseline: oracle, {a.cpu_steps}+1 steps on {usable_cores()} usable host cores")
             res["cpu_baseline"] = cpu_baseline(B, a.cpu_steps)

@@ -28,7 +28,7 @@ extern "C" {
 
 #define TG_ABI_VERSION 1
 
-enum { TG_F32 = 0, TG_BF16 = 1 };
+enum { TG_F32 = 0, TG_BF16 = 1, TG_F16 = 2 };  /* TG_F16: IEEE half, same layouts as TG_BF16 (loss scaling: tg_adam) */
 
 enum {
   TG_OK = 0,
@@ -267,15 +267,15 @@ int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const float* b, co
  * pp_T > 0 (ping-pong, T == 2*pp_T-1): acc[6] += sum |gen_t - gen_{2(pp_T-1)-t}| over t < pp_T-1 and the gradient
  * pp_coef*sign(gen_t - gen_partner) is added before the sigmoid derivative (code/train.py:275-283). */
 int tg_content_loss(int dtype, const float* gen, const float* y, void* dpre, float* acc, int B, int T, int H, int W,
-                    float gscale, int t0, int t1, int pp_T, float pp_coef, void* stream);
+                    float gscale, int t0, int t1, int pp_T, float pp_coef, const float* loss_scale, void* stream);
 /* All step scalars on device + d(logit) for the discriminator loss (code/train.py:287-333). */
 int tg_loss_finalize(const float* prob, const float* acc, float* scalars, float* dlogit, int tb, const float* cfg,
-                     void* stream);
+                     const float* loss_scale, void* stream);
 
 /* d(logit) of the REAL half only: dlogit[n] = -(1/tb) * pr*(1-pr)/(pr+eps), n < tb (the real-half term of t_discrim_loss,
  * code/train.py:304-307; eps = cfg[6]).  Lets the real half's D backward start before the fake half exists;
  * tg_loss_finalize later writes the same values again. */
-int tg_dlogit_real(const float* prob, float* dlogit, int tb, const float* cfg, void* stream);
+int tg_dlogit_real(const float* prob, float* dlogit, int tb, const float* cfg, const float* loss_scale, void* stream);
 
 /* dst[i] (+)= sum_r src[r*stride + i], i < n: folds the replicated per-channel statistics of tg_conv. */
 int tg_reduce_replicas(const float* src, int replicas, int stride, int n, float* dst, int accumulate, void* stream);
@@ -284,6 +284,40 @@ int tg_reduce_replicas(const float* src, int replicas, int stride, int n, float*
 /* hyper_dev (device floats): lr, beta1, beta2, eps, 1-beta1^t, 1-beta2^t, grad_scale - in memory so that a captured
  * hipGraph picks up each step's values. */
 int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, void* stream);
+
+/* ---- dynamic loss scaling of the fp16 mode (torch.cuda.amp.GradScaler as used at code/train.py:9,335-342) ---------- */
+/* `loss_scale` (device float, nullable) of tg_content_loss / tg_loss_finalize / tg_dlogit_real / tg_cosine_loss multiplies
+ * every backward seed, so all gradient tensors and both flat gradient buffers carry the scale.  scaler_state (device
+ * floats): 0 scale, 1 growth tracker, 2 found_inf of the generator, 3 of the discriminator, 4 1/scale.
+ * tg_check_finite: *flag = 1 if any g[i] is inf/NaN (flag = scaler_state + 2 + which).
+ * tg_adam_scaled: tg_adam on g / scale, skipped entirely when found_inf[which] is set (GradScaler.step).
+ * tg_scaler_update: the two GradScaler.update() calls of one training step (generator's first), then clears the flags. */
+int tg_check_finite(const float* g, int64_t n, float* flag, void* stream);
+int tg_adam_scaled(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev,
+                   const float* scaler_state, int which, void* stream);
+int tg_scaler_update(float* scaler_state, float growth, float backoff, int interval, void* stream);
+
+/* ---- opt-in VGG feature loss (code/train.py:30-45,124-127,253-273; code/ops.py:144-213) ----------------- */
+/* The reference's VGG path cannot execute; DESIGN.md fixes its semantics.  The VGG-19 convolutions run
+ * on tg_conv / tg_conv3x3_rw; these are the HBM-bound pieces between them.
+ * tg_vgg_input: dst[n][y][x][c] = scale * src[n][c][y][x] + shift3[c] for c < 3, 0 for 3 <= c < 32
+ *   (deprocess(x) * 255 - VGG_MEAN with scale = 127.5, shift3[c] = 127.5 - VGG_MEAN[c], code/train.py:31-32). */
+int tg_vgg_input(int dtype, const float* src_nchw, void* dst_nhwc32, int N, int H, int W, float scale, const float* shift3,
+                 void* stream);
+/* per pixel p of [npix][C] (C % 32 == 0): cos_p = <g,t> / (sqrt(sum g^2 + 1e-12) sqrt(sum t^2 + 1e-12));
+ * *acc += sum_p cos_p;  dg[p][c] = coef * d cos_p / d g[p][c], zeroed where g <= 0 when relu_mask (g is a ReLU output).
+ * (code/train.py:258-266 with the per-pixel channel norm of code/train.py:39-40 as DESIGN.md fixes it). */
+int tg_cosine_loss(int dtype, const void* fg, const void* ft, void* dg, int64_t npix, int C, float coef, int relu_mask,
+                   float* acc, const float* loss_scale, void* stream);
+/* backward of nn.MaxPool2d((2,2), stride=2) (code/ops.py:149): out[n][y][x][c] = (res ? res : 0) + (dpool of the window
+ * if (y,x) is the window's first maximum of `a`), zeroed where a <= 0 when relu_mask.  a, res, out [N][H][W][C],
+ * dpool [N][H/2][W/2][C]. */
+int tg_maxpool2_bwd(int dtype, const void* a, const void* dpool, const void* res, void* out, int N, int H, int W, int C,
+                    int relu_mask, void* stream);
+/* dpre[n][y][x][c] += dx[n][y][x][c] * scale * g (1 - g), g = gen[n][c][y][x], c < 3: chains d(loss)/d(vgg input) through
+ * tg_vgg_input and the generator's output sigmoid (code/models.py:86) into d(loss)/d(pre-sigmoid). */
+int tg_vgg_input_grad(int dtype, const void* dx_nhwc32, const float* gen_nchw, void* dpre_nhwc32, int N, int H, int W,
+                      float scale, void* stream);
 
 /* ---- step schedule support (no reference counterpart: the reference runs everything on one CUDA stream) ------- */
 /* Creates a stream confined to every CU except the first `reserve_cus` CU-mask bits (hipExtStreamCreateWithCUMask; 64 bits

@@ -3,7 +3,11 @@ start-up side effects and output file names; the training / inference loops call
 reference-named modules in ./code (FRVSR_Train, generator, discriminator).
 
 Extra flags (all optional): --synthetic N trains on N random sequences instead of --input_video_dir (no dataset needed),
---tg_dtype {bf16,fp32}, --tg_extend true (shapes the reference cannot run, e.g. 64->256 seq-16).  Multi-GPU: launch with torch.distributed.run; every rank then takes a disjoint shard of each batch.
+--tg_dtype {bf16,fp16,fp32} (fp16: with dynamic loss scaling), --tg_extend true (shapes the reference cannot run, e.g. 64->256 seq-16).
+Multi-GPU: launch with torch.distributed.run (one process per GPU).  Every rank builds the same models, rank 0's
+parameters / BN buffers / Adam moments are broadcast after construction and after a checkpoint load, a DistributedSampler
+gives each rank a disjoint 1/world of the sequences (4 per rank and step, as hard-coded at main.py:227 of the reference),
+gradients are averaged over RCCL inside FRVSR_Train, and rank 0 alone writes the outputs.
 """
 import argparse
 import os
@@ -51,7 +55,7 @@ def build_parser():
     a("--Dbalance", default=0.4, type=float); a("--crop_dt", default=0.75, type=float)
     a("--D_LAYERLOSS", default=True, type=str2bool)
     a("--synthetic", default=0, type=int, help="train on this many random sequences (no dataset)")
-    a("--tg_dtype", default=None, choices=[None, "bf16", "fp32"])
+    a("--tg_dtype", default=None, choices=[None, "bf16", "fp16", "fp32"])
     a("--tg_extend", default=False, type=str2bool,
       help="opt-in extension beyond what the reference can execute: RNN_N outside 9..11 and crop_size != 32 "
            "(discriminator fc sized from crop_size); parity with the reference is undefined there")
@@ -66,8 +70,7 @@ def main(argv=None):
     if args.output_dir is None:
         raise ValueError("The output directory is needed")
     for d in (args.output_dir, args.summary_dir):
-        if not os.path.exists(d):
-            os.mkdir(d)
+        os.makedirs(d, exist_ok=True)  # (several ranks start at once)
 
     import numpy as np
     import torch
@@ -75,12 +78,17 @@ def main(argv=None):
     from train import FRVSR_Train
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one GPU per rank; ranks beyond the visible devices wrap around (only the gloo test backend can share a device)
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("TECOGAN_DIST_BACKEND", "nccl")  # "nccl" is RCCL here; gloo: ranks sharing one GPU (tests)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.mode == "inference":
         if args.g_checkpoint is None:
@@ -105,7 +113,7 @@ def main(argv=None):
         raise ValueError("mode must be train or inference")
 
     if args.synthetic:
-        rng = np.random.default_rng(args.rand_seed + rank)
+        rng = np.random.default_rng(args.rand_seed)  # the same sequences on every rank; the sampler shards them
         T, cs = args.RNN_N, args.crop_size
         data = [(torch.from_numpy(rng.random((T, 3, cs, cs), dtype=np.float32)),
                  torch.from_numpy(rng.random((T, 3, 4 * cs, 4 * cs), dtype=np.float32))) for _ in range(args.synthetic)]
@@ -113,7 +121,21 @@ def main(argv=None):
     else:
         from dataloader import train_dataset
         dataset = train_dataset(args)
-    loader = torch.utils.data.DataLoader(dataset, batch_size=4, shuffle=True, drop_last=True)  # 4 is hard-coded (main.py:227)
+    sampler = None
+    if world > 1:
+        sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True,
+                                                                  seed=args.rand_seed, drop_last=True)
+    # batch size 4 is hard-coded in the reference (main.py:227); per rank here.  drop_last: the step is a static launch
+    # sequence for ONE batch shape (the reference would run a short last batch through eager PyTorch)
+    # real data: the PNG decode + resize pipeline of code/dataloader.py runs in --queue_thread worker processes (the flag the
+    # reference defines and never uses, main.py:64) with pinned, prefetched batches, so ingest overlaps the GPU step
+    workers = 0 if args.synthetic else max(0, min(int(args.queue_thread), len(os.sched_getaffinity(0))))
+    loader = torch.utils.data.DataLoader(dataset, batch_size=4, shuffle=sampler is None, sampler=sampler, drop_last=True,
+                                         num_workers=workers, pin_memory=True, persistent_workers=workers > 0,
+                                         prefetch_factor=4 if workers > 0 else None)
+    if len(loader) == 0:
+        raise ValueError(f"{len(dataset)} training sequences give rank {rank} of {world} no full batch of 4: nothing would "
+                         "be trained")
 
     G, D = generator(3, args=args).to(dev), discriminator(args=args).to(dev)
     lr_d = args.learning_rate * (1.0 if args.Dt_mergeDs else 0.3)
@@ -130,11 +152,16 @@ def main(argv=None):
         d_ck = torch.load(args.d_checkpoint, map_location=dev)
         D.load_state_dict(d_ck["model_state_dict"])
         opt_d.load_state_dict(d_ck["optimizer_state_dict"])
+    if world > 1:  # replicas start equal: every rank drew its own initial weights above
+        from pytorch_tecogan_amd import parallel
+        parallel.broadcast_state((G, D), (opt_g, opt_d))
 
     since = time.time()
     for e in range(epoch0, args.max_epochs):
         g_loss = d_loss = 0.0
         output = inputs = targets = None
+        if sampler is not None:
+            sampler.set_epoch(e)
         for batch_idx, (inputs, targets) in enumerate(loader):
             inputs, targets = inputs.to(dev, non_blocking=True), targets.to(dev, non_blocking=True)
             output = FRVSR_Train(inputs, targets, args, D, G, batch_idx, 0.0, 0.0, opt_g, opt_d)
@@ -142,18 +169,25 @@ def main(argv=None):
             d_loss = d_loss + (output.d_loss.data - d_loss) / (batch_idx + 1)
         sch_d.step()
         sch_g.step()
+        if world > 1:
+            from pytorch_tecogan_amd import parallel
+            if not parallel.replicas_equal((G, D)):
+                raise RuntimeError(f"data-parallel replicas diverged (rank {rank}, epoch {e + 1})")
+            if rank == 0:
+                print(f"replica check ok ({world} ranks)")
         if rank == 0 and output is not None:
             print("Epoch: {}".format(e + 1))
             print("\nGenerator loss is: {} \nDiscriminator loss is: {}".format(float(g_loss), float(d_loss)))
             print(f"\nGenerator lr is: {opt_g.param_groups[0]['lr']}, Discriminator lr is: {opt_d.param_groups[0]['lr']}")
-            try:
-                from ops import save_as_gif
-                idx = np.random.randint(0, targets.shape[0])
-                save_as_gif(output.gen_output[idx][:args.RNN_N].cpu(), "gan.gif")
-                save_as_gif(targets[idx].cpu(), "real.gif")
-                save_as_gif(inputs[idx].cpu(), "original.gif")
-            except ImportError:
-                pass  # imageio is optional
+            from ops import save_as_gif, save_image  # per-epoch samples of main.py:281-294
+            idx = np.random.randint(0, targets.shape[0])
+            save_as_gif(output.gen_output[idx][:args.RNN_N].cpu(), "gan.gif")
+            save_as_gif(targets[idx].cpu(), "real.gif")
+            save_as_gif(inputs[idx].cpu(), "original.gif")
+            cs, n = args.crop_size, targets.shape[0] * args.RNN_N
+            save_image(output.gen_output.reshape(-1, 3, cs * 4, cs * 4), "Gan_examples.jpg")
+            save_image(targets.reshape(n, 3, cs * 4, cs * 4), "real_image.jpg")
+            save_image(inputs.reshape(n, 3, cs, cs), "original_image.jpg")
             print("\nSaving model...")
             torch.save({"epoch": e, "model_state_dict": G.state_dict(), "optimizer_state_dict": opt_g.state_dict()},
                        "generator.pt")

@@ -419,6 +419,70 @@ class AdamState:
             p.addcdiv_(self.m[k], denom, value=-(self.lr / bc1))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Opt-in VGG feature loss.  PARITY UNPINNED: the reference's path (code/train.py:30-45,124-127,253-273, code/ops.py:144-213)
+# cannot execute - VGG19_slim is called without its `reuse` argument, Conv3_1.. have no kernel size, torch.min(dim=1)
+# returns a tuple, the three layer terms have different shapes, and a fresh random VGG19 is built per call.  What is
+# stated here is the documented fix: the TensorFlow original's semantics, which the reference transcribed.
+VGG_MEAN = (123.68, 116.78, 103.94)  # code/train.py:6
+VGG_LAYERS = (("Conv1_1", 3, 64), ("Conv1_2", 64, 64), "pool1", ("Conv2_1", 64, 128), ("Conv2_2", 128, 128), "pool2",
+              ("Conv3_1", 128, 256), ("Conv3_2", 256, 256), ("Conv3_3", 256, 256), ("Conv3_4", 256, 256), "pool3",
+              ("Conv4_1", 256, 512), ("Conv4_2", 512, 512), ("Conv4_3", 512, 512), ("Conv4_4", 512, 512))
+VGG_TAPS = ("Conv2_2", "Conv3_4", "Conv4_4")  # vgg_19/conv2_2, conv3_4, conv4_4 (code/train.py:125)
+
+
+def vgg_param_shapes():
+    s = collections.OrderedDict()
+    for l in VGG_LAYERS:
+        if isinstance(l, tuple):
+            s[f"{l[0]}.0.weight"], s[f"{l[0]}.0.bias"] = (l[2], l[1], 3, 3), (l[2],)
+    return s
+
+
+def vgg_default_params():
+    """the build's default frozen extractor: He-uniform weights under numpy seed 19, zero biases (models.VGG19)"""
+    rng = np.random.default_rng(19)
+    out = collections.OrderedDict()
+    for name, shp in vgg_param_shapes().items():
+        if name.endswith("weight"):
+            b = math.sqrt(6.0 / (shp[1] * 9))
+            out[name] = torch.from_numpy(rng.uniform(-b, b, size=shp).astype(np.float32))
+        else:
+            out[name] = torch.zeros(shp)
+    return out
+
+
+def vgg_features(vp, img):
+    """img [N,3,H,W] in [0,1] -> the three tap feature maps; input arithmetic of code/train.py:31-32 (deprocess, *255,
+    - VGG_MEAN per channel), 3x3 convs + ReLU + 2x2 max-pools of code/ops.py:146-165"""
+    x = (img + 1) / 2 * 255.0 - torch.tensor(VGG_MEAN, dtype=img.dtype).view(1, 3, 1, 1)
+    feats = {}
+    for l in VGG_LAYERS:
+        if isinstance(l, tuple):
+            x = F.relu(F.conv2d(x, vp[f"{l[0]}.0.weight"].to(x.dtype), vp[f"{l[0]}.0.bias"].to(x.dtype), padding=1))
+            if l[0] in VGG_TAPS:
+                feats[l[0]] = x
+        else:
+            x = F.max_pool2d(x, 2, 2)
+    return feats
+
+
+def vgg_loss_terms(vp, s_gen, s_tgt):
+    """per tap layer: 1 - mean over pixels of the cosine between the channel-normalised feature vectors
+    (f / sqrt(sum_c f^2 + 1e-12): the norm code/train.py:39-40 means; 1 - reduce_mean of the product summed over
+    channels: code/train.py:258-262 made shape-consistent).  The target branch carries no gradient."""
+    fg = vgg_features(vp, s_gen)
+    with torch.no_grad():
+        ft = vgg_features(vp, s_tgt)
+    terms = []
+    for t in VGG_TAPS:
+        g, tt = fg[t], ft[t]
+        g = g / torch.sqrt(torch.sum(g * g, dim=1, keepdim=True) + 1e-12)
+        tt = tt / torch.sqrt(torch.sum(tt * tt, dim=1, keepdim=True) + 1e-12)
+        terms.append(1.0 - torch.mean(torch.sum(g * tt, dim=1)))
+    return terms
+
+
 def tecogan_forward(gp, dp, dbufs, x, y, args, global_step, counter1=0.0, counter2=0.0, update_stats=True):
     """Forward part of code/train.py:49-333.  gp/dp tensors may require grad.  Returns a dict of everything
     the tests compare (losses are fp32 tensors attached to the autograd graph where the reference's are)."""
@@ -467,6 +531,14 @@ def tecogan_forward(gp, dp, dbufs, x, y, args, global_step, counter1=0.0, counte
     warp_loss = torch.mean(torch.sum(torch.square(lr_next - lr_warp), dim=[3]))
     vals.append(warp_loss)
     names.append("l2_warp_loss")
+    if float(getattr(args, "vgg_scaling", -1.0)) > 0.0:  # opt-in, parity unpinned (see vgg_loss_terms)
+        vp = getattr(args, "tg_vgg_params", None) or vgg_default_params()
+        terms = vgg_loss_terms(vp, s_gen, s_tgt)
+        vgg_all = terms[0] + terms[1] + terms[2]
+        # gen_loss += s*vgg ; fnet_loss += s*vgg.detach() on ONE aliased tensor (code/train.py:268-269)
+        total = total + args.vgg_scaling * vgg_all + args.vgg_scaling * vgg_all.detach()
+        vals += terms + [vgg_all]
+        names += ["vgg_loss_2", "vgg_loss_3", "vgg_loss_4", "vgg_all"]
     pp = None
     if args.pingpang:
         n = int(args.RNN_N)

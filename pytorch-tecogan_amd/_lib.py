@@ -11,7 +11,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtecogan_hip.so")
 
-TG_F32, TG_BF16 = 0, 1
+TG_F32, TG_BF16, TG_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_TANH24 = 0, 1, 2, 3, 4
 MASK_NONE, MASK_RELU, MASK_LRELU = 0, 1, 2
 OUT_NHWC, OUT_NCHW_F32 = 0, 1
@@ -79,11 +79,18 @@ _PROTOS = {
     "tg_fc_head_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tg_absdiff_sum": (_I, [_I, _P, _P, _P, _L, _I, _I, _P]),
     "tg_absdiff_nchw": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
-    "tg_content_loss": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _I, _F, _P]),
-    "tg_loss_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P]),
-    "tg_dlogit_real": (_I, [_P, _P, _I, _P, _P]),
+    "tg_content_loss": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _I, _F, _P, _P]),
+    "tg_loss_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P, _P]),
+    "tg_dlogit_real": (_I, [_P, _P, _I, _P, _P, _P]),
     "tg_reduce_replicas": (_I, [_P, _I, _I, _I, _P, _I, _P]),
     "tg_adam": (_I, [_P, _P, _P, _P, _L, _P, _P]),
+    "tg_check_finite": (_I, [_P, _L, _P, _P]),
+    "tg_adam_scaled": (_I, [_P, _P, _P, _P, _L, _P, _P, _I, _P]),
+    "tg_scaler_update": (_I, [_P, _F, _F, _I, _P]),
+    "tg_vgg_input": (_I, [_I, _P, _P, _I, _I, _I, _F, _P, _P]),
+    "tg_cosine_loss": (_I, [_I, _P, _P, _P, _L, _I, _F, _I, _P, _P, _P]),
+    "tg_maxpool2_bwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "tg_vgg_input_grad": (_I, [_I, _P, _P, _P, _I, _I, _I, _F, _P]),
     "tg_stream_create_cumask": (_I, [_I, C.POINTER(C.c_void_p)]),
     "tg_stream_destroy": (_I, [_P]),
 }

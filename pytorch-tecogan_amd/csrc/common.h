@@ -5,6 +5,7 @@
 #include "../../include/tecogan_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -12,6 +13,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 struct BF16 {};  // tag types: element type is a template tag, never a runtime branch inside kernels
 struct F32 {};
+struct F16 {};   // IEEE half (BASELINE configs[3]: the reference's fp16 autocast path); same layouts as BF16
 
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<F32> {
@@ -25,6 +27,17 @@ template <> struct ElemTraits<BF16> {
   static constexpr int kVec = 8;
 };
 
+template <> struct ElemTraits<F16> {
+  static constexpr int kBytes = 2;
+  static constexpr int kChunk = 32;
+  static constexpr int kVec = 8;
+};
+
+__device__ __forceinline__ float f16_bits_to_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ unsigned short f32_to_f16_bits(float f) {
+  _Float16 h = (_Float16)f;  // v_cvt_f16_f32: RNE, overflow -> inf (what the loss-scale overflow check looks for)
+  return __builtin_bit_cast(unsigned short, h);
+}
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
   __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
@@ -63,7 +76,25 @@ template <> struct Vec<BF16> {
   }
 };
 
+template <> struct Vec<F16> {
+  static constexpr int N = 8;
+  __device__ __forceinline__ static void load(const void* p, float* v) {
+    f16x8 t = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+  }
+  __device__ __forceinline__ static void store(void* p, const float* v) {
+    f16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (_Float16)v[i];
+    *reinterpret_cast<f16x8*>(p) = t;
+  }
+};
+
 template <typename T> __device__ __forceinline__ float load_elem(const void* base, int64_t i);
+template <> __device__ __forceinline__ float load_elem<F16>(const void* base, int64_t i) {
+  return f16_bits_to_f32(reinterpret_cast<const unsigned short*>(base)[i]);
+}
 template <> __device__ __forceinline__ float load_elem<F32>(const void* base, int64_t i) {
   return reinterpret_cast<const float*>(base)[i];
 }
@@ -77,6 +108,9 @@ template <> __device__ __forceinline__ void store_elem<F32>(void* base, int64_t 
 template <> __device__ __forceinline__ void store_elem<BF16>(void* base, int64_t i, float v) {
   reinterpret_cast<unsigned short*>(base)[i] = f32_to_bf16_bits(v);
 }
+template <> __device__ __forceinline__ void store_elem<F16>(void* base, int64_t i, float v) {
+  reinterpret_cast<unsigned short*>(base)[i] = f32_to_f16_bits(v);
+}
 
 // Packed-weight row order.  Row R of the packed matrix holds output channel row_to_channel(R): for bf16 two
 // adjacent 16-row MFMA tiles are interleaved so that one lane's 2x4 accumulator rows are 8 consecutive
@@ -87,6 +121,30 @@ template <> __host__ __device__ __forceinline__ int row_to_channel<BF16>(int R) 
   int tile = R >> 4, r = R & 15, q = r >> 2, j = r & 3;
   return 32 * (tile >> 1) + 8 * q + 4 * (tile & 1) + j;
 }
+
+template <> __host__ __device__ __forceinline__ int row_to_channel<F16>(int R) { return row_to_channel<BF16>(R); }
+
+// 16x16x32 MFMA on 16-bit operands (8 values per lane and operand), fp32 accumulate
+template <typename T> struct Mma16;
+template <> struct Mma16<BF16> {
+  __device__ __forceinline__ static f32x4 run(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma16<F16> {
+  __device__ __forceinline__ static f32x4 run(bf16x8 a, bf16x8 b, f32x4 c) {  // fragments travel as raw 16-byte vectors
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+// run `expr(Tag)` for the element type `dtype` (TG_F32 / TG_BF16 / TG_F16)
+#define TG_DISPATCH_DTYPE(dtype, STMT_BF16, STMT_F16, STMT_F32) \
+  do {                                                         \
+    if ((dtype) == TG_BF16) { STMT_BF16; }                     \
+    else if ((dtype) == TG_F16) { STMT_F16; }                  \
+    else if ((dtype) == TG_F32) { STMT_F32; }                  \
+    else return TG_E_BADARG;                                   \
+  } while (0)
 
 #define TG_CHECK_HIP(expr)                 \
   do {                                     \

@@ -45,6 +45,12 @@ template <> struct MmaT<BF16> {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
 };
+template <> struct MmaT<F16> {
+  using Frag = f16x8;
+  __device__ __forceinline__ static f32x4 run(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
 template <> struct MmaT<F32> {
   using Frag = f32x4;
   __device__ __forceinline__ static f32x4 run(Frag a, Frag b, f32x4 c) {
@@ -247,7 +253,7 @@ int launch_s2(int dtype, const void* in, const void* w_packed, const float* bias
   k.in = (const char*)in; k.w = (const char*)w_packed; k.bias = bias; k.out = (char*)out; k.stats = stats;
   k.N = N; k.IH = IH; k.IW = IW; k.Cin = Cin; k.OH = IH / 2; k.OW = IW / 2; k.Cout = Cout;
   k.stats_groups = stats ? stats_groups : 1;
-  k.nchunks = Cin / (dtype == TG_BF16 ? 32 : 16);
+  k.nchunks = Cin / (dtype == TG_F32 ? 16 : 32);
   k.tiles_x = (k.OW + 15) / 16; k.tiles_y = (k.OH + TH - 1) / TH;
   const long long gx = (long long)k.tiles_x * k.tiles_y * N;
   if (gx > 0x7fffffffLL) return TG_E_UNSUPPORTED;
@@ -260,9 +266,12 @@ int launch_s2(int dtype, const void* in, const void* w_packed, const float* bias
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2_gather_kernel<F32, KS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2_gather_kernel<F16, KS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
   if (dtype == TG_BF16) hipLaunchKernelGGL((conv_s2_gather_kernel<BF16, KS>), grid, dim3(NTHR), lds, st, k);
+  else if (dtype == TG_F16) hipLaunchKernelGGL((conv_s2_gather_kernel<F16, KS>), grid, dim3(NTHR), lds, st, k);
   else hipLaunchKernelGGL((conv_s2_gather_kernel<F32, KS>), grid, dim3(NTHR), lds, st, k);
   return tg_launch_status();
 }
@@ -270,7 +279,7 @@ int launch_s2(int dtype, const void* in, const void* w_packed, const float* bias
 int check_s2(int dtype, const void* in, const void* w_packed, const float* bias, void* out, int N, int IH, int IW, int Cin,
              int Cout) {
   if (!in || !w_packed || !out || N <= 0 || IH <= 0 || IW <= 0 || Cin <= 0 || Cout <= 0) return TG_E_BADARG;
-  if (dtype != TG_BF16 && dtype != TG_F32) return TG_E_BADARG;
+  if (dtype != TG_BF16 && dtype != TG_F32 && dtype != TG_F16) return TG_E_BADARG;
   if ((IH & 1) || (IW & 1)) return TG_E_UNSUPPORTED;
   if (Cin % 32 || Cout % 32) return TG_E_ALIGN;
   if (Cout % CO_TILE) return TG_E_UNSUPPORTED;  // run tg_conv instead

@@ -81,6 +81,12 @@ template <> struct Mma<BF16> {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
 };
+template <> struct Mma<F16> {
+  using Frag = f16x8;
+  __device__ __forceinline__ static f32x4 run(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
 template <> struct Mma<F32> {
   using Frag = f32x4;
   __device__ __forceinline__ static f32x4 run(Frag a, Frag b, f32x4 c) {
@@ -593,7 +599,7 @@ TileCfg tile_cfg(int cfg) {
 
 extern "C" int64_t tg_packed_weight_bytes(int dtype, int nslots, int cout_p, int cin_p) {
   if (nslots <= 0 || cout_p <= 0 || cin_p <= 0) return TG_E_BADARG;
-  return (int64_t)nslots * cout_p * cin_p * (dtype == TG_BF16 ? 2 : 4);
+  return (int64_t)nslots * cout_p * cin_p * (dtype == TG_F32 ? 4 : 2);
 }
 
 extern "C" int tg_pack_conv_weights(int dtype, const float* w, void* packed, int cout, int cin, int cout_p, int cin_p,
@@ -601,16 +607,14 @@ extern "C" int tg_pack_conv_weights(int dtype, const float* w, void* packed, int
                                     void* stream) {
   if (!w || !packed || !slot_off_dev || cout <= 0 || cin <= 0 || nslots <= 0) return TG_E_BADARG;
   if (cout_p % 32 || cin_p % 32 || cout > cout_p || cin > cin_p) return TG_E_ALIGN;
-  if (dtype != TG_F32 && dtype != TG_BF16) return TG_E_BADARG;
   const long long total = (long long)nslots * cout_p * cin_p;
   const int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TG_BF16)
-    hipLaunchKernelGGL(pack_weights_kernel<BF16>, dim3(blocks), dim3(256), 0, st, w, (char*)packed, cout, cin, cout_p,
-                       cin_p, (long long)s_co, (long long)s_ci, nslots, slot_off_dev);
-  else
-    hipLaunchKernelGGL(pack_weights_kernel<F32>, dim3(blocks), dim3(256), 0, st, w, (char*)packed, cout, cin, cout_p,
-                       cin_p, (long long)s_co, (long long)s_ci, nslots, slot_off_dev);
+#define TG_PACK(TAG)                                                                                                  \
+  hipLaunchKernelGGL(pack_weights_kernel<TAG>, dim3(blocks), dim3(256), 0, st, w, (char*)packed, cout, cin, cout_p, \
+                     cin_p, (long long)s_co, (long long)s_ci, nslots, slot_off_dev)
+  TG_DISPATCH_DTYPE(dtype, TG_PACK(BF16), TG_PACK(F16), TG_PACK(F32));
+#undef TG_PACK
   return tg_launch_status();
 }
 
@@ -652,7 +656,7 @@ static int prepare_conv(const tg_conv_desc* d, const void* in, const void* w_pac
                         int& cfg_out) {
   if (!d) return TG_E_BADARG;
   if (check_ptrs && (!in || !w_packed || !out)) return TG_E_BADARG;
-  if (d->dtype != TG_F32 && d->dtype != TG_BF16) return TG_E_BADARG;
+  if (d->dtype != TG_F32 && d->dtype != TG_BF16 && d->dtype != TG_F16) return TG_E_BADARG;
   if (d->N <= 0 || d->IH <= 0 || d->IW <= 0 || d->OH <= 0 || d->OW <= 0 || d->S <= 0 || d->OS <= 0) return TG_E_BADARG;
   if (d->ncls <= 0 || d->ncls > TG_MAX_CLASSES) return TG_E_BADARG;
   if (d->Cin <= 0 || d->Cout <= 0 || d->Cin % 32 || d->Cout % 32) return TG_E_ALIGN;
@@ -681,7 +685,7 @@ static int prepare_conv(const tg_conv_desc* d, const void* in, const void* w_pac
   k.out_mode = d->out_mode; k.c_real = d->c_real; k.out_n_stride = d->out_n_stride;
   k.stats_replicas = d->stats_replicas > 1 ? d->stats_replicas : 1;
   if (k.stats_replicas & (k.stats_replicas - 1)) return TG_E_BADARG;  // power of two
-  const int chunk = d->dtype == TG_BF16 ? 32 : 16;
+  const int chunk = d->dtype == TG_F32 ? 16 : 32;
   k.nchunks = d->Cin / chunk;
 
   int max_ohc = 0, max_owc = 0, max_rows = 0, max_taps = 0;
@@ -799,7 +803,9 @@ extern "C" int tg_conv(const tg_conv_desc* d, const void* in, const void* w_pack
   const int rc = prepare_conv(d, in, w_packed, bias, res, mask, out, stats, true, k, grid, lds, cfg);
   if (rc != TG_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  return d->dtype == TG_BF16 ? dispatch_conv<BF16>(cfg, k, grid, lds, st) : dispatch_conv<F32>(cfg, k, grid, lds, st);
+  if (d->dtype == TG_BF16) return dispatch_conv<BF16>(cfg, k, grid, lds, st);
+  if (d->dtype == TG_F16) return dispatch_conv<F16>(cfg, k, grid, lds, st);
+  return dispatch_conv<F32>(cfg, k, grid, lds, st);
 }
 
 // ---------------------------------------------------------------------------------------- table-driven repack
@@ -836,11 +842,9 @@ extern "C" int tg_pack_conv_weights_multi(int dtype, const int64_t* jobs_dev, in
                                           void* stream) {
   if (!jobs_dev || njobs <= 0 || blocks_per_job <= 0) return TG_E_BADARG;
   dim3 grid((unsigned)blocks_per_job, (unsigned)njobs);
-  if (dtype == TG_BF16)
-    hipLaunchKernelGGL(pack_multi_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, (const long long*)jobs_dev);
-  else if (dtype == TG_F32)
-    hipLaunchKernelGGL(pack_multi_kernel<F32>, grid, dim3(256), 0, (hipStream_t)stream, (const long long*)jobs_dev);
-  else
-    return TG_E_BADARG;
+#define TG_PACKM(TAG) \
+  hipLaunchKernelGGL(pack_multi_kernel<TAG>, grid, dim3(256), 0, (hipStream_t)stream, (const long long*)jobs_dev)
+  TG_DISPATCH_DTYPE(dtype, TG_PACKM(BF16), TG_PACKM(F16), TG_PACKM(F32));
+#undef TG_PACKM
   return tg_launch_status();
 }

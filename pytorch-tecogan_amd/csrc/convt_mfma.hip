@@ -61,6 +61,12 @@ template <> struct MmaT<BF16> {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
 };
+template <> struct MmaT<F16> {
+  using Frag = f16x8;
+  __device__ __forceinline__ static f32x4 run(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
 template <> struct MmaT<F32> {
   using Frag = f32x4;
   __device__ __forceinline__ static f32x4 run(Frag a, Frag b, f32x4 c) {
@@ -243,7 +249,7 @@ int launch_subpixel(int dtype, const void* in, const void* w_packed, const float
   k.in = (const char*)in; k.w = (const char*)w_packed; k.bias = bias; k.out = (char*)out;
   k.mask = (const char*)mask; k.mask_mode = mask ? mask_mode : TG_MASK_NONE;
   k.N = N; k.IH = IH; k.IW = IW; k.Cin = Cin; k.Cout = Cout; k.act = act;
-  k.nchunks = Cin / (dtype == TG_BF16 ? 32 : 16);
+  k.nchunks = Cin / (dtype == TG_F32 ? 16 : 32);
   k.tiles_x = (IW + 15) / 16; k.tiles_y = (IH + TH - 1) / TH;
   const long long gx = (long long)k.tiles_x * k.tiles_y * N;
   if (gx > 0x7fffffffLL) return TG_E_UNSUPPORTED;
@@ -256,9 +262,12 @@ int launch_subpixel(int dtype, const void* in, const void* w_packed, const float
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(subpixel_kernel<F32, PAT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(subpixel_kernel<F16, PAT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
   if (dtype == TG_BF16) hipLaunchKernelGGL((subpixel_kernel<BF16, PAT>), grid, dim3(NTHR), lds, st, k);
+  else if (dtype == TG_F16) hipLaunchKernelGGL((subpixel_kernel<F16, PAT>), grid, dim3(NTHR), lds, st, k);
   else hipLaunchKernelGGL((subpixel_kernel<F32, PAT>), grid, dim3(NTHR), lds, st, k);
   return tg_launch_status();
 }
@@ -266,7 +275,7 @@ int launch_subpixel(int dtype, const void* in, const void* w_packed, const float
 int check_subpixel(int dtype, const void* in, const void* w_packed, const float* bias, void* out, int N, int IH, int IW,
                    int Cin, int Cout, int act) {
   if (!in || !w_packed || !out || N <= 0 || IH <= 0 || IW <= 0 || Cin <= 0 || Cout <= 0) return TG_E_BADARG;
-  if (dtype != TG_BF16 && dtype != TG_F32) return TG_E_BADARG;
+  if (dtype != TG_BF16 && dtype != TG_F32 && dtype != TG_F16) return TG_E_BADARG;
   if (act != TG_ACT_NONE && act != TG_ACT_RELU && act != TG_ACT_LRELU) return TG_E_UNSUPPORTED;
   if (Cin % 32 || Cout % 32) return TG_E_ALIGN;
   if (Cout % CO_TILE) return TG_E_UNSUPPORTED;  // run tg_conv with the four-class descriptor instead

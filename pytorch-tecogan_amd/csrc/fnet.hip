@@ -84,9 +84,12 @@ __global__ void up2_bilinear_kernel(const char* __restrict__ src, char* __restri
 extern "C" int tg_maxpool2(int dtype, const void* src, void* dst, int N, int H, int W, int C, void* stream) {
   if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1)) return TG_E_BADARG;
   if (C % 32 || !tg_aligned16(src) || !tg_aligned16(dst)) return TG_E_ALIGN;
-  const long long total = (long long)N * (H / 2) * (W / 2) * (C / (dtype == TG_BF16 ? 8 : 4));
+  const long long total = (long long)N * (H / 2) * (W / 2) * (C / (dtype == TG_F32 ? 4 : 8));
   if (dtype == TG_BF16)
     hipLaunchKernelGGL(maxpool2_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const char*)src, (char*)dst, N, H, W, C);
+  else if (dtype == TG_F16)
+    hipLaunchKernelGGL(maxpool2_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const char*)src, (char*)dst, N, H, W, C);
   else if (dtype == TG_F32)
     hipLaunchKernelGGL(maxpool2_kernel<F32>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
@@ -99,9 +102,12 @@ extern "C" int tg_maxpool2(int dtype, const void* src, void* dst, int N, int H, 
 extern "C" int tg_up2_bilinear(int dtype, const void* src, void* dst, int N, int H, int W, int C, void* stream) {
   if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || C <= 0) return TG_E_BADARG;
   if (C % 32 || !tg_aligned16(src) || !tg_aligned16(dst)) return TG_E_ALIGN;
-  const long long total = (long long)N * (2 * H) * (2 * W) * (C / (dtype == TG_BF16 ? 8 : 4));
+  const long long total = (long long)N * (2 * H) * (2 * W) * (C / (dtype == TG_F32 ? 4 : 8));
   if (dtype == TG_BF16)
     hipLaunchKernelGGL(up2_bilinear_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const char*)src, (char*)dst, N, H, W, C);
+  else if (dtype == TG_F16)
+    hipLaunchKernelGGL(up2_bilinear_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const char*)src, (char*)dst, N, H, W, C);
   else if (dtype == TG_F32)
     hipLaunchKernelGGL(up2_bilinear_kernel<F32>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,

@@ -309,6 +309,9 @@ extern "C" int tg_gen_input(int dtype, const float* lr, int64_t lr_n_stride, con
   if (dtype == TG_BF16)
     hipLaunchKernelGGL(gen_input_kernel<BF16>, dim3(g), dim3(256), 0, (hipStream_t)stream, lr, (long long)lr_n_stride,
                        prev, (long long)prev_n_stride, grid, (long long)grid_n_stride, (char*)dst, B, h, w);
+  else if (dtype == TG_F16)
+    hipLaunchKernelGGL(gen_input_kernel<F16>, dim3(g), dim3(256), 0, (hipStream_t)stream, lr, (long long)lr_n_stride,
+                       prev, (long long)prev_n_stride, grid, (long long)grid_n_stride, (char*)dst, B, h, w);
   else if (dtype == TG_F32)
     hipLaunchKernelGGL(gen_input_kernel<F32>, dim3(g), dim3(256), 0, (hipStream_t)stream, lr, (long long)lr_n_stride,
                        prev, (long long)prev_n_stride, grid, (long long)grid_n_stride, (char*)dst, B, h, w);
@@ -326,6 +329,9 @@ extern "C" int tg_d_assemble(int dtype, const float* x, const float* y, const fl
   if (dtype == TG_BF16)
     hipLaunchKernelGGL(d_assemble_kernel<BF16>, dim3(grid_for(total, 128)), dim3(128), 0, (hipStream_t)stream, x, y,
                        gen, tvel, (char*)dst, B, T, K, h, border, half);
+  else if (dtype == TG_F16)
+    hipLaunchKernelGGL(d_assemble_kernel<F16>, dim3(grid_for(total, 128)), dim3(128), 0, (hipStream_t)stream, x, y,
+                       gen, tvel, (char*)dst, B, T, K, h, border, half);
   else if (dtype == TG_F32)
     hipLaunchKernelGGL(d_assemble_kernel<F32>, dim3(grid_for(total, 128)), dim3(128), 0, (hipStream_t)stream, x, y,
                        gen, tvel, (char*)dst, B, T, K, h, border, half);
@@ -338,9 +344,12 @@ extern "C" int tg_nchw_to_nhwc(int dtype, const float* src, int64_t src_n_stride
                                int H, int W, void* stream) {
   if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || C > Cp) return TG_E_BADARG;
   if (Cp % 32 || !tg_aligned16(dst)) return TG_E_ALIGN;
-  const long long total = (long long)N * H * W * (Cp / (dtype == TG_BF16 ? 8 : 4));
+  const long long total = (long long)N * H * W * (Cp / (dtype == TG_F32 ? 4 : 8));
   if (dtype == TG_BF16)
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
+                       (long long)src_n_stride, (char*)dst, N, C, Cp, H, W);
+  else if (dtype == TG_F16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
                        (long long)src_n_stride, (char*)dst, N, C, Cp, H, W);
   else if (dtype == TG_F32)
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<F32>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
@@ -356,6 +365,9 @@ extern "C" int tg_nhwc_to_nchw(int dtype, const void* src, float* dst, int64_t d
   const long long total = (long long)N * C * H * W;
   if (dtype == TG_BF16)
     hipLaunchKernelGGL(nhwc_to_nchw_kernel<BF16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const char*)src, dst, (long long)dst_n_stride, N, C, Cp, H, W);
+  else if (dtype == TG_F16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<F16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const char*)src, dst, (long long)dst_n_stride, N, C, Cp, H, W);
   else if (dtype == TG_F32)
     hipLaunchKernelGGL(nhwc_to_nchw_kernel<F32>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,

@@ -40,6 +40,11 @@ template <> __device__ __forceinline__ void unpack16<BF16>(const u32x4& v, float
     f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
   }
 }
+template <> __device__ __forceinline__ void unpack16<F16>(const u32x4& v, float* f) {
+  const f16x8 h = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = (float)h[i];
+}
 template <> __device__ __forceinline__ void unpack16<F32>(const u32x4& v, float* f) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v[i]);
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_kernel(const WgradK p) {
           const s16x8 cat = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           const bf16x8 af = __builtin_bit_cast(bf16x8, cat);
 #pragma unroll
-          for (int b = 0; b < BT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[b], acc[t][b], 0, 0, 0);
+          for (int b = 0; b < BT; ++b) acc[t][b] = Mma16<T>::run(af, bf[b], acc[t][b]);
         }
       } else {
 #pragma unroll 2
@@ -412,7 +417,7 @@ extern "C" int tg_wgrad_multi(const tg_wgrad_desc* d, const int64_t* jobs_dev, i
 namespace {
 int wgrad_launch(const tg_wgrad_desc* d, const void* x, const void* y, float* slab, const int64_t* jobs, int njobs,
                  void* stream) {
-  if (d->dtype != TG_F32 && d->dtype != TG_BF16) return TG_E_BADARG;
+  if (d->dtype != TG_F32 && d->dtype != TG_BF16 && d->dtype != TG_F16) return TG_E_BADARG;
   if (d->N <= 0 || d->XH <= 0 || d->XW <= 0 || d->YH <= 0 || d->YW <= 0 || d->S <= 0 || d->S > 2 || d->nsplit <= 0)
     return TG_E_BADARG;
   if (d->Cx % 32 || d->Cy % 32 || d->Cx <= 0 || d->Cy <= 0) return TG_E_ALIGN;
@@ -447,13 +452,14 @@ int wgrad_launch(const tg_wgrad_desc* d, const void* x, const void* y, float* sl
   k.nsplit = d->nsplit;
   k.ysum = d->y_sum ? 1 : 0;
   k.b_blocks = d->Cy / c.b_blk;
-  const int eb = d->dtype == TG_BF16 ? 2 : 4;
-  const int padb = d->dtype == TG_BF16 ? 32 : 16;  // row padding of the kernel (PADB)
+  const bool is16 = d->dtype != TG_F32;
+  const int eb = is16 ? 2 : 4;
+  const int padb = is16 ? 32 : 16;  // row padding of the kernel (PADB)
   const size_t lds = (size_t)tw * th * (c.b_blk * eb + padb) + (size_t)k.ih * k.iw * (c.a_blk * eb + padb);
   if (lds > 160 * 1024) return TG_E_UNSUPPORTED;
   {  // register staging capacity of the kernel (UX / UY pieces per thread)
     const int xv = c.a_blk * eb / 16, yv = c.b_blk * eb / 16;
-    const int ux = d->dtype == TG_BF16 ? 11 : 22, uy = d->dtype == TG_BF16 ? 4 : 8;
+    const int ux = is16 ? 11 : 22, uy = is16 ? 4 : 8;
     if (k.ih * k.iw * xv > 256 * ux || tw * th * yv > 256 * uy) return TG_E_UNSUPPORTED;
   }
   const int tpw = d->taps_per_wg > 0 ? d->taps_per_wg : d->ntaps;
@@ -470,6 +476,15 @@ int wgrad_launch(const tg_wgrad_desc* d, const void* x, const void* y, float* sl
       case 1: if (split) TG_WG(BF16, 9, 3, 2, 2); else TG_WG(BF16, 9, 9, 2, 2);
       case 2: if (split) TG_WG(BF16, 9, 3, 4, 2); else return launch_wgrad<BF16, 9, 9, 4, 1, 8>(k, grid, lds, st);
       case 3: if (split) TG_WG(BF16, 16, 4, 4, 2); else return launch_wgrad<BF16, 16, 16, 4, 1, 8>(k, grid, lds, st);
+    }
+  } else if (d->dtype == TG_F16) {
+    switch (cfg) {
+      case 0:
+        if (split) TG_WG(F16, 9, 3, 4, 4);
+        else return launch_wgrad<F16, 9, 9, 4, 2, 8>(k, grid, lds, st);
+      case 1: if (split) TG_WG(F16, 9, 3, 2, 2); else TG_WG(F16, 9, 9, 2, 2);
+      case 2: if (split) TG_WG(F16, 9, 3, 4, 2); else return launch_wgrad<F16, 9, 9, 4, 1, 8>(k, grid, lds, st);
+      case 3: if (split) TG_WG(F16, 16, 4, 4, 2); else return launch_wgrad<F16, 16, 16, 4, 1, 8>(k, grid, lds, st);
     }
   } else {
     switch (cfg) {

@@ -28,7 +28,7 @@ class FlatParams:
     """One contiguous fp32 buffer (plus grad / exp_avg / exp_avg_sq twins) holding every parameter of a network.
     Each tensor's slot is padded to 32 floats so that kernels can read channel-padded bias / BN vectors in place."""
 
-    def __init__(self, shapes, device):
+    def __init__(self, shapes, device, train=True):
         self.shapes = OrderedDict(shapes)
         self.offsets = OrderedDict()
         off = 0
@@ -41,9 +41,10 @@ class FlatParams:
         self.total = off
         self.device = device
         self.p = torch.zeros(off, dtype=torch.float32, device=device)
-        self.g = torch.zeros_like(self.p)
-        self.m = torch.zeros_like(self.p)
-        self.v = torch.zeros_like(self.p)
+        # frozen networks (the VGG feature extractor) carry no gradient / Adam-moment twins
+        self.g = torch.zeros_like(self.p) if train else None
+        self.m = torch.zeros_like(self.p) if train else None
+        self.v = torch.zeros_like(self.p) if train else None
 
     def view(self, buf, name):
         off, n = self.offsets[name]
@@ -77,6 +78,35 @@ class Workspace:
         return self.slab
 
 
+class ShapeSets:
+    """Activation / gradient buffer sets of an engine, one per launch shape, kept alive while in use.
+
+    A captured hipGraph holds raw pointers into the set it was captured on, and the module surface (generator.forward,
+    .recurrent, discriminator.forward) may run the same engine at another shape between two training steps.  So switching
+    shapes SELECTS another set instead of freeing the current one; sets pinned by a live TecoGANStep are never dropped,
+    the others are dropped oldest-first beyond `keep`."""
+
+    def __init__(self, keep=2):
+        self.sets, self.pinned, self.keep = OrderedDict(), set(), keep
+
+    def get(self, shape, make):
+        ent = self.sets.get(shape)
+        if ent is None:
+            ent = self.sets[shape] = make()
+            loose = [k for k in self.sets if k not in self.pinned and k != shape]
+            for k in loose[:max(0, len(loose) + 1 - self.keep)]:
+                del self.sets[k]
+        else:
+            self.sets.move_to_end(shape)
+        return ent
+
+    def pin(self, shape):
+        self.pinned.add(shape)
+
+    def unpin(self, shape):
+        self.pinned.discard(shape)
+
+
 _SUBPIX_CT = os.environ.get("TECOGAN_SUBPIX_CT", "1") != "0"
 _FAST_C4S2 = os.environ.get("TECOGAN_FAST_C4S2", "1") != "0"
 
@@ -88,9 +118,9 @@ class Conv:
         self.flat, self.spec, self.dt, self.ws = flat, spec, dtype_t, ws
         self.tg = K.tg_dtype(dtype_t)
         self.w = flat.view(flat.p, wname)
-        self.gw = flat.view(flat.g, wname)
+        self.gw = flat.view(flat.g, wname) if flat.g is not None else None
         self.bias = flat.padded(flat.p, bname) if bname else None
-        self.gbias = flat.padded(flat.g, bname) if bname else None
+        self.gbias = flat.padded(flat.g, bname) if (bname and flat.g is not None) else None
         dev = flat.device
         self.slots = K.slot_table(spec.nslots, dev)
         self.cin_p, self.cout_p = pad32(spec.cin), pad32(spec.cout)
@@ -130,8 +160,8 @@ class Conv:
             K.conv4s2_fwd(x, self.wf, self.bias, out, stats, groups)
             return
         if self.spec.kind == "c3" and nchw is None and self.tile == L.TILE_AUTO and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) \
-                and K.rw_eligible(self.dt, self.cin_p, self.cout_p, N * H * W):
-            self.last_desc = "rw"  # persistent register-weights kernel (csrc/conv3_rw.hip)
+                and K.rw_eligible(self.dt, self.cin_p, self.cout_p, N, H, W):
+            self.last_desc, self.last_rw_nch = "rw", self.cin_p // 32  # persistent register-weights kernel (csrc/conv3_rw.hip)
             K.conv3x3_rw(x, self.wf, out, False, bias=self.bias, res=res, act=act, stats=stats, stats_mode=2, groups=groups)
             return
         key = ("f", N, H, W, act, res is not None, stats is not None, groups, nchw is not None and nchw[2:])
@@ -179,8 +209,8 @@ class Conv:
             K.conv4s2_dgrad(dout, self.wb, out, mask, mask_mode if mask is not None else L.MASK_NONE)
             return
         st = bias_grad_of.gbias if bias_grad_of is not None else None
-        if self.spec.kind == "c3" and self.tile == L.TILE_AUTO and K.rw_eligible(self.dt, self.cout_p, self.cin_p, N * H * W):
-            self.last_desc = "rw"  # the input-gradient of a 3x3 conv is the same conv with mirrored taps
+        if self.spec.kind == "c3" and self.tile == L.TILE_AUTO and K.rw_eligible(self.dt, self.cout_p, self.cin_p, N, H, W):
+            self.last_desc, self.last_rw_nch = "rw", self.cout_p // 32  # the input-gradient of a 3x3 conv is the same conv with mirrored taps
             K.conv3x3_rw(dout, self.wb, out, True, res=res, mask=mask, mask_mode=mask_mode, stats=st, stats_mode=1)
             return
         key = ("d", N, OH, OW, mask_mode, res is not None, st is not None)
@@ -425,6 +455,7 @@ class GeneratorEngine:
                                                                             self.c32, self.ct4, self.c6, self.cout]
         self.act = None
         self.shape = None
+        self.sets = ShapeSets()
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
         self.trunk_group = WgradGroup() if os.environ.get("TECOGAN_WGRAD_GROUPS", "1") != "0" else None
@@ -438,17 +469,22 @@ class GeneratorEngine:
         self.repacker.run()
 
     def alloc(self, NS, h, w):
-        """activation storage for NS samples (NS = T*B when training, B for inference)."""
+        """selects (creating it on first use) the activation storage for NS samples (NS = T*B when training, B for
+        inference); another shape's set stays alive while a step has it pinned (ShapeSets)."""
         if self.shape == (NS, h, w):
             return
         dev, dt = self.flat.device, self.dt
         e = lambda n, hh, ww, c: torch.empty(n, hh, ww, c, dtype=dt, device=dev)
-        a = {"in0": e(NS, h, w, 64), "a": [e(NS, h, w, 64) for _ in range(self.nrb + 1)],
-             "h": [e(NS, h, w, 64) for _ in range(self.nrb)], "u0": e(NS, 2 * h, 2 * w, 64),
-             "hh": e(NS, 2 * h, 2 * w, 64), "u1": e(NS, 2 * h, 2 * w, 64), "h2": e(NS, 2 * h, 2 * w, 128),
-             "u2": e(NS, 2 * h, 2 * w, 128), "u3": e(NS, 4 * h, 4 * w, 128), "u4": e(NS, 4 * h, 4 * w, 64)}
-        self.act, self.shape = a, (NS, h, w)
-        self.grad = None
+
+        def make():
+            return {"act": {"in0": e(NS, h, w, 64), "a": [e(NS, h, w, 64) for _ in range(self.nrb + 1)],
+                            "h": [e(NS, h, w, 64) for _ in range(self.nrb)], "u0": e(NS, 2 * h, 2 * w, 64),
+                            "hh": e(NS, 2 * h, 2 * w, 64), "u1": e(NS, 2 * h, 2 * w, 64),
+                            "h2": e(NS, 2 * h, 2 * w, 128), "u2": e(NS, 2 * h, 2 * w, 128),
+                            "u3": e(NS, 4 * h, 4 * w, 128), "u4": e(NS, 4 * h, 4 * w, 64)}, "grad": None}
+
+        self.cur = self.sets.get((NS, h, w), make)
+        self.act, self.shape, self.grad = self.cur["act"], (NS, h, w), self.cur["grad"]
 
     def forward(self, s0, B, out_buf, out_off, out_n_stride):
         """runs samples [s0, s0+B) of act['in0'] through the net; sigmoid output goes to out_buf (fp32 NCHW)."""
@@ -477,11 +513,13 @@ class GeneratorEngine:
     def _alloc_grad(self, chunk=None):
         """gradient scratch for a backward pass over `chunk` samples (default: all).  Every gradient tensor has its own
         buffer: the grouped weight-gradient launch at the end of the pass reads all of them."""
+        if self.grad is not None and chunk is None:
+            return
         NS, h, w = self.shape
         NC = chunk or NS
         dev, dt = self.flat.device, self.dt
         e = lambda hh, ww, c: torch.empty(NC, hh, ww, c, dtype=dt, device=dev)
-        self.grad = {"dpre": e(4 * h, 4 * w, 32), "hr64": e(4 * h, 4 * w, 64), "hr128": e(4 * h, 4 * w, 128),
+        self.cur["grad"] = self.grad = {"dpre": e(4 * h, 4 * w, 32), "hr64": e(4 * h, 4 * w, 64), "hr128": e(4 * h, 4 * w, 128),
                      "m128a": e(2 * h, 2 * w, 128), "m128b": e(2 * h, 2 * w, 128), "m64a": e(2 * h, 2 * w, 64),
                      "m64b": e(2 * h, 2 * w, 64), "m64c": e(2 * h, 2 * w, 64),
                      "dA": [e(h, w, 64) for _ in range(self.nrb + 1)], "dH": [e(h, w, 64) for _ in range(self.nrb)]}
@@ -571,6 +609,7 @@ class FNetEngine:
         self.convs = [c for _, a, b, _ in self.blocks for c in (a, b)] + [self.o0, self.o2]
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.shape, self.act = None, None
+        self.sets = ShapeSets()
 
     def repack(self):
         self.repacker.run()
@@ -582,12 +621,16 @@ class FNetEngine:
             return
         dev, dt = self.flat.device, self.dt
         e = lambda hh, ww, c: torch.empty(N, hh, ww, pad32(c), dtype=dt, device=dev)
-        bufs, hh, ww = [], h, w
-        for i, (_, _, _, co) in enumerate(self.blocks):
-            a, b = e(hh, ww, co), e(hh, ww, co)
-            hh, ww = (hh // 2, ww // 2) if i < 4 else (hh * 2, ww * 2)
-            bufs.append((a, b, e(hh, ww, co)))
-        self.act = {"in": e(h, w, 3), "blocks": bufs, "o0": e(h, w, 32)}
+
+        def make():
+            bufs, hh, ww = [], h, w
+            for i, (_, _, _, co) in enumerate(self.blocks):
+                a, b = e(hh, ww, co), e(hh, ww, co)
+                hh, ww = (hh // 2, ww // 2) if i < 4 else (hh * 2, ww * 2)
+                bufs.append((a, b, e(hh, ww, co)))
+            return {"in": e(h, w, 3), "blocks": bufs, "o0": e(h, w, 32)}
+
+        self.act = self.sets.get((N, h, w), make)
         self.shape = (N, h, w)
 
     def forward(self, out):
@@ -603,6 +646,120 @@ class FNetEngine:
             x = r
         self.o0.fwd(x, self.act["o0"], act=L.ACT_LRELU)
         self.o2.fwd(self.act["o0"], None, act=L.ACT_TANH24, nchw=(out, 0, 2 * h * w, 2))
+
+
+# =============================================================================================================
+VGG_LAYERS = (("Conv1_1", 3, 64), ("Conv1_2", 64, 64), "pool1", ("Conv2_1", 64, 128), ("Conv2_2", 128, 128), "pool2",
+              ("Conv3_1", 128, 256), ("Conv3_2", 256, 256), ("Conv3_3", 256, 256), ("Conv3_4", 256, 256), "pool3",
+              ("Conv4_1", 256, 512), ("Conv4_2", 512, 512), ("Conv4_3", 512, 512), ("Conv4_4", 512, 512))
+VGG_TAPS = ("Conv2_2", "Conv3_4", "Conv4_4")   # vgg_19/conv2_2, conv3_4, conv4_4 (code/train.py:125)
+VGG_MEAN = (123.68, 116.78, 103.94)            # code/train.py:6
+
+
+def vgg_shapes():
+    """state_dict keys of the reference's VGG19 module (code/ops.py:146-165) up to Conv4_4 - nothing deeper is ever read
+    (code/train.py:125); the 3x3 kernel size the reference leaves out from Conv3_1 on is VGG-19's"""
+    s = OrderedDict()
+    for l in VGG_LAYERS:
+        if isinstance(l, tuple):
+            s[f"{l[0]}.0.weight"], s[f"{l[0]}.0.bias"] = (l[2], l[1], 3, 3), (l[2],)
+    return s
+
+
+class VGGEngine:
+    """Opt-in VGG feature loss (semantics fixed in DESIGN.md because the reference's cannot execute):
+    a FROZEN VGG-19 conv stack up to Conv4_4 on tg_conv, run on the generated and the target frames as one batch; per tap
+    layer the per-pixel cosine similarity of the channel-normalised features; input-gradient of the generated half back
+    to d(loss)/d(pre-sigmoid) of the generator.  No weight gradients (the network is a fixed feature extractor)."""
+
+    def __init__(self, flat, dtype_t):
+        self.flat, self.dt = flat, dtype_t
+        self.ws = Workspace(flat.device)
+        self.convs = OrderedDict()
+        for l in VGG_LAYERS:
+            if isinstance(l, tuple):
+                self.convs[l[0]] = Conv(flat, f"{l[0]}.0.weight", f"{l[0]}.0.bias", ConvSpec("c3", l[1], l[2]), dtype_t,
+                                        self.ws, need_dgrad=True)
+        self.repacker = Repacker(list(self.convs.values()), dtype_t, flat.device)
+        self.sets = ShapeSets()
+        self.shape = None
+
+    def repack(self):
+        self.repacker.run()
+
+    def alloc(self, N, H, W):
+        """N generated + N target frames of H x W"""
+        if H % 8 or W % 8:
+            raise ValueError("the VGG loss needs frame sizes divisible by 8 (three 2x2 max-pools)")
+        if self.shape == (N, H, W):
+            return
+        dev, dt = self.flat.device, self.dt
+
+        def make():
+            act, grad, hh, ww = OrderedDict(), OrderedDict(), H, W
+            act["in"] = torch.empty(2 * N, H, W, 32, dtype=dt, device=dev)
+            grad["in"] = torch.empty(N, H, W, 32, dtype=dt, device=dev)
+            for l in VGG_LAYERS:
+                if isinstance(l, tuple):
+                    act[l[0]] = torch.empty(2 * N, hh, ww, l[2], dtype=dt, device=dev)
+                    grad[l[0]] = torch.empty(N, hh, ww, l[2], dtype=dt, device=dev)      # d loss / d (conv output, pre-ReLU)
+                    c = l[2]
+                else:
+                    hh, ww = hh // 2, ww // 2
+                    act[l] = torch.empty(2 * N, hh, ww, c, dtype=dt, device=dev)
+                    grad[l] = torch.empty(N, hh, ww, c, dtype=dt, device=dev)
+            for t in VGG_TAPS[:-1]:
+                grad["tap_" + t] = torch.empty_like(grad[t])
+            return {"act": act, "grad": grad}
+
+        cur = self.sets.get((N, H, W), make)
+        self.act, self.grad, self.shape = cur["act"], cur["grad"], (N, H, W)
+
+    def forward(self, gen_nchw, tgt_nchw):
+        """gen / tgt: fp32 [N,3,H,W] in [0,1] -> activations of both halves (generated first)"""
+        N = self.shape[0]
+        a = self.act
+        shift = [127.5 - m for m in VGG_MEAN]
+        K.vgg_input(gen_nchw, a["in"][:N], 127.5, shift)
+        K.vgg_input(tgt_nchw, a["in"][N:], 127.5, shift)
+        x = a["in"]
+        for l in VGG_LAYERS:
+            if isinstance(l, tuple):
+                self.convs[l[0]].fwd(x, a[l[0]], act=L.ACT_RELU)
+                x = a[l[0]]
+            else:
+                K.maxpool2(x, a[l])
+                x = a[l]
+
+    def loss_backward(self, acc3, coef_scale, gen_nchw, dpre, loss_scale=None):
+        """acc3[i] += sum of per-pixel cosines of tap layer i; d(loss)/d(pre-sigmoid) of the generated frames is ADDED to
+        dpre, for loss = coef_scale * sum_i (1 - mean cosine_i)."""
+        N = self.shape[0]
+        a, g = self.act, self.grad
+        for i, t in enumerate(VGG_TAPS):
+            f = a[t]
+            npix = N * f.shape[1] * f.shape[2]
+            last = t == VGG_TAPS[-1]
+            # the deepest tap starts the backward chain: its gradient is masked by its own ReLU here; the shallower taps
+            # are added (and masked) where the chain passes them (tg_maxpool2_bwd)
+            K.cosine_loss(f[:N], f[N:], g[t] if last else g["tap_" + t], -coef_scale / npix, last, acc3[i:i + 1],
+                          loss_scale=loss_scale)
+        names = [l if isinstance(l, str) else l[0] for l in VGG_LAYERS]
+        for j in range(len(names) - 1, -1, -1):
+            name = names[j]
+            below = names[j - 1] if j > 0 else "in"
+            if name.startswith("pool"):
+                # d(pool out) -> d(conv out below, pre-ReLU), + that layer's tap gradient, x relu'
+                K.maxpool2_bwd(a[below][:N], g[name], g[below], res=g.get("tap_" + below), relu_mask=True)
+                continue
+            conv = self.convs[name]
+            if below == "in":
+                conv.dgrad(g[name], g["in"])
+            elif below.startswith("pool"):
+                conv.dgrad(g[name], g[below])                       # the ReLU below a pool is handled by tg_maxpool2_bwd
+            else:
+                conv.dgrad(g[name], g[below], mask=a[below][:N], mask_mode=L.MASK_RELU)
+        K.vgg_input_grad(g["in"], gen_nchw, dpre, 127.5)
 
 
 def discriminator_shapes(resblocks=4, ch=128, fc_in=48):
@@ -665,6 +822,7 @@ class DiscriminatorEngine:
                           mk(f"resids{st}.{j}.0.2.weight", None, "c3", cout[st], cout[st]),
                           bn(f"resids{st}.{j}.1", cout[st])) for j in range(resblocks)] for st in (1, 2, 3)}
         self.cout = cout
+        self.sets = ShapeSets()
         self.fc_w, self.fc_b = flat.view(flat.p, "fc.weight"), flat.padded(flat.p, "fc.bias")
         self.g_fc_w, self.g_fc_b = flat.view(flat.g, "fc.weight"), flat.padded(flat.g, "fc.bias")
         self.convs = [self.conv0] + [self.blk[k][0] for k in range(1, 6)] + [c for st in (1, 2, 3) for (c1, c2, _) in
@@ -678,8 +836,18 @@ class DiscriminatorEngine:
         self.repacker.run()
 
     def alloc(self, N, H):
+        """selects (creating it on first use) the buffer set for N samples of H x H (see ShapeSets)"""
         if self.shape == (N, H):
             return
+        self.fc_hw = (H // 32) ** 2
+        if self.fc_w.numel() != 3 * self.fc_hw:
+            raise L.TecoganHipError(f"fc expects {self.fc_w.numel()} inputs but the D input gives {3 * self.fc_hw} "
+                                    "(code/models.py:123 hard-wires 48 = 128x128 HR)")
+        cur = self.sets.get((N, H), lambda: self._make_set(N, H))
+        self.act, self.gbuf, self.g_c0, self.prob, self.dlogit = (cur[k] for k in ("act", "gbuf", "g_c0", "prob", "dlogit"))
+        self.shape = (N, H)
+
+    def _make_set(self, N, H):
         dev, dt = self.flat.device, self.dt
         e = lambda hh, c: torch.empty(N, hh, hh, pad32(c), dtype=dt, device=dev)
         a = {"in": e(H, 27), "c0": e(H, 64), "z": {}, "n": {}, "h": {}, "r": {}, "net": {}}
@@ -691,12 +859,6 @@ class DiscriminatorEngine:
                 a["h"][k] = [e(hh, self.cout[k]) for _ in range(self.nrb)]
                 a["r"][k] = [e(hh, self.cout[k]) for _ in range(self.nrb)]
                 a["net"][k] = [e(hh, self.cout[k]) for _ in range(self.nrb)]
-        self.act, self.shape = a, (N, H)
-        self.prob = torch.empty(N, device=dev)
-        self.fc_hw = (H // 32) ** 2
-        if self.fc_w.numel() != 3 * self.fc_hw:
-            raise L.TecoganHipError(f"fc expects {self.fc_w.numel()} inputs but the D input gives {3 * self.fc_hw} "
-                                    "(code/models.py:123 hard-wires 48 = 128x128 HR)")
         g = {"dz": {}, "dn": {}, "dr": {}, "dh": {}, "dnet": {}}  # one buffer per gradient tensor (see GeneratorEngine)
         hh = H
         for k in range(1, 6):
@@ -706,9 +868,8 @@ class DiscriminatorEngine:
                 g["dr"][k] = [e(hh, self.cout[k]) for _ in range(self.nrb)]
                 g["dh"][k] = [e(hh, self.cout[k]) for _ in range(self.nrb)]
                 g["dnet"][k] = [e(hh, self.cout[k]) for _ in range(self.nrb)]
-        self.gbuf = g
-        self.g_c0 = e(H, 64)
-        self.dlogit = torch.empty(N, device=dev)
+        return {"act": a, "gbuf": g, "g_c0": e(H, 64), "prob": torch.empty(N, device=dev),
+                "dlogit": torch.empty(N, device=dev)}
 
     def stage_out(self, k):
         return self.act["net"][k][self.nrb - 1] if (k <= 3 and self.nrb > 0) else self.act["n"][k]

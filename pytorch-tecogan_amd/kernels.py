@@ -20,11 +20,12 @@ def tg_dtype(dt):
         return L.TG_BF16
     if dt == torch.float32:
         return L.TG_F32
+    if dt == torch.float16:
+        return L.TG_F16
     raise L.TecoganHipError(f"unsupported element type {dt}")
 
 
-_RW = os.environ.get("TECOGAN_RW", "0") != "0"  # routing switched on once the step tests have run with it
-_RW_MINPIX = int(os.environ.get("TECOGAN_RW_MINPIX", "8192"))
+_RW = os.environ.get("TECOGAN_RW", "1")  # 0: never, 1: where it measured faster (rw_eligible), all: every shape it takes
 
 
 def _stream():
@@ -184,10 +185,20 @@ def conv3x3_rw(x, w_packed, out, flip=False, bias=None, res=None, mask=None, mas
                                    _stream()), "tg_conv3x3_rw")
 
 
-def rw_eligible(dtype_t, cin_p, cout_p, npix):
-    """launch shapes the register-weights kernel takes (TECOGAN_RW=0 switches it off; TECOGAN_RW_MINPIX: smallest
-    N*H*W routed to it)"""
-    return _RW and dtype_t == torch.bfloat16 and cin_p in (64, 128) and cout_p % 64 == 0 and npix >= _RW_MINPIX
+def rw_eligible(dtype_t, cin_p, cout_p, N, H, W):
+    """launch shapes routed to the persistent register-weights 3x3 kernel (csrc/conv3_rw.hip).  cin_p = reduction channels.
+    Measured against tg_conv on the step's dense shapes (tools/mb_rw.py, profiles/r02_c_mb_rw.log):
+      64 -> 64  @64x64   N=40  32.7 -> 20.0 us      64 -> 128 @128x128 N=40  154 -> 106 us     128 -> 128 @64x64 N=40 78.5 -> 74.1
+      128 -> 128 @32x32  N=12  14.9 -> 11.9 us
+    and slower on the rest (128 -> 64, the 32x32 trunk at N=40, every N=4 launch of the recurrent pass, 16x16 images)."""
+    if _RW == "0" or dtype_t != torch.bfloat16 or cin_p not in (64, 128) or cout_p % 64:
+        return False
+    if _RW == "all":
+        return N * H * W >= 8192
+    npix = N * H * W
+    if cin_p == 64:
+        return npix >= 131072
+    return cout_p == 128 and (npix >= 131072 or (H == 32 and W == 32 and npix >= 8192))
 
 
 def slot_table(n, device):
@@ -330,6 +341,33 @@ def maxpool2(src, dst):
     L.check(L.load().tg_maxpool2(tg_dtype(src.dtype), _ptr(src), _ptr(dst), N, H, W, C_, _stream()), "tg_maxpool2")
 
 
+def vgg_input(src_nchw, dst, scale, shift3):
+    """fp32 [N,3,H,W] -> NHWC [N,H,W,32] of dst.dtype: scale * x + shift3[c] on the 3 live channels (csrc/vgg.hip)"""
+    N, _, H, W = src_nchw.shape
+    sh = (C.c_float * 3)(*[float(v) for v in shift3])
+    L.check(L.load().tg_vgg_input(tg_dtype(dst.dtype), _ptr(src_nchw), _ptr(dst), N, H, W, float(scale), sh, _stream()),
+            "tg_vgg_input")
+
+
+def cosine_loss(fg, ft, dg, coef, relu_mask, acc, loss_scale=None):
+    """per-pixel cosine similarity of two NHWC feature maps; acc[0] += sum; dg = coef [* loss_scale] * d(sum cos)/d(fg)"""
+    N, H, W, C_ = fg.shape
+    L.check(L.load().tg_cosine_loss(tg_dtype(fg.dtype), _ptr(fg), _ptr(ft), _ptr(dg), N * H * W, C_, float(coef),
+                                    int(bool(relu_mask)), _ptr(acc), _ptr(loss_scale), _stream()), "tg_cosine_loss")
+
+
+def maxpool2_bwd(a, dpool, out, res=None, relu_mask=True):
+    N, H, W, C_ = a.shape
+    L.check(L.load().tg_maxpool2_bwd(tg_dtype(a.dtype), _ptr(a), _ptr(dpool), _ptr(res), _ptr(out), N, H, W, C_,
+                                     int(bool(relu_mask)), _stream()), "tg_maxpool2_bwd")
+
+
+def vgg_input_grad(dx, gen_nchw, dpre, scale):
+    N, H, W, _ = dx.shape
+    L.check(L.load().tg_vgg_input_grad(tg_dtype(dx.dtype), _ptr(dx), _ptr(gen_nchw), _ptr(dpre), N, H, W, float(scale),
+                                       _stream()), "tg_vgg_input_grad")
+
+
 def up2_bilinear(src, dst):
     N, H, W, C_ = src.shape
     L.check(L.load().tg_up2_bilinear(tg_dtype(src.dtype), _ptr(src), _ptr(dst), N, H, W, C_, _stream()), "tg_up2_bilinear")
@@ -419,24 +457,41 @@ def absdiff_sum(a, b, acc, acc_idx, npix, C_, Cp):
                                     _stream()), "tg_absdiff_sum")
 
 
-def content_loss(gen, y, dpre, acc, B, T, H, W, gscale, t0=0, t1=None, pp_T=0, pp_coef=0.0):
+def content_loss(gen, y, dpre, acc, B, T, H, W, gscale, t0=0, t1=None, pp_T=0, pp_coef=0.0, loss_scale=None):
+    """loss_scale: device float (fp16 mode) multiplied into every backward seed - here d(loss)/d(pre-sigmoid)"""
     dt = tg_dtype(dpre.dtype) if dpre is not None else L.TG_F32
     L.check(L.load().tg_content_loss(dt, _ptr(gen), _ptr(y), _ptr(dpre), _ptr(acc), B, T, H, W, gscale, t0,
-                                     T if t1 is None else t1, pp_T, pp_coef, _stream()), "tg_content_loss")
+                                     T if t1 is None else t1, pp_T, pp_coef, _ptr(loss_scale), _stream()), "tg_content_loss")
 
 
-def dlogit_real(prob, dlogit, tb, cfg):
-    L.check(L.load().tg_dlogit_real(_ptr(prob), _ptr(dlogit), tb, _ptr(cfg), _stream()), "tg_dlogit_real")
+def dlogit_real(prob, dlogit, tb, cfg, loss_scale=None):
+    L.check(L.load().tg_dlogit_real(_ptr(prob), _ptr(dlogit), tb, _ptr(cfg), _ptr(loss_scale), _stream()), "tg_dlogit_real")
 
 
-def loss_finalize(prob, acc, scalars, dlogit, tb, cfg):
-    L.check(L.load().tg_loss_finalize(_ptr(prob), _ptr(acc), _ptr(scalars), _ptr(dlogit), tb, _ptr(cfg), _stream()),
-            "tg_loss_finalize")
+def loss_finalize(prob, acc, scalars, dlogit, tb, cfg, loss_scale=None):
+    L.check(L.load().tg_loss_finalize(_ptr(prob), _ptr(acc), _ptr(scalars), _ptr(dlogit), tb, _ptr(cfg), _ptr(loss_scale),
+                                      _stream()), "tg_loss_finalize")
 
 
 def adam_hyper(lr, beta1, beta2, eps, step, grad_scale=1.0):
     return [lr, beta1, beta2, eps, 1.0 - beta1 ** step, 1.0 - beta2 ** step, grad_scale, 0.0]
 
 
-def adam(p, g, m, v, hyper_dev):
-    L.check(L.load().tg_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper_dev), _stream()), "tg_adam")
+def adam(p, g, m, v, hyper_dev, scaler=None, which=0):
+    """scaler: the 8-float loss-scale state of the fp16 mode (then g is divided by the scale and the update is skipped when
+    found_inf[which] is set); None: plain tg_adam"""
+    if scaler is None:
+        L.check(L.load().tg_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper_dev), _stream()), "tg_adam")
+    else:
+        L.check(L.load().tg_adam_scaled(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper_dev), _ptr(scaler),
+                                        which, _stream()), "tg_adam_scaled")
+
+
+def check_finite(g, flag):
+    L.check(L.load().tg_check_finite(_ptr(g), g.numel(), _ptr(flag), _stream()), "tg_check_finite")
+
+
+def scaler_update(state, growth=2.0, backoff=0.5, interval=2000):
+    """the two GradScaler.update() calls of one step (torch defaults: growth 2, backoff 0.5, interval 2000)"""
+    L.check(L.load().tg_scaler_update(_ptr(state), float(growth), float(backoff), int(interval), _stream()),
+            "tg_scaler_update")

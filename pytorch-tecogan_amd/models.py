@@ -19,14 +19,18 @@ from .step import RecurrentGenerator
 
 
 def compute_dtype(args=None):
-    """bf16 by default (BASELINE config 2); TECOGAN_DTYPE=fp32 or args.tg_dtype='fp32' selects the fp32 parity mode."""
+    """bf16 by default (BASELINE config 2); TECOGAN_DTYPE / args.tg_dtype = 'fp32' selects the fp32 parity mode, 'fp16' the
+    reference's own autocast element type (BASELINE configs[3]) - the training step then runs with dynamic loss scaling
+    (step.TecoGANStep, torch.cuda.amp.GradScaler semantics of code/train.py:9,335-342)."""
     name = getattr(args, "tg_dtype", None) or os.environ.get("TECOGAN_DTYPE", "bf16")
     name = str(name).lower()
     if name in ("fp32", "f32", "float32"):
         return torch.float32
     if name in ("bf16", "bfloat16"):
         return torch.bfloat16
-    raise ValueError(f"unsupported compute dtype {name!r} (use bf16 or fp32)")
+    if name in ("fp16", "f16", "float16", "half"):
+        return torch.float16
+    raise ValueError(f"unsupported compute dtype {name!r} (use bf16, fp16 or fp32)")
 
 
 class _Node(nn.Module):
@@ -78,6 +82,18 @@ class _HipModule(nn.Module):
     """common flat-buffer binding logic"""
 
     _shapes = None
+    _dirty = False
+
+    def mark_weights_changed(self):
+        """The engines compute from PACKED copies of the conv weights (rebuilt after every Adam step).  Anything else that
+        writes the parameters in place - load_state_dict on an already bound module (hooked below), a broadcast, a manual
+        p.data.copy_() - must call this so the copies are rebuilt before the next launch."""
+        self._dirty = True
+
+    def _install_hooks(self):
+        if not getattr(self, "_hooked", False):
+            self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_weights_changed())
+            self._hooked = True
 
     def _bound(self):
         flat = getattr(self, "_flat", None)
@@ -95,7 +111,11 @@ class _HipModule(nn.Module):
         if dev.type != "cuda":
             raise L.TecoganHipError("the HIP path needs the module on a GPU: call .cuda() first (no CPU fallback)")
         L.load()
+        self._install_hooks()
         if self._bound() and self._dtype == dtype_t:
+            if self._dirty:
+                self._engine.repack()
+                self._dirty = False
             return
         old_flat = getattr(self, "_flat", None)
         flat = E.FlatParams(self._shapes, dev)
@@ -112,6 +132,7 @@ class _HipModule(nn.Module):
         self._flat, self._dtype = flat, dtype_t
         self._make_engine(flat, dtype_t)
         self._engine.repack()
+        self._dirty = False
 
     def flat_params(self):
         return self._flat
@@ -158,6 +179,8 @@ class generator(_HipModule):
         eng = self.engine()
         B, T, _, h, w = frames.shape
         if self._rec is None or (self._rec.B, self._rec.h, self._rec.w, self._rec.use_graph) != (B, h, w, use_graph):
+            if self._rec is not None:
+                self._rec.close()
             self._rec = RecurrentGenerator(eng, B, h, w, frames.device, use_graph)
         return self._rec.run(frames.contiguous().float())
 
@@ -229,3 +252,70 @@ class f_net(_HipModule):
         out = torch.empty(N, 2, h, w, dtype=torch.float32, device=x.device)
         eng.forward(out)
         return out
+
+
+class VGG19(_HipModule):
+    """code/ops.py:144-213, as far as it is ever read: the conv stack up to Conv4_4 (the step taps conv2_2, conv3_4 and
+    conv4_4, code/train.py:125), with the reference module's parameter names (Conv1_1.0.weight ...).  FROZEN feature
+    extractor of the opt-in VGG loss (args.vgg_scaling > 0).  Weights: args.vgg_ckpt (a torch file holding a state_dict
+    with these keys, extra keys ignored) or a deterministic He-uniform initialisation under numpy seed 19 - the reference
+    builds a fresh randomly initialised VGG19 on every call and never loads vgg_ckpt (code/train.py:33); see DESIGN.md.
+    forward(x[N,3,H,W] in [0,1]) -> dict of the three tap feature maps (fp32 NCHW), input arithmetic of
+    code/train.py:31-32 included."""
+
+    def __init__(self, args=None):
+        super().__init__()
+        self._args = args
+        self._shapes = E.vgg_shapes()
+        import numpy as np
+        rng = np.random.default_rng(19)
+        for name, shp in self._shapes.items():
+            lname, _, leaf = name.split(".")
+            if lname not in self._modules:
+                self.add_module(lname, _Node())
+                self._modules[lname].add_module("0", _Node())
+            if leaf == "weight":
+                bound = math.sqrt(6.0 / (shp[1] * 9))
+                t = torch.from_numpy(rng.uniform(-bound, bound, size=shp).astype("float32"))
+            else:
+                t = torch.zeros(shp)
+            self._modules[lname]._modules["0"].register_parameter(leaf, nn.Parameter(t, requires_grad=False))
+        ck = getattr(args, "vgg_ckpt", None) if args is not None else None
+        if ck:
+            sd = torch.load(ck, map_location="cpu")
+            sd = sd.get("model_state_dict", sd)
+            self.load_state_dict({k: v for k, v in sd.items() if k in self._shapes}, strict=True)
+
+    def _bind(self, dtype_t):
+        """frozen: one flat parameter buffer, no gradient / moment twins"""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise L.TecoganHipError("the HIP path needs the module on a GPU: call .cuda() first (no CPU fallback)")
+        L.load()
+        self._install_hooks()
+        if self._bound() and self._dtype == dtype_t:
+            if self._dirty:
+                self._engine.repack()
+                self._dirty = False
+            return
+        flat = E.FlatParams(self._shapes, dev, train=False)
+        for name, p in self.named_parameters():
+            v = flat.view(flat.p, name)
+            v.copy_(p.data)
+            p.data = v
+        named = list(self.named_parameters())
+        self._edge_params = (named[0], named[-1])
+        self._flat, self._dtype = flat, dtype_t
+        self._engine = E.VGGEngine(flat, dtype_t)
+        self._engine.repack()
+        self._dirty = False
+
+    def forward(self, x):
+        eng = self.engine()
+        N, C_, H, W = x.shape
+        if C_ != 3:
+            raise ValueError("VGG19 expects 3 input channels")
+        eng.alloc(N, H, W)
+        xx = x.contiguous().float()
+        eng.forward(xx, xx)
+        return {"vgg_19/" + t.lower(): K.to_nchw(eng.act[t][:N], eng.act[t].shape[3]) for t in E.VGG_TAPS}

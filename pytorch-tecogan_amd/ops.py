@@ -1,5 +1,7 @@
 """Helpers of the reference's code/ops.py that sit on (or next to) the hot path, same names and argument meaning.
 Tensor math that the step uses runs on HIP kernels; image/GIF writers stay optional host utilities."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -77,15 +79,56 @@ def denselayer(inputs, output_size):
     return fc
 
 
+def VGG19(args=None):
+    """code/ops.py:146: the VGG-19 feature extractor of the opt-in VGG loss (models.VGG19, conv stack up to Conv4_4)"""
+    from .models import VGG19 as _VGG19
+    return _VGG19(args)
+
+
 def load_ckpt(checkpoint, model):
     return model.load_state_dict(torch.load(checkpoint))
 
 
 def save_as_gif(tensor, filepath):
-    """code/ops.py:234-237 (needs imageio, which is optional)."""
-    import imageio
-    img = tensor.float().numpy() * 255.0
-    imageio.mimsave(filepath, np.transpose(img.astype(np.uint8), (0, 2, 3, 1)))
+    """code/ops.py:234-237: (T,3,H,W) in [0,1] -> an animation at `filepath` through imageio.  Without imageio (it is
+    optional here) the frames are written as an animated GIF with PIL - next to `filepath` with a .gif extension when the
+    requested container is not a GIF (main.py:220 asks for .mp4 by default) - and the path written is returned."""
+    img = np.transpose((tensor.float().numpy() * 255.0).astype(np.uint8), (0, 2, 3, 1))
+    try:
+        import imageio
+    except ImportError:
+        from PIL import Image
+        path = filepath if str(filepath).lower().endswith(".gif") else os.path.splitext(str(filepath))[0] + ".gif"
+        frames = [Image.fromarray(f) for f in img]
+        frames[0].save(path, save_all=True, append_images=frames[1:], duration=40, loop=0)
+        return path
+    imageio.mimsave(filepath, img)
+    return filepath
+
+
+def save_image(tensor, fp, nrow=8, padding=2):
+    """torchvision.utils.save_image with its defaults (main.py:287-294: the per-epoch Gan_examples.jpg / real_image.jpg /
+    original_image.jpg grids): (N,3,H,W) in [0,1] -> one image, `nrow` tiles per row, `padding` black pixels between
+    tiles, values *255 + 0.5 clamped to uint8.  Written with PIL (torchvision is not a dependency here)."""
+    from PIL import Image
+    t = tensor.detach().float().cpu()
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    n, c, h, w = t.shape
+    if c == 1:
+        t = t.expand(n, 3, h, w)
+    xmaps = min(nrow, n)
+    ymaps = (n + xmaps - 1) // xmaps
+    if n == 1:  # make_grid returns a single image unpadded
+        grid = t[0]
+    else:
+        H, W = h + padding, w + padding
+        grid = torch.zeros(3, H * ymaps + padding, W * xmaps + padding)
+        for k in range(n):
+            yy, xx = k // xmaps, k % xmaps
+            grid[:, yy * H + padding:yy * H + padding + h, xx * W + padding:xx * W + padding + w] = t[k]
+    arr = grid.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    Image.fromarray(arr).save(fp)
 
 
 def save_img(out_path, img):

@@ -2,8 +2,10 @@
 
 The reference has no distributed code at all; this is new.  Per step and per network ONE flat fp32
 gradient buffer is all-reduced (sum) over RCCL ("nccl" backend == RCCL on ROCm; gloo on CPU for the tests) and the
-1/world scaling is folded into the fused Adam kernel (hyper[6]).  Both all-reduces are launched (async, concurrently) right
-after the forward+backward graph segment and awaited before the update segment (step.TecoGANStep._run).
+1/world scaling is folded into the fused Adam kernel (hyper[6]).  The G all-reduce is issued behind the G backward (lane A) while lane B
+is still in the fake half of the D backward, the D all-reduce behind lane B (step.TecoGANStep._run_lanes).  Replicas must
+start equal: broadcast_state() sends rank 0's parameters, BN buffers and Adam moments to every rank (main.py calls it
+after construction and after a checkpoint load).
 
 BatchNorm statistics stay per rank (standard DDP; the reference's D is called on per-rank batches anyway), so an N-rank run
 equals "N shards evaluated with local BN, gradients averaged" - that is what tests/test_parallel_cpu.py checks on gloo."""
@@ -30,10 +32,60 @@ def shard_bounds(n, world, rank):
 
 
 def allreduce_sum_async(buf, group, world):
-    """launches the all-reduce of one flat gradient buffer; returns a work handle (None when single process)."""
+    """launches the all-reduce of one flat gradient buffer; returns a work handle (None when single process, and None
+    on a gloo group: gloo is the CPU rendezvous used by the tests, device buffers are staged through the host there,
+    synchronously on the current stream)."""
     if group is None or world == 1:
         return None
+    if buf.is_cuda and dist.get_backend(group) == "gloo":
+        host = buf.cpu()                       # synchronises with the current stream: the gradients are final
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        buf.copy_(host)
+        return None
     return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def broadcast_state(modules, optimizers=(), group=None, src=0):
+    """makes every rank a replica of rank `src`: parameters and buffers of `modules` (BN running statistics included)
+    and the tensor state of `optimizers` (exp_avg, exp_avg_sq, step).  In-place, so views of the flat buffers stay views.
+    Returns the number of tensors sent.  No-op without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    staged = dist.get_backend(group) == "gloo"
+    n = 0
+    seen = set()
+
+    def send(t):
+        nonlocal n
+        key = (t.data_ptr(), t.numel())
+        if key in seen:          # the fused update keeps ONE step tensor per optimiser
+            return
+        seen.add(key)
+        if staged and t.is_cuda:
+            h = t.detach().cpu()
+            dist.broadcast(h, src=src, group=group)
+            t.detach().copy_(h)
+        else:
+            dist.broadcast(t.detach(), src=src, group=group)
+        n += 1
+
+    for m in modules:
+        for p in m.parameters():
+            send(p.data)
+        for b in m.buffers():
+            send(b)
+        if hasattr(m, "mark_weights_changed"):
+            m.mark_weights_changed()       # packed compute copies are rebuilt before the next launch
+    for opt in optimizers:
+        for grp in opt.param_groups:
+            for p in grp["params"]:
+                st = opt.state.get(p)
+                if not st:
+                    continue
+                for key in ("exp_avg", "exp_avg_sq", "step"):
+                    if torch.is_tensor(st.get(key)):
+                        send(st[key])
+    return n
 
 
 def wait_all(works):
@@ -50,3 +102,23 @@ def average_gradients_(bufs, group, world):
         for b in bufs:
             b.mul_(1.0 / world)
     return bufs
+
+
+def replicas_equal(modules, group=None):
+    """True when every rank holds bit-identical parameters (compared through per-module fp64 checksums gathered from all
+    ranks; cheap enough for once per epoch).  Data-parallel training keeps replicas equal by construction - equal start
+    (broadcast_state), equal all-reduced gradients, deterministic update - so a False here means a broken invariant."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return True
+    vals = []
+    for m in modules:
+        flat = torch.cat([p.detach().double().flatten() for p in m.parameters()])
+        vals += [flat.sum(), flat.abs().sum(), (flat * torch.arange(1, flat.numel() + 1, device=flat.device,
+                                                                    dtype=torch.float64)).sum()]
+    mine = torch.stack(vals).cpu()
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) != "gloo":
+        mine = mine.to(next(modules[0].parameters()).device)
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine, group=group)
+    return all(torch.equal(both[0], b) for b in both[1:])

@@ -97,7 +97,8 @@ def lane_stream(device, reserve_cus):
 class TecoGANStep:
     """The step as two LANES of launches (each a linear sequence, so each is one hipGraph replayed on its own stream):
 
-        lane A (current stream): prep (zeroing, pseudo-flow, T_vel) | generator chain, T passes | G backward (T*B samples)
+        lane A (current stream): prep (zeroing, pseudo-flow, T_vel) | generator chain, T passes (the pass(es) D never sees
+                                 - frame 9 of 10 - after lane B's fake half has been released) | G backward (T*B samples)
         lane B (stream sB)     :          D input (real), D forward + backward of the REAL half | D input (fake), D forward,
                                           layer losses, loss scalars, D backward of the FAKE half
         update (lane A)        : [data parallel: all-reduce G grads after lane A, D grads after lane B] 2 x Adam, repack
@@ -117,8 +118,11 @@ class TecoGANStep:
         if not getattr(args, "Dt_mergeDs", True):
             raise RuntimeError("Dt_mergeDs=False feeds 9 channels into a 27-channel conv in the reference and raises "
                                "there too (SURVEY.md 8a8)")
-        if float(getattr(args, "vgg_scaling", -1.0)) > 0.0:
-            raise NotImplementedError("vgg_scaling>0 crashes in the reference (code/train.py:126 vs :30); not built")
+        # vgg_scaling > 0 (opt-in; the reference's own VGG path cannot execute, DESIGN.md fixes its semantics): needs the
+        # frozen feature extractor as args.tg_vgg (train.get_step builds the default one)
+        self.vgg_scaling = max(0.0, float(getattr(args, "vgg_scaling", -1.0)))
+        if self.vgg_scaling > 0.0 and getattr(args, "tg_vgg", None) is None:
+            raise ValueError("vgg_scaling > 0 needs args.tg_vgg (a models.VGG19 module); train.get_step provides it")
         # ping-pong (code/train.py:56-62): the step runs on x followed by reverse(x)[1:], i.e. 2T-1 frames
         self.pingpang = bool(getattr(args, "pingpang", False))
         self.T_in = T
@@ -140,14 +144,27 @@ class TecoGANStep:
         self.tvel = torch.empty(B * self.tsize, H, H, 2, **f32)
         self.target = torch.empty(self.tb, 27, H, H, **f32)
         self.acc = torch.zeros(16, **f32)
-        self.scalars = torch.zeros(48, **f32)
+        self.scalars = torch.zeros(64, **f32)
         # per-step host parameters (loss config, Adam bias corrections, lr) travel through ONE small async copy from a
         # ring of pinned slots, so the CPU may run many steps ahead of the GPU without overwriting a pending copy
-        self.params_dev = torch.zeros(32, **f32)
-        self.cfg = self.params_dev[0:16]
+        self.params_dev = torch.zeros(48, **f32)   # [0:16] loss config, [16:32] two Adam rows, [32:48] VGG loss config
+        self.cfg = self.params_dev                  # tg_loss_finalize reads cfg[32..35] when the VGG flag is set
         self.hyper = self.params_dev[16:32].view(2, 8)
-        self.ring = torch.zeros(256, 32, dtype=torch.float32).pin_memory()
+        self.ring = torch.zeros(256, 48, dtype=torch.float32).pin_memory()
+        # fp16 element type: dynamic loss scaling, state on the device (scale, growth tracker, found_inf G / D, 1/scale) so
+        # that the captured graphs read the current scale and a skipped update needs no host round trip.  The reference
+        # shares ONE GradScaler (init 65536) between both optimisers and updates it after each step() (code/train.py:9,
+        # 335-342).  Here both backward passes of a step start from the same scale - they run concurrently - and the two
+        # update() calls follow the two Adam launches; the unscaled gradients are the same either way.
+        self.scaler = None
+        if G.dt == torch.float16:
+            s0 = float(getattr(args, "tg_loss_scale", 65536.0))
+            self.scaler = torch.tensor([s0, 0.0, 0.0, 0.0, 1.0 / s0, 0.0, 0.0, 0.0], **f32)
+        self.loss_scale = self.scaler[0:1] if self.scaler is not None else None
         self.ring_i = 0
+        # the engines keep one buffer set per launch shape; this step's sets are pinned (its graphs hold their addresses)
+        # and re-selected at the start of every run(), so a module forward at another shape in between is harmless
+        G.sets.pin((T * B, h, h))
         G.alloc(T * B, h, h)
         G._alloc_grad()
         self.dpre = torch.empty(T * B, H, H, 32, dtype=G.dt, device=device)
@@ -162,8 +179,14 @@ class TecoGANStep:
         self.sA = torch.cuda.Stream(device=device)
         self.sB = lane_stream(device, self.reserve)
         self.dreal_bwd_early = os.environ.get("TECOGAN_DREAL_BWD", "1") != "0"
-        self.ev = {k: torch.cuda.Event() for k in ("prep", "chain", "d")}
+        self.ev = {k: torch.cuda.Event() for k in ("prep", "chain", "tail", "d")}
+        D.sets.pin((2 * self.tb, H))
         D.alloc(2 * self.tb, H)
+        self.V = None
+        if self.vgg_scaling > 0.0:
+            self.V = args.tg_vgg.engine(G.dt)
+            self.V.sets.pin((T * B, H, H))
+            self.V.alloc(T * B, H, H)
         self._tables()
         self.graphs = None
         self.adam_t = [0, 0]
@@ -175,6 +198,7 @@ class TecoGANStep:
         fn = getattr(self.args, "tg_fnet", None)
         self.F = fn.engine(self.G.dt) if fn is not None else None
         if self.F is not None:
+            self.F.sets.pin((self.B * self.T, self.h, self.h))
             self.F.alloc(self.B * self.T, self.h, self.h)
             self.fx = torch.empty(self.B * self.T, 2, self.h, self.h, dtype=torch.float32, device=self.dev)
         t = build_tables(self.B, self.T, self.h, self.K, self.pingpang, fnet_flow=self.F is not None)
@@ -184,13 +208,33 @@ class TecoGANStep:
         self.tv_csrc, self.tv_cdst, self.n_tvc = _i64(t["tv_csrc"], dev), _i64(t["tv_cdst"], dev), len(t["tv_csrc"])
         self.tv_bsrc, self.tv_bdst, self.n_tvb = _i64(t["tv_bsrc"], dev), _i64(t["tv_bdst"], dev), len(t["tv_bsrc"])
 
+    def _select_sets(self):
+        self.G.alloc(self.T * self.B, self.h, self.h)
+        self.G._alloc_grad()
+        self.D.alloc(2 * self.tb, self.H)
+        if self.F is not None:
+            self.F.alloc(self.B * self.T, self.h, self.h)
+        if self.V is not None:
+            self.V.alloc(self.T * self.B, self.H, self.H)
+
+    def close(self):
+        """releases the pins on the engines' buffer sets (train.get_step calls it when another configuration replaces
+        this one); the graphs of a closed step must not be replayed"""
+        self.graphs = None
+        self.G.sets.unpin((self.T * self.B, self.h, self.h))
+        self.D.sets.unpin((2 * self.tb, self.H))
+        if self.F is not None:
+            self.F.sets.unpin((self.B * self.T, self.h, self.h))
+        if self.V is not None:
+            self.V.sets.unpin((self.T * self.B, self.H, self.H))
+
     # ----------------------------------------------------------------------------------------------------------
     def _host_params(self, global_step, lr_g, lr_d, betas_g, betas_d, eps_g, eps_d):
         a = self.args
         B, T, h, H = self.B, self.T, self.h, self.H
         slot = self.ring[self.ring_i % self.ring.shape[0]]
         self.ring_i += 1
-        c = [0.0] * 32
+        c = [0.0] * 48
         c[0] = B * T * 3 * H                      # content: mean over (BT,3,H) of sum over W
         c[1] = B * (T - 1) * 3 * h                # warp loss
         for i, l in enumerate(self.D.layers()):
@@ -198,7 +242,12 @@ class TecoGANStep:
             c[12 + i] = LAYER_NORM[i]
         c[6], c[7] = a.EPS, a.ratio
         c[8] = min(a.Dt_ratio_max, a.Dt_ratio_0 + a.Dt_ratio_add * float(global_step))
-        c[9] = 1.0 if a.D_LAYERLOSS else 0.0
+        c[9] = (1.0 if a.D_LAYERLOSS else 0.0) + (2.0 if self.V is not None else 0.0)   # flag word
+        if self.V is not None:
+            c[32] = self.vgg_scaling
+            for i, t in enumerate(("Conv2_2", "Conv3_4", "Conv4_4")):
+                f = self.V.act[t]
+                c[33 + i] = float(B * T * f.shape[1] * f.shape[2])
         c[10] = float(B * (self.T_in - 1) * 3 * H * H) if self.pingpang else 0.0
         c[11] = a.pp_scaling
         self.dt_ratio = c[8]
@@ -240,15 +289,18 @@ class TecoGANStep:
         K.nhwc_to_nchw(D.act["in"][:tb], self.target, 27 * H * H, tb, 27, H, H)
         D.forward(update_stats=True, half=0)
         if backward:
-            K.dlogit_real(D.prob, D.dlogit, tb, self.cfg)
+            K.dlogit_real(D.prob, D.dlogit, tb, self.cfg, self.loss_scale)
             D.backward(groups=2, half=0)
 
-    def _chain(self):
-        """the T recurrent generator passes (each: warp + pack, conv0, residual trunk, up-sampling stage), then the content
-        loss and d(loss)/d(pre-sigmoid) of all frames"""
+    def _chain(self, t0=0, t1=None, loss=False):
+        """recurrent generator passes t0..t1-1 (each: warp + pack, conv0, residual trunk, up-sampling stage).  The piece
+        'chain' runs the frames the discriminator sees (the first 3*(T//3), code/train.py:138-142), 'chain_tail' the rest
+        (frame 9 of 10) and then the content loss and d(loss)/d(pre-sigmoid) of all frames - so the fake half of the
+        discriminator starts one pass earlier, beside the tail"""
         G, B, T, h, H = self.G, self.B, self.T, self.h, self.H
         hh, HH = h * h, H * H
-        for t in range(T):
+        t1 = self.tsize if t1 is None else t1
+        for t in range(t0, t1):
             dst = G.act["in0"][t * B:(t + 1) * B]
             if t == 0:
                 K.gen_input(self.x, 0, T * 3 * hh, None, 0, 0, None, 0, 0, dst, B, h, h)
@@ -256,9 +308,16 @@ class TecoGANStep:
                 K.gen_input(self.x, t * 3 * hh, T * 3 * hh, self.gen, (t - 1) * 3 * HH, T * 3 * HH, self.flow,
                             (t - 1) * 2 * HH, (T - 1) * 2 * HH, dst, B, h, h)
             G.forward(t * B, B, self.gen, t * 3 * HH, T * 3 * HH)
+        if not loss:
+            return
         pp_T = self.T_in if self.pingpang else 0
         pp_coef = (2.0 * self.args.pp_scaling / (B * (self.T_in - 1) * 3 * H * H)) if (self.pingpang and self.args.pp_scaling > 0) else 0.0
-        K.content_loss(self.gen, self.y, self.dpre, self.acc, B, T, H, H, 1.0 / (B * T * 3 * H), 0, T, pp_T, pp_coef)
+        K.content_loss(self.gen, self.y, self.dpre, self.acc, B, T, H, H, 1.0 / (B * T * 3 * H), 0, T, pp_T, pp_coef,
+                       loss_scale=self.loss_scale)
+        if self.V is not None:  # VGG features of all generated and target frames; its input-gradient is added to dpre
+            gen, tgt = self.gen.view(B * T, 3, H, H), self.y.view(B * T, 3, H, H)
+            self.V.forward(gen, tgt)
+            self.V.loss_backward(self.acc[11:14], self.vgg_scaling, gen, self.dpre, loss_scale=self.loss_scale)
 
     def _g_backward(self):
         """G backward for all T*B samples as ONE batch (the passes are independent in backward: every generator input is
@@ -267,9 +326,8 @@ class TecoGANStep:
         G.backward(0, self.T * self.B, dpre=self.dpre)
         G.cout.gbias[:3] += self.acc[8:11]
 
-    def _d_fake(self, backward=True):
-        """fake half: input assembly from the generated frames, forward, layer losses, every loss scalar and d(logit),
-        then the backward pass of the fake half (or of both halves when the real half has not run its own yet)"""
+    def _d_fake(self):
+        """fake half, forward: input assembly from the generated frames the discriminator sees, forward, layer losses"""
         D, B, T, h, tb = self.D, self.B, self.T, self.h, self.tb
         K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"][tb:], B, T, self.K, h, self.border, half=1)
         D.forward(update_stats=True, half=1)
@@ -277,7 +335,12 @@ class TecoGANStep:
             for i, l in enumerate(D.layers()):
                 n = tb * l.shape[1] * l.shape[2]
                 K.absdiff_sum(l[:tb], l[tb:], self.acc, 2 + i, n, l.shape[3], l.shape[3])
-        K.loss_finalize(D.prob, self.acc, self.scalars, D.dlogit, tb, self.cfg)
+
+    def _d_fake_bwd(self, backward=True):
+        """every loss scalar (needs the content loss of lane A's tail) and d(logit), then the backward pass of the fake
+        half (or of both halves when the real half has not run its own yet)"""
+        D, tb = self.D, self.tb
+        K.loss_finalize(D.prob, self.acc, self.scalars, D.dlogit, tb, self.cfg, self.loss_scale)
         if backward:
             if self.dreal_bwd_early:
                 D.backward(groups=2, half=1)
@@ -285,17 +348,34 @@ class TecoGANStep:
                 D.backward(groups=2)
 
     def _update(self):
-        G, D = self.G, self.D
-        K.adam(G.flat.p, G.flat.g, G.flat.m, G.flat.v, self.hyper[0])
-        K.adam(D.flat.p, D.flat.g, D.flat.m, D.flat.v, self.hyper[1])
+        G, D, sc = self.G, self.D, self.scaler
+        if sc is not None:  # GradScaler.step: inf/NaN anywhere in a network's (all-reduced) gradients skips its update
+            K.check_finite(G.flat.g, sc[2:3])
+            K.check_finite(D.flat.g, sc[3:4])
+        K.adam(G.flat.p, G.flat.g, G.flat.m, G.flat.v, self.hyper[0], scaler=sc, which=0)
+        K.adam(D.flat.p, D.flat.g, D.flat.m, D.flat.v, self.hyper[1], scaler=sc, which=1)
+        if sc is not None:
+            K.scaler_update(sc)
         G.repack()
         D.repack()
 
-    PIECES = ("prep", "d_real", "chain", "d_fake", "g_bwd", "update")
+    def scaler_state(self):
+        """{'scale', 'growth_tracker'} of the fp16 loss scaler (GradScaler.state_dict() keys), None otherwise; synchronises"""
+        if self.scaler is None:
+            return None
+        v = self.scaler.cpu()
+        return {"scale": float(v[0]), "growth_tracker": int(v[1])}
+
+    def _chain_tail(self):
+        self._chain(self.tsize, self.T, loss=True)
+
+    PIECES = ("prep", "d_real", "chain", "chain_tail", "d_fake", "d_fake_bwd", "g_bwd", "update")
+    LANE_B = ("d_real", "d_fake", "d_fake_bwd")
 
     def _piece_fns(self):
-        return {"prep": self._prep, "d_real": self._d_real, "chain": self._chain, "d_fake": self._d_fake,
-                "g_bwd": self._g_backward, "update": self._update}
+        return {"prep": self._prep, "d_real": self._d_real, "chain": self._chain, "chain_tail": self._chain_tail,
+                "d_fake": self._d_fake, "d_fake_bwd": self._d_fake_bwd, "g_bwd": self._g_backward,
+                "update": self._update}
 
     def _forward_backward(self, include_d_backward=True):
         """everything up to the update on the CURRENT stream alone, in dependency order (serial; tools and bench.py's
@@ -303,7 +383,9 @@ class TecoGANStep:
         self._prep()
         self._d_real()
         self._chain()
-        self._d_fake(backward=include_d_backward)
+        self._chain_tail()
+        self._d_fake()
+        self._d_fake_bwd(backward=include_d_backward)
         self._g_backward()
 
     # ---------------------------------------------------------------------------------------------------------- schedule
@@ -329,6 +411,11 @@ class TecoGANStep:
         sB.wait_event(ev["chain"])
         with torch.cuda.stream(sB):
             fn["d_fake"]()
+        fn["chain_tail"]()
+        ev["tail"].record(main)
+        sB.wait_event(ev["tail"])
+        with torch.cuda.stream(sB):
+            fn["d_fake_bwd"]()
         fn["g_bwd"]()
         w1 = self._allreduce(self.G.flat.g)
         with torch.cuda.stream(sB):
@@ -352,6 +439,10 @@ class TecoGANStep:
         sB.wait_stream(main)
         with torch.cuda.stream(sB):
             self._d_fake()
+        self._chain_tail()
+        sB.wait_stream(main)
+        with torch.cuda.stream(sB):
+            self._d_fake_bwd()
         self._g_backward()
         main.wait_stream(sB)
 
@@ -378,7 +469,7 @@ class TecoGANStep:
 
         if self.lanes:
             fns = self._piece_fns()
-            self.graphs = {k: cap(fns[k], self.sB if k in ("d_real", "d_fake") else None) for k in self.PIECES}
+            self.graphs = {k: cap(fns[k], self.sB if k in self.LANE_B else None) for k in self.PIECES}
         else:
             self.graphs = (cap(self._fork_join), cap(self._update))
 
@@ -389,6 +480,7 @@ class TecoGANStep:
         Ti = self.T_in
         if tuple(x.shape) != (self.B, Ti, 3, self.h, self.h) or tuple(y.shape) != (self.B, Ti, 3, self.H, self.H):
             raise ValueError(f"step built for B={self.B}, T={Ti}, crop {self.h}; got {tuple(x.shape)} / {tuple(y.shape)}")
+        self._select_sets()
         self.x[:, :Ti].copy_(x)
         self.y[:, :Ti].copy_(y)
         if self.pingpang:  # reverse(x)[1:] appended (data movement only)
@@ -434,8 +526,13 @@ class RecurrentGenerator:
                 src.append((b * 3 + c) * hh)
                 dst.append((b * 2 + c) * HH)
         self.fsrc, self.fdst = _i64(src, device), _i64(dst, device)
+        G.sets.pin((B, h, w))   # the per-frame graph holds addresses of this buffer set (engine.ShapeSets)
         G.alloc(B, h, w)
         self.graph = None
+
+    def close(self):
+        self.graph = None
+        self.G.sets.unpin((self.B, self.h, self.w))
 
     def _frame(self):
         G, B, h, w = self.G, self.B, self.h, self.w
@@ -448,6 +545,7 @@ class RecurrentGenerator:
         """frames (B,T,3,h,w) fp32 device -> (B,T,3,4h,4w)."""
         B, T = frames.shape[:2]
         h, w = self.h, self.w
+        self.G.alloc(B, h, w)   # re-select this loop's buffer set (a training step may have selected its own since)
         outs = torch.empty(B, T, 3, 4 * h, 4 * w, dtype=torch.float32, device=self.dev)
         self.lr.copy_(frames[:, 0])
         K.gen_input(self.lr, 0, 3 * h * w, None, 0, 0, None, 0, 0, self.G.act["in0"], B, h, w)

@@ -26,7 +26,13 @@ def _bind_optimizer(opt, module):
     flat = module.flat_params()
     tag = (id(flat), id(opt))
     if getattr(opt, "_tg_bound", None) == tag:
-        return
+        # optimizer.load_state_dict() after the first step swaps in fresh state tensors without touching the tag:
+        # trust the binding only while the state still IS the flat moment buffer
+        name0, p0 = next(iter(module.named_parameters()))
+        st0 = opt.state.get(p0)
+        if st0 and torch.is_tensor(st0.get("exp_avg")) and st0["exp_avg"].data_ptr() == flat.view(flat.m, name0).data_ptr() \
+                and st0.get("step") is opt._tg_step:
+            return
     shared_step = None
     for name, p in module.named_parameters():
         st = opt.state.get(p, None)
@@ -48,12 +54,18 @@ def get_step(generator_F, discriminator_F, B, T, h, args, device, dtype_t=None, 
     if use_graph is None:
         use_graph = os.environ.get("TECOGAN_GRAPH", "1") != "0"
     Ge, De = generator_F.engine(dtype_t), discriminator_F.engine(dtype_t)
-    key = (id(Ge), id(De), B, T, h, use_graph, bool(getattr(args, "pingpang", False)), id(getattr(args, "tg_fnet", None)))
+    if float(getattr(args, "vgg_scaling", -1.0)) > 0.0 and getattr(args, "tg_vgg", None) is None:
+        from .models import VGG19          # the frozen feature extractor is built ONCE and kept on args
+        args.tg_vgg = VGG19(args).to(device)
+    key = (id(Ge), id(De), B, T, h, use_graph, bool(getattr(args, "pingpang", False)), id(getattr(args, "tg_fnet", None)),
+           id(getattr(args, "tg_vgg", None)) if float(getattr(args, "vgg_scaling", -1.0)) > 0.0 else None)
     st = _STEPS.get(key)
     if st is None:
         pg, world = parallel.dist_info()
         st = TecoGANStep(Ge, De, B, T, h, args, device, use_graph=use_graph, process_group=pg, world_size=world)
-        _STEPS.clear()  # one live configuration: activation buffers are large
+        for old in _STEPS.values():  # one live configuration: activation buffers are large
+            old.close()
+        _STEPS.clear()
         _STEPS[key] = st
     return st
 
@@ -92,12 +104,14 @@ def _network(st, args, global_step, counter1, counter2):
     if args.D_LAYERLOSS:
         names += ["D_layer_%d_loss" % i for i in range(4)] + ["D_layer_loss_sum"]
     names += ["l2_content_loss", "l2_warp_loss"]  # l2_content_loss holds the aliased total (code/train.py:244,293,299)
+    if st.V is not None:  # code/train.py:271-273: one entry per tap layer, then their sum
+        names += ["vgg_loss_2", "vgg_loss_3", "vgg_loss_4", "vgg_all"]
     if getattr(args, "pingpang", False):
         names += ["PingPang"]
     names += ["t_adversarial_loss", "t_discrim_loss", "t_discrim_real_output", "t_discrim_fake_output", "All_loss_Gen"]
     n = len(names)
     vals = [s[16 + i] for i in range(n)]
-    avg = [s[32 + i] for i in range(n)]
+    avg = [s[40 + i] for i in range(n)]
     tb = s[14]
     avg += [tb, torch.tensor(st.dt_ratio), counter1, counter2]
     names_all = names + ["t_balance", "Dst_ratio", "withD_counter", "w_o_D_counter"]

@@ -139,9 +139,11 @@ def test_step_b2_fixture_of_the_reference_on_gpu(golden_dir, monkeypatch):
         if s == 0:
             np.testing.assert_allclose(dict(G.named_parameters())["output.weight"].grad.cpu().numpy(),
                                        gold["g_grad_output_weight"], rtol=1e-3, atol=1e-7)
-            # (the two halves of the D batch add their fc gradients separately: one more rounding on near-zero entries)
-            np.testing.assert_allclose(dict(D.named_parameters())["fc.weight"].grad.cpu().numpy(), gold["d_grad_fc_weight"],
-                                       rtol=1e-3, atol=2e-6)
+            # (the two halves of the D batch add their fc gradients separately and the BN statistics are float-atomic sums:
+            # entries of size ~1e-3 move by up to 3e-6 from run to run; the vector as a whole is held to 1e-4)
+            fcg = dict(D.named_parameters())["fc.weight"].grad.cpu()
+            np.testing.assert_allclose(fcg.numpy(), gold["d_grad_fc_weight"], rtol=1e-3, atol=6e-6)
+            assert rel(fcg, gold["d_grad_fc_weight"]) < 1e-4
             # BN-affine gradients at BN batches of 6 samples: fp32 is itself ~1e-2 from fp64 here (test_step_gpu.py yardstick)
             assert rel(dict(D.named_parameters())["block1.1.weight"].grad.cpu(), gold["d_grad_block1_bn_weight"]) < 3e-2
 

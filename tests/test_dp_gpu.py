@@ -1,0 +1,60 @@
+"""Data-parallel step with TWO ranks on the one GPU of the test box (gloo rendezvous, device buffers staged through the
+host; RCCL refuses two ranks per device).  This is the first place where world_size > 1 meets the real step: 1/world in
+tg_adam (hyper[6] = 0.5), the collectives between the per-lane hipGraphs, replica bit-equality, and main.py's broadcast /
+DistributedSampler path."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(script_args, port, env_extra, cwd, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + script_args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=cwd)
+    if r.returncode != 0:  # the ranks' tracebacks come first in stderr, the launcher's summary last
+        lines = [l for l in r.stderr.splitlines() if "[Gloo]" not in l]
+        print("\n".join(lines[:60]))
+    return r
+
+
+@pytest.mark.timeout(1200)
+def test_two_rank_step_equals_two_shards_with_local_bn_and_averaged_gradients(tmp_path):
+    out = tmp_path / "dp"
+    r = _launch([os.path.join(ROOT, "tests", "dp_worker.py"), str(out)], 29541, {}, ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    res = [json.load(open(f"{out}.{k}")) for k in range(2)]
+    for x in res:
+        assert x["replicas_bit_equal"], x
+    r0 = res[0]
+    assert r0["scal_err"] < 1e-3, r0                       # rank 0's loss scalars are those of its own shard
+    assert r0["grad_vec_g"] < 1e-3 and r0["grad_sum_g"] < 3e-2, r0   # SUM over ranks / world == averaged oracle gradients
+    # D: BatchNorm batches of 3 samples make its gradients ill-conditioned in fp32 - the CPU oracle is itself percent-level
+    # from an fp64 evaluation (yardstick note in test_step_gpu) - so the bound only has to separate "averaged over both
+    # shards" from "own shard only" (~70 % off) or "summed" (100 % off); the mechanism is the one G is held to above
+    assert r0["grad_vec_d"] < 0.15 and r0["grad_sum_d"] < 0.5, r0
+    assert r0["adam_m_g"] < 2e-3, r0                       # exp_avg = 0.1 * g/world + 0.9 * ...: wrong without hyper[6]
+    assert r0["w_g"] < 1e-4 and r0["w_d"] < 1e-3, r0          # (D: two Adam steps on the noisy gradients above)
+    assert r0["bn_rm"] < 1e-3, r0                          # BN running statistics stay per rank
+
+
+@pytest.mark.timeout(900)
+def test_main_py_two_ranks_broadcast_sampler_and_replica_check(tmp_path):
+    """main.py under torch.distributed.run with 2 ranks: every rank draws its own initial weights (unseeded), rank 0's are
+    broadcast, the DistributedSampler halves the 16 synthetic sequences (2 steps of 4 per rank), rank 0 writes the
+    checkpoints and the end-of-epoch replica check passes."""
+    r = _launch([os.path.join(ROOT, "main.py"), "--synthetic", "16", "--max_epochs", "1", "--tg_dtype", "bf16",
+                 "--num_resblock", "2", "--discrim_resblocks", "1"], 29543, {"TECOGAN_DIST_BACKEND": "gloo"}, str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "replica check ok (2 ranks)" in r.stdout, r.stdout[-1500:]
+    g_ck = torch.load(tmp_path / "generator.pt")
+    assert float(g_ck["optimizer_state_dict"]["state"][0]["step"]) == 2.0     # 16 sequences / 2 ranks / 4 per step
+    for name in ("Gan_examples.jpg", "real_image.jpg", "original_image.jpg", "discrim.pt"):
+        assert (tmp_path / name).exists(), name

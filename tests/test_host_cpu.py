@@ -297,3 +297,38 @@ def test_dataloader_semantics(tmp_path):
                                             crop_size=8))
     inf = DL.inference_dataset(argparse.Namespace(input_dir_LR=str(tmp_path), input_dir_HR=None, crop_size=8))
     assert len(inf) == 2 and inf[0].shape[1:] == (3, 8, 8)
+
+
+def test_shape_sets_keep_pinned_sets_alive_and_drop_loose_ones():
+    """a module forward at another shape must not free the buffers a captured step points into"""
+    from pytorch_tecogan_amd.engine import ShapeSets
+    s = ShapeSets(keep=2)
+    made = []
+    mk = lambda tag: (lambda: made.append(tag) or {"tag": tag})  # noqa: E731
+    s.pin((40, 32, 32))
+    a = s.get((40, 32, 32), mk("train"))
+    for i in range(5):
+        s.get((1, 16 * (i + 1), 16), mk(f"inf{i}"))
+    assert s.get((40, 32, 32), mk("again")) is a and "again" not in made      # pinned: survived five other shapes
+    loose = [k for k in s.sets if k not in s.pinned]
+    assert len(loose) <= 2 and (1, 80, 16) in s.sets                           # most recent loose sets kept
+    s.unpin((40, 32, 32))
+    for i in range(3):
+        s.get((2, 16 * (i + 1), 16), mk(f"x{i}"))
+    assert (40, 32, 32) not in s.sets
+
+
+def test_save_image_grid_layout(tmp_path):
+    """ops.save_image = torchvision.utils.save_image defaults (main.py:287-294): 8 tiles per row, 2 px padding"""
+    import numpy as np
+    from PIL import Image
+    from pytorch_tecogan_amd import ops
+    t = torch.zeros(10, 3, 4, 6)
+    t[9] = 1.0
+    fp = tmp_path / "grid.png"
+    ops.save_image(t, str(fp))
+    img = np.asarray(Image.open(fp))
+    assert img.shape == (2 * (4 + 2) + 2, 8 * (6 + 2) + 2, 3)
+    assert img[8:12, 10:16].min() == 255 and img[:8].max() == 0 and img[8:12, :10].max() == 0   # tile 9 = row 1, column 1
+    ops.save_image(torch.full((1, 3, 5, 5), 0.5), str(fp))
+    assert np.asarray(Image.open(fp)).shape == (5, 5, 3)

@@ -1,0 +1,130 @@
+"""State handling of the nn.Module surface around the captured step:
+  * a module forward at ANOTHER shape between two graph replays must not free / re-point the buffers the captured step uses;
+  * load_state_dict on an already bound module must reach the packed compute weights;
+  * optimizer.load_state_dict after the first step must reach the flat Adam moments."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(1, os.path.join(ROOT, "code"))
+import models  # noqa: E402
+import train  # noqa: E402
+import tecogan_oracle as orc  # noqa: E402
+
+
+def synth(B, T, cs, seed):
+    rng = np.random.default_rng(seed)
+    return (torch.from_numpy(rng.random((B, T, 3, cs, cs), dtype=np.float32)),
+            torch.from_numpy(rng.random((B, T, 3, 4 * cs, 4 * cs), dtype=np.float32)))
+
+
+def build(seed, dtype, **over):
+    args = orc.default_args(**over)
+    args.tg_dtype = dtype
+    gp = orc.init_params(orc.generator_param_shapes(args.num_resblock), seed + 100)
+    dp = orc.init_params(orc.discriminator_param_shapes(args.discrim_resblocks, args.discrim_channels), seed + 200)
+    G, D = models.generator(3, args), models.discriminator(args)
+    G.load_state_dict(gp)
+    D.load_state_dict(dp, strict=False)
+    G, D = G.cuda(), D.cuda()
+    og = torch.optim.Adam(G.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
+    od = torch.optim.Adam(D.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
+    return args, G, D, og, od, gp, dp
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().flatten().cpu(), torch.as_tensor(b).double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def run_steps(n, interleave, monkeypatch, graph):
+    monkeypatch.setenv("TECOGAN_GRAPH", "1" if graph else "0")
+    args, G, D, og, od, _, _ = build(3, "fp32", num_resblock=2, discrim_resblocks=1)
+    x, y = synth(1, 10, 32, 5)
+    x, y = x.cuda(), y.cuda()
+    outs = []
+    for s in range(n):
+        out = train.FRVSR_Train(x, y, args, D, G, s, 0.0, 0.0, og, od)
+        outs.append((out.gen_output.clone(), [float(v) for v in out.update_list]))
+        if interleave:  # validation-style forwards at other shapes between training steps
+            v = G(torch.rand(3, 51, 16, 16, device="cuda"))
+            assert v.shape == (3, 3, 64, 64) and bool(torch.isfinite(v).all())
+            r = G.recurrent(torch.rand(2, 3, 3, 48, 32, device="cuda"))
+            assert r.shape == (2, 3, 3, 192, 128)
+            p, layers = D(torch.rand(2, 27, 128, 128, device="cuda"))
+            assert p.shape == (2, 1) and len(layers) == 4
+    torch.cuda.synchronize()
+    w = torch.cat([p.detach().flatten() for p in G.parameters()]).clone()
+    return outs, w
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_module_forward_at_another_shape_between_steps_leaves_the_step_intact(monkeypatch, graph):
+    """4 steps (step 0 eager, capture, replays) with G(x) / G.recurrent / D(x) at other shapes in between == the same 4
+    steps without them.  D(x) in between updates the BN running statistics but those do not enter a training step."""
+    ref, w_ref = run_steps(4, False, monkeypatch, graph)
+    got, w_got = run_steps(4, True, monkeypatch, graph)
+    for (g0, s0), (g1, s1) in zip(ref, got):
+        assert rel(g1, g0) < 1e-5
+        np.testing.assert_allclose(s1, s0, rtol=2e-4, atol=1e-6)
+    # Adam turns last-bit differences of tiny gradients (float-atomic bias sums) into ~1e-5 relative weight differences;
+    # a stale or freed buffer would show up at the size of the updates themselves (~3e-3 per step)
+    assert rel(w_got, w_ref) < 2e-4
+
+
+def test_load_state_dict_after_the_first_forward_reaches_the_packed_weights():
+    args, G, _, _, _, gp, _ = build(1, "fp32", num_resblock=2)
+    x = torch.rand(2, 51, 16, 16, device="cuda")
+    y0 = G(x).clone()
+    gp2 = orc.init_params(orc.generator_param_shapes(2), 777)
+    G.load_state_dict(gp2)                       # in-place copy into the flat-buffer views: the module stays bound
+    y1 = G(x).clone()
+    G2 = models.generator(3, args)
+    G2.load_state_dict(gp2)
+    y2 = G2.cuda()(x)
+    assert rel(y1, y2) < 1e-6 and rel(y1, y0) > 1e-3
+    # the documented hook for other in-place writers
+    with torch.no_grad():
+        for p in G.parameters():
+            p.data.mul_(0.5)
+    G.mark_weights_changed()
+    G2 = models.generator(3, args)
+    G2.load_state_dict({k: v * 0.5 for k, v in gp2.items()})
+    assert rel(G(x), G2.cuda()(x)) < 1e-6
+
+
+def test_optimizer_load_state_dict_after_the_first_step_is_applied(monkeypatch):
+    """two runs: (a) 3 uninterrupted steps; (b) 2 steps, optimiser state saved, 1 throw-away step, weights AND optimiser
+    state restored, 1 step.  (b) must land on (a)'s weights - it does only if the restored moments / step count are used."""
+    monkeypatch.setenv("TECOGAN_GRAPH", "0")
+    x, y = synth(1, 10, 32, 9)
+    x, y = x.cuda(), y.cuda()
+
+    def run(restore):
+        args, G, D, og, od, _, _ = build(4, "fp32", num_resblock=2, discrim_resblocks=1)
+        for s in range(2):
+            train.FRVSR_Train(x, y, args, D, G, s, 0.0, 0.0, og, od)
+        if restore:
+            torch.cuda.synchronize()
+            sg, sd = copy.deepcopy(og.state_dict()), copy.deepcopy(od.state_dict())
+            wg, wd = copy.deepcopy(G.state_dict()), copy.deepcopy(D.state_dict())
+            train.FRVSR_Train(x, y, args, D, G, 2, 0.0, 0.0, og, od)   # moves weights, moments and the step count
+            G.load_state_dict(wg)
+            D.load_state_dict(wd)
+            og.load_state_dict(sg)
+            od.load_state_dict(sd)
+        train.FRVSR_Train(x, y, args, D, G, 2, 0.0, 0.0, og, od)
+        torch.cuda.synchronize()
+        assert int(og.state_dict()["state"][0]["step"]) == 3
+        return (torch.cat([p.detach().flatten() for p in G.parameters()]).clone(),
+                torch.cat([p.detach().flatten() for p in D.parameters()]).clone())
+
+    (g_a, d_a), (g_b, d_b) = run(False), run(True)
+    assert rel(g_b, g_a) < 2e-4 and rel(d_b, d_a) < 2e-4   # ignoring the restored moments / step would cost ~3e-3

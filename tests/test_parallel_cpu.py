@@ -141,3 +141,63 @@ def test_shard_bounds():
     assert [parallel.shard_bounds(32, 8, r) for r in (0, 7)] == [(0, 4), (28, 32)]
     with pytest.raises(ValueError):
         parallel.shard_bounds(10, 4, 0)
+
+
+def _bcast_worker(rank, world, port, q):
+    try:
+        if ROOT not in sys.path:
+            sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import argparse
+        import pytorch_tecogan_amd  # noqa: F401
+        from pytorch_tecogan_amd import models as M, parallel
+        args = argparse.Namespace(num_resblock=1, discrim_resblocks=1, discrim_channels=128, crop_size=32)
+        torch.manual_seed(100 + rank)                      # every rank draws its OWN initial weights (main.py does too)
+        G, D = M.generator(3, args), M.discriminator(args)
+        D.block1._modules["1"].running_mean.fill_(float(rank + 1))
+        og = torch.optim.Adam(G.parameters(), 1e-4)
+        for p in G.parameters():                            # a populated optimiser state, different per rank
+            og.state[p] = {"step": torch.tensor(float(3 + rank)), "exp_avg": torch.full_like(p, rank + 1.0),
+                           "exp_avg_sq": torch.full_like(p, rank + 2.0)}
+        n = parallel.broadcast_state((G, D), (og,))
+        dig = torch.tensor([float(sum(p.double().sum() for p in G.parameters())),
+                            float(sum(p.double().sum() for p in D.parameters())),
+                            float(sum(b.double().sum() for b in D.buffers())),
+                            float(sum(s["exp_avg"].double().sum() + s["exp_avg_sq"].double().sum() + s["step"].double()
+                                      for s in og.state.values()))], dtype=torch.float64)
+        both = [torch.zeros(4, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(both, dig)
+        q.put({"rank": rank, "n": n, "digests": [b.tolist() for b in both], "dirty": (G._dirty, D._dirty)})
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put({"rank": rank, "error": traceback.format_exc()})
+        raise
+
+
+@pytest.mark.timeout(300)
+def test_broadcast_state_makes_replicas_of_rank0():
+    """ranks construct different initial weights; parallel.broadcast_state must make all of them
+    (parameters, BN buffers, Adam moments and step) equal to rank 0's and mark the packed weights stale."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert "error" not in r, r.get("error")
+        assert r["digests"][0] == r["digests"][1], r
+        assert r["n"] > 50 and r["dirty"] == (True, True)
+    # rank 0's own state is what everybody has: its BN running_mean was filled with 1.0, its Adam step was 3
+    assert results[0]["digests"][0] == results[1]["digests"][0]
+
+
+def test_broadcast_state_is_a_noop_without_a_process_group():
+    from pytorch_tecogan_amd import parallel
+    assert parallel.broadcast_state((torch.nn.Linear(2, 2),)) == 0

@@ -39,7 +39,7 @@ def main():
         print(f"{'update':44s} {timeit(g[1]):7.3f} ms")
         return
     for k in st.PIECES:  # buffers hold valid data from the warm-up steps, so every piece can replay alone
-        if k in ("d_real", "d_fake"):
+        if k in st.LANE_B:
             def on_b(k=k):
                 with torch.cuda.stream(st.sB):
                     g[k]()
@@ -48,11 +48,11 @@ def main():
             print(f"{k + ' alone':44s} {timeit(g[k]):7.3f} ms")
 
     def lane_a():
-        g["prep"](); g["chain"](); g["g_bwd"]()
+        g["prep"](); g["chain"](); g["chain_tail"](); g["g_bwd"]()
 
     def lane_b():
         with torch.cuda.stream(st.sB):
-            g["d_real"](); g["d_fake"]()
+            g["d_real"](); g["d_fake"](); g["d_fake_bwd"]()
 
     def chain_and_dreal():
         g["prep"]()
