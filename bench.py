@@ -20,8 +20,14 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
-STEP_GFLOP_PER_SEQ = 380.0  # 10 G frames * 25.884 + 6 D samples * 20.196 GFLOP (T=10, cs=32)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+# BASELINE.json configs this bench can run: per-GPU batch, frames, LR crop, algorithmic GFLOP per sequence
+#   2: configs[1] (the headline metric; configs[2] is the same per GPU on 8 GPUs)        10 G frames * 25.884 + 6 D samples * 20.196
+#   4: configs[3] (64->256, seq-16, fp16 + loss scaling, 2 sequences per GPU; tg_extend)  16 * 103.54 + 10 * 80.78
+WORKLOADS = {2: dict(batch=4, T=10, cs=32, dtype="bf16", gflop_per_seq=380.0, extend=False,
+                     name="configs[1]: full G+pseudo-flow/warp+D+losses+2xAdam train step"),
+             4: dict(batch=2, T=16, cs=64, dtype="fp16", gflop_per_seq=2464.4, extend=True,
+                     name="configs[3]: same step at 64x64->256x256, seq-16, fp16 with dynamic loss scaling (tg_extend shapes)")}
 
 
 def parse():
@@ -29,8 +35,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4, help="sequences per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS), help="BASELINE.json config number (see WORKLOADS)")
+    ap.add_argument("--batch", type=int, default=None, help="sequences per GPU (default: the config's)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"], help="default: the config's")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -38,8 +45,8 @@ def parse():
     return ap.parse_args()
 
 
-def default_args(dtype):
-    return argparse.Namespace(RNN_N=10, crop_size=32, num_resblock=16, discrim_resblocks=4, discrim_channels=128,
+def default_args(dtype, T=10, cs=32, extend=False):
+    return argparse.Namespace(RNN_N=T, crop_size=cs, tg_extend=extend, num_resblock=16, discrim_resblocks=4, discrim_channels=128,
                               pingpang=False, pp_scaling=1.0, vgg_scaling=-0.002, crop_dt=0.75, Dt_mergeDs=True,
                               D_LAYERLOSS=True, EPS=1e-12, ratio=0.01, Dt_ratio_0=1.0, Dt_ratio_add=0.0, Dt_ratio_max=1.0,
                               learning_rate=1e-4, beta=0.9, adameps=1e-8, tg_dtype=dtype)
@@ -65,18 +72,21 @@ TILE_PARAMS = {1: "4, 4, 1, 4", 2: "2, 2, 2, 2", 3: "4, 4, 2, 2", 4: "2, 2, 1, 4
                7: "2, 2, 2, 4"}
 
 
+TAG = {"bf16": "BF16", "fp16": "F16", "fp32": "F32"}
+
+
 def kernel_name(conv, dtype):
     """the rocprofv3 kernel name of the launch `conv` just made (template parameters from the C library's launch plan)"""
     import ctypes
     from pytorch_tecogan_amd import _lib as L
     if conv.last_desc is None or conv.last_desc == "c4d":  # the sub-pixel launches (csrc/convt_mfma.hip)
-        return f"subpixel_kernel<{'BF16' if dtype == 'bf16' else 'F32'}, {0 if conv.last_desc is None else 1}>"
+        return f"subpixel_kernel<{TAG[dtype]}, {0 if conv.last_desc is None else 1}>"
     if conv.last_desc in ("c4s2", "ctd"):  # csrc/conv4s2_mfma.hip
-        return f"conv_s2_gather_kernel<{'BF16' if dtype == 'bf16' else 'F32'}, {4 if conv.last_desc == 'c4s2' else 3}>"
+        return f"conv_s2_gather_kernel<{TAG[dtype]}, {4 if conv.last_desc == 'c4s2' else 3}>"
     if conv.last_desc == "rw":  # csrc/conv3_rw.hip (NCH = input channels / 32; statistics variant not distinguished)
         return f"conv3_rw_kernel<{conv.last_rw_nch}, ..>"
     plan = L.load().tg_conv_pick_tile(ctypes.byref(conv.last_desc))
-    t = "BF16" if dtype == "bf16" else "F32"
+    t = TAG[dtype]
     return f"conv_gather_kernel<{t}, {TILE_PARAMS[plan & 255]}, {'true' if plan >> 8 else 'false'}>"
 
 
@@ -106,8 +116,7 @@ def roofline_pass(st, dtype):
             return r
         setattr(obj, name, wrapper)
 
-    T16 = "BF16" if dtype == "bf16" else "F32"
-    es = 2 if dtype == "bf16" else 4
+    T16 = {"bf16": "BF16", "fp16": "F16"}.get(dtype, "F32")
     nb = lambda *ts: float(sum(t.numel() * t.element_size() for t in ts if t is not None))  # noqa: E731
 
     # ---- MFMA launches
@@ -254,13 +263,17 @@ def main():
     from pytorch_tecogan_amd import models as M
     from pytorch_tecogan_amd import train as TR
 
-    args = default_args(a.dtype)
+    wl = WORKLOADS[a.config]
+    a.dtype = a.dtype or wl["dtype"]
+    a.batch = a.batch or wl["batch"]
+    args = default_args(a.dtype, wl["T"], wl["cs"], wl["extend"])
     torch.manual_seed(1)
     G, D = M.generator(3, args).to(dev), M.discriminator(args).to(dev)
     og = torch.optim.Adam(G.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
     od = torch.optim.Adam(D.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
-    B, T = a.batch, 10
-    x, y = synth(B, T, 32, 1 + rank)  # every rank owns different sequences (weak scaling)
+    B, T, cs = a.batch, wl["T"], wl["cs"]
+    STEP_GFLOP_PER_SEQ = wl["gflop_per_seq"]
+    x, y = synth(B, T, cs, 1 + rank)  # every rank owns different sequences (weak scaling)
     x, y = x.to(dev), y.to(dev)       # inputs resident in HBM before the timed region
 
     def barrier():
@@ -295,12 +308,12 @@ def main():
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * B * T * a.steps / dt
-        res = {"metric": "HR frames/sec per train step, 4x 32->128 seq-10", "value": round(value, 2),
+        res = {"metric": f"HR frames/sec per train step, 4x {cs}->{4 * cs} seq-{T}", "value": round(value, 2),
                "unit": "HR-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": "configs[1]: full G+pseudo-flow/warp+D+losses+2xAdam train step, "
-                                      f"B={B} sequences/GPU, T=10, 32x32->128x128", "global_batch": world * B,
+               "config": {"workload": f"{wl['name']}, B={B} sequences/GPU, T={T}, {cs}x{cs}->{4 * cs}x{4 * cs}",
+                          "global_batch": world * B,
                           "seq_len": T, "parallelism": f"dp{world}", "hipgraph": not a.no_graph},
                "step_tflops": round(world * B * STEP_GFLOP_PER_SEQ / 1e3 / (dt / a.steps), 2),
                "step_mfma_frac": round(B * STEP_GFLOP_PER_SEQ / 1e3 / (dt / a.steps) / MFMA_PEAK_TFLOPS[a.dtype], 5),
@@ -335,7 +348,7 @@ def main():
                                                    "GBps": round(v["work"] / (v["ms"] * 1e-3) / 1e9, 1),
                                                    "frac_of_8TBps": round(v["work"] / (v["ms"] * 1e-3) / 8e12, 4)}
                                                for k, v in sorted(hbm.items(), key=lambda kv: -kv[1]["ms"])}}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and a.config == 2:
             log(f"cpu baseline: oracle, {a.cpu_steps}+1 steps on {usable_cores()} usable host cores")
             res["cpu_baseline"] = cpu_baseline(B, a.cpu_steps)
         print(json.dumps(res), flush=True)

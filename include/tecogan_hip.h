@@ -315,9 +315,10 @@ int tg_cosine_loss(int dtype, const void* fg, const void* ft, void* dg, int64_t 
 int tg_maxpool2_bwd(int dtype, const void* a, const void* dpool, const void* res, void* out, int N, int H, int W, int C,
                     int relu_mask, void* stream);
 /* dpre[n][y][x][c] += dx[n][y][x][c] * scale * g (1 - g), g = gen[n][c][y][x], c < 3: chains d(loss)/d(vgg input) through
- * tg_vgg_input and the generator's output sigmoid (code/models.py:86) into d(loss)/d(pre-sigmoid). */
+ * tg_vgg_input and the generator's output sigmoid (code/models.py:86) into d(loss)/d(pre-sigmoid); bias_acc3[c] (nullable)
+ * += the per-channel sum of what was added (the output layer's bias gradient, as in tg_content_loss). */
 int tg_vgg_input_grad(int dtype, const void* dx_nhwc32, const float* gen_nchw, void* dpre_nhwc32, int N, int H, int W,
-                      float scale, void* stream);
+                      float scale, float* bias_acc3, void* stream);
 
 /* ---- step schedule support (no reference counterpart: the reference runs everything on one CUDA stream) ------- */
 /* Creates a stream confined to every CU except the first `reserve_cus` CU-mask bits (hipExtStreamCreateWithCUMask; 64 bits

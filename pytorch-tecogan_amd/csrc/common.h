@@ -137,6 +137,14 @@ template <> struct Mma16<F16> {
   }
 };
 
+// bits <-> float of one 16-bit element of tag T (BF16 / F16)
+template <typename T> __device__ __forceinline__ float bits16_to_f32(unsigned short b);
+template <> __device__ __forceinline__ float bits16_to_f32<BF16>(unsigned short b) { return bf16_bits_to_f32(b); }
+template <> __device__ __forceinline__ float bits16_to_f32<F16>(unsigned short b) { return f16_bits_to_f32(b); }
+template <typename T> __device__ __forceinline__ unsigned short f32_to_bits16(float f);
+template <> __device__ __forceinline__ unsigned short f32_to_bits16<BF16>(float f) { return f32_to_bf16_bits(f); }
+template <> __device__ __forceinline__ unsigned short f32_to_bits16<F16>(float f) { return f32_to_f16_bits(f); }
+
 // run `expr(Tag)` for the element type `dtype` (TG_F32 / TG_BF16 / TG_F16)
 #define TG_DISPATCH_DTYPE(dtype, STMT_BF16, STMT_F16, STMT_F32) \
   do {                                                         \

@@ -50,14 +50,12 @@ struct RwK {
   int flip, act, mask_mode, stats_groups, stats_mode;
 };
 
-__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
+template <typename T> __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return Mma16<T>::run(a, b, c); }
 
 // LDS-only barrier: __syncthreads() would also wait for the epilogue's global stores and the next tile's patch loads
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NCH, bool STATS>
+template <int NCH, bool STATS, typename T = BF16>
 __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
   static_assert(NCH == 2 || NCH == 4, "Cin = 64 or 128");
   constexpr int PT = NCH == 2 ? 2 : 4;          // output rows per wave in the k-loop
@@ -229,7 +227,7 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
         for (int b = 0; b < PT; ++b) {
           const bf16x8 xf = *reinterpret_cast<const bf16x8*>(img + ci * kChunkBytes + xoff(b, so % 3) + (so / 3) * kPitch * kRow);
 #pragma unroll
-          for (int a = 0; a < 2; ++a) acc[a][b] = mma(wfr[ci][so][a], xf, acc[a][b]);
+          for (int a = 0; a < 2; ++a) acc[a][b] = mma<T>(wfr[ci][so][a], xf, acc[a][b]);
         }
       }
     }
@@ -286,7 +284,7 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
         }
         if (p.res) {
           float r[8];
-          Vec<BF16>::load(p.res + eoff, r);
+          Vec<T>::load(p.res + eoff, r);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
@@ -299,12 +297,12 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
         }
         if (p.mask_mode != TG_MASK_NONE) {
           float m[8];
-          Vec<BF16>::load(p.mask + eoff, m);
+          Vec<T>::load(p.mask + eoff, m);
           const float neg = p.mask_mode == TG_MASK_LRELU ? 0.2f : 0.f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= (m[e] > 0.f ? 1.f : neg);
         }
-        Vec<BF16>::store(p.out + eoff, v);
+        Vec<T>::store(p.out + eoff, v);
         if constexpr (STATS) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -323,10 +321,10 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
   }
 }
 
-template <int NCH, bool STATS>
+template <int NCH, bool STATS, typename T>
 int launch_rw(const RwK& k, dim3 grid, hipStream_t st) {
   constexpr int lds = 2 * NCH * kChunkBytes + (NCH == 4 ? kXchgBytes : 0) + kRedBytes;
-  auto fn = conv3_rw_kernel<NCH, STATS>;
+  auto fn = conv3_rw_kernel<NCH, STATS, T>;
   static bool attr_done = false;  // one-time function attribute (benign race: idempotent)
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -342,7 +340,7 @@ extern "C" int tg_conv3x3_rw(int dtype, const void* in, const void* w_packed, co
                              const void* mask, void* out, float* stats, int N, int H, int W, int Cin, int Cout, int flip,
                              int act, int mask_mode, int stats_mode, int stats_groups, int max_workgroups, void* stream) {
   if (!in || !w_packed || !out || N <= 0 || H <= 0 || W <= 0) return TG_E_BADARG;
-  if (dtype != TG_BF16 || (Cin != 64 && Cin != 128) || Cout <= 0 || Cout % 64) return TG_E_UNSUPPORTED;
+  if ((dtype != TG_BF16 && dtype != TG_F16) || (Cin != 64 && Cin != 128) || Cout <= 0 || Cout % 64) return TG_E_UNSUPPORTED;
   if (act != TG_ACT_NONE && act != TG_ACT_RELU && act != TG_ACT_LRELU) return TG_E_UNSUPPORTED;
   if (mask_mode != TG_MASK_NONE && !mask) return TG_E_BADARG;
   if (stats && (stats_groups <= 0 || N % stats_groups || stats_mode < 1 || stats_mode > 2)) return TG_E_BADARG;
@@ -368,6 +366,10 @@ extern "C" int tg_conv3x3_rw(int dtype, const void* in, const void* w_packed, co
   const int gx = (k.ntiles + rounds - 1) / rounds;
   dim3 grid((unsigned)gx, (unsigned)co_tiles);
   hipStream_t st = (hipStream_t)stream;
-  if (Cin == 64) return stats ? launch_rw<2, true>(k, grid, st) : launch_rw<2, false>(k, grid, st);
-  return stats ? launch_rw<4, true>(k, grid, st) : launch_rw<4, false>(k, grid, st);
+  if (dtype == TG_F16) {
+    if (Cin == 64) return stats ? launch_rw<2, true, F16>(k, grid, st) : launch_rw<2, false, F16>(k, grid, st);
+    return stats ? launch_rw<4, true, F16>(k, grid, st) : launch_rw<4, false, F16>(k, grid, st);
+  }
+  if (Cin == 64) return stats ? launch_rw<2, true, BF16>(k, grid, st) : launch_rw<2, false, BF16>(k, grid, st);
+  return stats ? launch_rw<4, true, BF16>(k, grid, st) : launch_rw<4, false, BF16>(k, grid, st);
 }

@@ -96,22 +96,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* __restri
     s1[e] = s2[e] = 0.f;
   }
   const long long base = (long long)grp * npix;
-  for (long long p = (long long)blockIdx.x * rows + prow; p < npix; p += (long long)gridDim.x * rows) {
-    const long long off = ((base + p) * C + vec * E) * TR::kBytes;
-    float d[E], zz[E];
-    Vec<T>::load(dy + off, d);
-    Vec<T>::load(z + off, zz);
-    if (act == TG_ACT_LRELU) {
-      float a[E];
-      Vec<T>::load(yact + off, a);
-#pragma unroll
-      for (int e = 0; e < E; ++e) d[e] *= (a[e] > 0.f ? 1.f : 0.2f);
-    }
+  const long long step = (long long)gridDim.x * rows;
+  auto accum = [&](const float* d, const float* zz, const float* a) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      s1[e] += d[e];
-      s2[e] += d[e] * (zz[e] - mean[e]) * invstd[e];
+      const float dd = (act == TG_ACT_LRELU) ? d[e] * (a[e] > 0.f ? 1.f : 0.2f) : d[e];
+      s1[e] += dd;
+      s2[e] += dd * (zz[e] - mean[e]) * invstd[e];
     }
+  };
+  long long p = (long long)blockIdx.x * rows + prow;
+  // four pixels per trip with all their loads issued before the first use: a workgroup walks its pixels serially, and with
+  // one pixel per trip every trip paid a full memory round trip (11.5 us for two 6 MB tensors on 96 workgroups)
+  for (; p + 3 * step < npix; p += 4 * step) {
+    float d[4][E], zz[4][E], a[4][E];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long off = ((base + p + u * step) * C + vec * E) * TR::kBytes;
+      Vec<T>::load(dy + off, d[u]);
+      Vec<T>::load(z + off, zz[u]);
+      if (act == TG_ACT_LRELU) Vec<T>::load(yact + off, a[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) accum(d[u], zz[u], a[u]);
+  }
+  for (; p < npix; p += step) {
+    const long long off = ((base + p) * C + vec * E) * TR::kBytes;
+    float d[E], zz[E], a[E];
+    Vec<T>::load(dy + off, d);
+    Vec<T>::load(z + off, zz);
+    if (act == TG_ACT_LRELU) Vec<T>::load(yact + off, a);
+    accum(d, zz, a);
   }
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -463,7 +478,7 @@ extern "C" int tg_bn_bwd_reduce(int dtype, const void* dy, const void* yact, con
   if (act == TG_ACT_LRELU && !yact) return TG_E_BADARG;
   if (!bn_shape_ok(dtype, C)) return TG_E_UNSUPPORTED;
   const int rows = 256 / (C / (dtype == TG_F32 ? 4 : 8));
-  dim3 grid(grid_for((long long)(N / groups) * HW, rows * 16, 256), groups);
+  dim3 grid(grid_for((long long)(N / groups) * HW, rows * 8, 512), groups);  // two trips of four pixels per thread
   TG_DISPATCH(dtype, bn_bwd_reduce_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)dy, (const char*)yact,
               (const char*)z, save, red, N, HW, C, groups, act);
   return tg_launch_status();

@@ -74,9 +74,7 @@ struct ResblockK {
   const char* hmask;  // BWD: the block's saved forward activation h (relu mask of the first stage)
 };
 
-__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
+template <typename T> __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return Mma16<T>::run(a, b, c); }
 
 
 // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the weight stream and the h stores
@@ -92,10 +90,10 @@ template <int N> struct Packed16 {
   __device__ __forceinline__ int get(int i) const { return (i & 1) ? (int)(v[i >> 1] >> 16) : (int)(v[i >> 1] & 0xffffu); }
 };
 
-__device__ __forceinline__ uint2 pack4(const float* v) {
+template <typename T> __device__ __forceinline__ uint2 pack4(const float* v) {
   uint2 pk;
-  pk.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-  pk.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+  pk.x = (unsigned)f32_to_bits16<T>(v[0]) | ((unsigned)f32_to_bits16<T>(v[1]) << 16);
+  pk.y = (unsigned)f32_to_bits16<T>(v[2]) | ((unsigned)f32_to_bits16<T>(v[3]) << 16);
   return pk;
 }
 
@@ -104,7 +102,7 @@ __device__ __forceinline__ uint2 pack4(const float* v) {
 // i.e. stage 1 = transposed conv with the role-swapped packing of W2 (taps mirrored: weight slot 8 - t goes with spatial
 // offset t), bias + relu replaced by the mask h > 0; stage 2 = transposed conv with W1, skip = dOut.  dH is stored like h
 // (the weight-gradient launch of the first conv reads it; its channel sums are that conv's bias gradient).
-template <bool BWD>
+template <bool BWD, typename T = BF16>
 __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_in = smem;
@@ -213,7 +211,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
       if (tt + kAhead < 18) issue_w(tt + kAhead);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 7; ++t) acc[t] = mma(wfr[tt], xf[tt & 1][t], acc[t]);
+      for (int t = 0; t < 7; ++t) acc[t] = mma<T>(wfr[tt], xf[tt & 1][t], acc[t]);
       __builtin_amdgcn_sched_barrier(0);
     }
     RB_STAMP(4);
@@ -239,14 +237,14 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
           for (int e = 0; e < 4; ++e) {
             if constexpr (BWD) {
               const unsigned word = (e < 2) ? hm[j].x : hm[j].y;
-              const float hv = __uint_as_float((e & 1) ? (word & 0xffff0000u) : (word << 16));
+              const float hv = bits16_to_f32<T>((unsigned short)((e & 1) ? (word >> 16) : (word & 0xffffu)));
               v[e] = hv > 0.f ? acc[t][e] + other[e] : 0.f;
             } else {
               v[e] = fmaxf(acc[t][e] + other[e] + bias[e], 0.f);
             }
             v[e] = inside ? v[e] : 0.f;
           }
-          const uint2 pk = pack4(v);
+          const uint2 pk = pack4<T>(v);
           *reinterpret_cast<uint2*>(lds_h + chunk * kHRows * kRow + lds_off(hy * kHP + hx, g) + half * 8) = pk;
           if (inside && hy >= 1 && hy <= 8 && hx >= 1 && hx <= 8)
             *reinterpret_cast<uint2*>(p.out_h + (((size_t)n * p.H + y) * p.W + x) * 128 + ch0 * 2) = pk;
@@ -286,7 +284,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
       if (9 + tt + kAhead < 18) issue_w(9 + tt + kAhead);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = mma(wfr[9 + tt], xf[tt & 1][t], acc[t]);
+      for (int t = 0; t < 4; ++t) acc[t] = mma<T>(wfr[9 + tt], xf[tt & 1][t], acc[t]);
       __builtin_amdgcn_sched_barrier(0);
     }
     RB_STAMP(8);
@@ -322,11 +320,11 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
                                                            lds_off((oy + 2) * kInP + ox + 2, g) + half * 8);
           const float sk = p.skip ? 1.f : 0.f;
           float v[4];
-          v[0] = acc[t][0] + other[0] + sk * __uint_as_float(rr.x << 16);
-          v[1] = acc[t][1] + other[1] + sk * __uint_as_float(rr.x & 0xffff0000u);
-          v[2] = acc[t][2] + other[2] + sk * __uint_as_float(rr.y << 16);
-          v[3] = acc[t][3] + other[3] + sk * __uint_as_float(rr.y & 0xffff0000u);
-          *reinterpret_cast<uint2*>(p.out_a + (((size_t)n * p.H + y) * p.W + x) * 128 + ch0 * 2) = pack4(v);
+          v[0] = acc[t][0] + other[0] + sk * bits16_to_f32<T>((unsigned short)(rr.x & 0xffffu));
+          v[1] = acc[t][1] + other[1] + sk * bits16_to_f32<T>((unsigned short)(rr.x >> 16));
+          v[2] = acc[t][2] + other[2] + sk * bits16_to_f32<T>((unsigned short)(rr.y & 0xffffu));
+          v[3] = acc[t][3] + other[3] + sk * bits16_to_f32<T>((unsigned short)(rr.y >> 16));
+          *reinterpret_cast<uint2*>(p.out_a + (((size_t)n * p.H + y) * p.W + x) * 128 + ch0 * 2) = pack4<T>(v);
         }
       }
     };
@@ -340,6 +338,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
 }  // namespace
 
 namespace {
+template <typename T>
 int resblock_launch(bool bwd, const void* in, const void* wa, const float* b1, const void* wb2, const void* hmask, void* out_h,
                     void* out_a, int N, int H, int W, int add_skip, const void* next_w1, const void* next_w2, void* stream) {
   ResblockK k;
@@ -353,14 +352,14 @@ int resblock_launch(bool bwd, const void* in, const void* wa, const float* b1, c
   if (blocks > 0x7fffffffLL) return TG_E_UNSUPPORTED;
   static bool attr_done = false;
   if (!attr_done) {
-    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<false>),
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<false, T>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal));
-    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<true>),
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<true, T>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal));
     attr_done = true;
   }
-  if (bwd) hipLaunchKernelGGL(resblock_kernel<true>, dim3((unsigned)blocks), dim3(512), kLdsTotal, (hipStream_t)stream, k);
-  else hipLaunchKernelGGL(resblock_kernel<false>, dim3((unsigned)blocks), dim3(512), kLdsTotal, (hipStream_t)stream, k);
+  if (bwd) hipLaunchKernelGGL((resblock_kernel<true, T>), dim3((unsigned)blocks), dim3(512), kLdsTotal, (hipStream_t)stream, k);
+  else hipLaunchKernelGGL((resblock_kernel<false, T>), dim3((unsigned)blocks), dim3(512), kLdsTotal, (hipStream_t)stream, k);
   return tg_launch_status();
 }
 }  // namespace
@@ -369,12 +368,15 @@ extern "C" int tg_resblock_fwd(int dtype, const void* in, const void* w1_packed,
                                void* out_h, void* out_a, int N, int H, int W, int C, int add_skip,
                                const void* next_w1_packed, const void* next_w2_packed, void* stream) {
   if (!in || !w1_packed || !b1 || !w2_packed || !out_h || !out_a || N <= 0 || H <= 0 || W <= 0) return TG_E_BADARG;
-  if (dtype != TG_BF16 || C != 64) return TG_E_UNSUPPORTED;  // the trunk shape; anything else runs as two tg_conv launches
+  if ((dtype != TG_BF16 && dtype != TG_F16) || C != 64) return TG_E_UNSUPPORTED;  // the trunk shape, 16-bit; else two tg_conv launches
   if (!tg_aligned16(in) || !tg_aligned16(w1_packed) || !tg_aligned16(w2_packed) || !tg_aligned16(out_h) ||
       !tg_aligned16(out_a) || !tg_aligned16(b1))
     return TG_E_ALIGN;
-  return resblock_launch(false, in, w1_packed, b1, w2_packed, nullptr, out_h, out_a, N, H, W, add_skip, next_w1_packed,
-                         next_w2_packed, stream);
+  if (dtype == TG_F16)
+    return resblock_launch<F16>(false, in, w1_packed, b1, w2_packed, nullptr, out_h, out_a, N, H, W, add_skip, next_w1_packed,
+                                next_w2_packed, stream);
+  return resblock_launch<BF16>(false, in, w1_packed, b1, w2_packed, nullptr, out_h, out_a, N, H, W, add_skip, next_w1_packed,
+                               next_w2_packed, stream);
 }
 
 extern "C" int tg_resblock_bwd(int dtype, const void* dout, const void* w2_dgrad_packed, const void* h, const void* w1_dgrad_packed,
@@ -382,10 +384,13 @@ extern "C" int tg_resblock_bwd(int dtype, const void* dout, const void* w2_dgrad
                                const void* next_wb_packed, void* stream) {
   if (!dout || !w2_dgrad_packed || !h || !w1_dgrad_packed || !out_dh || !out_din || N <= 0 || H <= 0 || W <= 0)
     return TG_E_BADARG;
-  if (dtype != TG_BF16 || C != 64) return TG_E_UNSUPPORTED;
+  if ((dtype != TG_BF16 && dtype != TG_F16) || C != 64) return TG_E_UNSUPPORTED;
   if (!tg_aligned16(dout) || !tg_aligned16(w2_dgrad_packed) || !tg_aligned16(w1_dgrad_packed) || !tg_aligned16(out_dh) ||
       !tg_aligned16(out_din) || !tg_aligned16(h))
     return TG_E_ALIGN;
-  return resblock_launch(true, dout, w2_dgrad_packed, nullptr, w1_dgrad_packed, h, out_dh, out_din, N, H, W, 1, next_wa_packed,
-                         next_wb_packed, stream);
+  if (dtype == TG_F16)
+    return resblock_launch<F16>(true, dout, w2_dgrad_packed, nullptr, w1_dgrad_packed, h, out_dh, out_din, N, H, W, 1,
+                                next_wa_packed, next_wb_packed, stream);
+  return resblock_launch<BF16>(true, dout, w2_dgrad_packed, nullptr, w1_dgrad_packed, h, out_dh, out_din, N, H, W, 1,
+                               next_wa_packed, next_wb_packed, stream);
 }

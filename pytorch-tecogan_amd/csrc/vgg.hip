@@ -146,9 +146,11 @@ __global__ void maxpool2_bwd_kernel(const char* __restrict__ a, const char* __re
 }
 
 template <typename T>
-__global__ void vgg_input_grad_kernel(const char* __restrict__ dx, const float* __restrict__ gen, char* __restrict__ dpre,
-                                      long long npix, int HW, float scale) {
+__global__ __launch_bounds__(256) void vgg_input_grad_kernel(const char* __restrict__ dx, const float* __restrict__ gen,
+                                                            char* __restrict__ dpre, long long npix, int HW, float scale,
+                                                            float* __restrict__ bias_acc) {
   using TR = ElemTraits<T>;
+  float cs[3] = {0.f, 0.f, 0.f};
   for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
     const long long n = p / HW, q = p % HW;
     const float* g = gen + n * 3 * HW + q;
@@ -158,9 +160,22 @@ __global__ void vgg_input_grad_kernel(const char* __restrict__ dx, const float* 
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float s = g[c * (long long)HW];
-      o[c] += d[c] * scale * s * (1.f - s);
+      const float add = d[c] * scale * s * (1.f - s);
+      o[c] += add;
+      cs[c] += add;
     }
     Vec<T>::store(dpre + p * 32 * TR::kBytes, o);
+  }
+  if (bias_acc) {  // the output layer's bias gradient is the channel sum of d(loss)/d(pre-sigmoid): add this part of it
+    __shared__ float sh[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) cs[c] += __shfl_xor(cs[c], m);
+      if ((threadIdx.x & 63) == 0) sh[c][threadIdx.x >> 6] = cs[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(bias_acc + threadIdx.x, sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3]);
   }
 }
 
@@ -205,11 +220,11 @@ extern "C" int tg_maxpool2_bwd(int dtype, const void* a, const void* dpool, cons
 }
 
 extern "C" int tg_vgg_input_grad(int dtype, const void* dx_nhwc32, const float* gen_nchw, void* dpre_nhwc32, int N, int H,
-                                 int W, float scale, void* stream) {
+                                 int W, float scale, float* bias_acc3, void* stream) {
   if (!dx_nhwc32 || !gen_nchw || !dpre_nhwc32 || N <= 0 || H <= 0 || W <= 0) return TG_E_BADARG;
   if (!tg_aligned16(dx_nhwc32) || !tg_aligned16(dpre_nhwc32)) return TG_E_ALIGN;
   const long long npix = (long long)N * H * W;
-  VGG_DISPATCH(dtype, vgg_input_grad_kernel, dim3(vgg_grid(npix)), dim3(256), (hipStream_t)stream, (const char*)dx_nhwc32,
-               gen_nchw, (char*)dpre_nhwc32, npix, H * W, scale);
+  VGG_DISPATCH(dtype, vgg_input_grad_kernel, dim3(vgg_grid(npix, 1024)), dim3(256), (hipStream_t)stream, (const char*)dx_nhwc32,
+               gen_nchw, (char*)dpre_nhwc32, npix, H * W, scale, bias_acc3);
   return tg_launch_status();
 }

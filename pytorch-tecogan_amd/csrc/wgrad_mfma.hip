@@ -344,12 +344,83 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
 // All weight gradients of a network folded in ONE launch: blockIdx.y selects the job.
 // Job = 12 x int64: slab ptr, grad ptr, s_a, s_b, nsplit, ntaps, ca_p, cb_p, ca, cb, bias-grad ptr or 0, slab stride
 // in floats (slot t adds kernel offset t).
+//
+// Second version.  The first one (fold_job above, still behind tg_wgrad_finalize) gave every thread 4 consecutive b of one
+// (t, a) and wrote them straight to grad[b][a][t]: reads were wide, but the WRITES were 4-byte read-modify-writes 2304 bytes
+// apart - PMC: 66 MB written + 66 MB re-read per launch for 7-13 MB of gradients, and 2.4 TB/s overall.  Here a workgroup
+// owns a tile of AB a-rows x BB b-columns x all taps for a chunk of KC splits: 16-byte loads with NT independent loads in
+// flight per split, the tile summed in registers, transposed through LDS, and added to the gradient in runs of AB*NT
+// consecutive floats per b (576 bytes for a 3x3 layer).  Split chunks of one tile meet in the gradient through float atomics
+// (the buffers are zeroed at the start of the step and every producer accumulates), so the summation order over chunks is
+// not fixed: weight gradients are reproducible to rounding, like the bias / BN sums already were.
+template <int NT, int BB>
+__device__ __forceinline__ void fold2_job(const float* __restrict__ slab, float* __restrict__ grad, long long s_a, long long s_b,
+                                          int nsplit, int ca_p, int cb_p, int ca, int cb, float* __restrict__ bias_grad,
+                                          size_t slab_sz, float* __restrict__ sh) {
+  constexpr int AB = 1024 / BB, NB4 = BB / 4, KC = 8, ROW = AB * NT, PITCH = ROW + 1;
+  const int tid = threadIdx.x, ai = tid / NB4, bj = tid % NB4;
+  const int tiles_b = cb_p / BB, tiles = (ca_p / AB) * tiles_b;
+  const int nchunks = (nsplit + KC - 1) / KC;
+  for (int u = blockIdx.x; u < tiles * nchunks; u += gridDim.x) {
+    const int chunk = u % nchunks, tile = u / nchunks;
+    const int tb = tile % tiles_b, ta = tile / tiles_b;
+    const int a = ta * AB + ai, b = tb * BB + 4 * bj;
+    const int k0 = chunk * KC, k1 = min(nsplit, k0 + KC);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a < ca && b < cb) {  // padded rows / columns are never read
+      const float* src = slab + (size_t)a * cb_p + b;
+      for (int k = k0; k < k1; ++k) {
+        const float* sk = src + (size_t)k * slab_sz;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] += *reinterpret_cast<const f32x4*>(sk + (size_t)t * ca_p * cb_p);
+      }
+    }
+    __syncthreads();  // the previous tile's readers are done with the LDS image
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sh[(4 * bj + e) * PITCH + ai * NT + t] = acc[t][e];
+    __syncthreads();
+    for (int i = tid; i < BB * ROW; i += 256) {
+      const int lb = i / ROW, r = i - lb * ROW;
+      const int la = r / NT, t = r - la * NT;
+      const int aa = ta * AB + la, bb = tb * BB + lb;
+      if (aa < ca && bb < cb) atomicAdd(grad + aa * s_a + t + bb * s_b, sh[lb * PITCH + r]);
+    }
+    if (bias_grad && ta == 0 && tid < NB4) {  // channel sums of Y behind the taps of every slab (the conv's bias gradient)
+      const int b4 = tb * BB + 4 * tid;
+      if (b4 < cb) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = k0; k < k1; ++k)
+          s += *reinterpret_cast<const f32x4*>(slab + (size_t)k * slab_sz + (size_t)NT * ca_p * cb_p + b4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (b4 + e < cb) atomicAdd(bias_grad + b4 + e, s[e]);
+      }
+    }
+  }
+}
+
+constexpr int kFold2Lds = (64 * (16 * 16 + 1)) * 4;  // the largest image: 16 taps, BB = 64 -> 65792 bytes
+
 __global__ __launch_bounds__(256) void wgrad_finalize_multi_kernel(const long long* __restrict__ jobs) {
-  __shared__ f32x4 sh[4][64];
+  extern __shared__ __attribute__((aligned(16))) float fold_sh[];
   const long long* j = jobs + 12 * blockIdx.y;
-  fold_job(reinterpret_cast<const float*>(j[0]), reinterpret_cast<float*>(j[1]), j[2], j[3], (int)j[4], (int)j[5],
-           (int)j[6], (int)j[7], (int)j[8], (int)j[9], nullptr, 1, blockIdx.x, gridDim.x, sh,
-           reinterpret_cast<float*>(j[10]), (size_t)j[11]);
+  const float* slab = reinterpret_cast<const float*>(j[0]);
+  float* grad = reinterpret_cast<float*>(j[1]);
+  const int nsplit = (int)j[4], ntaps = (int)j[5], ca_p = (int)j[6], cb_p = (int)j[7], ca = (int)j[8], cb = (int)j[9];
+  float* bias = reinterpret_cast<float*>(j[10]);
+  const size_t sz = (size_t)j[11];
+  const bool wide = (cb_p % 64) == 0;
+  if (ntaps == 9) {
+    if (wide) fold2_job<9, 64>(slab, grad, j[2], j[3], nsplit, ca_p, cb_p, ca, cb, bias, sz, fold_sh);
+    else fold2_job<9, 32>(slab, grad, j[2], j[3], nsplit, ca_p, cb_p, ca, cb, bias, sz, fold_sh);
+  } else if (ntaps == 16) {
+    if (wide) fold2_job<16, 64>(slab, grad, j[2], j[3], nsplit, ca_p, cb_p, ca, cb, bias, sz, fold_sh);
+    else fold2_job<16, 32>(slab, grad, j[2], j[3], nsplit, ca_p, cb_p, ca, cb, bias, sz, fold_sh);
+  }
 }
 
 struct WgCfg {
@@ -516,7 +587,13 @@ extern "C" int tg_wgrad_finalize(const float* slab, int nsplit, int ntaps, int c
 
 extern "C" int tg_wgrad_finalize_multi(const int64_t* jobs_dev, int njobs, int blocks_per_job, void* stream) {
   if (!jobs_dev || njobs <= 0 || blocks_per_job <= 0) return TG_E_BADARG;
-  hipLaunchKernelGGL(wgrad_finalize_multi_kernel, dim3((unsigned)blocks_per_job, (unsigned)njobs), dim3(256), 0,
+  static bool attr_done = false;  // one-time function attribute (benign race: idempotent)
+  if (!attr_done) {
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_finalize_multi_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kFold2Lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wgrad_finalize_multi_kernel, dim3((unsigned)blocks_per_job, (unsigned)njobs), dim3(256), kFold2Lds,
                      (hipStream_t)stream, (const long long*)jobs_dev);
   return tg_launch_status();
 }

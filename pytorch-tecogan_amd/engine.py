@@ -459,7 +459,7 @@ class GeneratorEngine:
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
         self.trunk_group = WgradGroup() if os.environ.get("TECOGAN_WGRAD_GROUPS", "1") != "0" else None
-        self.fused_rb = dtype_t == torch.bfloat16 and os.environ.get("TECOGAN_FUSED_RESBLOCK", "1") != "0"
+        self.fused_rb = dtype_t in (torch.bfloat16, torch.float16) and os.environ.get("TECOGAN_FUSED_RESBLOCK", "1") != "0"
         # the fused input-gradient launch (tg_resblock_bwd) is numerically identical and was measured EQUAL in time on the
         # batched backward (15 x 28.2 us vs 30 x 14.9 us at 40 samples: 640 workgroups each re-read 147 KB of weights), so
         # it stays an option
@@ -731,9 +731,10 @@ class VGGEngine:
                 K.maxpool2(x, a[l])
                 x = a[l]
 
-    def loss_backward(self, acc3, coef_scale, gen_nchw, dpre, loss_scale=None):
+    def loss_backward(self, acc3, coef_scale, gen_nchw, dpre, loss_scale=None, bias_acc=None):
         """acc3[i] += sum of per-pixel cosines of tap layer i; d(loss)/d(pre-sigmoid) of the generated frames is ADDED to
-        dpre, for loss = coef_scale * sum_i (1 - mean cosine_i)."""
+        dpre (and its channel sums to bias_acc[0:3], the output layer's bias gradient), for loss = coef_scale * sum_i (1 - mean
+        cosine_i)."""
         N = self.shape[0]
         a, g = self.act, self.grad
         for i, t in enumerate(VGG_TAPS):
@@ -759,7 +760,7 @@ class VGGEngine:
                 conv.dgrad(g[name], g[below])                       # the ReLU below a pool is handled by tg_maxpool2_bwd
             else:
                 conv.dgrad(g[name], g[below], mask=a[below][:N], mask_mode=L.MASK_RELU)
-        K.vgg_input_grad(g["in"], gen_nchw, dpre, 127.5)
+        K.vgg_input_grad(g["in"], gen_nchw, dpre, 127.5, bias_acc=bias_acc)
 
 
 def discriminator_shapes(resblocks=4, ch=128, fc_in=48):

@@ -191,7 +191,7 @@ def rw_eligible(dtype_t, cin_p, cout_p, N, H, W):
       64 -> 64  @64x64   N=40  32.7 -> 20.0 us      64 -> 128 @128x128 N=40  154 -> 106 us     128 -> 128 @64x64 N=40 78.5 -> 74.1
       128 -> 128 @32x32  N=12  14.9 -> 11.9 us
     and slower on the rest (128 -> 64, the 32x32 trunk at N=40, every N=4 launch of the recurrent pass, 16x16 images)."""
-    if _RW == "0" or dtype_t != torch.bfloat16 or cin_p not in (64, 128) or cout_p % 64:
+    if _RW == "0" or dtype_t not in (torch.bfloat16, torch.float16) or cin_p not in (64, 128) or cout_p % 64:
         return False
     if _RW == "all":
         return N * H * W >= 8192
@@ -362,10 +362,10 @@ def maxpool2_bwd(a, dpool, out, res=None, relu_mask=True):
                                      int(bool(relu_mask)), _stream()), "tg_maxpool2_bwd")
 
 
-def vgg_input_grad(dx, gen_nchw, dpre, scale):
+def vgg_input_grad(dx, gen_nchw, dpre, scale, bias_acc=None):
     N, H, W, _ = dx.shape
     L.check(L.load().tg_vgg_input_grad(tg_dtype(dx.dtype), _ptr(dx), _ptr(gen_nchw), _ptr(dpre), N, H, W, float(scale),
-                                       _stream()), "tg_vgg_input_grad")
+                                       _ptr(bias_acc), _stream()), "tg_vgg_input_grad")
 
 
 def up2_bilinear(src, dst):

@@ -317,7 +317,8 @@ class TecoGANStep:
         if self.V is not None:  # VGG features of all generated and target frames; its input-gradient is added to dpre
             gen, tgt = self.gen.view(B * T, 3, H, H), self.y.view(B * T, 3, H, H)
             self.V.forward(gen, tgt)
-            self.V.loss_backward(self.acc[11:14], self.vgg_scaling, gen, self.dpre, loss_scale=self.loss_scale)
+            self.V.loss_backward(self.acc[11:14], self.vgg_scaling, gen, self.dpre, loss_scale=self.loss_scale,
+                                 bias_acc=self.acc[8:11])
 
     def _g_backward(self):
         """G backward for all T*B samples as ONE batch (the passes are independent in backward: every generator input is

@@ -550,7 +550,7 @@ def test_content_loss_pingpong_term(dt):
     torch.testing.assert_close(got, pre.grad, rtol=1e-2 if dt != torch.float32 else 1e-4, atol=1e-6)
     # the sequence must be x ++ reverse(x)[1:]
     assert L.load().tg_content_loss(K.tg_dtype(dt), gen.to(DEV).data_ptr(), y.to(DEV).data_ptr(), dpre.data_ptr(),
-                                    acc.data_ptr(), B, T, H, H, gscale, 0, T, n + 1, 0.0, None) == -1
+                                    acc.data_ptr(), B, T, H, H, gscale, 0, T, n + 1, 0.0, None, None) == -1
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -73,7 +73,10 @@ def test_module_forward_at_another_shape_between_steps_leaves_the_step_intact(mo
     got, w_got = run_steps(4, True, monkeypatch, graph)
     for (g0, s0), (g1, s1) in zip(ref, got):
         assert rel(g1, g0) < 1e-5
-        np.testing.assert_allclose(s1, s0, rtol=2e-4, atol=1e-6)
+        # the discriminator's part of the scalars is chaotic at this size (BN batches of 3 samples, float-atomic statistics,
+        # Adam): two identical runs drift apart by 5e-4 / 1.5e-3 / 3.5e-3 over steps 1..3 (tools/debug_interleave.py), so
+        # the bound only has to catch a step that ran on stale or foreign buffers (garbage, O(1) off)
+        np.testing.assert_allclose(s1, s0, rtol=6e-2, atol=1e-6)
     # Adam turns last-bit differences of tiny gradients (float-atomic bias sums) into ~1e-5 relative weight differences;
     # a stale or freed buffer would show up at the size of the updates themselves (~3e-3 per step)
     assert rel(w_got, w_ref) < 2e-4
@@ -127,4 +130,5 @@ def test_optimizer_load_state_dict_after_the_first_step_is_applied(monkeypatch):
                 torch.cat([p.detach().flatten() for p in D.parameters()]).clone())
 
     (g_a, d_a), (g_b, d_b) = run(False), run(True)
-    assert rel(g_b, g_a) < 2e-4 and rel(d_b, d_a) < 2e-4   # ignoring the restored moments / step would cost ~3e-3
+    # (D: chaotic at this size, see above; ignoring the restored moments / step count would cost ~3e-3 on G as well)
+    assert rel(g_b, g_a) < 2e-4 and rel(d_b, d_a) < 2e-3

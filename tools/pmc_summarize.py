@@ -1,10 +1,13 @@
 """Folds the rocprofv3 --pmc passes into one table per kernel:
   * HBM bytes per launch from FETCH_SIZE and WRITE_SIZE (KB per dispatch).  gfx950: FETCH_SIZE tallies a 128-byte request as
     64 bytes, hence 2*FETCH_SIZE (MI355X_MICROARCH.md, HBM section);
-  * MFMA-pipe busy share: SQ_VALU_MFMA_BUSY_CYCLES (busy cycles summed over all SIMDs) / (GRBM_GUI_ACTIVE * 1024 SIMDs),
-    i.e. the share of SIMD-cycles of the dispatch in which a matrix pipe was busy - padded-channel MFMAs included, which is
-    what separates it from the algorithmic roofline fraction bench.py prints.
-usage: pmc_summarize.py <fetch dir> <write dir> <out.json> [<sq/grbm dir>]"""
+  * MFMA-pipe busy share: SQ_VALU_MFMA_BUSY_CYCLES (matrix-pipe busy cycles summed over all 1024 SIMDs; 16 per
+    v_mfma_f32_16x16x32_bf16) / (1024 SIMDs * the kernel's average duration in the UNINSTRUMENTED --kernel-trace --stats run
+    * 2.4 GHz, the clock the 2.5 PFLOP/s dense peak assumes).  It counts every MFMA issued - padded channels, halo recompute -
+    so it is >= the algorithmic roofline fraction bench.py prints, and their ratio is the share of issued MFMAs that were
+    algorithmically necessary.  (GRBM_GUI_ACTIVE, also collected, sums the 8 XCDs and includes the counter pass's own dispatch
+    overhead, so it is kept as a raw column only.)
+usage: pmc_summarize.py <fetch dir> <write dir> <out.json> [<sq/grbm dir> [<kernel_stats.csv of the plain run>]]"""
 import csv, glob, json, re, sys
 from collections import defaultdict
 
@@ -32,7 +35,7 @@ out = {"note": "rocprofv3 --kernel-trace --pmc <counters> (FETCH_SIZE | WRITE_SI
                "GRBM_GUI_ACTIVE: separate passes) over `bench.py --steps 2 --warmup 2 --no-roofline --no-cpu-baseline`; per-launch "
                "averages over all launches of the kernel; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: "
                "FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md 'HBM'); mfma_busy_pct = 100 * "
-               "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs)",
+               "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * avg_ns of the uninstrumented kernel-trace run * 2.4 cycles/ns)",
        "kernels": {}}
 for k in sorted(fetch, key=lambda k: -fetch[k][1]):
     n, fk = fetch[k]
@@ -41,14 +44,20 @@ for k in sorted(fetch, key=lambda k: -fetch[k][1]):
                          "hbm_bytes_per_launch": int((2 * fk / n + wk / max(1, wn)) * 1024)}
 if len(sys.argv) > 4:
     mf, gui, sqb = (load(sys.argv[4], c) for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES"))
+    avg_ns = {}
+    if len(sys.argv) > 5:
+        for r in csv.DictReader(open(sys.argv[5])):
+            avg_ns[clean(r["Name"])] = float(r["AverageNs"])
     for k, (n, v) in mf.items():
         e = out["kernels"].setdefault(k, {"launches": n})
         e["mfma_busy_cycles"] = round(v / n, 1)
         if k in gui and gui[k][1] > 0:
-            e["gui_active_cycles"] = round(gui[k][1] / gui[k][0], 1)
-            e["mfma_busy_pct"] = round(100.0 * v / (gui[k][1] * 1024.0), 2)
+            e["gui_active_cycles_8xcd"] = round(gui[k][1] / gui[k][0], 1)
         if k in sqb:
             e["sq_busy_cycles"] = round(sqb[k][1] / sqb[k][0], 1)
+        if k in avg_ns:
+            e["avg_ns"] = round(avg_ns[k], 1)
+            e["mfma_busy_pct"] = round(100.0 * (v / n) / (1024.0 * avg_ns[k] * 2.4), 2)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k in list(out["kernels"])[:14]:
     print(k[:80], out["kernels"][k])

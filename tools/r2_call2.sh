@@ -2,8 +2,8 @@
 set -uo pipefail
 cd "${GRAFT_REPO_ROOT:?}"
 mkdir -p gpurun_out
-timeout -k 10 700 python -m pytest tests -m gpu -x -q > gpurun_out/c2_pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -4 gpurun_out/c2_pytest.log
-[ $rc -eq 0 ] || exit 1
+timeout -k 10 700 python -m pytest tests -m gpu -q > gpurun_out/c2_pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -4 gpurun_out/c2_pytest.log
+[ $rc -eq 0 ] || echo "TESTS FAILED (continuing with measurements)"
 for v in "TECOGAN_DREAL_BWD=1" "TECOGAN_DREAL_BWD=0" "TECOGAN_RW=0" "TECOGAN_RW=all"; do
   echo "== $v" >> gpurun_out/c2_matrix.log
   env $v timeout -k 10 120 python bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['final_losses'])" >> gpurun_out/c2_matrix.log 2>&1
