@@ -325,7 +325,7 @@ template <int NCH, bool STATS, typename T>
 int launch_rw(const RwK& k, dim3 grid, hipStream_t st) {
   constexpr int lds = 2 * NCH * kChunkBytes + (NCH == 4 ? kXchgBytes : 0) + kRedBytes;
   auto fn = conv3_rw_kernel<NCH, STATS, T>;
-  static bool attr_done = false;  // one-time function attribute (benign race: idempotent)
+  static std::atomic<bool> attr_done{false};  // one-time function attribute (benign race: idempotent)
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;

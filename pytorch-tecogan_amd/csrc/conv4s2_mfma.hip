@@ -260,7 +260,7 @@ int launch_s2(int dtype, const void* in, const void* w_packed, const float* bias
   dim3 grid((unsigned)gx, (unsigned)(Cout / CO_TILE));
   hipStream_t st = (hipStream_t)stream;
   constexpr int lds = Geo<KS>::kLds;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2_gather_kernel<BF16, KS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));

@@ -548,7 +548,7 @@ struct TileCfg {
 template <typename T, int CT, int PT, int WC, int WP, bool STD3>
 int launch_conv_impl(const ConvK& k, dim3 grid, size_t lds, hipStream_t st) {
   auto fn = conv_gather_kernel<T, CT, PT, WC, WP, STD3>;
-  static bool attr_done = false;  // one-time function attribute (benign race: idempotent)
+  static std::atomic<bool> attr_done{false};  // one-time function attribute (benign race: idempotent)
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024));

@@ -256,7 +256,7 @@ int launch_subpixel(int dtype, const void* in, const void* w_packed, const float
   dim3 grid((unsigned)gx, (unsigned)(Cout / CO_TILE));
   hipStream_t st = (hipStream_t)stream;
   constexpr int lds = PGeo<PAT>::kLds;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(subpixel_kernel<BF16, PAT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));

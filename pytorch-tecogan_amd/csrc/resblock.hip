@@ -350,7 +350,7 @@ int resblock_launch(bool bwd, const void* in, const void* wa, const float* b1, c
   k.tiles_x = (W + 7) / 8; k.tiles_y = (H + 7) / 8;
   const long long blocks = (long long)k.tiles_x * k.tiles_y * N;
   if (blocks > 0x7fffffffLL) return TG_E_UNSUPPORTED;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<false, T>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal));

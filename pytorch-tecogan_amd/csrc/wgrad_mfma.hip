@@ -430,7 +430,7 @@ struct WgCfg {
 template <typename T, int NTAPS, int TPW, int AW, int BT, int NW = 4>
 int launch_wgrad(const WgradK& k, dim3 grid, size_t lds, hipStream_t st) {
   auto fn = wgrad_kernel<T, NTAPS, TPW, AW, BT, NW>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024));
@@ -587,7 +587,7 @@ extern "C" int tg_wgrad_finalize(const float* slab, int nsplit, int ntaps, int c
 
 extern "C" int tg_wgrad_finalize_multi(const int64_t* jobs_dev, int njobs, int blocks_per_job, void* stream) {
   if (!jobs_dev || njobs <= 0 || blocks_per_job <= 0) return TG_E_BADARG;
-  static bool attr_done = false;  // one-time function attribute (benign race: idempotent)
+  static std::atomic<bool> attr_done{false};  // one-time function attribute (benign race: idempotent)
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_finalize_multi_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kFold2Lds));

@@ -107,8 +107,9 @@ class TecoGANStep:
     QUEUEING: its launches need CUs with free LDS, and a dense launch holds every CU with workgroups that run for tens of
     microseconds.  Stream priorities do nothing on MI355X and a CU mask does not survive inside one forked graph capture
     (profiles/r02_a_overlap_probe_priority_cumask.log), hence one graph per lane; lane B's stream can be masked off the
-    first TECOGAN_CU_RESERVE CUs so that the chain's residual-block launches (64 workgroups) always start at once (default 0:
-    with the real kernels the dense lane loses more on 192 CUs than the chain gains, profiles/r02_b_lane_matrix.log).
+    first TECOGAN_CU_RESERVE CUs so that the chain's residual-block launches (64 workgroups) always start at once.  Masking
+    all of lane B lost more than it gained (profiles/r02_b_lane_matrix.log: the fake half runs beside the dense G backward
+    and needs the whole chip), so only the REAL half - the part that runs beside the chain - goes on the masked stream.
     The real half of the discriminator does not depend on the generator at all (code/train.py:160-185,199-203,304-307:
     separate BN statistics, loss = mean of per-half terms), so its forward AND backward run beside the chain; only the
     fake half is left for the time after the chain, beside the G backward."""
@@ -177,9 +178,12 @@ class TecoGANStep:
         # hipExtStreamCreateWithCUMask makes a BLOCKING stream: it serialises against the legacy default stream.  Lane A
         # therefore runs on a stream of its own as well (the caller's stream only brackets the step)
         self.sA = torch.cuda.Stream(device=device)
-        self.sB = lane_stream(device, self.reserve)
+        self.sB = torch.cuda.Stream(device=device)
+        # the real half runs BESIDE the chain (phase 1): only there can a CU reservation pay - its stream may be masked off
+        # the first TECOGAN_CU_RESERVE CUs; the fake half (phase 2, beside the dense G backward) always has the whole chip
+        self.sBm = lane_stream(device, self.reserve) if self.reserve > 0 else self.sB
         self.dreal_bwd_early = os.environ.get("TECOGAN_DREAL_BWD", "1") != "0"
-        self.ev = {k: torch.cuda.Event() for k in ("prep", "chain", "tail", "d")}
+        self.ev = {k: torch.cuda.Event() for k in ("prep", "chain", "tail", "d", "dreal")}
         D.sets.pin((2 * self.tb, H))
         D.alloc(2 * self.tb, H)
         self.V = None
@@ -401,12 +405,15 @@ class TecoGANStep:
         recorded between the pieces; the collectives of data-parallel mode are issued where their inputs become final: the
         G all-reduce behind lane A's G backward - it then runs while lane B is still in the fake half's backward - and the
         D all-reduce behind lane B.  Work.wait() of the RCCL backend makes the current STREAM wait (no host block)."""
-        main, sB, ev = torch.cuda.current_stream(), self.sB, self.ev
+        main, sB, sBm, ev = torch.cuda.current_stream(), self.sB, self.sBm, self.ev
         fn["prep"]()
         ev["prep"].record(main)
-        sB.wait_event(ev["prep"])
-        with torch.cuda.stream(sB):
+        sBm.wait_event(ev["prep"])
+        with torch.cuda.stream(sBm):
             fn["d_real"]()
+        if sBm is not sB:
+            ev["dreal"].record(sBm)
+            sB.wait_event(ev["dreal"])
         fn["chain"]()
         ev["chain"].record(main)
         sB.wait_event(ev["chain"])
@@ -470,7 +477,8 @@ class TecoGANStep:
 
         if self.lanes:
             fns = self._piece_fns()
-            self.graphs = {k: cap(fns[k], self.sB if k in self.LANE_B else None) for k in self.PIECES}
+            lane = lambda k: self.sBm if k == "d_real" else (self.sB if k in self.LANE_B else None)  # noqa: E731
+            self.graphs = {k: cap(fns[k], lane(k)) for k in self.PIECES}
         else:
             self.graphs = (cap(self._fork_join), cap(self._update))
 
