@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libtecogan_hip.so")
+LIB_PATH = os.environ.get("TECOGAN_LIB") or os.path.join(_HERE, "csrc", "libtecogan_hip.so")  # TECOGAN_LIB: A/B builds (tools)
 
 TG_F32, TG_BF16, TG_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_TANH24 = 0, 1, 2, 3, 4
