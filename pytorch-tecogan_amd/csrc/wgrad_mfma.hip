@@ -116,16 +116,11 @@ __global__ __launch_bounds__(64 * NW) void wgrad_kernel(const WgradK p) {
   // workgroup per CU (its accumulators fill the register file), so no other workgroup would hide that latency.
   constexpr int UX = ((TR::kBytes == 2) ? 11 : 22) * 4 / NW + (NW == 8 ? 1 : 0);  // 16-byte pieces per thread: X patch up to 10x34 pixels x A_BLK channels
   constexpr int UY = ((TR::kBytes == 2) ? 4 : 8) * 4 / NW;                           //                            Y tile 128 pixels x B_BLK channels
-#ifndef TG_WGRAD_AHEAD
-#define TG_WGRAD_AHEAD 2  // tiles in flight ahead of the one being multiplied (1: the round-1 pipeline)
-#endif
-  // (the fp32 parity kernels stage twice the bytes per tile and would spill with two register sets: one step ahead there)
-  constexpr int AHEAD = (TR::kBytes == 2) ? TG_WGRAD_AHEAD : 1;
-  u32x4 vxs[AHEAD][UX], vys[AHEAD][UY];
+  u32x4 vx[UX], vy[UY];
   const float inv_iw = 1.0f / (float)p.iw;
   const int nx = prow_n * XV, ny = ypix * YV;
 
-  auto issue = [&](int tile, u32x4* __restrict__ vx, u32x4* __restrict__ vy) {
+  auto issue = [&](int tile) {
     int r = tile;
     const int txb = r % p.tiles_x;
     r /= p.tiles_x;
@@ -160,10 +155,9 @@ __global__ __launch_bounds__(64 * NW) void wgrad_kernel(const WgradK p) {
     }
   };
 
-  // One tile: its staged registers -> LDS, the loads of the tile AHEAD steps ahead issued into the same registers,
-  // then the MFMAs.  With one step ahead a tile's loads had only the ~2300 MFMA cycles of its predecessor to land, less than
-  // the loaded HBM latency; two register sets give them two tiles' worth.
-  auto process = [&](int tile, u32x4* __restrict__ vx, u32x4* __restrict__ vy) {
+  int tile = split;
+  if (tile < p.tiles_total) issue(tile);
+  for (; tile < p.tiles_total; tile += p.nsplit) {
     __syncthreads();  // the previous tile's fragment reads are done
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
@@ -188,7 +182,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad_kernel(const WgradK p) {
       }
     }
     __syncthreads();
-    if (tile + AHEAD * p.nsplit < p.tiles_total) issue(tile + AHEAD * p.nsplit, vx, vy);  // in flight during the MFMAs
+    if (tile + p.nsplit < p.tiles_total) issue(tile + p.nsplit);  // in flight during the MFMAs below
 
     for (int k0 = 0; k0 < ypix; k0 += 32) {
       if constexpr (TR::kBytes == 2) {
@@ -243,18 +237,6 @@ __global__ __launch_bounds__(64 * NW) void wgrad_kernel(const WgradK p) {
           }
         }
       }
-    }
-  };
-
-  {
-    int tile = split;
-#pragma unroll
-    for (int a = 0; a < AHEAD; ++a)
-      if (tile + a * p.nsplit < p.tiles_total) issue(tile + a * p.nsplit, vxs[a], vys[a]);
-    for (; tile < p.tiles_total; tile += AHEAD * p.nsplit) {
-#pragma unroll
-      for (int a = 0; a < AHEAD; ++a)
-        if (tile + a * p.nsplit < p.tiles_total) process(tile + a * p.nsplit, vxs[a], vys[a]);
     }
   }
 
