@@ -14,6 +14,28 @@
 // Replaces aten::convolution_backward (weight path) behind code/train.py:336,340.
 #include "common.h"
 
+#ifdef TG_STAMP
+// Diagnostic build only (build.sh -DTG_STAMP): wave 0 of workgroup 0 accumulates s_memtime differences per phase of the tile
+// loop into a buffer nothing else reads (slot 0 barrier wait, 1 LDS stores, 2 second barrier, 3 issue of the next tile's
+// loads, 4 k-loop, 5 tiles); the production library contains no stamp.  tools/stamp_wgrad.py prints them.
+__device__ long long tg_wg_stamps[8];
+#define TG_WG_MARK(i)                                                                          \
+  do {                                                                                         \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {           \
+      const long long _n = (long long)__builtin_amdgcn_s_memtime();                            \
+      tg_wg_stamps[i] += _n - _wg_t;                                                           \
+      _wg_t = _n;                                                                              \
+    }                                                                                          \
+  } while (0)
+extern "C" int tg_debug_wgrad_stamps(long long* out, int reset) {
+  long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (reset) return (int)hipMemcpyToSymbol(HIP_SYMBOL(tg_wg_stamps), z, sizeof(z));
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_wg_stamps), sizeof(z));
+}
+#else
+#define TG_WG_MARK(i) do {} while (0)
+#endif
+
 namespace {
 
 struct WgradK {
@@ -117,8 +139,35 @@ __global__ __launch_bounds__(64 * NW) void wgrad_kernel(const WgradK p) {
   constexpr int UX = ((TR::kBytes == 2) ? 11 : 22) * 4 / NW + (NW == 8 ? 1 : 0);  // 16-byte pieces per thread: X patch up to 10x34 pixels x A_BLK channels
   constexpr int UY = ((TR::kBytes == 2) ? 4 : 8) * 4 / NW;                           //                            Y tile 128 pixels x B_BLK channels
   u32x4 vx[UX], vy[UY];
-  const float inv_iw = 1.0f / (float)p.iw;
   const int nx = prow_n * XV, ny = ypix * YV;
+
+  // Per-thread piece constants.  Which patch pixel / channel piece a thread stages does not depend on the tile, so the
+  // global offset relative to the patch origin, the LDS offset and the (row, column) for the bounds test are computed ONCE:
+  // with the divisions and multiplies inside the per-tile loops, issuing a tile's 8 loads cost ~1700 cycles and the tap
+  // address arithmetic doubled the k-loop (in-kernel stamps, tools/stamp_wgrad.py).
+  int xg[UX], xl[UX], xrc[UX], yg[UY], yl[UY], yrc[UY];
+#pragma unroll
+  for (int u = 0; u < UX; ++u) {
+    const int i = tid + u * NTHR;
+    const int prow = i / XV, s2 = i - prow * XV;  // XV is a power of two
+    const int py = prow / p.iw, px = prow - py * p.iw;
+    xg[u] = (int)(((size_t)py * p.XW + px) * xpix_bytes) + s2 * 16;
+    xl[u] = i < nx ? prow * XROW + s2 * 16 : -1;
+    xrc[u] = py | (px << 16);
+  }
+#pragma unroll
+  for (int u = 0; u < UY; ++u) {
+    const int i = tid + u * NTHR;
+    const int prow = i / YV, s2 = i - prow * YV;
+    const int ry = prow >> p.tw_log2, rx = prow & (tw - 1);
+    yg[u] = (int)(((size_t)ry * p.YW + rx) * ypix_bytes) + s2 * 16;
+    yl[u] = i < ny ? prow * YROW + s2 * 16 : -1;
+    yrc[u] = ry | (rx << 16);
+  }
+  // LDS byte offset of tap t relative to the tap-less row of a pixel (uniform: lives in scalar registers)
+  int tapb[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) tapb[t] = ((p.dy[tap0 + t] - p.dymin) * p.iw + (p.dx[tap0 + t] - p.dxmin)) * XROW;
 
   auto issue = [&](int tile) {
     int r = tile;
@@ -128,51 +177,39 @@ __global__ __launch_bounds__(64 * NW) void wgrad_kernel(const WgradK p) {
     const int n = r / p.tiles_y;
     const int ty0 = tyb * p.th, tx0 = txb * tw;
     const int iy0 = ty0 * p.S + p.dymin, ix0 = tx0 * p.S + p.dxmin;
-    const char* xn = xbase + (size_t)n * p.XH * p.XW * xpix_bytes + (size_t)a0 * TR::kBytes;
+    // origin pixel of the patch (may lie outside the image: only in-bounds pieces are dereferenced)
+    const char* xo = xbase + ((size_t)n * p.XH * p.XW + (long long)iy0 * p.XW + ix0) * (long long)xpix_bytes + (size_t)a0 * TR::kBytes;
 #pragma unroll
     for (int u = 0; u < UX; ++u) {
-      const int i = tid + u * NTHR;
+      const int iy = iy0 + (xrc[u] & 0xffff), ix = ix0 + (xrc[u] >> 16);
       vx[u] = u32x4{0u, 0u, 0u, 0u};
-      if (i < nx) {
-        const int prow = i / XV, s2 = i - prow * XV;  // XV is a power of two
-        const int py = (int)(((float)prow + 0.5f) * inv_iw), px = prow - py * p.iw;
-        const int iy = iy0 + py, ix = ix0 + px;
-        if (iy >= 0 && iy < p.XH && ix >= 0 && ix < p.XW)
-          vx[u] = *reinterpret_cast<const u32x4*>(xn + ((size_t)iy * p.XW + ix) * xpix_bytes + s2 * 16);
-      }
+      if (xl[u] >= 0 && (unsigned)iy < (unsigned)p.XH && (unsigned)ix < (unsigned)p.XW)
+        vx[u] = *reinterpret_cast<const u32x4*>(xo + xg[u]);
     }
-    const char* yn = ybase + (size_t)n * p.YH * p.YW * ypix_bytes + (size_t)b0 * TR::kBytes;
+    const char* yo = ybase + ((size_t)n * p.YH * p.YW + (size_t)ty0 * p.YW + tx0) * ypix_bytes + (size_t)b0 * TR::kBytes;
 #pragma unroll
     for (int u = 0; u < UY; ++u) {
-      const int i = tid + u * NTHR;
+      const int yy = ty0 + (yrc[u] & 0xffff), xx = tx0 + (yrc[u] >> 16);
       vy[u] = u32x4{0u, 0u, 0u, 0u};
-      if (i < ny) {
-        const int prow = i / YV, s2 = i - prow * YV;
-        const int yy = ty0 + (prow >> p.tw_log2), xx = tx0 + (prow & (tw - 1));
-        if (yy < p.YH && xx < p.YW)
-          vy[u] = *reinterpret_cast<const u32x4*>(yn + ((size_t)yy * p.YW + xx) * ypix_bytes + s2 * 16);
-      }
+      if (yl[u] >= 0 && yy < p.YH && xx < p.YW) vy[u] = *reinterpret_cast<const u32x4*>(yo + yg[u]);
     }
   };
 
   int tile = split;
   if (tile < p.tiles_total) issue(tile);
+#ifdef TG_STAMP
+  long long _wg_t = (long long)__builtin_amdgcn_s_memtime();
+#endif
   for (; tile < p.tiles_total; tile += p.nsplit) {
     __syncthreads();  // the previous tile's fragment reads are done
+    TG_WG_MARK(0);
 #pragma unroll
-    for (int u = 0; u < UX; ++u) {
-      const int i = tid + u * NTHR;
-      if (i < nx) {
-        const int prow = i / XV, s2 = i - prow * XV;
-        *reinterpret_cast<u32x4*>(lds_x + prow * XROW + s2 * 16) = vx[u];
-      }
-    }
+    for (int u = 0; u < UX; ++u)
+      if (xl[u] >= 0) *reinterpret_cast<u32x4*>(lds_x + xl[u]) = vx[u];
 #pragma unroll
     for (int u = 0; u < UY; ++u) {
-      const int i = tid + u * NTHR;
-      if (i < ny) {
-        const int prow = i / YV, s2 = i - prow * YV;
-        *reinterpret_cast<u32x4*>(lds_y + prow * YROW + s2 * 16) = vy[u];
+      if (yl[u] >= 0) {
+        *reinterpret_cast<u32x4*>(lds_y + yl[u]) = vy[u];
         if (ysum) {
           float f[E];
           unpack16<T>(vy[u], f);
@@ -181,8 +218,11 @@ __global__ __launch_bounds__(64 * NW) void wgrad_kernel(const WgradK p) {
         }
       }
     }
+    TG_WG_MARK(1);
     __syncthreads();
+    TG_WG_MARK(2);
     if (tile + p.nsplit < p.tiles_total) issue(tile + p.nsplit);  // in flight during the MFMAs below
+    TG_WG_MARK(3);
 
     for (int k0 = 0; k0 < ypix; k0 += 32) {
       if constexpr (TR::kBytes == 2) {
@@ -204,15 +244,14 @@ __global__ __launch_bounds__(64 * NW) void wgrad_kernel(const WgradK p) {
         const int ty_lo = k_lo >> p.tw_log2, tx_lo = k_lo & (tw - 1);
         const int ty_hi = k_hi >> p.tw_log2, tx_hi = k_hi & (tw - 1);
         const int cha = (wa * 16 + 4 * pp) * 2;
+        const char* x_lo = lds_x + ((ty_lo * p.iw + tx_lo) * p.S) * XROW + cha;  // the pixel's row without a tap offset
+        const char* x_hi = lds_x + ((ty_hi * p.iw + tx_hi) * p.S) * XROW + cha;
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-          const int oy = p.dy[tap0 + t] - p.dymin, ox = p.dx[tap0 + t] - p.dxmin;
-          const int r_lo = (ty_lo * p.S + oy) * p.iw + tx_lo * p.S + ox;
-          const int r_hi = (ty_hi * p.S + oy) * p.iw + tx_hi * p.S + ox;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(lds_x + r_lo * XROW + cha));
+              (s16x4 __attribute__((address_space(3)))*)(x_lo + tapb[t]));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(lds_x + r_hi * XROW + cha));
+              (s16x4 __attribute__((address_space(3)))*)(x_hi + tapb[t]));
           typedef __attribute__((ext_vector_type(8))) short s16x8;
           const s16x8 cat = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           const bf16x8 af = __builtin_bit_cast(bf16x8, cat);
@@ -228,16 +267,20 @@ __global__ __launch_bounds__(64 * NW) void wgrad_kernel(const WgradK p) {
           for (int b = 0; b < BT; ++b)
             bv[b] = *reinterpret_cast<const float*>(lds_y + k * YROW + ((wb * BT + b) * 16 + idx) * 4);
           const int ty = k >> p.tw_log2, tx = k & (tw - 1);
+          const char* x_k = lds_x + ((ty * p.iw + tx) * p.S) * XROW + (wa * 16 + idx) * 4;
 #pragma unroll
           for (int t = 0; t < TPW; ++t) {
-            const int rr = (ty * p.S + p.dy[tap0 + t] - p.dymin) * p.iw + tx * p.S + p.dx[tap0 + t] - p.dxmin;
-            const float av = *reinterpret_cast<const float*>(lds_x + rr * XROW + (wa * 16 + idx) * 4);
+            const float av = *reinterpret_cast<const float*>(x_k + tapb[t]);
 #pragma unroll
             for (int b = 0; b < BT; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[b], acc[t][b], 0, 0, 0);
           }
         }
       }
     }
+    TG_WG_MARK(4);
+#ifdef TG_STAMP
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) tg_wg_stamps[5] += 1;
+#endif
   }
 
   // slab[split][t][a][b] (+ [Cy] channel sums of Y when ysum); accumulator rows 4g+j are the X channel, column idx the Y channel
