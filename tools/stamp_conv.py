@@ -7,7 +7,7 @@ lib = L.load()
 lib.tg_debug_read_stamps.restype = ctypes.c_int
 lib.tg_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 dt = torch.bfloat16
-for (kind, cin, cout, N, H, tile) in (("c3",64,64,4,32,5), ("c3",64,64,40,32,6), ("ct",128,128,4,64,6), ("c4s2",128,64,12,16,2), ("c4s2",128,128,12,32,2), ("c4s2",64,64,12,128,1)):
+for (kind, cin, cout, N, H, tile) in (("c3",64,64,4,32,5), ("c3",64,64,40,32,6), ("c3",64,64,12,64,6), ("c3",128,128,12,16,5), ("c3",128,128,12,32,5), ("c3",128,64,4,128,7), ("ct",128,128,4,64,6), ("c4s2",128,64,12,16,2), ("c4s2",128,128,12,32,2), ("c4s2",64,64,12,128,1)):
     spec = K.ConvSpec(kind, cin, cout)
     OH, OW = spec.out_hw(H, H)
     x = torch.randn(N, H, H, K.pad32(cin), device="cuda").to(dt)
