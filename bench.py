@@ -214,9 +214,21 @@ def pmc_traffic(kernel):
             tab = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
         except (OSError, ValueError, KeyError):
             continue
-        ent = tab.get(kernel)
-        if ent:
-            return ent, f"profiles/{name} (rocprofv3 --pmc, separate passes of this same command; not live)"
+        src = f"profiles/{name} (rocprofv3 --pmc, separate passes of this same command; not live)"
+        if kernel in tab:
+            return dict(tab[kernel], rocprof_names=[kernel]), src
+        # a bench label leaves trailing template arguments open ("conv_gather_kernel<BF16, 4, 2, 1, 4, true>" covers the slim
+        # and the general epilogue build): launch-weighted average over every profiled kernel the label is a prefix of
+        stem = kernel.split(" (")[0].rstrip(">").rstrip(".").rstrip(", ")
+        hits = {k: v for k, v in tab.items() if k.startswith(stem + ",") or k.startswith(stem + ">")}
+        if hits:
+            n = sum(v["launches"] for v in hits.values())
+            ent = {"launches": n, "rocprof_names": sorted(hits)}
+            for key in ("hbm_bytes_per_launch", "mfma_busy_pct", "avg_ns"):
+                vals = [(v[key], v["launches"]) for v in hits.values() if key in v]
+                if vals:
+                    ent[key] = round(sum(a * b for a, b in vals) / sum(b for _, b in vals), 2)
+            return ent, src
     return None, None
 
 
@@ -335,6 +347,7 @@ def main():
                                "frac": round(ach / MFMA_PEAK_TFLOPS[a.dtype], 5),
                                "traffic": int(pmc["hbm_bytes_per_launch"]) if pmc else None,
                                "traffic_source": pmc_src, "mfma_busy_pct": busy(dom),
+                               "rocprof_names": pmc["rocprof_names"] if pmc else None,
                                "launches_per_step": d["launches"],
                                "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
                                "avg_launch_gflop": round(d["work"] / d["launches"] / 1e9, 3),
