@@ -62,8 +62,27 @@ class inference_dataset(Dataset):
         return torch.stack(frames, dim=0)
 
 
+def frames_to_batches(frames_u8, crop_size, first_frame_crop=True):
+    """GPU half of the ingest when train_dataset(decode_only=True) is used: decoded uint8 frames (B,T,H,W,3) on the device
+    -> (LR (B,T,3,cs,cs), HR (B,T,3,4cs,4cs)) fp32, PIL-BILINEAR resize bit for bit (pytorch_tecogan_amd.resize) and the
+    independent RandomResizedCrop of frame 0 of each sequence (:91-93 of the reference's dataloader)."""
+    from pytorch_tecogan_amd.resize import resize_frames
+    B, T, H, W, _ = frames_u8.shape
+    flat = frames_u8.reshape(B * T, H, W, 3)
+    lr = resize_frames(flat, crop_size).view(B, T, 3, crop_size, crop_size)
+    hr = resize_frames(flat, 4 * crop_size).view(B, T, 3, 4 * crop_size, 4 * crop_size)
+    if first_frame_crop:
+        for b in range(B):
+            hr[b, 0] = _random_resized_crop(hr[b, 0], 4 * crop_size)
+            lr[b, 0] = _random_resized_crop(lr[b, 0], crop_size)
+    return lr, hr
+
+
 class train_dataset(Dataset):
-    def __init__(self, args):
+    def __init__(self, args, decode_only=False):
+        """decode_only: __getitem__ returns the window's DECODED frames as one uint8 tensor (10,H,W,3); the resize to the LR
+        and HR sizes then happens on the GPU (frames_to_batches) - the PNG decode is all the workers do."""
+        self.decode_only = decode_only
         if args.input_video_dir == "":
             raise ValueError("Video input directory input_video_dir is not provided")
         if not os.path.exists(args.input_video_dir):
@@ -87,6 +106,8 @@ class train_dataset(Dataset):
 
     def __getitem__(self, idx):
         cs = self.args.crop_size
+        if self.decode_only:
+            return torch.from_numpy(np.stack([np.asarray(Image.open(p).convert("RGB")) for p in self.windows[idx]]))
         lr, hr = [], []
         for i, path in enumerate(self.windows[idx]):
             img = Image.open(path)

@@ -320,6 +320,15 @@ int tg_maxpool2_bwd(int dtype, const void* a, const void* dpool, const void* res
 int tg_vgg_input_grad(int dtype, const void* dx_nhwc32, const float* gen_nchw, void* dpre_nhwc32, int N, int H, int W,
                       float scale, float* bias_acc3, void* stream);
 
+/* ---- data ingest: GPU-side frame resize (code/dataloader.py:84-88 of the reference: torchvision resize of PIL frames) --- */
+/* PIL Image.resize(BILINEAR) + ToTensor, bit-exact: frames uint8 [N][H][W][3] -> tmp uint8 [N][H][OW][3] (horizontal pass)
+ * -> out fp32 [N][3][OH][OW] = value / 255 (vertical pass).  bounds_* int32 [out][2] (first input index, count), kk_* int32
+ * [out][ksize] 22-bit fixed-point coefficients, built on the host exactly as Pillow's Resample.c builds them
+ * (pytorch-tecogan_amd/resize.py). */
+int tg_resample_u8(const void* frames_u8, void* tmp_u8, float* out_nchw, const int32_t* bounds_w, const int32_t* kk_w,
+                   int ksize_w, const int32_t* bounds_h, const int32_t* kk_h, int ksize_h, int N, int H, int W, int OH,
+                   int OW, void* stream);
+
 /* ---- step schedule support (no reference counterpart: the reference runs everything on one CUDA stream) ------- */
 /* Creates a stream confined to every CU except the first `reserve_cus` CU-mask bits (hipExtStreamCreateWithCUMask; 64 bits
  * = 8 CUs on each of the 8 XCDs of an MI355X).  The dense lane of the step runs there, so that the generator chain's

@@ -56,6 +56,9 @@ def build_parser():
     a("--D_LAYERLOSS", default=True, type=str2bool)
     a("--synthetic", default=0, type=int, help="train on this many random sequences (no dataset)")
     a("--tg_dtype", default=None, choices=[None, "bf16", "fp16", "fp32"])
+    a("--tg_gpu_resize", default=False, type=str2bool,
+      help="data ingest: the workers only decode the PNGs; the PIL-bilinear resize to the LR / HR sizes runs on the GPU "
+           "(bit-exact restatement of PIL's resize; frames of one dataset must share a size)")
     a("--tg_extend", default=False, type=str2bool,
       help="opt-in extension beyond what the reference can execute: RNN_N outside 9..11 and crop_size != 32 "
            "(discriminator fc sized from crop_size); parity with the reference is undefined there")
@@ -120,7 +123,7 @@ def main(argv=None):
         dataset = data
     else:
         from dataloader import train_dataset
-        dataset = train_dataset(args)
+        dataset = train_dataset(args, decode_only=bool(args.tg_gpu_resize))
     sampler = None
     if world > 1:
         sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True,
@@ -162,8 +165,13 @@ def main(argv=None):
         output = inputs = targets = None
         if sampler is not None:
             sampler.set_epoch(e)
-        for batch_idx, (inputs, targets) in enumerate(loader):
-            inputs, targets = inputs.to(dev, non_blocking=True), targets.to(dev, non_blocking=True)
+        for batch_idx, batch in enumerate(loader):
+            if torch.is_tensor(batch):  # --tg_gpu_resize: decoded uint8 frames (B,T,H,W,3); resize on the device
+                from dataloader import frames_to_batches
+                inputs, targets = frames_to_batches(batch.to(dev, non_blocking=True), args.crop_size)
+            else:
+                inputs, targets = batch
+                inputs, targets = inputs.to(dev, non_blocking=True), targets.to(dev, non_blocking=True)
             output = FRVSR_Train(inputs, targets, args, D, G, batch_idx, 0.0, 0.0, opt_g, opt_d)
             g_loss = g_loss + (output.gen_loss.data - g_loss) / (batch_idx + 1)   # running means stay on the device
             d_loss = d_loss + (output.d_loss.data - d_loss) / (batch_idx + 1)

@@ -91,6 +91,7 @@ _PROTOS = {
     "tg_cosine_loss": (_I, [_I, _P, _P, _P, _L, _I, _F, _I, _P, _P, _P]),
     "tg_maxpool2_bwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "tg_vgg_input_grad": (_I, [_I, _P, _P, _P, _I, _I, _I, _F, _P, _P]),
+    "tg_resample_u8": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "tg_stream_create_cumask": (_I, [_I, C.POINTER(C.c_void_p)]),
     "tg_stream_destroy": (_I, [_P]),
 }

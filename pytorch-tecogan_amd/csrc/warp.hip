@@ -376,3 +376,75 @@ extern "C" int tg_nhwc_to_nchw(int dtype, const void* src, float* dst, int64_t d
     return TG_E_BADARG;
   return tg_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GPU-side frame resize of the data ingest: PIL Image.resize(BILINEAR) - what the reference's
+// torchvision resize does on the PIL frames it opens - as two 8-bit fixed-point passes with a uint8 rounding in between
+// (Pillow libImaging/Resample.c).  The coefficient tables come from the host (pytorch-tecogan_amd/resize.py, pinned
+// against PIL); bit-exact by construction: int32 accumulate from 2^21, arithmetic shift by 22, clip to 0..255.
+namespace {
+__global__ void resample_h_u8_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
+                                     const int* __restrict__ bounds, const int* __restrict__ kk, int ksize, long long rows,
+                                     int W, int OW) {
+  const long long total = rows * OW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    const long long row = i / OW;
+    const int x0 = bounds[2 * ox], n = bounds[2 * ox + 1];
+    const int* k = kk + (long long)ox * ksize;
+    const unsigned char* src = in + (row * W + x0) * 3;
+    int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+    for (int x = 0; x < n; ++x) {
+      const int w = k[x];
+      a0 += src[3 * x] * w;
+      a1 += src[3 * x + 1] * w;
+      a2 += src[3 * x + 2] * w;
+    }
+    unsigned char* dst = out + i * 3;
+    dst[0] = (unsigned char)min(max(a0 >> 22, 0), 255);
+    dst[1] = (unsigned char)min(max(a1 >> 22, 0), 255);
+    dst[2] = (unsigned char)min(max(a2 >> 22, 0), 255);
+  }
+}
+
+// vertical pass + ToTensor: tmp [N][H][OW][3] uint8 -> out [N][3][OH][OW] fp32 = value / 255
+__global__ void resample_v_u8_kernel(const unsigned char* __restrict__ tmp, float* __restrict__ out,
+                                     const int* __restrict__ bounds, const int* __restrict__ kk, int ksize, int N, int H,
+                                     int OH, int OW) {
+  const long long total = (long long)N * OH * OW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    long long r = i / OW;
+    const int oy = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const int y0 = bounds[2 * oy], cnt = bounds[2 * oy + 1];
+    const int* k = kk + (long long)oy * ksize;
+    const unsigned char* src = tmp + (((long long)n * H + y0) * OW + ox) * 3;
+    int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+    for (int y = 0; y < cnt; ++y) {
+      const int w = k[y];
+      const unsigned char* p = src + (long long)y * OW * 3;
+      a0 += p[0] * w;
+      a1 += p[1] * w;
+      a2 += p[2] * w;
+    }
+    const long long plane = (long long)OH * OW, o = (long long)n * 3 * plane + (long long)oy * OW + ox;
+    out[o] = __fdiv_rn((float)min(max(a0 >> 22, 0), 255), 255.0f);
+    out[o + plane] = __fdiv_rn((float)min(max(a1 >> 22, 0), 255), 255.0f);
+    out[o + 2 * plane] = __fdiv_rn((float)min(max(a2 >> 22, 0), 255), 255.0f);
+  }
+}
+}  // namespace
+
+extern "C" int tg_resample_u8(const void* frames_u8, void* tmp_u8, float* out_nchw, const int32_t* bounds_w,
+                              const int32_t* kk_w, int ksize_w, const int32_t* bounds_h, const int32_t* kk_h, int ksize_h,
+                              int N, int H, int W, int OH, int OW, void* stream) {
+  if (!frames_u8 || !tmp_u8 || !out_nchw || !bounds_w || !kk_w || !bounds_h || !kk_h) return TG_E_BADARG;
+  if (N <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || ksize_w <= 0 || ksize_h <= 0) return TG_E_BADARG;
+  const long long rows = (long long)N * H;
+  hipLaunchKernelGGL(resample_h_u8_kernel, dim3(grid_for(rows * OW)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char*)frames_u8, (unsigned char*)tmp_u8, bounds_w, kk_w, ksize_w, rows, W, OW);
+  hipLaunchKernelGGL(resample_v_u8_kernel, dim3(grid_for((long long)N * OH * OW)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char*)tmp_u8, out_nchw, bounds_h, kk_h, ksize_h, N, H, OH, OW);
+  return tg_launch_status();
+}

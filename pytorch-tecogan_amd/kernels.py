@@ -368,6 +368,15 @@ def vgg_input_grad(dx, gen_nchw, dpre, scale, bias_acc=None):
                                        _ptr(bias_acc), _stream()), "tg_vgg_input_grad")
 
 
+def resample_u8(frames_u8, plan, out):
+    """PIL-BILINEAR resize + ToTensor of decoded uint8 frames on the GPU (resize.ResizePlan holds the coefficient tables)"""
+    N, H, W, _ = frames_u8.shape
+    tmp = torch.empty(N, H, plan.out_w, 3, dtype=torch.uint8, device=frames_u8.device)
+    L.check(L.load().tg_resample_u8(_ptr(frames_u8), _ptr(tmp), _ptr(out), _ptr(plan.bw), _ptr(plan.kw), plan.kw_n,
+                                    _ptr(plan.bh), _ptr(plan.kh), plan.kh_n, N, H, W, plan.out_h, plan.out_w, _stream()),
+            "tg_resample_u8")
+
+
 def up2_bilinear(src, dst):
     N, H, W, C_ = src.shape
     L.check(L.load().tg_up2_bilinear(tg_dtype(src.dtype), _ptr(src), _ptr(dst), N, H, W, C_, _stream()), "tg_up2_bilinear")

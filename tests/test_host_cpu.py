@@ -332,3 +332,22 @@ def test_save_image_grid_layout(tmp_path):
     assert img[8:12, 10:16].min() == 255 and img[:8].max() == 0 and img[8:12, :10].max() == 0   # tile 9 = row 1, column 1
     ops.save_image(torch.full((1, 3, 5, 5), 0.5), str(fp))
     assert np.asarray(Image.open(fp)).shape == (5, 5, 3)
+
+
+@pytest.mark.parametrize("hw,out", [((40, 56), 16), ((37, 23), 32), ((24, 24), 8), ((24, 24), 96), ((180, 320), 32),
+                                    ((180, 320), 128), ((32, 32), 32)])
+def test_resize_restatement_equals_pil_bilinear_bit_for_bit(hw, out):
+    """data ingest, GPU-side resize: the host-built fixed-point coefficient tables and the two-pass 8-bit
+    arithmetic reproduce PIL's Image.resize(BILINEAR) - the reference's frame resize - exactly"""
+    from PIL import Image
+    from pytorch_tecogan_amd import resize as R
+    rng = np.random.default_rng(hw[0] * 1000 + out)
+    img = rng.integers(0, 256, size=(hw[0], hw[1], 3), dtype=np.uint8)
+    img[:5, :7] = 255
+    img[-3:, -9:] = 0
+    exp = np.asarray(Image.fromarray(img).resize((out, out), Image.BILINEAR))
+    got = R.resize_u8_reference(img, out, out)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+    b, k = R.pil_bilinear_coeffs(hw[1], out)
+    assert b.shape == (out, 2) and int((b[:, 0] + b[:, 1]).max()) <= hw[1] and int(b[:, 1].min()) >= 1
+    assert abs(int(k.sum(axis=1).max()) - (1 << R.PRECISION_BITS)) <= k.shape[1]   # rows sum to one in fixed point

@@ -92,3 +92,37 @@ def test_main_py_inference_mode_on_a_folder_of_frames(tmp_path, monkeypatch):
         assert im.size == (128, 128)
     with pytest.raises(ValueError):
         tg_main.main(["--mode", "inference", "--input_dir_LR", str(tmp_path / "lr"), "--output_dir", "out"])  # no checkpoint
+
+
+def test_gpu_resize_equals_pil_bit_for_bit_and_feeds_main(tmp_path, monkeypatch):
+    """data ingest with --tg_gpu_resize: tg_resample_u8 == PIL Image.resize(BILINEAR) + ToTensor exactly (down- and
+    up-scaling, non-square frames), and main.py trains from decode-only workers"""
+    import importlib.util
+    from PIL import Image
+    from pytorch_tecogan_amd import resize as R
+    rng = np.random.default_rng(3)
+    for (H, W, out) in ((180, 320, 32), (180, 320, 128), (37, 23, 32), (24, 24, 96), (32, 32, 32)):
+        fr = rng.integers(0, 256, size=(3, H, W, 3), dtype=np.uint8)
+        got = R.resize_frames(torch.from_numpy(fr).cuda(), out).cpu().numpy()
+        for n in range(3):
+            exp = np.asarray(Image.fromarray(fr[n]).resize((out, out), Image.BILINEAR), dtype=np.float32) / 255.0
+            assert np.array_equal(got[n], exp.transpose(2, 0, 1)), (H, W, out)
+    # end to end: 4 scenes of 120 frames of 48x40 pixels, one epoch through main.py with GPU-side resize
+    for scene in range(1000, 1004):
+        d = tmp_path / "data" / ("scene_%04d" % scene)
+        d.mkdir(parents=True)
+        base = rng.integers(0, 256, size=(40, 48, 3), dtype=np.uint8)
+        for k in range(120):
+            Image.fromarray(np.roll(base, k, axis=1)).save(d / ("col_high_%04d.png" % k))
+    spec = importlib.util.spec_from_file_location("tg_main_ingest", os.path.join(ROOT, "main.py"))
+    tg_main = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tg_main)
+    monkeypatch.chdir(tmp_path)
+    import pytorch_tecogan_amd.train as hip_train
+    hip_train._STEPS.clear()
+    tg_main.main(["--input_video_dir", str(tmp_path / "data"), "--max_epochs", "1", "--tg_gpu_resize", "true",
+                  "--num_resblock", "2", "--discrim_resblocks", "1", "--queue_thread", "2"])
+    ck = torch.load(tmp_path / "generator.pt")
+    assert float(ck["optimizer_state_dict"]["state"][0]["step"]) == 1.0     # 4 scenes -> one batch of 4 windows
+    assert (tmp_path / "Gan_examples.jpg").exists()
+    hip_train._STEPS.clear()
