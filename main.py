@@ -155,6 +155,9 @@ def main(argv=None):
         d_ck = torch.load(args.d_checkpoint, map_location=dev)
         D.load_state_dict(d_ck["model_state_dict"])
         opt_d.load_state_dict(d_ck["optimizer_state_dict"])
+        if g_ck.get("tg_scaler"):  # fp16 mode: the dynamic loss scale is part of the training state (extra key)
+            from pytorch_tecogan_amd.train import load_loss_scaler_state
+            load_loss_scaler_state(g_ck["tg_scaler"])
     if world > 1:  # replicas start equal: every rank drew its own initial weights above
         from pytorch_tecogan_amd import parallel
         parallel.broadcast_state((G, D), (opt_g, opt_d))
@@ -197,8 +200,11 @@ def main(argv=None):
             save_image(targets.reshape(n, 3, cs * 4, cs * 4), "real_image.jpg")
             save_image(inputs.reshape(n, 3, cs, cs), "original_image.jpg")
             print("\nSaving model...")
-            torch.save({"epoch": e, "model_state_dict": G.state_dict(), "optimizer_state_dict": opt_g.state_dict()},
-                       "generator.pt")
+            from pytorch_tecogan_amd.train import loss_scaler_state
+            g_state = {"epoch": e, "model_state_dict": G.state_dict(), "optimizer_state_dict": opt_g.state_dict()}
+            if loss_scaler_state() is not None:
+                g_state["tg_scaler"] = loss_scaler_state()
+            torch.save(g_state, "generator.pt")
             torch.save({"model_state_dict": D.state_dict(), "optimizer_state_dict": opt_d.state_dict()}, "discrim.pt")
             el = time.time() - since
             print("\nTraining complete in {:.0f}m {:.0f}s".format(el // 60, el % 60))

@@ -49,6 +49,33 @@ def _bind_optimizer(opt, module):
     opt._tg_step = shared_step
 
 
+_PENDING_SCALER = None
+
+
+def loss_scaler_state():
+    """GradScaler.state_dict()-style {'scale', 'growth_tracker'} of the live step's fp16 loss scaler (None outside fp16 mode):
+    what main.py stores next to the optimiser state as the extra checkpoint key `tg_scaler`."""
+    for st in _STEPS.values():
+        return st.scaler_state()
+    return None
+
+
+def load_loss_scaler_state(state):
+    """restores a saved loss-scaler state; applied to the live step, or to the next one that is built"""
+    global _PENDING_SCALER
+    _PENDING_SCALER = dict(state) if state else None
+    for st in _STEPS.values():
+        _apply_scaler(st)
+
+
+def _apply_scaler(st):
+    global _PENDING_SCALER
+    if _PENDING_SCALER is not None and st.scaler is not None:
+        s = float(_PENDING_SCALER["scale"])
+        st.scaler.copy_(torch.tensor([s, float(_PENDING_SCALER.get("growth_tracker", 0)), 0.0, 0.0, 1.0 / s, 0.0, 0.0, 0.0]))
+        _PENDING_SCALER = None
+
+
 def get_step(generator_F, discriminator_F, B, T, h, args, device, dtype_t=None, use_graph=None):
     dtype_t = dtype_t or compute_dtype(args)
     if use_graph is None:
@@ -67,6 +94,7 @@ def get_step(generator_F, discriminator_F, B, T, h, args, device, dtype_t=None, 
             old.close()
         _STEPS.clear()
         _STEPS[key] = st
+        _apply_scaler(st)
     return st
 
 

@@ -201,3 +201,27 @@ def test_fp16_generator_inference_matches_fp32_oracle():
         ref = orc.recurrent_generator(gp, x, orc.pseudo_flow(x))
     for graph in (False, True):
         assert rel(G.recurrent(x.cuda(), use_graph=graph), ref) < 3e-3
+
+
+def test_main_py_fp16_checkpoint_carries_the_loss_scaler(tmp_path, monkeypatch):
+    """--tg_dtype fp16 through main.py: generator.pt gains the extra key tg_scaler (GradScaler.state_dict() fields) and a
+    resumed run starts from it"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tg_main_fp16", os.path.join(ROOT, "main.py"))
+    tg_main = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tg_main)
+    monkeypatch.chdir(tmp_path)
+    hip_train._STEPS.clear()
+    common = ["--synthetic", "4", "--max_epochs", "1", "--tg_dtype", "fp16", "--num_resblock", "2", "--discrim_resblocks", "1"]
+    tg_main.main(common)
+    ck = torch.load(tmp_path / "generator.pt")
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "tg_scaler"}
+    assert ck["tg_scaler"]["scale"] in (65536.0, 32768.0, 16384.0) and ck["tg_scaler"]["growth_tracker"] in (0, 1, 2)
+    ck["tg_scaler"] = {"scale": 1024.0, "growth_tracker": 7}
+    torch.save(ck, tmp_path / "generator.pt")
+    hip_train._STEPS.clear()
+    tg_main.main(common + ["--pre_trained_model", "true", "--g_checkpoint", str(tmp_path / "generator.pt"), "--d_checkpoint",
+                           str(tmp_path / "discrim.pt")])
+    ck2 = torch.load(tmp_path / "generator.pt")
+    assert ck2["tg_scaler"] == {"scale": 1024.0, "growth_tracker": 9}      # one step = two update() calls, no overflow at 1024
+    hip_train._STEPS.clear()
