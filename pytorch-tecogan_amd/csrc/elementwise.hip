@@ -56,23 +56,35 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ 
     if (nbt && c == 0) *nbt += groups;  // num_batches_tracked: one per forward call of the reference
   }
   const long long base = (long long)grp * npix;
-  for (long long p = (long long)blockIdx.x * rows + prow; p < npix; p += (long long)gridDim.x * rows) {
-    const long long off = ((base + p) * C + vec * E) * TR::kBytes;
-    float v[E];
-    Vec<T>::load(z + off, v);
+  const long long step = (long long)gridDim.x * rows;
+  auto finish = [&](float* v, const float* sk, long long off) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       v[e] = v[e] * scale[e] + shift[e];
       if (act == TG_ACT_LRELU) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
       else if (act == TG_ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
-    }
-    if (skip) {
-      float s[E];
-      Vec<T>::load(skip + off, s);
-#pragma unroll
-      for (int e = 0; e < E; ++e) v[e] += s[e];
+      if (skip) v[e] += sk[e];
     }
     Vec<T>::store(y + off, v);
+  };
+  long long p = (long long)blockIdx.x * rows + prow;
+  for (; p + 3 * step < npix; p += 4 * step) {  // four pixels per trip, all loads issued before the first use
+    float v[4][E], sk[4][E];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long off = ((base + p + u * step) * C + vec * E) * TR::kBytes;
+      Vec<T>::load(z + off, v[u]);
+      if (skip) Vec<T>::load(skip + off, sk[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) finish(v[u], sk[u], ((base + p + u * step) * C + vec * E) * TR::kBytes);
+  }
+  for (; p < npix; p += step) {
+    const long long off = ((base + p) * C + vec * E) * TR::kBytes;
+    float v[E], sk[E];
+    Vec<T>::load(z + off, v);
+    if (skip) Vec<T>::load(skip + off, sk);
+    finish(v, sk, off);
   }
 }
 
@@ -178,23 +190,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
     dbeta[c] += db;
   }
   const long long base = (long long)grp * npix;
-  for (long long p = (long long)blockIdx.x * rows + prow; p < npix; p += (long long)gridDim.x * rows) {
-    const long long off = ((base + p) * C + vec * E) * TR::kBytes;
-    float d[E], zz[E];
-    Vec<T>::load(dy + off, d);
-    Vec<T>::load(z + off, zz);
-    if (act == TG_ACT_LRELU) {
-      float a[E];
-      Vec<T>::load(yact + off, a);
-#pragma unroll
-      for (int e = 0; e < E; ++e) d[e] *= (a[e] > 0.f ? 1.f : 0.2f);
-    }
+  const long long step = (long long)gridDim.x * rows;
+  auto finish = [&](float* d, const float* zz, const float* a, long long off) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
+      const float dd = (act == TG_ACT_LRELU) ? d[e] * (a[e] > 0.f ? 1.f : 0.2f) : d[e];
       const float xh = (zz[e] - mean[e]) * invstd[e];
-      d[e] = k0[e] * (d[e] - m1[e] - xh * m2[e]);
+      d[e] = k0[e] * (dd - m1[e] - xh * m2[e]);
     }
     Vec<T>::store(dz + off, d);
+  };
+  long long p = (long long)blockIdx.x * rows + prow;
+  for (; p + 3 * step < npix; p += 4 * step) {  // four pixels per trip, all loads issued before the first use
+    float d[4][E], zz[4][E], a[4][E];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long off = ((base + p + u * step) * C + vec * E) * TR::kBytes;
+      Vec<T>::load(dy + off, d[u]);
+      Vec<T>::load(z + off, zz[u]);
+      if (act == TG_ACT_LRELU) Vec<T>::load(yact + off, a[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) finish(d[u], zz[u], a[u], ((base + p + u * step) * C + vec * E) * TR::kBytes);
+  }
+  for (; p < npix; p += step) {
+    const long long off = ((base + p) * C + vec * E) * TR::kBytes;
+    float d[E], zz[E], a[E];
+    Vec<T>::load(dy + off, d);
+    Vec<T>::load(z + off, zz);
+    if (act == TG_ACT_LRELU) Vec<T>::load(yact + off, a);
+    finish(d, zz, a, off);
   }
 }
 
