@@ -173,7 +173,7 @@ def roofline_pass(st, dtype):
     try:
         torch.cuda.synchronize()
         st._forward_backward(True)
-        st._update()
+        st._update_all()
         torch.cuda.synchronize()
     finally:
         for obj, name, orig in saved:

@@ -177,13 +177,15 @@ class TecoGANStep:
         self.reserve = int(os.environ.get("TECOGAN_CU_RESERVE", "0")) if self.lanes else 0
         # hipExtStreamCreateWithCUMask makes a BLOCKING stream: it serialises against the legacy default stream.  Lane A
         # therefore runs on a stream of its own as well (the caller's stream only brackets the step)
-        self.sA = torch.cuda.Stream(device=device)
+        # lane A is the caller's stream (no hand-over: two cross-stream waits cost ~15 us of idle chip each, every step) -
+        # except beside a CU-masked lane B, whose BLOCKING stream would serialise against the legacy default stream
+        self.sA = torch.cuda.Stream(device=device) if self.reserve > 0 else None
         self.sB = torch.cuda.Stream(device=device)
         # the real half runs BESIDE the chain (phase 1): only there can a CU reservation pay - its stream may be masked off
         # the first TECOGAN_CU_RESERVE CUs; the fake half (phase 2, beside the dense G backward) always has the whole chip
         self.sBm = lane_stream(device, self.reserve) if self.reserve > 0 else self.sB
         self.dreal_bwd_early = os.environ.get("TECOGAN_DREAL_BWD", "1") != "0"
-        self.ev = {k: torch.cuda.Event() for k in ("prep", "chain", "tail", "d", "dreal")}
+        self.ev = {k: torch.cuda.Event() for k in ("start", "prep", "chain", "tail", "d", "dreal")}
         D.sets.pin((2 * self.tb, H))
         D.alloc(2 * self.tb, H)
         self.V = None
@@ -259,7 +261,16 @@ class TecoGANStep:
         c[16:24] = K.adam_hyper(lr_g, betas_g[0], betas_g[1], eps_g, self.adam_t[0] + 1, gs)
         c[24:32] = K.adam_hyper(lr_d, betas_d[0], betas_d[1], eps_d, self.adam_t[1] + 1, gs)
         slot.copy_(torch.tensor(c, dtype=torch.float32))
-        self.params_dev.copy_(slot, non_blocking=True)
+        self._params_slot = slot   # copied to the device at the head of lane B (_stage_inputs_b)
+
+    def _stage_inputs_b(self):
+        """HR targets -> the static buffer the graphs read, parameter block -> device (current stream: lane B's)"""
+        y, Ti = self._y_src, self.T_in
+        self.y[:, :Ti].copy_(y)
+        if self.pingpang:
+            self.y[:, Ti:].copy_(torch.flip(y, dims=[1])[:, 1:])
+        self.params_dev.copy_(self._params_slot, non_blocking=True)
+        self._y_src = None
 
     # ---------------------------------------------------------------------------------------------------------- pieces
     # Each piece is a linear launch sequence on the CURRENT stream (no forks inside), so it can be captured as one graph
@@ -352,17 +363,30 @@ class TecoGANStep:
             else:
                 D.backward(groups=2)
 
-    def _update(self):
-        G, D, sc = self.G, self.D, self.scaler
+    def _update_d(self):
+        """discriminator: Adam + repack.  Runs at the tail of lane B, as soon as D's gradients are final - lane B is done
+        ~0.3 ms before lane A's G backward, so this is off the step's serial tail."""
+        D, sc = self.D, self.scaler
         if sc is not None:  # GradScaler.step: inf/NaN anywhere in a network's (all-reduced) gradients skips its update
-            K.check_finite(G.flat.g, sc[2:3])
             K.check_finite(D.flat.g, sc[3:4])
-        K.adam(G.flat.p, G.flat.g, G.flat.m, G.flat.v, self.hyper[0], scaler=sc, which=0)
         K.adam(D.flat.p, D.flat.g, D.flat.m, D.flat.v, self.hyper[1], scaler=sc, which=1)
+        D.repack()
+
+    def _update(self, with_d=False):
+        """generator: Adam + repack (+ the loss scaler's two update() calls, which need both networks' found_inf flags: the
+        caller has joined lane B by now).  with_d: the single-stream schedules run the discriminator's update here too."""
+        G, sc = self.G, self.scaler
+        if sc is not None:
+            K.check_finite(G.flat.g, sc[2:3])
+        K.adam(G.flat.p, G.flat.g, G.flat.m, G.flat.v, self.hyper[0], scaler=sc, which=0)
+        if with_d:
+            self._update_d()
         if sc is not None:
             K.scaler_update(sc)
         G.repack()
-        D.repack()
+
+    def _update_all(self):
+        self._update(with_d=True)
 
     def scaler_state(self):
         """{'scale', 'growth_tracker'} of the fp16 loss scaler (GradScaler.state_dict() keys), None otherwise; synchronises"""
@@ -374,13 +398,20 @@ class TecoGANStep:
     def _chain_tail(self):
         self._chain(self.tsize, self.T, loss=True)
 
-    PIECES = ("prep", "d_real", "chain", "chain_tail", "d_fake", "d_fake_bwd", "g_bwd", "update")
-    LANE_B = ("d_real", "d_fake", "d_fake_bwd")
+    def _chain0(self):
+        self._chain(0, 1)
+
+    def _chain_rest(self):
+        self._chain(1, self.tsize)
+
+    PIECES = ("prep", "d_real", "chain0", "chain", "chain_tail", "d_fake", "d_fake_bwd", "g_bwd", "update_d", "update")
+    LANE_B = ("prep", "d_real", "d_fake", "d_fake_bwd", "update_d")
 
     def _piece_fns(self):
-        return {"prep": self._prep, "d_real": self._d_real, "chain": self._chain, "chain_tail": self._chain_tail,
+        return {"prep": self._prep, "d_real": self._d_real, "chain0": self._chain0, "chain": self._chain_rest,
+                "chain_tail": self._chain_tail,
                 "d_fake": self._d_fake, "d_fake_bwd": self._d_fake_bwd, "g_bwd": self._g_backward,
-                "update": self._update}
+                "update_d": self._update_d, "update": self._update}
 
     def _forward_backward(self, include_d_backward=True):
         """everything up to the update on the CURRENT stream alone, in dependency order (serial; tools and bench.py's
@@ -406,14 +437,22 @@ class TecoGANStep:
         G all-reduce behind lane A's G backward - it then runs while lane B is still in the fake half's backward - and the
         D all-reduce behind lane B.  Work.wait() of the RCCL backend makes the current STREAM wait (no host block)."""
         main, sB, sBm, ev = torch.cuda.current_stream(), self.sB, self.sBm, self.ev
-        fn["prep"]()
-        ev["prep"].record(main)
-        sBm.wait_event(ev["prep"])
+        # the step's prologue (zeroing, pseudo-flow, T_vel: 8 small launches, ~60 us) runs at the head of lane B while lane A
+        # is already in the first generator pass - frame 0 has no previous frame, so it needs neither the flow nor any of
+        # the zeroed accumulators; lane A picks the prologue up before pass 1 (kernel trace: 125 us from the previous
+        # step's last kernel to this step's first convolution when the prologue ran in front of both lanes)
+        ev["start"].record(main)
+        sBm.wait_event(ev["start"])
         with torch.cuda.stream(sBm):
+            self._stage_inputs_b()
+            fn["prep"]()
+            ev["prep"].record(sBm)
             fn["d_real"]()
         if sBm is not sB:
             ev["dreal"].record(sBm)
             sB.wait_event(ev["dreal"])
+        fn["chain0"]()
+        main.wait_event(ev["prep"])
         fn["chain"]()
         ev["chain"].record(main)
         sB.wait_event(ev["chain"])
@@ -428,11 +467,13 @@ class TecoGANStep:
         w1 = self._allreduce(self.G.flat.g)
         with torch.cuda.stream(sB):
             w2 = self._allreduce(self.D.flat.g)
+            if w2 is not None:
+                w2.wait()          # (RCCL: makes lane B's stream wait, no host block)
+            fn["update_d"]()
             ev["d"].record(sB)
+        if w1 is not None:
+            w1.wait()
         main.wait_event(ev["d"])
-        for w in (w1, w2):
-            if w is not None:
-                w.wait()
         fn["update"]()
 
     def _fork_join(self):
@@ -477,10 +518,10 @@ class TecoGANStep:
 
         if self.lanes:
             fns = self._piece_fns()
-            lane = lambda k: self.sBm if k == "d_real" else (self.sB if k in self.LANE_B else None)  # noqa: E731
+            lane = lambda k: self.sBm if k in ("prep", "d_real") else (self.sB if k in self.LANE_B else None)  # noqa: E731
             self.graphs = {k: cap(fns[k], lane(k)) for k in self.PIECES}
         else:
-            self.graphs = (cap(self._fork_join), cap(self._update))
+            self.graphs = (cap(self._fork_join), cap(self._update_all))
 
     # ----------------------------------------------------------------------------------------------------------
     def run(self, x, y, global_step, lr_g, lr_d, betas_g=(0.9, 0.999), betas_d=(0.9, 0.999), eps_g=1e-8, eps_d=1e-8):
@@ -490,17 +531,22 @@ class TecoGANStep:
         if tuple(x.shape) != (self.B, Ti, 3, self.h, self.h) or tuple(y.shape) != (self.B, Ti, 3, self.H, self.H):
             raise ValueError(f"step built for B={self.B}, T={Ti}, crop {self.h}; got {tuple(x.shape)} / {tuple(y.shape)}")
         self._select_sets()
+        # the LR frames are all the first generator pass needs: they are copied here, on the caller's stream (lane A); the HR
+        # targets and the step's parameter block go in at the head of lane B (_stage_inputs_b), off lane A's critical path
         self.x[:, :Ti].copy_(x)
-        self.y[:, :Ti].copy_(y)
         if self.pingpang:  # reverse(x)[1:] appended (data movement only)
             self.x[:, Ti:].copy_(torch.flip(x, dims=[1])[:, 1:])
-            self.y[:, Ti:].copy_(torch.flip(y, dims=[1])[:, 1:])
+        self._y_src = y
         self._host_params(global_step + 1, lr_g, lr_d, betas_g, betas_d, eps_g, eps_d)
+        if not self.lanes:
+            self._stage_inputs_b()
         eager = (lambda: self._run_lanes(self._piece_fns())) if self.lanes else \
-            (lambda: self._run_single(self._fork_join, self._update))
+            (lambda: self._run_single(self._fork_join, self._update_all))
         caller = torch.cuda.current_stream()
-        self.sA.wait_stream(caller)
-        with torch.cuda.stream(self.sA):
+        laneA = self.sA if self.sA is not None else caller
+        if laneA is not caller:
+            laneA.wait_stream(caller)
+        with torch.cuda.stream(laneA):
             if self.use_graph and self.graphs is None:
                 eager()   # warm-up: one-time attribute setup, workspace growth, job tables
                 torch.cuda.synchronize()
@@ -511,7 +557,8 @@ class TecoGANStep:
                 self._run_single(*self.graphs)
             else:
                 eager()
-        caller.wait_stream(self.sA)
+        if laneA is not caller:
+            caller.wait_stream(laneA)
         self.adam_t = [self.adam_t[0] + 1, self.adam_t[1] + 1]
 
 

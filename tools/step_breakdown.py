@@ -41,34 +41,35 @@ def main():
     for k in st.PIECES:  # buffers hold valid data from the warm-up steps, so every piece can replay alone
         if k in st.LANE_B:
             def on_b(k=k):
-                with torch.cuda.stream(st.sBm if k == "d_real" else st.sB):
+                with torch.cuda.stream(st.sBm if k in ("prep", "d_real") else st.sB):
                     g[k]()
             print(f"{k + ' alone (lane B stream)':44s} {timeit(on_b):7.3f} ms")
         else:
             print(f"{k + ' alone':44s} {timeit(g[k]):7.3f} ms")
 
     def lane_a():
-        g["prep"](); g["chain"](); g["chain_tail"](); g["g_bwd"]()
+        g["chain0"](); g["chain"](); g["chain_tail"](); g["g_bwd"]()
 
     def lane_b():
         with torch.cuda.stream(st.sBm):
-            g["d_real"]()
+            g["prep"](); g["d_real"]()
         if st.sBm is not st.sB:
             st.ev["dreal"].record(st.sBm); st.sB.wait_event(st.ev["dreal"])
         with torch.cuda.stream(st.sB):
             g["d_fake"](); g["d_fake_bwd"]()
 
     def chain_and_dreal():
-        g["prep"]()
-        st.ev["prep"].record(); st.sBm.wait_event(st.ev["prep"])
+        main = torch.cuda.current_stream()
+        st.ev["start"].record(main); st.sBm.wait_event(st.ev["start"])
         with torch.cuda.stream(st.sBm):
-            g["d_real"]()
-        g["chain"]()
+            g["prep"](); st.ev["prep"].record(st.sBm); g["d_real"]()
+        g["chain0"](); main.wait_event(st.ev["prep"]); g["chain"]()
 
-    torch.cuda.set_stream(st.sA)  # lane A's own stream (lane B's masked stream serialises against the default stream)
-    print(f"{'lane A alone (prep, chain, G backward)':44s} {timeit(lane_a):7.3f} ms")
-    print(f"{'lane B alone (D real, D fake)':44s} {timeit(lane_b):7.3f} ms")
-    print(f"{'prep + chain || D real':44s} {timeit(chain_and_dreal):7.3f} ms")
+    if st.sA is not None:
+        torch.cuda.set_stream(st.sA)  # lane A's own stream (lane B's masked stream serialises against the default stream)
+    print(f"{'lane A alone (chain, G backward)':44s} {timeit(lane_a):7.3f} ms")
+    print(f"{'lane B alone (prep, D real, D fake)':44s} {timeit(lane_b):7.3f} ms")
+    print(f"{'chain || prep + D real':44s} {timeit(chain_and_dreal):7.3f} ms")
     print(f"{'whole step (both lanes + update)':44s} {timeit(lambda: st._run_lanes(g)):7.3f} ms")
 
 
