@@ -137,6 +137,7 @@ class TecoGANStep:
         self.tsize = 3 * self.K
         self.tb = B * self.K
         self.use_graph, self.pg, self.world = use_graph, process_group, world_size
+        self._y_src = None
         f32 = dict(dtype=torch.float32, device=device)
         self.x = torch.empty(B, T, 3, h, h, **f32)
         self.y = torch.empty(B, T, 3, H, H, **f32)
@@ -266,6 +267,8 @@ class TecoGANStep:
     def _stage_inputs_b(self):
         """HR targets -> the static buffer the graphs read, parameter block -> device (current stream: lane B's)"""
         y, Ti = self._y_src, self.T_in
+        if y is None:   # a replay of the schedule on the inputs already staged (tools/step_breakdown.py)
+            return
         self.y[:, :Ti].copy_(y)
         if self.pingpang:
             self.y[:, Ti:].copy_(torch.flip(y, dims=[1])[:, 1:])
@@ -564,16 +567,17 @@ class TecoGANStep:
 
 class RecurrentGenerator:
     """Generator-only recurrent inference (main.py:171-219) without the per-frame CPU<->GPU bounces; the per-frame
-    step (warp -> pack -> G) can be captured once as a hipGraph and replayed for every frame."""
+    step (flow -> warp + pack -> G) is captured as a hipGraph and replayed for every frame.  The HR output and the LR
+    input live in two ping-pong slots each - frame t reads slot 1 - t%2 as "previous" and writes slot t%2 - so a frame costs
+    one 200 KB LR copy in, one graph replay and one copy of the result out (the first version moved the previous output
+    and both LR frames every frame: four copies around a 0.4 ms frame)."""
 
     def __init__(self, G, B, h, w, device, use_graph=False):
         self.G, self.B, self.h, self.w, self.dev, self.use_graph = G, B, h, w, device, use_graph
         H, W = 4 * h, 4 * w
         f32 = dict(dtype=torch.float32, device=device)
-        self.lr = torch.empty(B, 3, h, w, **f32)
-        self.prev_lr = torch.empty(B, 3, h, w, **f32)
-        self.prev = torch.zeros(B, 3, H, W, **f32)
-        self.out = torch.empty(B, 3, H, W, **f32)
+        self.lr = [torch.empty(B, 3, h, w, **f32) for _ in range(2)]
+        self.hr = [torch.zeros(B, 3, H, W, **f32) for _ in range(2)]
         self.flow = torch.empty(B, 2, H, W, **f32)
         hh, HH = h * w, H * W
         src, dst = [], []
@@ -582,20 +586,25 @@ class RecurrentGenerator:
                 src.append((b * 3 + c) * hh)
                 dst.append((b * 2 + c) * HH)
         self.fsrc, self.fdst = _i64(src, device), _i64(dst, device)
-        G.sets.pin((B, h, w))   # the per-frame graph holds addresses of this buffer set (engine.ShapeSets)
+        G.sets.pin((B, h, w))   # the per-frame graphs hold addresses of this buffer set (engine.ShapeSets)
         G.alloc(B, h, w)
-        self.graph = None
+        self.graphs = [None, None]
+
+    @property
+    def out(self):
+        return self.hr[0]
 
     def close(self):
-        self.graph = None
+        self.graphs = [None, None]
         self.G.sets.unpin((self.B, self.h, self.w))
 
-    def _frame(self):
+    def _frame(self, k):
+        """frame with parity k: previous LR / HR frames in slot 1-k, current LR frame in slot k, result into slot k"""
         G, B, h, w = self.G, self.B, self.h, self.w
         H, W = 4 * h, 4 * w
-        K.up4_planes(self.prev_lr, self.fsrc, self.flow, self.fdst, 2 * B, h, w, pre=4.0)
-        K.gen_input(self.lr, 0, 3 * h * w, self.prev, 0, 3 * H * W, self.flow, 0, 2 * H * W, G.act["in0"], B, h, w)
-        G.forward(0, B, self.out, 0, 3 * H * W)
+        K.up4_planes(self.lr[1 - k], self.fsrc, self.flow, self.fdst, 2 * B, h, w, pre=4.0)
+        K.gen_input(self.lr[k], 0, 3 * h * w, self.hr[1 - k], 0, 3 * H * W, self.flow, 0, 2 * H * W, G.act["in0"], B, h, w)
+        G.forward(0, B, self.hr[k], 0, 3 * H * W)
 
     def run(self, frames):
         """frames (B,T,3,h,w) fp32 device -> (B,T,3,4h,4w)."""
@@ -603,23 +612,23 @@ class RecurrentGenerator:
         h, w = self.h, self.w
         self.G.alloc(B, h, w)   # re-select this loop's buffer set (a training step may have selected its own since)
         outs = torch.empty(B, T, 3, 4 * h, 4 * w, dtype=torch.float32, device=self.dev)
-        self.lr.copy_(frames[:, 0])
-        K.gen_input(self.lr, 0, 3 * h * w, None, 0, 0, None, 0, 0, self.G.act["in0"], B, h, w)
-        self.G.forward(0, B, self.out, 0, 3 * 16 * h * w)
-        outs[:, 0].copy_(self.out)
+        self.lr[0].copy_(frames[:, 0])
+        K.gen_input(self.lr[0], 0, 3 * h * w, None, 0, 0, None, 0, 0, self.G.act["in0"], B, h, w)
+        self.G.forward(0, B, self.hr[0], 0, 3 * 16 * h * w)
+        outs[:, 0].copy_(self.hr[0])
         for t in range(1, T):
-            self.prev.copy_(self.out)
-            self.prev_lr.copy_(frames[:, t - 1])
-            self.lr.copy_(frames[:, t])
+            k = t & 1
+            self.lr[k].copy_(frames[:, t])
             if self.use_graph:
-                if self.graph is None:
-                    self._frame()
+                if self.graphs[k] is None:
+                    self._frame(k)
                     torch.cuda.synchronize()
-                    self.graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                        self._frame()
-                self.graph.replay()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._frame(k)
+                    self.graphs[k] = g
+                self.graphs[k].replay()
             else:
-                self._frame()
-            outs[:, t].copy_(self.out)
+                self._frame(k)
+            outs[:, t].copy_(self.hr[k])
         return outs
