@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of two library builds: tools/r2_ab.sh <other .so> [tests to run first]
+# same-box A/B of two library builds: tools/ab_libs.sh <other .so> [tests to run first]
 set -uo pipefail
 cd "${GRAFT_REPO_ROOT:?}"
 OTHER=$PWD/$1; shift
