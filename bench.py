@@ -83,6 +83,8 @@ def kernel_name(conv, dtype):
         return f"subpixel_kernel<{TAG[dtype]}, {0 if conv.last_desc is None else 1}>"
     if conv.last_desc in ("c4s2", "ctd"):  # csrc/conv4s2_mfma.hip
         return f"conv_s2_gather_kernel<{TAG[dtype]}, {4 if conv.last_desc == 'c4s2' else 3}>"
+    if conv.last_desc == "rgb":  # csrc/conv_rgb.hip (the generator's output layer)
+        return f"conv_rgb_kernel<{TAG[dtype]}>"
     if conv.last_desc == "rw":  # csrc/conv3_rw.hip (NCH = input channels / 32; statistics variant not distinguished)
         return f"conv3_rw_kernel<{conv.last_rw_nch}, ..>"
     plan = L.load().tg_conv_pick_tile(ctypes.byref(conv.last_desc))

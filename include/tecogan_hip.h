@@ -179,6 +179,15 @@ int tg_wgrad_finalize(const float* slab, int nsplit, int ntaps, int ca_p, int cb
  * slab stride in floats}. */
 int tg_wgrad_finalize_multi(const int64_t* jobs_dev, int njobs, int blocks_per_job, void* stream);
 
+/* ---- output layer of the generator (code/models.py:77-79 conv 64 -> 3 + sigmoid; the store replaces the permute + float()
+ * of code/train.py:97-99) --------------------------------------------------------------------------------------------
+ * out[n * out_n_stride + c * H * W + y * W + x] = act(conv3x3(in, w)[n][y][x][c] + bias[c]) for c < c_real <= 4, fp32;
+ * in NHWC [N][H][W][64] (16-bit), w_packed = the forward packing of tg_pack_conv_weights for Cout padded to 32 (9 slots);
+ * act = TG_ACT_NONE or TG_ACT_SIGMOID.  Same result as tg_conv with TG_OUT_NCHW_F32 (one 16-row MFMA tile instead of two).
+ * TG_E_UNSUPPORTED for fp32 or Cin != 64: use tg_conv then. */
+int tg_conv3x3_rgb(int dtype, const void* in, const void* w_packed, const float* bias, float* out, long long out_n_stride,
+                   int c_real, int N, int H, int W, int Cin, int act, void* stream);
+
 /* ---- fused residual block (code/ops.py:45-54; code/models.py:66-69), bf16, C == 64 ------------------------------
  * out_h = relu(conv3x3(in, w1) + b1), out_a = (add_skip ? in : 0) + conv3x3(out_h, w2) in ONE launch (add_skip = 0: the
  * conv-relu-conv pair of conv_trans.2, code/models.py:73); tensors NHWC [N][H][W][64]; w1 / w2 are

@@ -23,6 +23,7 @@
 //   phase 3  conv2 on the 8x8 tile from the LDS copy of h, exchange, + a (from the LDS patch), store
 // MFMA operand roles and the packed-weight layout are those of conv_mfma.hip.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 #ifdef TG_STAMP
@@ -48,14 +49,26 @@ namespace {
 // fragment read of both convolutions (all taps, all pixel tiles) is conflict-free; the 80-byte padded rows of conv_mfma.hip
 // cost 2.6-3x on these pixel patterns (exhaustive count, tools/lds_layout.py).
 constexpr int kRow = 64;
-constexpr int kInW = 12, kInPix = 144;      // input patch 12 x 12 pixels ...
-constexpr int kInP = 18, kInRows = 12 * kInP;  // ... stored with a pitch of 18 rows
-constexpr int kHW = 10, kHPix = 100;        // h region 10 x 10 ...
-constexpr int kHP = 16, kHRows = 10 * kHP;  // ... stored with a pitch of 16 rows
-constexpr int kLdsIn = 2 * kInRows * kRow;  // [chunk][row][64]
-constexpr int kLdsH = 2 * kHRows * kRow;
-constexpr int kLdsX = 8 * 4 * 1024;          // exchange: [wave][slot][lane][16 B]
-constexpr int kLdsTotal = kLdsIn + kLdsH + kLdsX;
+constexpr int kInW = 12, kInP = 18;  // input patch 12 pixels wide, stored with a pitch of 18 rows
+constexpr int kHW = 10, kHP = 16;    // h region 10 pixels wide, stored with a pitch of 16 rows
+constexpr int kLdsX = 8 * 4 * 1024;  // exchange: [wave][slot][lane][16 B]
+
+// Output tile = 8 x TH pixels.  TH = 8: 12x12 patch, 10x10 h region (7 MFMA pixel tiles), 4 output pixel tiles.
+// TH = 4: 12x8 patch, 10x6 region (4 tiles), 2 output tiles - twice the workgroups with ~55 % of the MFMA / LDS work each:
+// the recurrent pass has only 4 x 32x32 pixels per launch (64 tiles of 8x8 on a 256-CU chip), and what a launch costs there
+// is the serial time of ONE workgroup, of which the two convolutions are the larger half (stamps, tools/stamp_resblock.py:
+// the fragment reads of conv1 alone are 1.3 of 6 us; the weight stream, once L2-resident, 0.5).
+template <int TH> struct Geo {
+  static constexpr int kInPix = (TH + 4) * kInW, kInRows = (TH + 4) * kInP;
+  static constexpr int kHPix = (TH + 2) * kHW, kHRows = (TH + 2) * kHP;
+  static constexpr int kLdsIn = 2 * kInRows * kRow;  // [chunk][row][64]
+  static constexpr int kLdsH = 2 * kHRows * kRow;
+  static constexpr int kLdsTotal = kLdsIn + kLdsH + kLdsX;
+  static constexpr int NT1 = (kHPix + 15) / 16;  // pixel tiles of conv1 (the last one partial)
+  static constexpr int NT2 = TH * 8 / 16;        // pixel tiles of conv2
+  static constexpr int F1 = (NT1 + 1) / 2;       // conv1 tiles finalised by K half 0 (K half 1: the rest)
+  static constexpr int NU = (2 * kInPix * 4 + 511) / 512;  // patch loads per thread
+};
 
 // byte offset of 16-byte piece `piece` of row `row` inside an image
 __device__ __forceinline__ int lds_off(int row, int piece) { return row * kRow + ((piece ^ ((row >> 1) & 2)) << 4); }
@@ -102,8 +115,11 @@ template <typename T> __device__ __forceinline__ uint2 pack4(const float* v) {
 // i.e. stage 1 = transposed conv with the role-swapped packing of W2 (taps mirrored: weight slot 8 - t goes with spatial
 // offset t), bias + relu replaced by the mask h > 0; stage 2 = transposed conv with W1, skip = dOut.  dH is stored like h
 // (the weight-gradient launch of the first conv reads it; its channel sums are that conv's bias gradient).
-template <bool BWD, typename T = BF16>
+template <bool BWD, typename T = BF16, int TH = 8>
 __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
+  using G_ = Geo<TH>;
+  constexpr int kInPix = G_::kInPix, kInRows = G_::kInRows, kHPix = G_::kHPix, kHRows = G_::kHRows;
+  constexpr int kLdsIn = G_::kLdsIn, kLdsH = G_::kLdsH, NT1 = G_::NT1, NT2 = G_::NT2, F1 = G_::F1, NU = G_::NU;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_in = smem;
   char* lds_h = smem + kLdsIn;
@@ -118,21 +134,21 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
   bx /= p.tiles_x;
   const int tyb = bx % p.tiles_y;
   const int n = bx / p.tiles_y;
-  const int y0 = tyb * 8, x0 = txb * 8;
+  const int y0 = tyb * TH, x0 = txb * 8;
   const char* in_n = p.in + (size_t)n * p.H * p.W * 128;
 
   RB_STAMP(0);
   // ---- phase 1.  Patch loads are unconditional from a clamped address and zeroed afterwards: a load under a divergent
   // `if` makes the compiler wait for each one before issuing the next.
-  u32x4 va[3];
-  int da[3];
-  bool ok[3];
+  u32x4 va[NU];
+  int da[NU];
+  bool ok[NU];
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int i = min(tid + u * 512, 2 * kInPix * 4 - 1);
     const int s = i & 3, r = i >> 2;
     const int cc = r >= kInPix ? 1 : 0, prow = r - cc * kInPix;
-    const int py = (prow * 171) >> 11, px = prow - py * kInW;  // prow / 12, exact for prow < 144
+    const int py = (prow * 171) >> 11, px = prow - py * kInW;  // prow / 12, exact for prow <= 144
     const int iy = y0 - 2 + py, ix = x0 - 2 + px;
     da[u] = (tid + u * 512 < 2 * kInPix * 4) ? cc * kInRows * kRow + lds_off(py * kInP + px, s) : -1;
     ok[u] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
@@ -145,12 +161,22 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
   bf16x8 wfr[18];
   auto issue_w = [&](int k) {  // compile-time k after unrolling
     const char* base = k < 9 ? p.w1 : p.w2;
+#if defined(RB_DIAG_SAMEW)   // diagnostic: every weight load hits the same KiB (vector-L1 resident): the kernel without the stream
+    wfr[k] = *reinterpret_cast<const bf16x8*>(base + wlane);
+#else
     wfr[k] = *reinterpret_cast<const bf16x8*>(base + (size_t)(BWD ? 8 - k % 9 : k % 9) * 8192 + wlane);
+#endif
   };
 #ifndef RB_AHEAD
 #define RB_AHEAD 9
 #endif
-  constexpr int kAhead = RB_AHEAD;  // all of W1 up front (the registers exist anyway), W2 one load per conv1 step
+#ifndef RB_AHEAD4
+#define RB_AHEAD4 6
+#endif
+  // weight loads issued before the first MFMA (the rest: one per k-step).  8x8 tiles: all of W1 up front (the registers
+  // exist anyway).  8x4 tiles have half the MFMAs per k-step to hide an issue behind, and every load issued up front
+  // (~130 cycles of the wave's time each) delays the first MFMA: 6 measured best (7.07 vs 7.34 us at 9, 7.65 at 12)
+  constexpr int kAhead = TH == 4 ? RB_AHEAD4 : RB_AHEAD;
 #pragma unroll
   for (int k = 0; k < kAhead; ++k) issue_w(k);
   // lane (idx, g) of row tile w ends up with channels ch0 .. ch0+3 of pixel idx (row_to_channel<BF16> of common.h)
@@ -159,11 +185,11 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
   f32x4 bias = {0.f, 0.f, 0.f, 0.f};
   if constexpr (!BWD) bias = *reinterpret_cast<const f32x4*>(p.b1 + ch0);
   // BWD: the relu mask of the (up to four) region tiles this wave finalises - 8 bytes per lane and tile, fetched now
-  uint2 hm[4];
+  uint2 hm[F1];
   if constexpr (BWD) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int hp = min((kc ? 4 + j : j) * 16 + idx, kHPix - 1);
+    for (int j = 0; j < F1; ++j) {
+      const int hp = min((kc ? F1 + j : j) * 16 + idx, kHPix - 1);
       const int hy = (hp * 205) >> 11, hx = hp - hy * kHW;
       const int y = min(max(y0 - 1 + hy, 0), p.H - 1), x = min(max(x0 - 1 + hx, 0), p.W - 1);  // clamped: unused outside
       hm[j] = *reinterpret_cast<const uint2*>(p.hmask + (((size_t)n * p.H + y) * p.W + x) * 128 + ch0 * 2);
@@ -171,12 +197,12 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
   }
   RB_STAMP(1);
 
-  // fragment offsets of conv1 (7 pixel tiles x 9 taps) inside one chunk image, computed while the loads are in flight.
-  // Pixel tile t covers region pixels 16t .. 16t+15 (row-major, 10 wide); tile 6 is partial: its spare lanes read a
+  // fragment offsets of conv1 (NT1 pixel tiles x 9 taps) inside one chunk image, computed while the loads are in flight.
+  // Pixel tile t covers region pixels 16t .. 16t+15 (row-major, 10 wide); the last tile is partial: its spare lanes read a
   // clamped pixel.
-  Packed16<63> xa;
+  Packed16<NT1 * 9> xa;
 #pragma unroll
-  for (int t = 0; t < 7; ++t) {
+  for (int t = 0; t < NT1; ++t) {
     int hp = t * 16 + idx;
     hp = hp < kHPix ? hp : kHPix - 1;
     const int hy = (hp * 205) >> 11, hx = hp - hy * kHW;  // hp / 10
@@ -184,7 +210,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
     for (int tt = 0; tt < 9; ++tt) xa.set(t * 9 + tt, lds_off((hy + tt / 3) * kInP + hx + tt % 3, g));
   }
 #pragma unroll
-  for (int u = 0; u < 3; ++u)
+  for (int u = 0; u < NU; ++u)
     if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_in + da[u]) = ok[u] ? va[u] : u32x4{0u, 0u, 0u, 0u};
   RB_STAMP(2);
   lds_barrier();
@@ -195,14 +221,14 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
 
   // ---- phase 2: conv1, k-steps of chunk kc.  Fragments of step st+1 are read from LDS before the MFMAs of step st.
   {
-    f32x4 acc[7];
+    f32x4 acc[NT1];
 #pragma unroll
-    for (int t = 0; t < 7; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 xf[2][7];
+    for (int t = 0; t < NT1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[2][NT1];
     const char* img = lds_in + kc * kInRows * kRow;
     auto frags = [&](int tt, int buf) {
 #pragma unroll
-      for (int t = 0; t < 7; ++t) xf[buf][t] = *reinterpret_cast<const bf16x8*>(img + xa.get(t * 9 + tt));
+      for (int t = 0; t < NT1; ++t) xf[buf][t] = *reinterpret_cast<const bf16x8*>(img + xa.get(t * 9 + tt));
     };
     frags(0, 0);
 #pragma unroll
@@ -211,13 +237,13 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
       if (tt + kAhead < 18) issue_w(tt + kAhead);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 7; ++t) acc[t] = mma<T>(wfr[tt], xf[tt & 1][t], acc[t]);
+      for (int t = 0; t < NT1; ++t) acc[t] = mma<T>(wfr[tt], xf[tt & 1][t], acc[t]);
       __builtin_amdgcn_sched_barrier(0);
     }
     RB_STAMP(4);
-    // exchange: K half 0 finalises tiles 0-3, K half 1 tiles 4-6; each wave hands the other tiles to its partner
+    // exchange: K half 0 finalises tiles 0 .. F1-1, K half 1 the rest; each wave hands the other tiles to its partner
     auto finish1 = [&](auto T0, auto NT) {
-      constexpr int t0 = decltype(T0)::value, nt = decltype(NT)::value, o0 = t0 ? 0 : 4, no = 7 - nt;
+      constexpr int t0 = decltype(T0)::value, nt = decltype(NT)::value, o0 = t0 ? 0 : F1, no = NT1 - nt;
 #pragma unroll
       for (int j = 0; j < no; ++j) *reinterpret_cast<f32x4*>(myx + j * 1024) = acc[o0 + j];
       RB_STAMP(10);
@@ -246,35 +272,35 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
           }
           const uint2 pk = pack4<T>(v);
           *reinterpret_cast<uint2*>(lds_h + chunk * kHRows * kRow + lds_off(hy * kHP + hx, g) + half * 8) = pk;
-          if (inside && hy >= 1 && hy <= 8 && hx >= 1 && hx <= 8)
+          if (inside && hy >= 1 && hy <= TH && hx >= 1 && hx <= 8)
             *reinterpret_cast<uint2*>(p.out_h + (((size_t)n * p.H + y) * p.W + x) * 128 + ch0 * 2) = pk;
         }
       }
     };
-    if (kc == 0) finish1(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
-    else finish1(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{});
+    if (kc == 0) finish1(std::integral_constant<int, 0>{}, std::integral_constant<int, F1>{});
+    else finish1(std::integral_constant<int, F1>{}, std::integral_constant<int, NT1 - F1>{});
   }
   RB_STAMP(5);
   lds_barrier();  // h complete
   RB_STAMP(6);
 
-  // ---- phase 3: conv2 on the 8x8 tile; pixel tile t = output rows 2t, 2t+1
+  // ---- phase 3: conv2 on the 8 x TH tile; pixel tile t = output rows 2t, 2t+1
   {
-    Packed16<36> xb;
+    Packed16<NT2 * 9> xb;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NT2; ++t) {
       const int op = t * 16 + idx;
 #pragma unroll
       for (int tt = 0; tt < 9; ++tt) xb.set(t * 9 + tt, lds_off(((op >> 3) + tt / 3) * kHP + (op & 7) + tt % 3, g));
     }
-    f32x4 acc[4];
+    f32x4 acc[NT2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 xf[2][4];
+    for (int t = 0; t < NT2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[2][NT2];
     const char* img = lds_h + kc * kHRows * kRow;
     auto frags = [&](int tt, int buf) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) xf[buf][t] = *reinterpret_cast<const bf16x8*>(img + xb.get(t * 9 + tt));
+      for (int t = 0; t < NT2; ++t) xf[buf][t] = *reinterpret_cast<const bf16x8*>(img + xb.get(t * 9 + tt));
     };
     frags(0, 0);
     RB_STAMP(7);
@@ -284,7 +310,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
       if (9 + tt + kAhead < 18) issue_w(9 + tt + kAhead);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = mma<T>(wfr[9 + tt], xf[tt & 1][t], acc[t]);
+      for (int t = 0; t < NT2; ++t) acc[t] = mma<T>(wfr[9 + tt], xf[tt & 1][t], acc[t]);
       __builtin_amdgcn_sched_barrier(0);
     }
     RB_STAMP(8);
@@ -295,7 +321,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
     // (plain volatile loads, consumed by an empty asm at the very end: the compiler then tracks the in-flight destination
     // registers; a hand-written asm load would let it reuse them while the data is still on its way)
     unsigned pfv0 = 0, pfv1 = 0, pfv2 = 0;
-    if (p.pf1) {
+    if (p.pf1 && (TH == 8 || (blockIdx.x >> 3) < 8)) {
       const int slice = (blockIdx.x >> 3) & 7;
       const int off = slice * 9216 + (wid * 64 + lane) * 16;  // 9 KiB per slice and image: 8 waves x 1 KiB + 1 KiB
       pfv0 = *reinterpret_cast<const volatile unsigned*>(p.pf1 + off);
@@ -303,12 +329,12 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
       if (wid < 2) pfv2 = *reinterpret_cast<const volatile unsigned*>((wid ? p.pf2 : p.pf1) + slice * 9216 + 8192 + lane * 16);
     }
     auto finish2 = [&](auto T0) {
-      constexpr int t0 = decltype(T0)::value, o0 = t0 ? 0 : 2;
+      constexpr int t0 = decltype(T0)::value, o0 = t0 ? 0 : NT2 / 2;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(myx + j * 1024) = acc[o0 + j];
+      for (int j = 0; j < NT2 / 2; ++j) *reinterpret_cast<f32x4*>(myx + j * 1024) = acc[o0 + j];
       lds_barrier();
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NT2 / 2; ++j) {
         const int t = t0 + j;
         const f32x4 other = *reinterpret_cast<const f32x4*>(px_ + j * 1024);
         const int op = t * 16 + idx;
@@ -329,7 +355,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
       }
     };
     if (kc == 0) finish2(std::integral_constant<int, 0>{});
-    else finish2(std::integral_constant<int, 2>{});
+    else finish2(std::integral_constant<int, NT2 / 2>{});
     asm volatile("" ::"v"(pfv0), "v"(pfv1), "v"(pfv2));
   }
   RB_STAMP(9);
@@ -347,19 +373,35 @@ int resblock_launch(bool bwd, const void* in, const void* wa, const float* b1, c
   k.pf1 = (next_w1 && next_w2) ? (const char*)next_w1 : nullptr;
   k.pf2 = (const char*)next_w2;
   k.N = N; k.H = H; k.W = W; k.skip = add_skip ? 1 : 0;
-  k.tiles_x = (W + 7) / 8; k.tiles_y = (H + 7) / 8;
+  k.tiles_x = (W + 7) / 8;
+  // 8x4 tiles while 8x8 tiles would leave half of the chip's CUs without a workgroup (TECOGAN_RB_TILE=8/4 forces one)
+  static const int forced = [] { const char* e = getenv("TECOGAN_RB_TILE"); return e ? atoi(e) : 0; }();
+  const long long blocks8 = (long long)k.tiles_x * ((H + 7) / 8) * N;
+  const int th = forced == 4 || forced == 8 ? forced : (blocks8 <= 128 ? 4 : 8);
+  k.tiles_y = (H + th - 1) / th;
   const long long blocks = (long long)k.tiles_x * k.tiles_y * N;
   if (blocks > 0x7fffffffLL) return TG_E_UNSUPPORTED;
   static std::atomic<bool> attr_done{false};
   if (!attr_done) {
-    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<false, T>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal));
-    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<true, T>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal));
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<false, T, 8>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Geo<8>::kLdsTotal));
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<true, T, 8>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Geo<8>::kLdsTotal));
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<false, T, 4>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::kLdsTotal));
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<true, T, 4>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::kLdsTotal));
     attr_done = true;
   }
-  if (bwd) hipLaunchKernelGGL((resblock_kernel<true, T>), dim3((unsigned)blocks), dim3(512), kLdsTotal, (hipStream_t)stream, k);
-  else hipLaunchKernelGGL((resblock_kernel<false, T>), dim3((unsigned)blocks), dim3(512), kLdsTotal, (hipStream_t)stream, k);
+  const dim3 grid((unsigned)blocks), blk(512);
+  hipStream_t st = (hipStream_t)stream;
+  if (th == 4) {
+    if (bwd) hipLaunchKernelGGL((resblock_kernel<true, T, 4>), grid, blk, Geo<4>::kLdsTotal, st, k);
+    else hipLaunchKernelGGL((resblock_kernel<false, T, 4>), grid, blk, Geo<4>::kLdsTotal, st, k);
+  } else {
+    if (bwd) hipLaunchKernelGGL((resblock_kernel<true, T, 8>), grid, blk, Geo<8>::kLdsTotal, st, k);
+    else hipLaunchKernelGGL((resblock_kernel<false, T, 8>), grid, blk, Geo<8>::kLdsTotal, st, k);
+  }
   return tg_launch_status();
 }
 }  // namespace

@@ -109,6 +109,7 @@ class ShapeSets:
 
 _SUBPIX_CT = os.environ.get("TECOGAN_SUBPIX_CT", "1") != "0"
 _FAST_C4S2 = os.environ.get("TECOGAN_FAST_C4S2", "1") != "0"
+_RGB_OUT = os.environ.get("TECOGAN_RGB_OUT", "1") != "0"
 
 
 class Conv:
@@ -158,6 +159,12 @@ class Conv:
                 (stats is None or K.stats_replicas_for(N * OH * OW) == 1):
             self.last_desc = "c4s2"  # compile-time-tap stride-2 kernel (csrc/conv4s2_mfma.hip)
             K.conv4s2_fwd(x, self.wf, self.bias, out, stats, groups)
+            return
+        if self.spec.kind == "c3" and nchw is not None and self.cin_p == 64 and self.spec.cout <= 4 and res is None and \
+                stats is None and act in (L.ACT_NONE, L.ACT_SIGMOID) and self.tile == L.TILE_AUTO and _RGB_OUT and \
+                self.dt in (torch.bfloat16, torch.float16):
+            self.last_desc = "rgb"  # one 16-row MFMA tile + fp32 NCHW store (csrc/conv_rgb.hip)
+            K.conv3x3_rgb(x, self.wf, self.bias, nchw[0], nchw[1], nchw[2], nchw[3], act)
             return
         if self.spec.kind == "c3" and nchw is None and self.tile == L.TILE_AUTO and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) \
                 and K.rw_eligible(self.dt, self.cin_p, self.cout_p, N, H, W):

@@ -299,6 +299,16 @@ def resblock_fwd(x, w1, b1, w2, out_h, out_a, next_w=None, skip=True):
                                      N, H, W, C_, int(skip), _ptr(n1), _ptr(n2), _stream()), "tg_resblock_fwd")
 
 
+def conv3x3_rgb(x, w_packed, bias, out_buf, out_off, n_stride, c_real, act=L.ACT_SIGMOID):
+    """the generator's output layer (conv 64 -> c_real <= 4, + bias, act) stored fp32 NCHW at element `out_off` of `out_buf`
+    with `n_stride` elements between samples (csrc/conv_rgb.hip)"""
+    N, H, W, cin = x.shape
+    if out_buf.dtype != torch.float32 or out_off + (N - 1) * n_stride + c_real * H * W > out_buf.numel():
+        raise L.TecoganHipError("tg_conv3x3_rgb: output window exceeds the fp32 buffer")
+    L.check(L.load().tg_conv3x3_rgb(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), out_buf.data_ptr() + 4 * out_off,
+                                    n_stride, c_real, N, H, W, cin, act, _stream()), "tg_conv3x3_rgb")
+
+
 def conv4s2_fwd(x, w_packed, bias, out, stats=None, groups=1):
     """conv k4 s2 p1 forward with compile-time taps; stats [groups][2][Cout] accumulated"""
     N, H, W, cin = x.shape

@@ -154,6 +154,47 @@ def test_conv_sigmoid_nchw_output(dt):
     assert float(g[:, 0].abs().max()) == 0.0 and float(g[:, 2].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W,act", [(2, 32, 32, "sigmoid"), (4, 128, 128, "sigmoid"), (1, 9, 21, "sigmoid"), (3, 17, 16, "none"),
+                                       (1, 1, 1, "sigmoid")])
+def test_rgb_output_layer_kernel(B, H, W, act, dt):
+    """tg_conv3x3_rgb (one 16-row MFMA tile, csrc/conv_rgb.hip) == the generic tg_conv launch with the fp32 NCHW store
+    (same packed weights, same bf16 products; only the fp32 accumulation order may differ) and close to torch; the
+    strided (B,T,3,H,W) window is written and nothing else."""
+    spec = K.ConvSpec("c3", 64, 3)
+    T, t = 6, 4    # (tg_conv wants a 16-byte aligned window: 4 * 3 * H * W floats in; the new kernel has no such limit)
+    x = q(rnd((B, 64, H, W), 19), dt)
+    w = q(rnd(spec.weight_shape, 20, -0.1, 0.1), dt)
+    b = rnd((3,), 21)
+    pre = ref_conv(spec, x, w, b)
+    ref = torch.sigmoid(pre) if act == "sigmoid" else pre
+    code = L.ACT_SIGMOID if act == "sigmoid" else L.ACT_NONE
+    xd = K.to_nhwc(x.to(DEV), dt)
+    rows, Kd, s_row, s_k = spec.fwd_pack()
+    wp = K.pack_weights(dt, w.to(DEV), rows, Kd, s_row, s_k, 9, K.slot_table(9, DEV))
+    bd = torch.zeros(32, device=DEV)
+    bd[:3] = b.to(DEV)
+    gen = torch.full((B, T, 3, H, W), -7.0, device=DEV)
+    K.conv3x3_rgb(xd, wp, bd, gen, t * 3 * H * W, T * 3 * H * W, 3, code)
+    old = torch.full((B, T, 3, H, W), -7.0, device=DEV)
+    d = K.make_conv_desc(spec.fwd_geom(), K.tg_dtype(dt), B, H, W, 64, H, W, 32, act=code,
+                         out_mode=L.OUT_NCHW_F32, c_real=3, out_n_stride=T * 3 * H * W)
+    L.check(L.load().tg_conv(__import__("ctypes").byref(d), xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), None, None,
+                             old.data_ptr() + t * 3 * H * W * 4, None, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    g, o = gen.cpu(), old.cpu()
+    assert float((g[:, :t] + 7.0).abs().max()) == 0.0 and float((g[:, t + 1:] + 7.0).abs().max()) == 0.0
+    torch.testing.assert_close(g[:, t], o[:, t], rtol=1e-5, atol=2e-6 if act == "sigmoid" else 2e-5)
+    torch.testing.assert_close(g[:, t], ref, rtol=1e-3, atol=5e-3)
+    lib = L.load()
+    args = (xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), gen.data_ptr(), T * 3 * H * W)
+    assert lib.tg_conv3x3_rgb(L.TG_F32, *args, 3, B, H, W, 64, code, None) == -2        # fp32: tg_conv
+    assert lib.tg_conv3x3_rgb(K.tg_dtype(dt), *args, 5, B, H, W, 64, code, None) == -1   # at most 4 channels
+    assert lib.tg_conv3x3_rgb(K.tg_dtype(dt), *args, 3, B, H, W, 64, L.ACT_RELU, None) == -2
+    assert lib.tg_conv3x3_rgb(K.tg_dtype(dt), xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), gen.data_ptr(), 3 * H * W - 1, 3,
+                              B, H, W, 64, code, None) == -1                             # sample stride smaller than a sample
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("kind,cin,cout,N,H,W", [
     ("c3", 64, 64, 2, 32, 32), ("c3", 64, 128, 1, 16, 24), ("c3", 128, 64, 1, 16, 16), ("c3", 64, 3, 1, 32, 32),
@@ -572,7 +613,8 @@ def test_fnet_resampling_kernels(N, H, W, C_, dt):
     assert lib.tg_up2_bilinear(K.tg_dtype(dt), xd.data_ptr(), up.data_ptr(), N, H, W, 40, None) == -3
 
 
-@pytest.mark.parametrize("N,H,W", [(4, 32, 32), (1, 8, 8), (2, 20, 12), (1, 9, 17)])
+# (launches of up to 128 8x8 tiles run 8x4 tiles, larger ones 8x8: both geometries, each with ragged edges)
+@pytest.mark.parametrize("N,H,W", [(4, 32, 32), (1, 8, 8), (2, 20, 12), (1, 9, 17), (9, 32, 32), (6, 36, 44)])
 def test_fused_resblock_forward(N, H, W):
     """tg_resblock_fwd == conv-relu-conv-skip of code/ops.py:45-54 as two tg_conv launches (bf16), and close to torch"""
     dt = torch.bfloat16
@@ -620,7 +662,7 @@ def test_fused_resblock_forward(N, H, W):
     assert torch.equal(h_p, h_f) and torch.equal(a_p, a_f)
 
 
-@pytest.mark.parametrize("N,H,W", [(5, 32, 32), (1, 8, 8), (2, 20, 12)])
+@pytest.mark.parametrize("N,H,W", [(5, 32, 32), (1, 8, 8), (2, 20, 12), (9, 32, 32), (6, 36, 44)])
 def test_fused_resblock_backward(N, H, W):
     """tg_resblock_bwd == the two masked input-gradient launches of the block, and close to torch autograd"""
     dt = torch.bfloat16

@@ -409,3 +409,26 @@ def test_data_parallel_segments_on_one_gpu(tmp_path):
     assert dp["n_gpus"] == 1 and dp["config"]["parallelism"] == "dp1"
     np.testing.assert_allclose(dp["final_losses"]["gen_loss"], sp["final_losses"]["gen_loss"], rtol=2e-3)
     np.testing.assert_allclose(dp["final_losses"]["d_loss"], sp["final_losses"]["d_loss"], rtol=5e-2, atol=2e-3)
+
+
+def test_bench_contract_line_with_roofline_pass():
+    """bench.py's default line (short run): the keys of the driver's contract, the roofline object measured live (every
+    launch of the step has to be labelled by the family pass - a new kernel without a label fails here, not at round end)
+    and the HBM-bound kernels as GB/s.  The CPU baseline leg is covered by smoke() / the oracle tests; off here for time."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    assert line["steps"] == 3 and line["n_gpus"] == 1 and line["dtype"] == "bf16" and "workload" in line["config"]
+    rf = line["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0.0 < rf["frac"] < 1.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    fam = rf["families"]
+    assert any(k.startswith("resblock_kernel<false") for k in fam) and any(k.startswith("conv_rgb_kernel") for k in fam)
+    assert all(v["launches"] > 0 and v["ms"] > 0 for v in fam.values())
+    assert rf["hbm_kernels"] and all(0.0 < v["frac_of_8TBps"] < 1.0 for v in rf["hbm_kernels"].values())

@@ -26,3 +26,22 @@ for rep in range(4):
     t = list(buf)
     print(" | ".join(f"{n} {t[i+1]-t[i]}" for i, n in enumerate(names)), "| total", t[9] - t[0], "ticks;",
           f"epilogue1 = exchange writes {t[10]-t[4]} + barrier {t[11]-t[10]} + finalise {t[5]-t[11]}")
+
+# wall time per launch of the same 16-launch trunk replayed as a hipGraph (what the step does; eager launches are host-bound)
+def trunk():
+    for i in range(NB):
+        K.resblock_fwd(a[i], wps[i][0], bs[i], wps[i][1], h[i], a[i + 1], next_w=(wps[i + 1] if i + 1 < NB and os.environ.get('RB_PREFETCH', '1') == '1' else None))
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        trunk()
+    for _ in range(3):
+        g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(side)
+    for rep in range(50):
+        g.replay()
+    e1.record(side)
+torch.cuda.synchronize()
+print(f"{e0.elapsed_time(e1) * 1e3 / (50 * NB):.2f} us per launch (hipGraph replay of the 16-launch trunk)")
