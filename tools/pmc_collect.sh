@@ -13,4 +13,4 @@ pass() {  # dir, counters...
 pass gpurun_out/pmc_fetch FETCH_SIZE
 pass gpurun_out/pmc_write WRITE_SIZE
 pass gpurun_out/pmc_mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
-python3 tools/pmc_summarize.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/${tag}_pmc_summary.json gpurun_out/pmc_mfma
+python3 tools/pmc_summarize.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/${tag}_pmc_summary.json gpurun_out/pmc_mfma ${2:-}
