@@ -1,5 +1,9 @@
-cd "${GRAFT_REPO_ROOT:?}"
-b() { timeout -k 10 150 python bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench', d['ms_per_step'])"; }
-for v in 0 4 0 4; do echo "== bench RB_TILE=$v"; TECOGAN_RB_TILE=$v b; done
-echo "== inference cfg5"; timeout -k 10 200 python tools/bench_inference.py 2>&1 | tail -2
-echo "== inference cfg5 RB_TILE=4"; TECOGAN_RB_TILE=4 timeout -k 10 200 python tools/bench_inference.py 2>&1 | tail -2
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
+timeout -k 10 600 python -m pytest tests/test_conv3_rw_gpu.py -q -x 2>&1 | tail -3 || exit 1
+for pc in g_bwd; do
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/pt_$pc -o t -- python3 tools/chain_trace.py run $pc > gpurun_out/pt_$pc.log 2>&1
+f=$(find gpurun_out/pt_$pc -name "*kernel_trace.csv" | head -1)
+python3 tools/chain_trace.py parse $f 20 > gpurun_out/piece_${pc}_new.log 2>&1
+rm -rf gpurun_out/pt_$pc
+done
+bash tools/ab_libs.sh build_tmp/lib_old.so

@@ -55,8 +55,27 @@ template <typename T> __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f
 // LDS-only barrier: __syncthreads() would also wait for the epilogue's global stores and the next tile's patch loads
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int NCH, bool STATS, typename T = BF16>
+template <typename T> __device__ __forceinline__ void unpack8(const u32x4 r, float* v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = bits16_to_f32<T>((unsigned short)(r[i] & 0xffffu));
+    v[2 * i + 1] = bits16_to_f32<T>((unsigned short)(r[i] >> 16));
+  }
+}
+
+// SM: statistics of the stored values - 0 none, 1 per-channel sums (a bias gradient), 2 sums and sums of squares (batch norm).
+// EARLY: the epilogue's mask (else residual) rows are fetched BEFORE the k-loop (8 registers live across it) instead of
+// behind it: a persistent workgroup walks ~40 tiles of ~1 us of MFMAs each, and a cold 16-byte-per-lane read behind every one
+// of them was a full HBM round trip in which all eight waves sat (c6's input-gradient, 128x128 x 40 samples: 164 us with the
+// relu mask against 106 without).  Off where the registers are not there (Cin = 128 spills already: 8 more registers cost
+// the discriminator's stage-2 launches more than the fetch saved).
+template <int NCH, int SM, typename T = BF16>
 __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
+  constexpr bool STATS = SM > 0;
+#ifndef RW_EARLY
+#define RW_EARLY (NCH == 2)
+#endif
+  constexpr bool EARLY = RW_EARLY;
   static_assert(NCH == 2 || NCH == 4, "Cin = 64 or 128");
   constexpr int PT = NCH == 2 ? 2 : 4;          // output rows per wave in the k-loop
   constexpr int PF = 2;                         // output rows per wave in the epilogue (NCH = 4: half of PT after the exchange)
@@ -164,11 +183,15 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
     return (int)((q & 1) ? xbase[q / 2] >> 16 : xbase[q / 2] & 0xffffu);
   };
 
-  float s1[STATS ? 8 : 1], s2[STATS ? 8 : 1];
+  float s1[STATS ? 8 : 1], s2[SM == 2 ? 8 : 1];
   int cur_grp = -1;
   if constexpr (STATS) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    for (int e = 0; e < 8; ++e) s1[e] = 0.f;
+  }
+  if constexpr (SM == 2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s2[e] = 0.f;
   }
   // per-channel statistics of the stored values: lanes -> wave -> workgroup -> one atomic per channel (uniform control flow)
   auto flush_stats = [&](int grp) {
@@ -178,7 +201,7 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
 #pragma unroll
         for (int m = 1; m < 16; m <<= 1) {
           s1[e] += __shfl_xor(s1[e], m);
-          s2[e] += __shfl_xor(s2[e], m);
+          if constexpr (SM == 2) s2[e] += __shfl_xor(s2[e], m);
         }
       }
       const int slot = NCH == 4 ? wp * 2 + kh : wp;  // the four waves that share a channel half
@@ -186,11 +209,11 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           red[(slot * 2 + 0) * 64 + wc * 32 + 8 * g + e] = s1[e];
-          red[(slot * 2 + 1) * 64 + wc * 32 + 8 * g + e] = s2[e];
+          if constexpr (SM == 2) red[(slot * 2 + 1) * 64 + wc * 32 + 8 * g + e] = s2[e];
         }
       }
       lds_barrier();
-      if (tid < 64 * p.stats_mode) {  // stats_mode 1: sums only ([groups][2][Cout] layout either way)
+      if (tid < 64 * SM) {  // SM = 1: sums only ([groups][2][Cout] layout either way)
         const int which = tid >> 6, chn = tid & 63;
         float s = 0.f;
 #pragma unroll
@@ -199,7 +222,11 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
       }
       lds_barrier();
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+      for (int e = 0; e < 8; ++e) s1[e] = 0.f;
+      if constexpr (SM == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s2[e] = 0.f;
+      }
     }
   };
 
@@ -211,6 +238,20 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
     int n, ty0, tx0;
     decode(tile, n, ty0, tx0);
     if (next < p.ntiles) issue_patch(next);  // in flight during this tile's MFMAs
+    // the epilogue's mask rows (a launch without a mask: its residual rows) of the two output rows this wave finalises
+    const int frow0 = NCH == 4 ? r0 + 2 * kh : r0;
+    const char* pre_src = p.mask_mode != TG_MASK_NONE ? p.mask : p.res;
+    u32x4 pre[PF];
+    auto issue_pre = [&]() {
+      if (pre_src) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+          const int cy = min(ty0 + frow0 + j, p.H - 1), cx = min(tx0 + idx, p.W - 1);  // clamped: unused outside the image
+          pre[j] = *reinterpret_cast<const u32x4*>(pre_src + ((((size_t)n * p.H + cy) * p.W + cx) * p.Cout + ch0) * 2);
+        }
+      }
+    };
+    if constexpr (EARLY) issue_pre();
 
     // ---- k-loop: 2 chunks x 9 taps, weights from registers, activation fragments from the patch image
     f32x4 acc[2][PT];
@@ -234,7 +275,6 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
 
     // ---- NCH = 4: the two K halves add their accumulators; each wave finalises two of the pair's four rows
     f32x4 fin[2][PF];
-    int frow0 = r0;
     if constexpr (NCH == 4) {
       char* myx = lds_x + (wid * 4 * 64 + lane) * 16;
       const char* px_ = lds_x + ((wid ^ 2) * 4 * 64 + lane) * 16;
@@ -255,7 +295,6 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
       };
       if (kh == 0) exchange(std::integral_constant<int, 0>{});
       else exchange(std::integral_constant<int, 2>{});
-      frow0 = r0 + 2 * kh;
     } else {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -284,7 +323,8 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
         }
         if (p.res) {
           float r[8];
-          Vec<T>::load(p.res + eoff, r);
+          if (EARLY && p.mask_mode == TG_MASK_NONE) unpack8<T>(pre[j], r);
+          else Vec<T>::load(p.res + eoff, r);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
@@ -297,7 +337,8 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
         }
         if (p.mask_mode != TG_MASK_NONE) {
           float m[8];
-          Vec<T>::load(p.mask + eoff, m);
+          if constexpr (EARLY) unpack8<T>(pre[j], m);
+          else Vec<T>::load(p.mask + eoff, m);
           const float neg = p.mask_mode == TG_MASK_LRELU ? 0.2f : 0.f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= (m[e] > 0.f ? 1.f : neg);
@@ -307,7 +348,7 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             s1[e] += v[e];
-            s2[e] += v[e] * v[e];
+            if constexpr (SM == 2) s2[e] += v[e] * v[e];
           }
         }
       }
@@ -321,10 +362,10 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
   }
 }
 
-template <int NCH, bool STATS, typename T>
+template <int NCH, int SM, typename T>
 int launch_rw(const RwK& k, dim3 grid, hipStream_t st) {
   constexpr int lds = 2 * NCH * kChunkBytes + (NCH == 4 ? kXchgBytes : 0) + kRedBytes;
-  auto fn = conv3_rw_kernel<NCH, STATS, T>;
+  auto fn = conv3_rw_kernel<NCH, SM, T>;
   static std::atomic<bool> attr_done{false};  // one-time function attribute (benign race: idempotent)
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -366,10 +407,10 @@ extern "C" int tg_conv3x3_rw(int dtype, const void* in, const void* w_packed, co
   const int gx = (k.ntiles + rounds - 1) / rounds;
   dim3 grid((unsigned)gx, (unsigned)co_tiles);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TG_F16) {
-    if (Cin == 64) return stats ? launch_rw<2, true, F16>(k, grid, st) : launch_rw<2, false, F16>(k, grid, st);
-    return stats ? launch_rw<4, true, F16>(k, grid, st) : launch_rw<4, false, F16>(k, grid, st);
-  }
-  if (Cin == 64) return stats ? launch_rw<2, true, BF16>(k, grid, st) : launch_rw<2, false, BF16>(k, grid, st);
-  return stats ? launch_rw<4, true, BF16>(k, grid, st) : launch_rw<4, false, BF16>(k, grid, st);
+  const int sm = k.stats_mode;
+#define RW_GO(NCH, TAG) (sm == 2 ? launch_rw<NCH, 2, TAG>(k, grid, st) : sm == 1 ? launch_rw<NCH, 1, TAG>(k, grid, st) \
+                                 : launch_rw<NCH, 0, TAG>(k, grid, st))
+  if (dtype == TG_F16) return Cin == 64 ? RW_GO(2, F16) : RW_GO(4, F16);
+  return Cin == 64 ? RW_GO(2, BF16) : RW_GO(4, BF16);
+#undef RW_GO
 }

@@ -1,12 +1,14 @@
-"""Anatomy of the recurrent generator pass (lane A's chain) alone.
+"""Anatomy of the recurrent generator pass (lane A's chain) alone - or of any other piece of the step.
   python tools/chain_trace.py run              replays only the chain graphs (chain0, chain, chain_tail) 20 times
   python tools/chain_trace.py parse <csv>      from a rocprofv3 --kernel-trace csv of the line above: the kernels of ONE frame in
                                                launch order with their average duration and the gap to the next kernel
+  python tools/chain_trace.py run g_bwd        replays the named pieces (TecoGANStep.PIECES) 20 times instead
+  python tools/chain_trace.py parse <csv> 20   ... and folds the trace's last 20 equal repetitions
 (rocprofv3 --kernel-trace --output-format csv -d gpurun_out/chain -o chain -- python3 tools/chain_trace.py run)"""
 import collections, csv, os, re, sys
 
 
-def run():
+def run(pieces=("chain0", "chain", "chain_tail")):
     import torch
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
     import pytorch_tecogan_amd  # noqa: F401
@@ -28,9 +30,37 @@ def run():
     for rep in range(21):
         if rep == 1:
             e0.record()
-        g["chain0"](); g["chain"](); g["chain_tail"]()
+        for k in pieces:
+            if k in st.LANE_B:
+                with torch.cuda.stream(st.sB):
+                    g[k]()
+                torch.cuda.current_stream().wait_stream(st.sB)
+            else:
+                g[k]()
     e1.record(); torch.cuda.synchronize()
-    print(f"chain alone: {e0.elapsed_time(e1) / 20:.3f} ms per step ({e0.elapsed_time(e1) / 200 * 1e3:.1f} us per frame)")
+    print(f"{'+'.join(pieces)} alone: {e0.elapsed_time(e1) / 20:.3f} ms per step")
+
+
+def parse_reps(path, reps):
+    """the last `reps` repetitions of a replayed piece: per launch position the average duration"""
+    rows = list(csv.DictReader(open(path)))
+    for r in rows:
+        r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    rows.sort(key=lambda r: r["s"])
+    short = lambda n: re.sub(r"\(anonymous namespace\)::|^void ", "", n).split("(")[0][:70]
+    names = [short(r["Kernel_Name"]) for r in rows]
+    n = next(n for n in range(1, len(rows) // reps + 1)   # period of the tail of the trace
+             if names[-n * reps:] == names[-n:] * reps)
+    reps_rows = [rows[len(rows) - (i + 1) * n:len(rows) - i * n] for i in range(reps)]
+    tot = 0.0
+    print(f"{reps} repetitions of {n} kernels")
+    for k in range(n):
+        d = sum(rr[k]["e"] - rr[k]["s"] for rr in reps_rows) / reps / 1e3
+        r0 = reps_rows[0][k]
+        wg = int(r0["Grid_Size_X"]) * int(r0["Grid_Size_Y"]) * int(r0["Grid_Size_Z"]) // max(1, int(r0["Workgroup_Size_X"]) * int(r0["Workgroup_Size_Y"]))
+        tot += d
+        print(f"{k:3d} {names[len(rows) - n + k]:72s} WGs {wg:6d}  {d:8.2f} us")
+    print(f"sum of durations {tot:.1f} us")
 
 
 def parse(path):
@@ -56,4 +86,9 @@ def parse(path):
 
 
 if __name__ == "__main__":
-    run() if sys.argv[1] == "run" else parse(sys.argv[2])
+    if sys.argv[1] == "run":
+        run(tuple(sys.argv[2:])) if len(sys.argv) > 2 else run()
+    elif len(sys.argv) > 3:
+        parse_reps(sys.argv[2], int(sys.argv[3]))
+    else:
+        parse(sys.argv[2])
