@@ -112,11 +112,12 @@ int tg_conv(const tg_conv_desc* d, const void* in, const void* w_packed, const f
  * w_packed = the role-swapped packing) for DENSE launches: persistent workgroups that keep their weights in registers and
  * walk pixel tiles of 8x16 with a double-buffered LDS patch (csrc/conv3_rw.hip).  bf16, Cin in {64, 128}, Cout % 64 == 0,
  * else TG_E_UNSUPPORTED (use tg_conv).  Epilogue as tg_conv: +bias, +res, act (NONE/RELU/LRELU), *act'(mask), NHWC store,
- * stats (may be null; stats_mode 1: per-channel sums, 2: sums and sums of squares; [stats_groups][2][Cout], ACCUMULATED).
+ * stats (may be null; stats_mode 1: per-channel sums, 2: sums and sums of squares; stats_replicas blocks of
+ * [stats_groups][2][Cout], ACCUMULATED - see "replica blocks" at tg_bn_apply).
  * max_workgroups: 0 = one per CU (256); the grid is min(tiles, max_workgroups / (Cout/64)) x Cout/64. */
 int tg_conv3x3_rw(int dtype, const void* in, const void* w_packed, const float* bias, const void* res, const void* mask,
                   void* out, float* stats, int N, int H, int W, int Cin, int Cout, int flip, int act, int mask_mode,
-                  int stats_mode, int stats_groups, int max_workgroups, void* stream);
+                  int stats_mode, int stats_groups, int stats_replicas, int max_workgroups, void* stream);
 
 /* Conv-transpose k3 s2 p1 op1 forward (code/ops.py:45-54 conv2_tran; code/models.py:72,74) as ONE sub-pixel launch: a
  * workgroup computes all four output classes of its input tile from one staged patch (tg_conv runs the classes as four sets
@@ -127,10 +128,11 @@ int tg_convt_fwd(int dtype, const void* in, const void* w_packed, const float* b
 
 /* 4x4 stride-2 padding-1 conv forward (the discriminator's down-sampling convs, code/models.py:90-94) with compile-time
  * taps and pipelined chunk staging; in [N][IH][IW][Cin] (IH, IW even) -> out [N][IH/2][IW/2][Cout]; w_packed = the 16-slot
- * forward packing; bias may be null; stats (may be null) = [stats_groups][2][Cout] per-channel sum / sum of squares of the
- * stored output, ACCUMULATED (zero it first).  TG_E_UNSUPPORTED unless Cout % 64 == 0 (use tg_conv then). */
+ * forward packing; bias may be null; stats (may be null) = stats_replicas blocks of [stats_groups][2][Cout] per-channel sum /
+ * sum of squares of the stored output, ACCUMULATED (zero it first; replica blocks: see tg_bn_apply).  TG_E_UNSUPPORTED unless
+ * Cout % 64 == 0 (use tg_conv then). */
 int tg_conv4s2_fwd(int dtype, const void* in, const void* w_packed, const float* bias, void* out, float* stats,
-                   int stats_groups, int N, int IH, int IW, int Cin, int Cout, void* stream);
+                   int stats_groups, int stats_replicas, int N, int IH, int IW, int Cin, int Cout, void* stream);
 
 /* Input-gradient of the 4x4 stride-2 convs (autograd of code/models.py:90-94) as one four-class sub-pixel launch (the
  * tg_convt_fwd kernel with a 3x3 window and 16 (class, tap) pairs): dout [N][OH][OW][Cout] -> din [N][2OH][2OW][Cin];
@@ -246,19 +248,23 @@ int tg_copy_blocks(const float* src, const int64_t* src_off_dev, float* dst, con
                    int64_t len, void* stream);
 
 /* ---- batch norm, training mode, eps/momentum as code/ops.py:75-77 -------------------------------------- */
-/* y = act(gamma*(z-mean)*invstd+beta) (+skip).  stats = [groups][2][C] sums from the producing conv.  Block 0 also
- * updates running_mean/var (group after group), adds `groups` to *num_batches_tracked (int64, may be null) and writes
- * mean/invstd to save[groups][2][C]. */
-int tg_bn_apply(int dtype, const void* z, const float* stats, const float* gamma, const float* beta, const void* skip,
-                void* y, float* running_mean, float* running_var, float* save, int N, int HW, int C, int groups,
-                int act, float eps, float momentum, int64_t* num_batches_tracked, void* stream);
-/* red[groups][2][C] += (sum dyp, sum dyp*xhat) where dyp = dy * act'(yact). */
-int tg_bn_bwd_reduce(int dtype, const void* dy, const void* yact, const void* z, const float* save, float* red, int N,
-                     int HW, int C, int groups, int act, void* stream);
+/* Replica blocks.  A per-channel accumulator ([groups][2][C] floats) that many workgroups add into is kept as R blocks of
+ * that shape (R a power of two, zeroed by the caller): producer workgroup b adds into block b mod R, the consumer sums the
+ * blocks in order.  A few hundred workgroups adding into the same 128 floats serialise in L2: the discriminator's stage-1
+ * conv takes 10.3 us without statistics, 19.9 with R = 1, 13.0 with R = 4 (tools/mb_stats.py).
+ * y = act(gamma*(z-mean)*invstd+beta) (+skip).  stats = stats_replicas blocks of [groups][2][C] sums from the producing conv
+ * (tg_conv: tg_conv_desc.stats_replicas).  Block 0 also updates running_mean/var (group after group), adds `groups` to
+ * *num_batches_tracked (int64, may be null) and writes mean/invstd to save[groups][2][C]. */
+int tg_bn_apply(int dtype, const void* z, const float* stats, int stats_replicas, const float* gamma, const float* beta,
+                const void* skip, void* y, float* running_mean, float* running_var, float* save, int N, int HW, int C,
+                int groups, int act, float eps, float momentum, int64_t* num_batches_tracked, void* stream);
+/* red (red_replicas blocks of [groups][2][C]) += (sum dyp, sum dyp*xhat) where dyp = dy * act'(yact). */
+int tg_bn_bwd_reduce(int dtype, const void* dy, const void* yact, const void* z, const float* save, float* red,
+                     int red_replicas, int N, int HW, int C, int groups, int act, void* stream);
 /* dz = gamma*invstd*(dyp - mean(dyp) - xhat*mean(dyp*xhat)); block 0 accumulates dgamma/dbeta. */
 int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, const void* z, const float* save, const float* red,
-                    const float* gamma, void* dz, float* dgamma, float* dbeta, int N, int HW, int C, int groups,
-                    int act, void* stream);
+                    int red_replicas, const float* gamma, void* dz, float* dgamma, float* dbeta, int N, int HW, int C,
+                    int groups, int act, void* stream);
 
 /* ---- heads and losses (code/models.py:143-145; code/train.py:205-333) ----------------------------------- */
 int tg_fc_head_fwd(int dtype, const void* feat, const float* w, const float* b, float* prob, int N, int HW, int C,

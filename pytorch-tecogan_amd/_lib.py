@@ -51,7 +51,7 @@ _PROTOS = {
     "tg_pack_conv_weights_multi": (_I, [_I, _P, _I, _I, _P]),
     "tg_conv_pick_tile": (_I, [C.POINTER(ConvDesc)]),
     "tg_conv": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
-    "tg_conv3x3_rw": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "tg_conv3x3_rw": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "tg_wgrad_slab_floats": (_L, [C.POINTER(WgradDesc)]),
     "tg_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P]),
     "tg_wgrad_multi": (_I, [C.POINTER(WgradDesc), _P, _I, _P]),
@@ -61,7 +61,7 @@ _PROTOS = {
     "tg_nhwc_to_nchw": (_I, [_I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "tg_resblock_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "tg_conv3x3_rgb": (_I, [_I, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
-    "tg_conv4s2_fwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "tg_conv4s2_fwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "tg_conv4s2_dgrad": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "tg_convt_dgrad": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "tg_convt_fwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -73,9 +73,9 @@ _PROTOS = {
     "tg_warp_nchw": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "tg_gen_input": (_I, [_I, _P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _P]),
     "tg_d_assemble": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "tg_bn_apply": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
-    "tg_bn_bwd_reduce": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "tg_bn_bwd_apply": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "tg_bn_apply": (_I, [_I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
+    "tg_bn_bwd_reduce": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "tg_bn_bwd_apply": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "tg_fc_head_fwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tg_fc_head_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tg_absdiff_sum": (_I, [_I, _P, _P, _P, _L, _I, _I, _P]),

@@ -47,7 +47,7 @@ struct RwK {
   float* stats;
   int N, H, W, Cout;
   int tiles_x, tiles_y, ntiles;
-  int flip, act, mask_mode, stats_groups, stats_mode;
+  int flip, act, mask_mode, stats_groups, stats_mode, stats_replicas;
 };
 
 template <typename T> __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return Mma16<T>::run(a, b, c); }
@@ -218,7 +218,8 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * 64 + chn];
-        atomicAdd(p.stats + ((size_t)grp * 2 + which) * p.Cout + co_base + chn, s);
+        const size_t rep = (size_t)(blockIdx.x & (p.stats_replicas - 1)) * p.stats_groups * 2 * p.Cout;
+        atomicAdd(p.stats + rep + ((size_t)grp * 2 + which) * p.Cout + co_base + chn, s);
       }
       lds_barrier();
 #pragma unroll
@@ -379,12 +380,14 @@ int launch_rw(const RwK& k, dim3 grid, hipStream_t st) {
 
 extern "C" int tg_conv3x3_rw(int dtype, const void* in, const void* w_packed, const float* bias, const void* res,
                              const void* mask, void* out, float* stats, int N, int H, int W, int Cin, int Cout, int flip,
-                             int act, int mask_mode, int stats_mode, int stats_groups, int max_workgroups, void* stream) {
+                             int act, int mask_mode, int stats_mode, int stats_groups, int stats_replicas, int max_workgroups,
+                             void* stream) {
   if (!in || !w_packed || !out || N <= 0 || H <= 0 || W <= 0) return TG_E_BADARG;
   if ((dtype != TG_BF16 && dtype != TG_F16) || (Cin != 64 && Cin != 128) || Cout <= 0 || Cout % 64) return TG_E_UNSUPPORTED;
   if (act != TG_ACT_NONE && act != TG_ACT_RELU && act != TG_ACT_LRELU) return TG_E_UNSUPPORTED;
   if (mask_mode != TG_MASK_NONE && !mask) return TG_E_BADARG;
   if (stats && (stats_groups <= 0 || N % stats_groups || stats_mode < 1 || stats_mode > 2)) return TG_E_BADARG;
+  if (stats && (stats_replicas < 1 || (stats_replicas & (stats_replicas - 1)))) return TG_E_BADARG;  // a power of two
   if (!tg_aligned16(in) || !tg_aligned16(w_packed) || !tg_aligned16(out) || (res && !tg_aligned16(res)) ||
       (mask && !tg_aligned16(mask)) || (bias && !tg_aligned16(bias)))
     return TG_E_ALIGN;
@@ -399,6 +402,7 @@ extern "C" int tg_conv3x3_rw(int dtype, const void* in, const void* w_packed, co
   k.flip = flip ? 1 : 0; k.act = act; k.mask_mode = mask ? mask_mode : TG_MASK_NONE;
   k.stats_groups = stats ? stats_groups : 1;
   k.stats_mode = stats ? stats_mode : 0;
+  k.stats_replicas = stats ? stats_replicas : 1;
   // persistent grid: one workgroup per CU (256 CUs shared by the Cout/64 channel tiles), pixel tiles dealt evenly
   const int co_tiles = Cout / 64;
   int cap = max_workgroups > 0 ? max_workgroups : 256;

@@ -35,7 +35,7 @@ struct C4K {
   const float* bias;
   char* out;
   float* stats;
-  int N, IH, IW, Cin, OH, OW, Cout, tiles_x, tiles_y, nchunks, stats_groups;
+  int N, IH, IW, Cin, OH, OW, Cout, tiles_x, tiles_y, nchunks, stats_groups, stats_replicas;
 };
 
 template <typename T> struct MmaT;
@@ -238,7 +238,8 @@ __global__ __launch_bounds__(NTHR) void conv_s2_gather_kernel(const C4K p) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < WP; ++w) s += red[(w * 2 + which) * CO_TILE + chn];
-      atomicAdd(p.stats + ((size_t)grp * 2 + which) * p.Cout + co_base + chn, s);
+      const size_t rep = (size_t)(blockIdx.x & (p.stats_replicas - 1)) * p.stats_groups * 2 * p.Cout;
+      atomicAdd(p.stats + rep + ((size_t)grp * 2 + which) * p.Cout + co_base + chn, s);
     }
   }
 }
@@ -248,11 +249,12 @@ __global__ __launch_bounds__(NTHR) void conv_s2_gather_kernel(const C4K p) {
 namespace {
 template <int KS>
 int launch_s2(int dtype, const void* in, const void* w_packed, const float* bias, void* out, float* stats, int stats_groups,
-              int N, int IH, int IW, int Cin, int Cout, void* stream) {
+              int stats_replicas, int N, int IH, int IW, int Cin, int Cout, void* stream) {
   C4K k;
   k.in = (const char*)in; k.w = (const char*)w_packed; k.bias = bias; k.out = (char*)out; k.stats = stats;
   k.N = N; k.IH = IH; k.IW = IW; k.Cin = Cin; k.OH = IH / 2; k.OW = IW / 2; k.Cout = Cout;
   k.stats_groups = stats ? stats_groups : 1;
+  k.stats_replicas = stats && stats_replicas > 1 ? stats_replicas : 1;
   k.nchunks = Cin / (dtype == TG_F32 ? 16 : 32);
   k.tiles_x = (k.OW + 15) / 16; k.tiles_y = (k.OH + TH - 1) / TH;
   const long long gx = (long long)k.tiles_x * k.tiles_y * N;
@@ -289,11 +291,12 @@ int check_s2(int dtype, const void* in, const void* w_packed, const float* bias,
 }  // namespace
 
 extern "C" int tg_conv4s2_fwd(int dtype, const void* in, const void* w_packed, const float* bias, void* out, float* stats,
-                              int stats_groups, int N, int IH, int IW, int Cin, int Cout, void* stream) {
+                              int stats_groups, int stats_replicas, int N, int IH, int IW, int Cin, int Cout, void* stream) {
   const int rc = check_s2(dtype, in, w_packed, bias, out, N, IH, IW, Cin, Cout);
   if (rc != TG_OK) return rc;
   if (stats && (stats_groups <= 0 || N % stats_groups)) return TG_E_BADARG;
-  return launch_s2<4>(dtype, in, w_packed, bias, out, stats, stats_groups, N, IH, IW, Cin, Cout, stream);
+  if (stats && (stats_replicas < 1 || (stats_replicas & (stats_replicas - 1)))) return TG_E_BADARG;  // a power of two
+  return launch_s2<4>(dtype, in, w_packed, bias, out, stats, stats_groups, stats_replicas, N, IH, IW, Cin, Cout, stream);
 }
 
 extern "C" int tg_convt_dgrad(int dtype, const void* dout, const void* w_dgrad_packed, void* din, int N, int OH, int OW,
@@ -301,5 +304,5 @@ extern "C" int tg_convt_dgrad(int dtype, const void* dout, const void* w_dgrad_p
   // din[y][x][ci] = sum_{dy,dx in -1..1} dout[2y+dy][2x+dx][co] * W[slot][ci][co]: the 3x3-window stride-2 gather
   const int rc = check_s2(dtype, dout, w_dgrad_packed, nullptr, din, N, OH, OW, Cout, Cin);
   if (rc != TG_OK) return rc;
-  return launch_s2<3>(dtype, dout, w_dgrad_packed, nullptr, din, nullptr, 1, N, OH, OW, Cout, Cin, stream);
+  return launch_s2<3>(dtype, dout, w_dgrad_packed, nullptr, din, nullptr, 1, 1, N, OH, OW, Cout, Cin, stream);
 }

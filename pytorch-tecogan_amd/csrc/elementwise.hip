@@ -12,9 +12,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Per-channel accumulators ([groups][2][C] floats: the statistics a conv epilogue adds up, the two sums of the backward pass)
+// come in R replica blocks: producer workgroup b adds into block b mod R, because a few hundred workgroups adding into the
+// same 128 floats serialise in L2 (the discriminator's stage-1 conv: 10.3 us without statistics, 19.9 with them at R = 1,
+// 13.0 at R = 4: tools/mb_stats.py).  The consumer folds the blocks first: sh[i] = sum_r acc[r][i], in replica order.
+constexpr int kFoldMax = 2048;
+__device__ __forceinline__ void fold_replicas(const float* __restrict__ acc, int R, int n, float* sh) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += acc[(size_t)r * n + i];
+    sh[i] = s;
+  }
+  __syncthreads();
+}
+
 // Threads are arranged [rows = 256/VPP][VPP] where VPP = C / kVec vectors per pixel (a power of two <= 32).
 template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ z, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ z, const float* __restrict__ stats_rep, int R,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const char* __restrict__ skip, char* __restrict__ y,
                                                       float* __restrict__ rmean, float* __restrict__ rvar,
@@ -28,6 +42,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ 
   const int grp = blockIdx.y;
   const long long npix = (long long)(N / groups) * HW;
   const float cnt = (float)npix;
+  __shared__ float stats[kFoldMax];
+  fold_replicas(stats_rep, R, groups * 2 * C, stats);
   float scale[E], shift[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -91,7 +107,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* __restrict__ dy, const char* __restrict__ yact,
                                                            const char* __restrict__ z, const float* __restrict__ save,
-                                                           float* __restrict__ red, int N, int HW, int C, int groups,
+                                                           float* __restrict__ red, int R, int N, int HW, int C, int groups,
                                                            int act) {
   using TR = ElemTraits<T>;
   constexpr int E = TR::kVec;
@@ -151,14 +167,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const char* __restri
     const int v = c / E, e = c % E;
     float s = 0.f;
     for (int r = 0; r < rows; ++r) s += sh[((r * vpp + v) * 2 + which) * E + e];
-    atomicAdd(red + (grp * 2 + which) * C + c, s);
+    atomicAdd(red + (size_t)(blockIdx.x & (R - 1)) * groups * 2 * C + (grp * 2 + which) * C + c, s);
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restrict__ dy, const char* __restrict__ yact,
                                                           const char* __restrict__ z, const float* __restrict__ save,
-                                                          const float* __restrict__ red, const float* __restrict__ gamma,
+                                                          const float* __restrict__ red_rep, int R, const float* __restrict__ gamma,
                                                           char* __restrict__ dz, float* __restrict__ dgamma,
                                                           float* __restrict__ dbeta, int N, int HW, int C, int groups,
                                                           int act) {
@@ -169,6 +185,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
   const int grp = blockIdx.y;
   const long long npix = (long long)(N / groups) * HW;
   const float inv_cnt = 1.f / (float)npix;
+  __shared__ float red[kFoldMax];
+  fold_replicas(red_rep, R, groups * 2 * C, red);
   float mean[E], invstd[E], k0[E], m1[E], m2[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -483,43 +501,46 @@ inline bool bn_shape_ok(int dtype, int C) {
     else return TG_E_BADARG;                                                                     \
   } while (0)
 
-extern "C" int tg_bn_apply(int dtype, const void* z, const float* stats, const float* gamma, const float* beta,
+extern "C" int tg_bn_apply(int dtype, const void* z, const float* stats, int stats_replicas, const float* gamma, const float* beta,
                            const void* skip, void* y, float* running_mean, float* running_var, float* save, int N,
                            int HW, int C, int groups, int act, float eps, float momentum, int64_t* num_batches_tracked,
                            void* stream) {
   if (!z || !stats || !gamma || !beta || !y || !save || N <= 0 || HW <= 0 || groups <= 0 || N % groups) return TG_E_BADARG;
-  if (!bn_shape_ok(dtype, C)) return TG_E_UNSUPPORTED;
+  if (stats_replicas < 1 || (stats_replicas & (stats_replicas - 1))) return TG_E_BADARG;
+  if (!bn_shape_ok(dtype, C) || groups * 2 * C > kFoldMax) return TG_E_UNSUPPORTED;
   const int rows = 256 / (C / (dtype == TG_F32 ? 4 : 8));
   dim3 grid(grid_for((long long)(N / groups) * HW, rows * 4, 1024), groups);
-  TG_DISPATCH(dtype, bn_apply_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)z, stats, gamma, beta,
+  TG_DISPATCH(dtype, bn_apply_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)z, stats, stats_replicas, gamma, beta,
               (const char*)skip, (char*)y, running_mean, running_var, save, N, HW, C, groups, act, eps, momentum,
               (long long*)num_batches_tracked);
   return tg_launch_status();
 }
 
 extern "C" int tg_bn_bwd_reduce(int dtype, const void* dy, const void* yact, const void* z, const float* save,
-                                float* red, int N, int HW, int C, int groups, int act, void* stream) {
+                                float* red, int red_replicas, int N, int HW, int C, int groups, int act, void* stream) {
   if (!dy || !z || !save || !red || N <= 0 || HW <= 0 || groups <= 0 || N % groups) return TG_E_BADARG;
+  if (red_replicas < 1 || (red_replicas & (red_replicas - 1))) return TG_E_BADARG;
   if (act == TG_ACT_LRELU && !yact) return TG_E_BADARG;
   if (!bn_shape_ok(dtype, C)) return TG_E_UNSUPPORTED;
   const int rows = 256 / (C / (dtype == TG_F32 ? 4 : 8));
   dim3 grid(grid_for((long long)(N / groups) * HW, rows * 8, 512), groups);  // two trips of four pixels per thread
   TG_DISPATCH(dtype, bn_bwd_reduce_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)dy, (const char*)yact,
-              (const char*)z, save, red, N, HW, C, groups, act);
+              (const char*)z, save, red, red_replicas, N, HW, C, groups, act);
   return tg_launch_status();
 }
 
 extern "C" int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, const void* z, const float* save,
-                               const float* red, const float* gamma, void* dz, float* dgamma, float* dbeta, int N,
-                               int HW, int C, int groups, int act, void* stream) {
+                               const float* red, int red_replicas, const float* gamma, void* dz, float* dgamma, float* dbeta,
+                               int N, int HW, int C, int groups, int act, void* stream) {
   if (!dy || !z || !save || !red || !gamma || !dz || !dgamma || !dbeta || N <= 0 || HW <= 0 || groups <= 0 || N % groups)
     return TG_E_BADARG;
   if (act == TG_ACT_LRELU && !yact) return TG_E_BADARG;
-  if (!bn_shape_ok(dtype, C)) return TG_E_UNSUPPORTED;
+  if (red_replicas < 1 || (red_replicas & (red_replicas - 1))) return TG_E_BADARG;
+  if (!bn_shape_ok(dtype, C) || groups * 2 * C > kFoldMax) return TG_E_UNSUPPORTED;
   const int rows = 256 / (C / (dtype == TG_F32 ? 4 : 8));
   dim3 grid(grid_for((long long)(N / groups) * HW, rows * 4, 1024), groups);
   TG_DISPATCH(dtype, bn_bwd_apply_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)dy, (const char*)yact,
-              (const char*)z, save, red, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act);
+              (const char*)z, save, red, red_replicas, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act);
   return tg_launch_status();
 }
 

@@ -110,6 +110,10 @@ class ShapeSets:
 _SUBPIX_CT = os.environ.get("TECOGAN_SUBPIX_CT", "1") != "0"
 _FAST_C4S2 = os.environ.get("TECOGAN_FAST_C4S2", "1") != "0"
 _RGB_OUT = os.environ.get("TECOGAN_RGB_OUT", "1") != "0"
+# replica blocks of the batch-norm accumulators (include/tecogan_hip.h, tg_bn_apply): a power of two; 1 = one shared block
+STATS_R = int(os.environ.get("TECOGAN_STATS_REPLICAS", "4"))
+if STATS_R < 1 or STATS_R & (STATS_R - 1):
+    raise ValueError("TECOGAN_STATS_REPLICAS must be a power of two")
 
 
 class Conv:
@@ -142,8 +146,9 @@ class Conv:
             rows, Kd, s_row, s_k = s.dgrad_pack()
             K.pack_weights(self.dt, self.w, rows, Kd, s_row, s_k, s.nslots, self.slots, out=self.wb)
 
-    def fwd(self, x, out, act=L.ACT_NONE, res=None, stats=None, groups=1, nchw=None):
-        """x [N,H,W,cin_p] -> out [N,OH,OW,cout_p]; nchw=(buffer, elem_offset, n_stride, c_real) for the fp32 NCHW store."""
+    def fwd(self, x, out, act=L.ACT_NONE, res=None, stats=None, groups=1, nchw=None, stats_r=1):
+        """x [N,H,W,cin_p] -> out [N,OH,OW,cout_p]; nchw=(buffer, elem_offset, n_stride, c_real) for the fp32 NCHW store.
+        stats: `stats_r` replica blocks of [groups][2][cout_p] (the consumer, BatchNorm.apply, folds them)."""
         N, H, W, _ = x.shape
         OH, OW = self.spec.out_hw(H, W)
         if self.spec.kind == "ct" and self.cout_p % 64 == 0 and res is None and stats is None and nchw is None and \
@@ -158,7 +163,7 @@ class Conv:
                 self.tile == L.TILE_AUTO and _FAST_C4S2 and H % 2 == 0 and W % 2 == 0 and \
                 (stats is None or K.stats_replicas_for(N * OH * OW) == 1):
             self.last_desc = "c4s2"  # compile-time-tap stride-2 kernel (csrc/conv4s2_mfma.hip)
-            K.conv4s2_fwd(x, self.wf, self.bias, out, stats, groups)
+            K.conv4s2_fwd(x, self.wf, self.bias, out, stats, groups, stats_replicas=stats_r)
             return
         if self.spec.kind == "c3" and nchw is not None and self.cin_p == 64 and self.spec.cout <= 4 and res is None and \
                 stats is None and act in (L.ACT_NONE, L.ACT_SIGMOID) and self.tile == L.TILE_AUTO and _RGB_OUT and \
@@ -169,16 +174,21 @@ class Conv:
         if self.spec.kind == "c3" and nchw is None and self.tile == L.TILE_AUTO and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) \
                 and K.rw_eligible(self.dt, self.cin_p, self.cout_p, N, H, W):
             self.last_desc, self.last_rw_nch = "rw", self.cin_p // 32  # persistent register-weights kernel (csrc/conv3_rw.hip)
-            K.conv3x3_rw(x, self.wf, out, False, bias=self.bias, res=res, act=act, stats=stats, stats_mode=2, groups=groups)
+            K.conv3x3_rw(x, self.wf, out, False, bias=self.bias, res=res, act=act, stats=stats, stats_mode=2, groups=groups,
+                         stats_replicas=stats_r)
             return
-        key = ("f", N, H, W, act, res is not None, stats is not None, groups, nchw is not None and nchw[2:])
+        key = ("f", N, H, W, act, res is not None, stats is not None, groups, nchw is not None and nchw[2:], stats_r)
         ent = self._desc.get(key)
         if ent is None:
+            # very large launches: private replica scratch folded into the caller's block 0; else the caller's own blocks
             R = K.stats_replicas_for(N * OH * OW) if stats is not None else 1
+            if R <= stats_r:
+                R = 1
             d = K.make_conv_desc(self.spec.fwd_geom(), self.tg, N, H, W, self.cin_p, OH, OW, self.cout_p, act=act,
                                  stats_mode=2 if stats is not None else 0, stats_groups=groups,
                                  out_mode=L.OUT_NCHW_F32 if nchw else L.OUT_NHWC, c_real=nchw[3] if nchw else 0,
-                                 out_n_stride=nchw[2] if nchw else 0, tile_cfg=self.tile, stats_replicas=R)
+                                 out_n_stride=nchw[2] if nchw else 0, tile_cfg=self.tile,
+                                 stats_replicas=R if R > 1 else stats_r)
             scratch = torch.zeros(R * groups * 2 * self.cout_p, device=x.device) if R > 1 else None
             ent = (d, R, scratch)
             self._desc[key] = ent
@@ -382,27 +392,39 @@ class BatchNorm:
         self.dgamma, self.dbeta = flat.padded(flat.g, prefix + ".weight"), flat.padded(flat.g, prefix + ".bias")
         self.rm, self.rv, self.nbt = bufs[prefix + ".running_mean"], bufs[prefix + ".running_var"], bufs[
             prefix + ".num_batches_tracked"]
-        self.stats = arena.take(2 * 2 * self.Cp).view(2, 2, self.Cp)
-        self.red = arena.take(2 * 2 * self.Cp).view(2, 2, self.Cp)
+        # accumulators in R replica blocks: [half][R][2][Cp] when the halves run as separate launches, [R][2 groups][2][Cp]
+        # for a whole-batch launch (zeroed once per step with the rest of the arena)
+        self.R = STATS_R
+        self.stats = arena.take(2 * self.R * 2 * self.Cp)
+        self.red = arena.take(2 * self.R * 2 * self.Cp)
         self.save = torch.empty(2, 2, self.Cp, device=flat.device)
+
+    def _slot(self, buf, half):
+        n = self.R * 2 * self.Cp
+        return buf if half is None else buf[half * n:(half + 1) * n]
+
+    def stats_slot(self, half=None):
+        """what the producing conv adds its statistics into (Conv.fwd(stats=..., stats_r=self.R))"""
+        return self._slot(self.stats, half)
 
     def apply(self, z, y, act, groups, skip=None, update=True, half=None):
         """half=None: z holds `groups` equal sample groups.  half=g: z holds only group g of 2 (the reference's g-th D
         call of the step); statistics slot g is used and the running statistics get ONE update."""
         N, H, W, C_ = z.shape
-        stats, save = (self.stats, self.save) if half is None else (self.stats[half], self.save[half])
+        stats, save = self._slot(self.stats, half), (self.save if half is None else self.save[half])
         g = groups if half is None else 1
         K.bn_apply(z, stats, self.gamma, self.beta, y, save, N, H * W, C_, g, act, skip=skip,
                    running_mean=self.rm if update else None, running_var=self.rv if update else None,
-                   nbt=self.nbt if update else None)
+                   nbt=self.nbt if update else None, replicas=self.R)
 
     def backward(self, dy, yact, z, dz, act, groups, half=None):
         """half=g: the tensors hold only group g of 2 (see apply); that group's saved statistics / reduction slots are used"""
         N, H, W, C_ = z.shape
-        save, red = (self.save, self.red) if half is None else (self.save[half], self.red[half])
+        save, red = (self.save if half is None else self.save[half]), self._slot(self.red, half)
         g = groups if half is None else 1
-        K.bn_bwd_reduce(dy, yact, z, save, red, N, H * W, C_, g, act)
-        K.bn_bwd_apply(dy, yact, z, save, red, self.gamma, dz, self.dgamma, self.dbeta, N, H * W, C_, g, act)
+        K.bn_bwd_reduce(dy, yact, z, save, red, N, H * W, C_, g, act, replicas=self.R)
+        K.bn_bwd_apply(dy, yact, z, save, red, self.gamma, dz, self.dgamma, self.dbeta, N, H * W, C_, g, act,
+                       replicas=self.R)
 
 
 class Arena:
@@ -818,7 +840,7 @@ class DiscriminatorEngine:
     def __init__(self, flat, bufs, dtype_t, resblocks=4, ch=128):
         self.flat, self.dt, self.nrb, self.ch = flat, dtype_t, resblocks, ch
         self.ws = Workspace(flat.device)
-        self.arena = Arena(64 * 1024, flat.device)
+        self.arena = Arena(32 * 1024 * STATS_R, flat.device)
         mk = lambda w, b, kind, ci, co, dg=True: Conv(flat, w, b, ConvSpec(kind, ci, co), dtype_t, self.ws, need_dgrad=dg)
         bn = lambda p, c: BatchNorm(flat, p, c, bufs, dtype_t, self.arena)
         self.conv0 = mk("conv.0.weight", "conv.0.bias", "c3", 27, 64, dg=False)
@@ -891,23 +913,23 @@ class DiscriminatorEngine:
         a = self.act
         N = a["in"].shape[0]
         if half is None:
-            sl, st_of = slice(0, N), (lambda bn: bn.stats)
+            sl, st_of = slice(0, N), (lambda bn: bn.stats_slot())
         else:
             hb = N // 2
-            sl, st_of = slice(half * hb, (half + 1) * hb), (lambda bn: bn.stats[half])
+            sl, st_of = slice(half * hb, (half + 1) * hb), (lambda bn: bn.stats_slot(half))
             groups = 1
         v = lambda t: t[sl]
         self.conv0.fwd(v(a["in"]), v(a["c0"]), act=L.ACT_LRELU)
         prev = v(a["c0"])
         for k in range(1, 6):
             conv, bn = self.blk[k]
-            conv.fwd(prev, v(a["z"][k]), stats=st_of(bn), groups=groups)
+            conv.fwd(prev, v(a["z"][k]), stats=st_of(bn), groups=groups, stats_r=bn.R)
             bn.apply(v(a["z"][k]), v(a["n"][k]), L.ACT_LRELU, groups, update=update_stats, half=half)
             net = v(a["n"][k])
             if k <= 3:
                 for j, (c1, c2, bnj) in enumerate(self.res[k]):
                     c1.fwd(net, v(a["h"][k][j]), act=L.ACT_RELU)
-                    c2.fwd(v(a["h"][k][j]), v(a["r"][k][j]), stats=st_of(bnj), groups=groups)
+                    c2.fwd(v(a["h"][k][j]), v(a["r"][k][j]), stats=st_of(bnj), groups=groups, stats_r=bnj.R)
                     bnj.apply(v(a["r"][k][j]), v(a["net"][k][j]), L.ACT_NONE, groups, skip=net, update=update_stats,
                               half=half)
                     net = v(a["net"][k][j])

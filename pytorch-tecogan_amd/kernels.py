@@ -175,14 +175,14 @@ def conv(desc, x, w_packed, out, bias=None, res=None, mask=None, stats=None):
 
 
 def conv3x3_rw(x, w_packed, out, flip=False, bias=None, res=None, mask=None, mask_mode=L.MASK_NONE, act=L.ACT_NONE,
-               stats=None, stats_mode=2, groups=1, max_workgroups=0):
+               stats=None, stats_mode=2, groups=1, max_workgroups=0, stats_replicas=1):
     """3x3 stride-1 conv / input-gradient through the persistent register-weights kernel (csrc/conv3_rw.hip):
     x [N,H,W,Cin] -> out [N,H,W,Cout], bf16, Cin in {64,128}, Cout % 64 == 0"""
     N, H, W, cin = x.shape
     L.check(L.load().tg_conv3x3_rw(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(res), _ptr(mask), _ptr(out),
                                    _ptr(stats), N, H, W, cin, out.shape[3], int(flip), act,
-                                   mask_mode if mask is not None else L.MASK_NONE, stats_mode, groups, max_workgroups,
-                                   _stream()), "tg_conv3x3_rw")
+                                   mask_mode if mask is not None else L.MASK_NONE, stats_mode, groups, stats_replicas,
+                                   max_workgroups, _stream()), "tg_conv3x3_rw")
 
 
 def rw_eligible(dtype_t, cin_p, cout_p, N, H, W):
@@ -309,11 +309,11 @@ def conv3x3_rgb(x, w_packed, bias, out_buf, out_off, n_stride, c_real, act=L.ACT
                                     n_stride, c_real, N, H, W, cin, act, _stream()), "tg_conv3x3_rgb")
 
 
-def conv4s2_fwd(x, w_packed, bias, out, stats=None, groups=1):
-    """conv k4 s2 p1 forward with compile-time taps; stats [groups][2][Cout] accumulated"""
+def conv4s2_fwd(x, w_packed, bias, out, stats=None, groups=1, stats_replicas=1):
+    """conv k4 s2 p1 forward with compile-time taps; stats: `stats_replicas` blocks of [groups][2][Cout], accumulated"""
     N, H, W, cin = x.shape
     L.check(L.load().tg_conv4s2_fwd(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(stats),
-                                    groups, N, H, W, cin, out.shape[3], _stream()), "tg_conv4s2_fwd")
+                                    groups, stats_replicas, N, H, W, cin, out.shape[3], _stream()), "tg_conv4s2_fwd")
 
 
 def conv4s2_dgrad(dout, wb_packed, din, mask=None, mask_mode=L.MASK_NONE):
@@ -444,19 +444,20 @@ def d_assemble(x, y, gen, tvel, dst, B, T, K, h, border, half=-1):
 
 
 def bn_apply(z, stats, gamma, beta, y, save, N, HW, C_, groups, act, skip=None, running_mean=None, running_var=None,
-             eps=1e-3, momentum=0.1, nbt=None):
-    L.check(L.load().tg_bn_apply(tg_dtype(z.dtype), _ptr(z), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(skip), _ptr(y),
+             eps=1e-3, momentum=0.1, nbt=None, replicas=1):
+    """stats: `replicas` blocks of [groups][2][C] sums (see include/tecogan_hip.h, "replica blocks")"""
+    L.check(L.load().tg_bn_apply(tg_dtype(z.dtype), _ptr(z), _ptr(stats), replicas, _ptr(gamma), _ptr(beta), _ptr(skip), _ptr(y),
                                  _ptr(running_mean), _ptr(running_var), _ptr(save), N, HW, C_, groups, act, eps,
                                  momentum, _ptr(nbt), _stream()), "tg_bn_apply")
 
 
-def bn_bwd_reduce(dy, yact, z, save, red, N, HW, C_, groups, act):
-    L.check(L.load().tg_bn_bwd_reduce(tg_dtype(z.dtype), _ptr(dy), _ptr(yact), _ptr(z), _ptr(save), _ptr(red), N, HW,
+def bn_bwd_reduce(dy, yact, z, save, red, N, HW, C_, groups, act, replicas=1):
+    L.check(L.load().tg_bn_bwd_reduce(tg_dtype(z.dtype), _ptr(dy), _ptr(yact), _ptr(z), _ptr(save), _ptr(red), replicas, N, HW,
                                       C_, groups, act, _stream()), "tg_bn_bwd_reduce")
 
 
-def bn_bwd_apply(dy, yact, z, save, red, gamma, dz, dgamma, dbeta, N, HW, C_, groups, act):
-    L.check(L.load().tg_bn_bwd_apply(tg_dtype(z.dtype), _ptr(dy), _ptr(yact), _ptr(z), _ptr(save), _ptr(red),
+def bn_bwd_apply(dy, yact, z, save, red, gamma, dz, dgamma, dbeta, N, HW, C_, groups, act, replicas=1):
+    L.check(L.load().tg_bn_bwd_apply(tg_dtype(z.dtype), _ptr(dy), _ptr(yact), _ptr(z), _ptr(save), _ptr(red), replicas,
                                      _ptr(gamma), _ptr(dz), _ptr(dgamma), _ptr(dbeta), N, HW, C_, groups, act,
                                      _stream()), "tg_bn_bwd_apply")
 

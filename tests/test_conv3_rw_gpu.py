@@ -116,8 +116,10 @@ def test_rw_matches_tg_conv_bit_for_bit_on_the_trunk_shape():
 def test_rw_unsupported_shapes_are_refused():
     lib = L.load()
     args = [L.TG_BF16, 16, 16, None, None, None, 16, None, 1, 8, 8]
-    assert lib.tg_conv3x3_rw(*args, 32, 64, 0, 0, 0, 2, 1, 0, None) == -2      # Cin = 32
-    assert lib.tg_conv3x3_rw(*args, 64, 32, 0, 0, 0, 2, 1, 0, None) == -2      # Cout = 32
-    assert lib.tg_conv3x3_rw(L.TG_F32, *args[1:], 64, 64, 0, 0, 0, 2, 1, 0, None) == -2   # fp32 runs on tg_conv
-    assert lib.tg_conv3x3_rw(*args, 64, 64, 0, L.ACT_SIGMOID, 0, 2, 1, 0, None) == -2
-    assert lib.tg_conv3x3_rw(L.TG_BF16, None, 16, None, None, None, 16, None, 1, 8, 8, 64, 64, 0, 0, 0, 2, 1, 0, None) == -1
+    assert lib.tg_conv3x3_rw(*args, 32, 64, 0, 0, 0, 2, 1, 1, 0, None) == -2      # Cin = 32
+    assert lib.tg_conv3x3_rw(*args, 64, 32, 0, 0, 0, 2, 1, 1, 0, None) == -2      # Cout = 32
+    assert lib.tg_conv3x3_rw(L.TG_F32, *args[1:], 64, 64, 0, 0, 0, 2, 1, 1, 0, None) == -2   # fp32 runs on tg_conv
+    assert lib.tg_conv3x3_rw(*args, 64, 64, 0, L.ACT_SIGMOID, 0, 2, 1, 1, 0, None) == -2
+    assert lib.tg_conv3x3_rw(L.TG_BF16, None, 16, None, None, None, 16, None, 1, 8, 8, 64, 64, 0, 0, 0, 2, 1, 1, 0, None) == -1
+    st = [L.TG_BF16, 16, 16, None, None, None, 16, 16, 1, 8, 8]                      # with a statistics pointer
+    assert lib.tg_conv3x3_rw(*st, 64, 64, 0, 0, 0, 2, 1, 3, 0, None) == -1          # replica count: a power of two

@@ -358,29 +358,32 @@ def test_batchnorm_train_fwd_bwd(C_, act, skip, dt):
     ref_y, ref_dz = torch.cat(outs), torch.cat(dzs)
 
     zd = K.to_nhwc(z.to(DEV), dt)
-    stats = torch.zeros(G, 2, C_, device=DEV)
+    R = 4 if skip else 1                 # replica blocks: the sums arrive split over R blocks (here: unevenly, one negative)
+    stats = torch.zeros(R, G, 2, C_, device=DEV)
+    share = [1.0] if R == 1 else [0.5, 0.75, -0.5, 0.25]
     for g in range(G):
         zz = zd[2 * g:2 * g + 2].float()
-        stats[g, 0] = zz.sum(dim=(0, 1, 2))
-        stats[g, 1] = (zz * zz).sum(dim=(0, 1, 2))
+        for r in range(R):
+            stats[r, g, 0] = share[r] * zz.sum(dim=(0, 1, 2))
+            stats[r, g, 1] = share[r] * (zz * zz).sum(dim=(0, 1, 2))
     y = torch.empty_like(zd)
     save = torch.empty(G, 2, C_, device=DEV)
     rmd, rvd = torch.zeros(C_, device=DEV), torch.ones(C_, device=DEV)
     gd, bd = gamma.to(DEV), beta.to(DEV)
     nbt = torch.full((), 5, dtype=torch.long, device=DEV)
     K.bn_apply(zd, stats, gd, bd, y, save, N, H * W, C_, G, act, skip=K.to_nhwc(sk.to(DEV), dt) if skip else None,
-               running_mean=rmd, running_var=rvd, nbt=nbt)
+               running_mean=rmd, running_var=rvd, nbt=nbt, replicas=R)
     assert int(nbt) == 5 + G  # num_batches_tracked advances once per group (= per forward call of the reference)
     t = tol(dt)
     torch.testing.assert_close(K.to_nchw(y, C_).cpu(), ref_y, **t)
     torch.testing.assert_close(rmd.cpu(), rm, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(rvd.cpu(), rv, rtol=1e-4, atol=1e-5)
     dyd = K.to_nhwc(dy.to(DEV), dt)
-    red = torch.zeros(G, 2, C_, device=DEV)
-    K.bn_bwd_reduce(dyd, y, zd, save, red, N, H * W, C_, G, act)
+    red = torch.zeros(R, G, 2, C_, device=DEV)
+    K.bn_bwd_reduce(dyd, y, zd, save, red, N, H * W, C_, G, act, replicas=R)
     dz = torch.empty_like(zd)
     dgam, dbet = torch.zeros(C_, device=DEV), torch.zeros(C_, device=DEV)
-    K.bn_bwd_apply(dyd, y, zd, save, red, gd, dz, dgam, dbet, N, H * W, C_, G, act)
+    K.bn_bwd_apply(dyd, y, zd, save, red, gd, dz, dgam, dbet, N, H * W, C_, G, act, replicas=R)
     torch.cuda.synchronize()
     if skip and act == L.ACT_NONE or dt == torch.float32:
         torch.testing.assert_close(K.to_nchw(dz, C_).cpu(), ref_dz, **t)
@@ -809,7 +812,7 @@ def test_conv4s2_fast_forward_with_stats(cin, cout, N, H, W, G, dt):
                                    atol=1e-3 if f32 else 0.5)
         torch.testing.assert_close(stats[g, 1, :cout].cpu().double(), (r * r).sum(dim=(0, 2, 3)), rtol=1e-4 if f32 else 2e-2,
                                    atol=1e-3 if f32 else 0.5)
-    assert L.load().tg_conv4s2_fwd(K.tg_dtype(dt), xd.data_ptr(), wp.data_ptr(), None, out.data_ptr(), None, 1, N, H, W,
+    assert L.load().tg_conv4s2_fwd(K.tg_dtype(dt), xd.data_ptr(), wp.data_ptr(), None, out.data_ptr(), None, 1, 1, N, H, W,
                                    K.pad32(cin), 32, None) == -2
 
 
