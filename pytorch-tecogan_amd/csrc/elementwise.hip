@@ -298,13 +298,16 @@ __global__ __launch_bounds__(256) void absdiff_sum_kernel(const char* __restrict
   if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+// 1024 threads per block: the block count - and with it the number of atomics that serialise on the same four words at the
+// end - is a quarter of what 256-thread blocks give for the same number of threads in flight
+constexpr int kClThreads = 1024;
 template <typename T>
-__global__ __launch_bounds__(256) void content_loss_kernel(const float* __restrict__ gen, const float* __restrict__ y,
+__global__ __launch_bounds__(kClThreads) void content_loss_kernel(const float* __restrict__ gen, const float* __restrict__ y,
                                                           char* __restrict__ dpre, float* __restrict__ acc, int B,
                                                           int T_, int H, int W, float gscale, int t0, int t1, int pp_T,
                                                           float pp_coef, const float* __restrict__ loss_scale) {
   using TR = ElemTraits<T>;
-  __shared__ float sh[4];
+  constexpr int NW = kClThreads / 64;
   if (loss_scale) {  // fp16 mode: every backward seed carries the dynamic loss scale (tg_adam_scaled divides it out)
     gscale *= *loss_scale;
     pp_coef *= *loss_scale;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256) void content_loss_kernel(const float* __restri
   const long long HW = (long long)H * W;
   const long long total = (long long)B * (t1 - t0) * HW;  // frames [t0,t1); dpre holds only those, frame-major
   float s = 0.f, cs[3] = {0.f, 0.f, 0.f}, pps = 0.f;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += 256LL * gridDim.x) {
+  for (long long i = blockIdx.x * (long long)kClThreads + threadIdx.x; i < total; i += (long long)kClThreads * gridDim.x) {
     const long long pos = i % HW;
     const long long r = i / HW;
     const int b = (int)(r % B);
@@ -346,23 +349,25 @@ __global__ __launch_bounds__(256) void content_loss_kernel(const float* __restri
   }
   // block-level reduction, then ONE atomic per block and quantity: thousands of waves adding to the same four words
   // serialise at the memory side (measured: 428 us with per-wave atomics)
-  __shared__ float shc[4][4];
+  __shared__ float shc[5][NW];  // rows: channel sums 0-2, ping-pong sum, squared error
   s = wave_sum(s);
   pps = wave_sum(pps);
 #pragma unroll
   for (int c = 0; c < 3; ++c) cs[c] = wave_sum(cs[c]);
   if ((threadIdx.x & 63) == 0) {
-    sh[threadIdx.x >> 6] = s;
+    shc[4][threadIdx.x >> 6] = s;
     shc[3][threadIdx.x >> 6] = pps;
 #pragma unroll
     for (int c = 0; c < 3; ++c) shc[c][threadIdx.x >> 6] = cs[c];
   }
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
-  if (threadIdx.x == 4 && pp_T > 0) atomicAdd(acc + 6, shc[3][0] + shc[3][1] + shc[3][2] + shc[3][3]);
-  if (threadIdx.x >= 1 && threadIdx.x <= 3) {
-    const int c = threadIdx.x - 1;
-    atomicAdd(acc + 8 + c, shc[c][0] + shc[c][1] + shc[c][2] + shc[c][3]);  // output-layer bias gradient
+  if (threadIdx.x < 5) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += shc[threadIdx.x][w];
+    if (threadIdx.x == 4) atomicAdd(acc, t);
+    else if (threadIdx.x == 3) { if (pp_T > 0) atomicAdd(acc + 6, t); }
+    else atomicAdd(acc + 8 + threadIdx.x, t);  // output-layer bias gradient
   }
 }
 
@@ -584,7 +589,7 @@ extern "C" int tg_content_loss(int dtype, const float* gen, const float* y, void
   if (!gen || !y || !acc || B <= 0 || T <= 0 || H <= 0 || W <= 0 || t0 < 0 || t1 > T || t0 >= t1) return TG_E_BADARG;
   if (pp_T != 0 && T != 2 * pp_T - 1) return TG_E_BADARG;  // ping-pong: the sequence is x followed by reverse(x)[1:]
   const long long total = (long long)B * (t1 - t0) * H * W;
-  TG_DISPATCH(dtype, content_loss_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), (hipStream_t)stream, gen, y,
+  TG_DISPATCH(dtype, content_loss_kernel, dim3(grid_for(total, kClThreads, 256)), dim3(kClThreads), (hipStream_t)stream, gen, y,
               (char*)dpre, acc, B, T, H, W, gscale, t0, t1, pp_T, pp_coef, loss_scale);
   return tg_launch_status();
 }
