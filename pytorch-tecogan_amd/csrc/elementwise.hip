@@ -16,14 +16,41 @@ __device__ __forceinline__ float wave_sum(float v) {
 // come in R replica blocks: producer workgroup b adds into block b mod R, because a few hundred workgroups adding into the
 // same 128 floats serialise in L2 (the discriminator's stage-1 conv: 10.3 us without statistics, 19.9 with them at R = 1,
 // 13.0 at R = 4: tools/mb_stats.py).  The consumer folds the blocks first: sh[i] = sum_r acc[r][i], in replica order.
-constexpr int kFoldMax = 2048;
-__device__ __forceinline__ void fold_replicas(const float* __restrict__ acc, int R, int n, float* sh) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    float s = 0.f;
-    for (int r = 0; r < R; ++r) s += acc[(size_t)r * n + i];
-    sh[i] = s;
+// Every thread reads the E consecutive channels it owns from all R blocks: independent 16-byte loads, ALL issued before the
+// first use (R as a compile-time constant: a run-time loop waits for each block's loads before it issues the next block's -
+// R round trips, measured slower than a fold through LDS, which in turn put a barrier in front of the kernel's first tensor
+// loads: +1.2 us per launch).
+template <int E, int RR> __device__ __forceinline__ void load_folded_n(const float* __restrict__ acc, size_t block, float* out) {
+  f32x4 t[RR][E / 4];
+#pragma unroll
+  for (int r = 0; r < RR; ++r)
+#pragma unroll
+    for (int e = 0; e < E / 4; ++e) t[r][e] = *reinterpret_cast<const f32x4*>(acc + r * block + 4 * e);
+#pragma unroll
+  for (int e = 0; e < E; ++e) out[e] = 0.f;
+#pragma unroll
+  for (int r = 0; r < RR; ++r)
+#pragma unroll
+    for (int e = 0; e < E; ++e) out[e] += t[r][e / 4][e % 4];
+}
+template <int E> __device__ __forceinline__ void load_folded(const float* __restrict__ acc, int R, size_t block, float* out) {
+  switch (R) {
+    case 1: load_folded_n<E, 1>(acc, block, out); return;
+    case 2: load_folded_n<E, 2>(acc, block, out); return;
+    case 4: load_folded_n<E, 4>(acc, block, out); return;
+    case 8: load_folded_n<E, 8>(acc, block, out); return;
   }
-  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; ++e) out[e] = 0.f;
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) out[e] += acc[r * block + e];
+  }
+}
+__device__ __forceinline__ float load_folded1(const float* __restrict__ acc, int R, size_t block) {
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) s += acc[r * block];
+  return s;
 }
 
 // Threads are arranged [rows = 256/VPP][VPP] where VPP = C / kVec vectors per pixel (a power of two <= 32).
@@ -42,14 +69,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ 
   const int grp = blockIdx.y;
   const long long npix = (long long)(N / groups) * HW;
   const float cnt = (float)npix;
-  __shared__ float stats[kFoldMax];
-  fold_replicas(stats_rep, R, groups * 2 * C, stats);
-  float scale[E], shift[E];
+  const size_t rblock = (size_t)groups * 2 * C;
+  float scale[E], shift[E], sum1[E], sum2[E];
+  load_folded<E>(stats_rep + (grp * 2 + 0) * C + vec * E, R, rblock, sum1);
+  load_folded<E>(stats_rep + (grp * 2 + 1) * C + vec * E, R, rblock, sum2);
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int c = vec * E + e;
-    const float mean = stats[(grp * 2 + 0) * C + c] / cnt;
-    float var = stats[(grp * 2 + 1) * C + c] / cnt - mean * mean;
+    const float mean = sum1[e] / cnt;
+    float var = sum2[e] / cnt - mean * mean;
     var = var < 0.f ? 0.f : var;
     const float invstd = rsqrtf(var + eps);
     scale[e] = gamma[c] * invstd;
@@ -59,8 +87,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ 
     const int c = threadIdx.x;
     float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
     for (int g2 = 0; g2 < groups; ++g2) {  // sequential updates, one per forward call of the reference
-      const float mean = stats[(g2 * 2 + 0) * C + c] / cnt;
-      float var = stats[(g2 * 2 + 1) * C + c] / cnt - mean * mean;
+      const float mean = load_folded1(stats_rep + (g2 * 2 + 0) * C + c, R, rblock) / cnt;
+      float var = load_folded1(stats_rep + (g2 * 2 + 1) * C + c, R, rblock) / cnt - mean * mean;
       var = var < 0.f ? 0.f : var;
       save[(g2 * 2 + 0) * C + c] = mean;
       save[(g2 * 2 + 1) * C + c] = rsqrtf(var + eps);
@@ -185,24 +213,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
   const int grp = blockIdx.y;
   const long long npix = (long long)(N / groups) * HW;
   const float inv_cnt = 1.f / (float)npix;
-  __shared__ float red[kFoldMax];
-  fold_replicas(red_rep, R, groups * 2 * C, red);
+  const size_t rblock = (size_t)groups * 2 * C;
   float mean[E], invstd[E], k0[E], m1[E], m2[E];
+  load_folded<E>(red_rep + (grp * 2 + 0) * C + vec * E, R, rblock, m1);
+  load_folded<E>(red_rep + (grp * 2 + 1) * C + vec * E, R, rblock, m2);
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int c = vec * E + e;
     mean[e] = save[(grp * 2 + 0) * C + c];
     invstd[e] = save[(grp * 2 + 1) * C + c];
     k0[e] = gamma[c] * invstd[e];
-    m1[e] = red[(grp * 2 + 0) * C + c] * inv_cnt;
-    m2[e] = red[(grp * 2 + 1) * C + c] * inv_cnt;
+    m1[e] *= inv_cnt;
+    m2[e] *= inv_cnt;
   }
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < C) {
     const int c = threadIdx.x;
     float dg = 0.f, db = 0.f;
     for (int g2 = 0; g2 < groups; ++g2) {
-      db += red[(g2 * 2 + 0) * C + c];
-      dg += red[(g2 * 2 + 1) * C + c];
+      db += load_folded1(red_rep + (g2 * 2 + 0) * C + c, R, rblock);
+      dg += load_folded1(red_rep + (g2 * 2 + 1) * C + c, R, rblock);
     }
     dgamma[c] += dg;
     dbeta[c] += db;
@@ -512,7 +541,7 @@ extern "C" int tg_bn_apply(int dtype, const void* z, const float* stats, int sta
                            void* stream) {
   if (!z || !stats || !gamma || !beta || !y || !save || N <= 0 || HW <= 0 || groups <= 0 || N % groups) return TG_E_BADARG;
   if (stats_replicas < 1 || (stats_replicas & (stats_replicas - 1))) return TG_E_BADARG;
-  if (!bn_shape_ok(dtype, C) || groups * 2 * C > kFoldMax) return TG_E_UNSUPPORTED;
+  if (!bn_shape_ok(dtype, C)) return TG_E_UNSUPPORTED;
   const int rows = 256 / (C / (dtype == TG_F32 ? 4 : 8));
   dim3 grid(grid_for((long long)(N / groups) * HW, rows * 4, 1024), groups);
   TG_DISPATCH(dtype, bn_apply_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)z, stats, stats_replicas, gamma, beta,
@@ -541,7 +570,7 @@ extern "C" int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, cons
     return TG_E_BADARG;
   if (act == TG_ACT_LRELU && !yact) return TG_E_BADARG;
   if (red_replicas < 1 || (red_replicas & (red_replicas - 1))) return TG_E_BADARG;
-  if (!bn_shape_ok(dtype, C) || groups * 2 * C > kFoldMax) return TG_E_UNSUPPORTED;
+  if (!bn_shape_ok(dtype, C)) return TG_E_UNSUPPORTED;
   const int rows = 256 / (C / (dtype == TG_F32 ? 4 : 8));
   dim3 grid(grid_for((long long)(N / groups) * HW, rows * 4, 1024), groups);
   TG_DISPATCH(dtype, bn_bwd_apply_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)dy, (const char*)yact,

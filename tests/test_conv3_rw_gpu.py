@@ -97,6 +97,14 @@ def test_rw_statistics_groups_and_lrelu(cin, cout, N, H, W, cap, groups):
     lin = F.conv2d(x, w, None, 1, 1).double()
     torch.testing.assert_close(s1[0, 0].cpu().double() - 7.0, lin.sum(dim=(0, 2, 3)), rtol=2e-2, atol=0.5)
     assert float((s1[0, 1] - 7.0).abs().max()) == 0.0
+    # replica blocks (include/tecogan_hip.h, tg_bn_apply): workgroup b adds into block b mod R; the blocks sum to the same totals
+    R = 4
+    rep = torch.zeros(R, groups, 2, cout, device=DEV)
+    K.conv3x3_rw(K.to_nhwc(x.to(DEV), BF), packed(spec, w, False), out, False, act=L.ACT_LRELU, stats=rep, stats_mode=2,
+                 groups=groups, max_workgroups=cap, stats_replicas=R)
+    torch.testing.assert_close(rep.sum(0), stats, rtol=1e-4, atol=1e-2)
+    if cap == 0:  # a full grid (one workgroup per CU, >= R of them along x): every block was used
+        assert all(float(rep[r].abs().max()) > 0.0 for r in range(R))
 
 
 def test_rw_matches_tg_conv_bit_for_bit_on_the_trunk_shape():

@@ -812,6 +812,13 @@ def test_conv4s2_fast_forward_with_stats(cin, cout, N, H, W, G, dt):
                                    atol=1e-3 if f32 else 0.5)
         torch.testing.assert_close(stats[g, 1, :cout].cpu().double(), (r * r).sum(dim=(0, 2, 3)), rtol=1e-4 if f32 else 2e-2,
                                    atol=1e-3 if f32 else 0.5)
+    # replica blocks: workgroup b adds into block b mod R (tg_bn_apply folds them); the blocks sum to the same totals
+    R = 4
+    rep = torch.zeros(R, G, 2, K.pad32(cout), device=DEV)
+    K.conv4s2_fwd(xd, wp, None, out, rep, G, stats_replicas=R)
+    torch.testing.assert_close(rep.sum(0), stats, rtol=1e-4, atol=1e-2)
+    assert L.load().tg_conv4s2_fwd(K.tg_dtype(dt), xd.data_ptr(), wp.data_ptr(), None, out.data_ptr(), rep.data_ptr(), G, 3, N,
+                                   H, W, K.pad32(cin), K.pad32(cout), None) == (-1 if cout % 64 == 0 else -2)
     assert L.load().tg_conv4s2_fwd(K.tg_dtype(dt), xd.data_ptr(), wp.data_ptr(), None, out.data_ptr(), None, 1, 1, N, H, W,
                                    K.pad32(cin), 32, None) == -2
 

@@ -44,5 +44,7 @@ for name, N, H, C in (("D stage 1 (12 x 64x64 x 64)", 12, 64, 64), ("D stage 3 (
     print(name, " | ".join(f"{'no stats' if R == 0 else f'R={R}'} {t:.2f} us" for R, t in res))
     # batch-norm backward reduce on the same tensor (atomics of every workgroup into 2*C floats)
     save = torch.zeros(2 * C, device=dev); save[C:] = 1.0
-    red = torch.zeros(2 * C, device=dev)
-    print("   bn_bwd_reduce", f"{timed(lambda: K.bn_bwd_reduce(x, None, out, save, red, N, H * H, C, 1, L.ACT_NONE)):.2f} us")
+    for R in (1, 4):
+        red = torch.zeros(R * 2 * C, device=dev)
+        t = timed(lambda: K.bn_bwd_reduce(x, None, out, save, red, N, H * H, C, 1, L.ACT_NONE, replicas=R))
+        print(f"   bn_bwd_reduce R={R} {t:.2f} us")
