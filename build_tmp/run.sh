@@ -1,3 +1,4 @@
 cd "${GRAFT_REPO_ROOT:?}"
-timeout -k 10 900 python -m pytest tests/test_kernels_gpu.py -q -x -k "batchnorm" 2>&1 | tail -3 || exit 1
-bash tools/ab_libs.sh build_tmp/lib_old.so 2>&1 | grep -E "== lib|d_real alone|d_fake|whole step|bench"
+b() { timeout -k 10 150 python bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench', d['ms_per_step'])"; }
+for v in 0 96 80 64 48 0; do echo "== LDS_BUDGET_KB=$v"; TECOGAN_LDS_BUDGET_KB=$v b; done
+TECOGAN_LDS_BUDGET_KB=80 timeout -k 10 200 python tools/step_breakdown.py 2>&1 | grep -E "alone|chain \|\||whole step"
