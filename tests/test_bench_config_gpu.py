@@ -128,11 +128,21 @@ def test_step_b2_fixture_of_the_reference_on_gpu(golden_dir, monkeypatch):
         assert abs(np.linalg.norm(dnorm) / np.linalg.norm(gold[p + "d_grad_norms"]) - 1.0) < (1e-2 if s == 0 else 3e-2)
         sdG, sdD = G.state_dict(), D.state_dict()
         # step 0: the update itself is exact to rounding; step 1 is free-running (Adam divides by sqrt(v) of two noisy
-        # gradients): half of one Adam step (lr = 1e-4) is allowed
+        # gradients): half of one Adam step (lr = 1e-4) is allowed.  An entry whose gradient is at the level of the float-atomic
+        # summation noise can take its Adam step (m / sqrt(v) = +-1 after one step) in the other direction - a difference of
+        # two steps for that entry: at most 1 % of a tensor's entries may do so, none may be further off
         at = 5e-7 if s == 0 else 5e-5
-        np.testing.assert_allclose(sdG["output.weight"].cpu().numpy(), gold[p + "post_output_weight"], rtol=1e-5, atol=at)
-        np.testing.assert_allclose(sdD["fc.weight"].cpu().numpy(), gold[p + "post_fc_weight"], rtol=1e-5, atol=at)
-        np.testing.assert_allclose(sdD["block5.0.weight"].cpu().numpy(), gold[p + "post_block5_weight"], rtol=1e-5, atol=at)
+
+        def close(got, want):
+            d = np.abs(got.cpu().numpy() - want)
+            lim = at + 1e-5 * np.abs(want)
+            if s == 0:
+                assert float((d - lim).max()) <= 0.0, float(d.max())
+            else:
+                assert float((d > lim).mean()) <= 0.01 and float(d.max()) <= 2.5e-4, (float((d > lim).mean()), float(d.max()))
+        close(sdG["output.weight"], gold[p + "post_output_weight"])
+        close(sdD["fc.weight"], gold[p + "post_fc_weight"])
+        close(sdD["block5.0.weight"], gold[p + "post_block5_weight"])
         for bn in ("block1.1", "resids3.3.1"):
             np.testing.assert_allclose(sdD[bn + ".running_mean"].cpu().numpy(), gold[p + bn + ".running_mean"], rtol=tol,
                                        atol=1e-5)
