@@ -1,3 +1,3 @@
 cd "${GRAFT_REPO_ROOT:?}"
-for cfg in "0 0" "1 0" "1 4" "1 8"; do set -- $cfg; echo "== FUSED_RESBLOCK_BWD=$1 RB_TILE=$2"
-TECOGAN_FUSED_RESBLOCK_BWD=$1 TECOGAN_RB_TILE=$2 timeout -k 10 200 python tools/step_breakdown.py 2>&1 | grep -E "g_bwd alone|whole step"; done
+timeout -k 10 900 python -m pytest tests/test_kernels_gpu.py -q -x 2>&1 | tail -3 || exit 1
+bash tools/ab_libs.sh build_tmp/lib_old.so 2>&1 | grep -E "== lib|alone|whole step|bench"

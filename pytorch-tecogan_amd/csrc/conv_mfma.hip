@@ -423,6 +423,24 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gather_kernel(const ConvK p
 #pragma unroll
     for (int e = 0; e < E; ++e) s1[a][e] = s2[a][e] = 0.f;
 
+  // The mask vectors of the epilogue (a launch without a mask: its residual vectors), ALL fetched up front from clamped
+  // addresses: a load under the divergent `valid` test below makes the compiler wait for each one before it issues the next -
+  // PT * NG dependent round trips to cold data at the end of every workgroup
+  const char* pre_src = p.mask_mode != TG_MASK_NONE ? p.mask : p.res;
+  u32x4 pre[PT][NG];
+  if (pre_src) {  // uniform
+#pragma unroll
+    for (int b = 0; b < PT; ++b) {
+      const int cy = min(ty0 + wp * PT + b, OHc - 1), cx = min(tx0 + idx, OWc - 1);
+      const size_t pix = ((size_t)n * p.OH + cy * p.OS + cl.ooy) * p.OW + cx * p.OS + cl.oox;
+#pragma unroll
+      for (int a = 0; a < NG; ++a) {
+        const int ch0 = (TR::kBytes == 2) ? co_base + (wc * CT + 2 * a) * 16 + 8 * q : co_base + (wc * CT + a) * 16 + 4 * q;
+        pre[b][a] = *reinterpret_cast<const u32x4*>(pre_src + (pix * p.Cout + ch0) * TR::kBytes);
+      }
+    }
+  }
+
 #pragma unroll
   for (int b = 0; b < PT; ++b) {
     const int cy = ty0 + wp * PT + b, cx = tx0 + idx;
@@ -451,7 +469,8 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gather_kernel(const ConvK p
         const size_t eoff = (pix * p.Cout + ch0) * TR::kBytes;
         if (p.res) {
           float r[E];
-          Vec<T>::load(p.res + eoff, r);
+          if (p.mask_mode == TG_MASK_NONE) Vec<T>::load(&pre[b][a], r);
+          else Vec<T>::load(p.res + eoff, r);
 #pragma unroll
           for (int e = 0; e < E; ++e) v[e] += r[e];
         }
@@ -467,7 +486,7 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gather_kernel(const ConvK p
         }
         if (p.mask_mode != TG_MASK_NONE) {
           float m[E];
-          Vec<T>::load(p.mask + eoff, m);
+          Vec<T>::load(&pre[b][a], m);
           const float neg = p.mask_mode == TG_MASK_LRELU ? 0.2f : 0.f;
 #pragma unroll
           for (int e = 0; e < E; ++e) v[e] *= (m[e] > 0.f ? 1.f : neg);
