@@ -36,6 +36,7 @@ struct C4K {
   char* out;
   float* stats;
   int N, IH, IW, Cin, OH, OW, Cout, tiles_x, tiles_y, nchunks, stats_groups, stats_replicas;
+  int gx, ny;  // pixel tiles, output-channel tiles (ny > 1: the grid is one-dimensional, see the kernel)
 };
 
 template <typename T> struct MmaT;
@@ -75,14 +76,25 @@ __global__ __launch_bounds__(NTHR) void conv_s2_gather_kernel(const C4K p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wc = wid % WC, wp = wid / WC;
   const int idx = lane & 15, g = lane >> 4;
-  int bx = blockIdx.x;
+  // Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  The ny output-channel tiles of one
+  // pixel tile read the SAME input patch: as grid.y they were gx workgroups apart - same XCD, but launched long after each
+  // other, so a 168-MB input (conv_trans.4's input-gradient, 40 samples) came from HBM once per channel tile (PMC: 351 MB
+  // for 210 MB algorithmic).  One-dimensional grid instead: workgroups b and b + 8 - same XCD, dispatched together -
+  // are the channel tiles of one pixel tile.
+  int bx = blockIdx.x, by = 0;
+  if (p.ny > 1) {
+    const int r = bx % (8 * p.ny), grp = bx / (8 * p.ny);
+    by = r >> 3;
+    bx = grp * 8 + (r & 7);
+    if (bx >= p.gx) return;  // padding of the last group (uniform per workgroup, before any barrier)
+  }
   const int txb = bx % p.tiles_x;
   bx /= p.tiles_x;
   const int tyb = bx % p.tiles_y;
   const int n = bx / p.tiles_y;
   const int ty0 = tyb * TH, tx0 = txb * 16;
   const int iy0 = 2 * ty0 - 1, ix0 = 2 * tx0 - 1;
-  const int co_base = blockIdx.y * CO_TILE;
+  const int co_base = by * CO_TILE;
   const size_t in_pix = (size_t)p.Cin * TR::kBytes;
   const char* in_n = p.in + (size_t)n * p.IH * p.IW * in_pix;
 
@@ -258,8 +270,11 @@ int launch_s2(int dtype, const void* in, const void* w_packed, const float* bias
   k.nchunks = Cin / (dtype == TG_F32 ? 16 : 32);
   k.tiles_x = (k.OW + 15) / 16; k.tiles_y = (k.OH + TH - 1) / TH;
   const long long gx = (long long)k.tiles_x * k.tiles_y * N;
-  if (gx > 0x7fffffffLL) return TG_E_UNSUPPORTED;
-  dim3 grid((unsigned)gx, (unsigned)(Cout / CO_TILE));
+  k.ny = Cout / CO_TILE;
+  const long long total = k.ny > 1 ? (gx + 7) / 8 * 8 * k.ny : gx;
+  if (total > 0x7fffffffLL) return TG_E_UNSUPPORTED;
+  k.gx = (int)gx;
+  dim3 grid((unsigned)total, 1);
   hipStream_t st = (hipStream_t)stream;
   constexpr int lds = Geo<KS>::kLds;
   static std::atomic<bool> attr_done{false};
