@@ -226,7 +226,8 @@ class Conv:
             K.conv4s2_dgrad(dout, self.wb, out, mask, mask_mode if mask is not None else L.MASK_NONE)
             return
         st = bias_grad_of.gbias if bias_grad_of is not None else None
-        if self.spec.kind == "c3" and self.tile == L.TILE_AUTO and K.rw_eligible(self.dt, self.cout_p, self.cin_p, N, H, W):
+        if self.spec.kind == "c3" and self.tile == L.TILE_AUTO and \
+                K.rw_eligible(self.dt, self.cout_p, self.cin_p, N, H, W, masked=mask is not None):
             self.last_desc, self.last_rw_nch = "rw", self.cout_p // 32  # the input-gradient of a 3x3 conv is the same conv with mirrored taps
             K.conv3x3_rw(dout, self.wb, out, True, res=res, mask=mask, mask_mode=mask_mode, stats=st, stats_mode=1)
             return

@@ -185,7 +185,7 @@ def conv3x3_rw(x, w_packed, out, flip=False, bias=None, res=None, mask=None, mas
                                    max_workgroups, _stream()), "tg_conv3x3_rw")
 
 
-def rw_eligible(dtype_t, cin_p, cout_p, N, H, W):
+def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False):
     """launch shapes routed to the persistent register-weights 3x3 kernel (csrc/conv3_rw.hip).  cin_p = reduction channels.
     Measured against tg_conv on the step's dense shapes (tools/mb_rw.py, profiles/r02_c_mb_rw.log):
       64 -> 64  @64x64   N=40  32.7 -> 20.0 us      64 -> 128 @128x128 N=40  154 -> 106 us     128 -> 128 @64x64 N=40 78.5 -> 74.1
@@ -198,6 +198,8 @@ def rw_eligible(dtype_t, cin_p, cout_p, N, H, W):
     npix = N * H * W
     if cin_p == 64:
         return npix >= 131072
+    if masked and npix >= 131072:  # Cin = 128 has no registers for the early mask fetch: tg_conv's epilogue (all mask vectors in
+        return False               # one round trip) wins on c32's input-gradient, 88 vs 99 us
     return cout_p == 128 and (npix >= 131072 or (H == 32 and W == 32 and npix >= 8192))
 
 
