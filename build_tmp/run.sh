@@ -1,2 +1,2 @@
 cd "${GRAFT_REPO_ROOT:?}"
-for v in 1 0 1 0; do echo "== RW_128BIG=$v"; TECOGAN_RW_128BIG=$v timeout -k 10 200 python tools/step_breakdown.py 2>&1 | grep -E "g_bwd alone|whole step"; done
+for i in 1 2; do timeout -k 10 900 python -m pytest tests -m gpu -q 2>&1 | tail -2; done
