@@ -137,6 +137,7 @@ class Conv:
         self._desc = {}
         self.defer_finalize = False
         self.fin_job = None
+        self.persist_wgs = K.PERSIST_WGS  # workgroups of this layer's persistent launches (the engines set their network's cap)
 
     def repack(self):
         s = self.spec
@@ -175,7 +176,7 @@ class Conv:
                 and K.rw_eligible(self.dt, self.cin_p, self.cout_p, N, H, W):
             self.last_desc, self.last_rw_nch = "rw", self.cin_p // 32  # persistent register-weights kernel (csrc/conv3_rw.hip)
             K.conv3x3_rw(x, self.wf, out, False, bias=self.bias, res=res, act=act, stats=stats, stats_mode=2, groups=groups,
-                         stats_replicas=stats_r)
+                         stats_replicas=stats_r, max_workgroups=self.persist_wgs)
             return
         key = ("f", N, H, W, act, res is not None, stats is not None, groups, nchw is not None and nchw[2:], stats_r)
         ent = self._desc.get(key)
@@ -229,7 +230,8 @@ class Conv:
         if self.spec.kind == "c3" and self.tile == L.TILE_AUTO and \
                 K.rw_eligible(self.dt, self.cout_p, self.cin_p, N, H, W, masked=mask is not None):
             self.last_desc, self.last_rw_nch = "rw", self.cout_p // 32  # the input-gradient of a 3x3 conv is the same conv with mirrored taps
-            K.conv3x3_rw(dout, self.wb, out, True, res=res, mask=mask, mask_mode=mask_mode, stats=st, stats_mode=1)
+            K.conv3x3_rw(dout, self.wb, out, True, res=res, mask=mask, mask_mode=mask_mode, stats=st, stats_mode=1,
+                         max_workgroups=self.persist_wgs)
             return
         key = ("d", N, OH, OW, mask_mode, res is not None, st is not None)
         ent = self._desc.get(key)
@@ -264,7 +266,7 @@ class Conv:
         key = ("w", N, XH, XW, YH, YW, bias_sum)
         ent = self._desc.get(key)
         if ent is None:
-            nsplit, tpw = K.wgrad_plan(N, YH, YW, S, len(taps), cx, cy)
+            nsplit, tpw = K.wgrad_plan(N, YH, YW, S, len(taps), cx, cy, cap=self.persist_wgs)
             if self.ws.frozen:
                 raise L.TecoganHipError("new wgrad shape after graph capture")
             stride = len(taps) * cx * cy + (cy if bias_sum else 0)
@@ -317,7 +319,7 @@ class WgradGroup:
             N, XH, XW, cx = X0.shape
             _, YH, YW, cy = Y0.shape
             blocks = K.wgrad_blocks(len(taps), cx, cy)
-            nsplit = max(1, min(K.wgrad_tiles(N, YH, YW, S), 256 // (len(items) * blocks)))
+            nsplit = max(1, min(K.wgrad_tiles(N, YH, YW, S), c0.persist_wgs // (len(items) * blocks)))
             fin = []
             stride = len(taps) * cx * cy + (cy if any_bias else 0)
             for c, x_in, dout, b in items:
@@ -486,6 +488,8 @@ class GeneratorEngine:
         self.act = None
         self.shape = None
         self.sets = ShapeSets()
+        for c in self.convs:
+            c.persist_wgs = K.persist_wgs("G")
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
         self.trunk_group = WgradGroup() if os.environ.get("TECOGAN_WGRAD_GROUPS", "1") != "0" else None
@@ -859,6 +863,8 @@ class DiscriminatorEngine:
         self.convs = [self.conv0] + [self.blk[k][0] for k in range(1, 6)] + [c for st in (1, 2, 3) for (c1, c2, _) in
                                                                              self.res[st] for c in (c1, c2)]
         self.shape = None
+        for c in self.convs:
+            c.persist_wgs = K.persist_wgs("D")
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
         self.res_group = WgradGroup() if os.environ.get("TECOGAN_WGRAD_GROUPS", "1") != "0" else None

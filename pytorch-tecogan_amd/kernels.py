@@ -182,7 +182,7 @@ def conv3x3_rw(x, w_packed, out, flip=False, bias=None, res=None, mask=None, mas
     L.check(L.load().tg_conv3x3_rw(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(res), _ptr(mask), _ptr(out),
                                    _ptr(stats), N, H, W, cin, out.shape[3], int(flip), act,
                                    mask_mode if mask is not None else L.MASK_NONE, stats_mode, groups, stats_replicas,
-                                   max_workgroups, _stream()), "tg_conv3x3_rw")
+                                   max_workgroups or PERSIST_WGS, _stream()), "tg_conv3x3_rw")
 
 
 def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False):
@@ -257,7 +257,27 @@ def wgrad_nsplit(N, YH, YW, S, blocks=1):
     return max(1, min(tiles, 256 // max(1, blocks)))
 
 
-def wgrad_plan(N, YH, YW, S, ntaps, cx_p, cy_p):
+# Workgroups of a persistent launch (conv3_rw, wgrad): one per CU would be 256 - but a persistent workgroup holds its CU for
+# the whole launch (60-125 us for the G backward's HR-stage launches), and the OTHER lane's small launches then queue for a
+# CU the whole time: with 256, lane B's fake-half forward took 1.35 ms beside the G backward (0.6 ms alone) and lane A idled
+# 0.6 ms at the end of every step waiting for it (tools/lane_ends.py).  160 leaves 96 CUs to the neighbour: the persistent
+# launches lose ~10 %, the step 5.06 -> 4.71 ms (sweep 256/240/224/208/192/176/160/144/128/96: 5.06 5.05 4.91 4.88 4.75 4.79 4.71
+# 4.84 4.89 5.27, profiles/r02_q_persist_wgs_sweep.log).  Per network: TECOGAN_PERSIST_WGS_G / _D (else TECOGAN_PERSIST_WGS).
+PERSIST_WGS = int(os.environ.get("TECOGAN_PERSIST_WGS", "160"))
+
+
+def persist_wgs(net):
+    """cap for the persistent launches of network `net` ('G', 'D' or None).  Separate sweep with G = 160: D = 64/96/112/120/128/
+    160/192/256 -> 4.98 4.62 4.64 4.63 4.65 4.72 4.88 4.95 ms; with D = 128: G = 128/144/160/168/176/192 -> 4.89 4.78 4.65 4.73 4.75
+    4.76 (the discriminator's persistent launches - weight gradients, stage-2 convs - run beside the latency-bound chain and G
+    backward tail and should hold even fewer CUs)"""
+    if not net:
+        return PERSIST_WGS
+    default = {"G": PERSIST_WGS, "D": min(PERSIST_WGS, 96) if "TECOGAN_PERSIST_WGS" not in os.environ else PERSIST_WGS}
+    return int(os.environ.get(f"TECOGAN_PERSIST_WGS_{net}", default.get(net, PERSIST_WGS)))
+
+
+def wgrad_plan(N, YH, YW, S, ntaps, cx_p, cy_p, cap=None):
     """(nsplit, taps_per_wg).  Layers with few pixel tiles split the taps over workgroups (3 of 9 / 4 of 16 each): the fp32
     slab traffic (nsplit x taps x Cx x Cy x 4 B written, then read by the fold) is what bounds them; layers with thousands
     of tiles keep all taps in one workgroup (each staged tile is then used for every tap)."""
@@ -265,8 +285,8 @@ def wgrad_plan(N, YH, YW, S, ntaps, cx_p, cy_p):
     tiles = N * ((YW + tw - 1) // tw) * ((YH + th - 1) // th)
     blocks = wgrad_blocks(ntaps, cx_p, cy_p)
     if ntaps == 9 and tiles <= 512 and blocks == 1:  # measured: 21 vs 25 us on the 64-channel 32x32 trunk layers (N=40);
-        return max(1, min(tiles, 256 // 3)), 3       # slower on every larger layer (tools/microbench.py wgrad)
-    return max(1, min(tiles, 256 // max(1, blocks))), 0
+        return max(1, min(tiles, (cap or PERSIST_WGS) // 3)), 3       # slower on every larger layer (tools/microbench.py wgrad)
+    return max(1, min(tiles, (cap or PERSIST_WGS) // max(1, blocks))), 0
 
 
 def wgrad_blocks(ntaps, cx_p, cy_p):
