@@ -138,6 +138,7 @@ class Conv:
         self.defer_finalize = False
         self.fin_job = None
         self.persist_wgs = K.PERSIST_WGS  # workgroups of this layer's persistent launches (the engines set their network's cap)
+        self.persist_rw = 0               # ... of its register-weights conv launches, when different (0: the same)
 
     def repack(self):
         s = self.spec
@@ -176,7 +177,7 @@ class Conv:
                 and K.rw_eligible(self.dt, self.cin_p, self.cout_p, N, H, W):
             self.last_desc, self.last_rw_nch = "rw", self.cin_p // 32  # persistent register-weights kernel (csrc/conv3_rw.hip)
             K.conv3x3_rw(x, self.wf, out, False, bias=self.bias, res=res, act=act, stats=stats, stats_mode=2, groups=groups,
-                         stats_replicas=stats_r, max_workgroups=self.persist_wgs)
+                         stats_replicas=stats_r, max_workgroups=self.persist_rw or self.persist_wgs)
             return
         key = ("f", N, H, W, act, res is not None, stats is not None, groups, nchw is not None and nchw[2:], stats_r)
         ent = self._desc.get(key)
@@ -231,7 +232,7 @@ class Conv:
                 K.rw_eligible(self.dt, self.cout_p, self.cin_p, N, H, W, masked=mask is not None):
             self.last_desc, self.last_rw_nch = "rw", self.cout_p // 32  # the input-gradient of a 3x3 conv is the same conv with mirrored taps
             K.conv3x3_rw(dout, self.wb, out, True, res=res, mask=mask, mask_mode=mask_mode, stats=st, stats_mode=1,
-                         max_workgroups=self.persist_wgs)
+                         max_workgroups=self.persist_rw or self.persist_wgs)
             return
         key = ("d", N, OH, OW, mask_mode, res is not None, st is not None)
         ent = self._desc.get(key)
@@ -489,7 +490,7 @@ class GeneratorEngine:
         self.shape = None
         self.sets = ShapeSets()
         for c in self.convs:
-            c.persist_wgs = K.persist_wgs("G")
+            c.persist_wgs, c.persist_rw = K.persist_wgs("G"), int(os.environ.get("TECOGAN_PERSIST_RW_G", "0"))
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
         self.trunk_group = WgradGroup() if os.environ.get("TECOGAN_WGRAD_GROUPS", "1") != "0" else None
@@ -864,7 +865,7 @@ class DiscriminatorEngine:
                                                                              self.res[st] for c in (c1, c2)]
         self.shape = None
         for c in self.convs:
-            c.persist_wgs = K.persist_wgs("D")
+            c.persist_wgs, c.persist_rw = K.persist_wgs("D"), int(os.environ.get("TECOGAN_PERSIST_RW_D", "0"))
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
         self.res_group = WgradGroup() if os.environ.get("TECOGAN_WGRAD_GROUPS", "1") != "0" else None
