@@ -15,18 +15,30 @@ for s in range(3):
     TR.FRVSR_Train(x, y, args, D, G, s, 0., 0., og, od)
 torch.cuda.synchronize()
 st = next(iter(TR._STEPS.values())); g = st.graphs
-names = ["start", "chain_end", "tail_end", "gbwd_end", "step_end", "dreal_end", "dfake_end", "laneB_end"]
+# per-frame graphs of the chain (frames 1..8), so that events can sit between the frames
+frames = []
+for t in range(1, st.tsize):
+    st._chain(t, t + 1); torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+        st._chain(t, t + 1)
+    frames.append(gr)
+names = ["start", "chain_end", "tail_end", "gbwd_end", "step_end", "dreal_end", "dfake_end", "laneB_end"] + \
+        [f"frame{t}_end" for t in range(0, st.tsize)]
 acc = {k: 0.0 for k in names}
 R = 20
+evs = []
 for rep in range(R + 2):
     ev = {k: torch.cuda.Event(enable_timing=True) for k in names}
     main, sB, sBm = torch.cuda.current_stream(), st.sB, st.sBm
-    torch.cuda.synchronize()
-    ev["start"].record(main)
+    ev["start"].record(main)   # (no host sync between repetitions: the host runs ahead, as in training)
     st.ev["start"].record(main); sBm.wait_event(st.ev["start"])
     with torch.cuda.stream(sBm):
         g["prep"](); st.ev["prep"].record(sBm); g["d_real"](); ev["dreal_end"].record(sBm)
-    g["chain0"](); main.wait_event(st.ev["prep"]); g["chain"](); ev["chain_end"].record(main)
+    g["chain0"](); ev["frame0_end"].record(main); main.wait_event(st.ev["prep"])
+    for t, gr in enumerate(frames, start=1):
+        gr.replay(); ev[f"frame{t}_end"].record(main)
+    ev["chain_end"].record(main)
     st.ev["chain"].record(main); sB.wait_event(st.ev["chain"])
     with torch.cuda.stream(sB):
         g["d_fake"](); ev["dfake_end"].record(sB)
@@ -35,9 +47,10 @@ for rep in range(R + 2):
         g["d_fake_bwd"](); g["update_d"](); st.ev["d"].record(sB); ev["laneB_end"].record(sB)
     g["g_bwd"](); ev["gbwd_end"].record(main)
     main.wait_event(st.ev["d"]); g["update"](); ev["step_end"].record(main)
-    torch.cuda.synchronize()
-    if rep >= 2:
-        for k in names[1:]:
-            acc[k] += ev["start"].elapsed_time(ev[k])
+    evs.append(ev)
+torch.cuda.synchronize()
+for ev in evs[2:]:
+    for k in names[1:]:
+        acc[k] += ev["start"].elapsed_time(ev[k])
 for k in names[1:]:
     print(f"{k:12s} at {acc[k] / R:7.3f} ms")
