@@ -70,6 +70,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ 
   const long long npix = (long long)(N / groups) * HW;
   const float cnt = (float)npix;
   const size_t rblock = (size_t)groups * 2 * C;
+  // The first trip's tensor loads go out BEFORE the per-channel parameters are fetched (raw, from clamped addresses): the two
+  // do not depend on each other, and most workgroups make exactly one trip - their run time was two dependent round trips
+  const long long base = (long long)grp * npix;
+  const long long step = (long long)gridDim.x * rows;
+  long long p = (long long)blockIdx.x * rows + prow;
+  u32x4 rz[4], rs[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long pix = p + u * step < npix ? p + u * step : npix - 1;
+    const long long off = ((base + pix) * C + vec * E) * TR::kBytes;
+    rz[u] = *reinterpret_cast<const u32x4*>(z + off);
+    if (skip) rs[u] = *reinterpret_cast<const u32x4*>(skip + off);
+  }
   float scale[E], shift[E], sum1[E], sum2[E];
   load_folded<E>(stats_rep + (grp * 2 + 0) * C + vec * E, R, rblock, sum1);
   load_folded<E>(stats_rep + (grp * 2 + 1) * C + vec * E, R, rblock, sum2);
@@ -99,8 +112,6 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ 
     if (rvar) rvar[c] = rv;
     if (nbt && c == 0) *nbt += groups;  // num_batches_tracked: one per forward call of the reference
   }
-  const long long base = (long long)grp * npix;
-  const long long step = (long long)gridDim.x * rows;
   auto finish = [&](float* v, const float* sk, long long off) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -111,7 +122,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ 
     }
     Vec<T>::store(y + off, v);
   };
-  long long p = (long long)blockIdx.x * rows + prow;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {  // the trip fetched above
+    if (p + u * step < npix) {
+      float v[E], sk[E];
+      Vec<T>::load(&rz[u], v);
+      if (skip) Vec<T>::load(&rs[u], sk);
+      finish(v, sk, ((base + p + u * step) * C + vec * E) * TR::kBytes);
+    }
+  }
+  p += 4 * step;
   for (; p + 3 * step < npix; p += 4 * step) {  // four pixels per trip, all loads issued before the first use
     float v[4][E], sk[4][E];
 #pragma unroll
@@ -214,6 +234,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
   const long long npix = (long long)(N / groups) * HW;
   const float inv_cnt = 1.f / (float)npix;
   const size_t rblock = (size_t)groups * 2 * C;
+  // the first trip's tensor loads before the per-channel parameters (see bn_apply_kernel)
+  const long long base = (long long)grp * npix;
+  const long long step = (long long)gridDim.x * rows;
+  long long p = (long long)blockIdx.x * rows + prow;
+  u32x4 rd[4], rz[4], ra[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long pix = p + u * step < npix ? p + u * step : npix - 1;
+    const long long off = ((base + pix) * C + vec * E) * TR::kBytes;
+    rd[u] = *reinterpret_cast<const u32x4*>(dy + off);
+    rz[u] = *reinterpret_cast<const u32x4*>(z + off);
+    if (act == TG_ACT_LRELU) ra[u] = *reinterpret_cast<const u32x4*>(yact + off);
+  }
   float mean[E], invstd[E], k0[E], m1[E], m2[E];
   load_folded<E>(red_rep + (grp * 2 + 0) * C + vec * E, R, rblock, m1);
   load_folded<E>(red_rep + (grp * 2 + 1) * C + vec * E, R, rblock, m2);
@@ -236,8 +269,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
     dgamma[c] += dg;
     dbeta[c] += db;
   }
-  const long long base = (long long)grp * npix;
-  const long long step = (long long)gridDim.x * rows;
   auto finish = [&](float* d, const float* zz, const float* a, long long off) {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -247,7 +278,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
     }
     Vec<T>::store(dz + off, d);
   };
-  long long p = (long long)blockIdx.x * rows + prow;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {  // the trip fetched above
+    if (p + u * step < npix) {
+      float d[E], zz[E], a[E];
+      Vec<T>::load(&rd[u], d);
+      Vec<T>::load(&rz[u], zz);
+      if (act == TG_ACT_LRELU) Vec<T>::load(&ra[u], a);
+      finish(d, zz, a, ((base + p + u * step) * C + vec * E) * TR::kBytes);
+    }
+  }
+  p += 4 * step;
   for (; p + 3 * step < npix; p += 4 * step) {  // four pixels per trip, all loads issued before the first use
     float d[4][E], zz[4][E], a[4][E];
 #pragma unroll
