@@ -196,6 +196,24 @@ __global__ __launch_bounds__(NTHR) void subpixel_kernel(const ConvtK p) {
 
   // epilogue: class (oy, ox) of input pixel (cy, cx) is output pixel (2cy+oy, 2cx+ox)
   const int OH = 2 * p.IH, OW = 2 * p.IW;
+  // all mask vectors of the epilogue up front, from clamped addresses: under the divergent bounds test below every load
+  // would be waited for before the next is issued (PT * 4 * NG dependent round trips)
+  u32x4 mpre[PT][4][NG];
+  if (p.mask_mode != TG_MASK_NONE) {  // uniform
+#pragma unroll
+    for (int b = 0; b < PT; ++b) {
+      const int cy = min(ty0 + wp * PT + b, p.IH - 1), cx = min(tx0 + idx, p.IW - 1);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const size_t pix = ((size_t)n * OH + 2 * cy + (c >> 1)) * OW + 2 * cx + (c & 1);
+#pragma unroll
+        for (int a = 0; a < NG; ++a) {
+          const int ch0 = (TR::kBytes == 2) ? co_base + (wc * CT + 2 * a) * 16 + 8 * g : co_base + (wc * CT + a) * 16 + 4 * g;
+          mpre[b][c][a] = *reinterpret_cast<const u32x4*>(p.mask + (pix * p.Cout + ch0) * TR::kBytes);
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int b = 0; b < PT; ++b) {
     const int cy = ty0 + wp * PT + b, cx = tx0 + idx;
@@ -227,7 +245,7 @@ __global__ __launch_bounds__(NTHR) void subpixel_kernel(const ConvtK p) {
           }
           if (p.mask_mode != TG_MASK_NONE) {
             float m[E];
-            Vec<T>::load(p.mask + (pix * p.Cout + ch0) * TR::kBytes, m);
+            Vec<T>::load(&mpre[b][c][a], m);
             const float neg = p.mask_mode == TG_MASK_LRELU ? 0.2f : 0.f;
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] *= (m[e] > 0.f ? 1.f : neg);
