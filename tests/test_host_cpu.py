@@ -351,3 +351,26 @@ def test_resize_restatement_equals_pil_bilinear_bit_for_bit(hw, out):
     b, k = R.pil_bilinear_coeffs(hw[1], out)
     assert b.shape == (out, 2) and int((b[:, 0] + b[:, 1]).max()) <= hw[1] and int(b[:, 1].min()) >= 1
     assert abs(int(k.sum(axis=1).max()) - (1 << R.PRECISION_BITS)) <= k.shape[1]   # rows sum to one in fixed point
+
+
+def test_persistent_workgroup_caps_defaults_and_overrides(monkeypatch):
+    """kernels.persist_wgs: 160 workgroups for the generator's persistent launches, 96 for the discriminator's; one global
+    override (TECOGAN_PERSIST_WGS) applies to both, the per-network ones win; wgrad_plan deals pixel tiles over cap / blocks"""
+    import importlib
+    from pytorch_tecogan_amd import kernels as K
+    for k in ("TECOGAN_PERSIST_WGS", "TECOGAN_PERSIST_WGS_G", "TECOGAN_PERSIST_WGS_D"):
+        monkeypatch.delenv(k, raising=False)
+    K = importlib.reload(K)
+    assert (K.PERSIST_WGS, K.persist_wgs("G"), K.persist_wgs("D"), K.persist_wgs(None)) == (160, 160, 96, 160)
+    monkeypatch.setenv("TECOGAN_PERSIST_WGS_D", "128")
+    assert K.persist_wgs("D") == 128 and K.persist_wgs("G") == 160
+    monkeypatch.setenv("TECOGAN_PERSIST_WGS", "256")
+    K = importlib.reload(K)
+    monkeypatch.delenv("TECOGAN_PERSIST_WGS_D")
+    assert (K.persist_wgs("G"), K.persist_wgs("D")) == (256, 256)
+    # 9-tap 128 -> 64 layer on 40 x 128x128 pixels: 2 channel blocks; all taps in one workgroup
+    assert K.wgrad_plan(40, 128, 128, 1, 9, 128, 64, cap=160) == (80, 0)
+    assert K.wgrad_plan(40, 128, 128, 1, 9, 128, 64, cap=256) == (128, 0)
+    assert K.wgrad_plan(1, 8, 8, 1, 9, 64, 64, cap=160)[0] >= 1            # never zero splits
+    monkeypatch.delenv("TECOGAN_PERSIST_WGS")
+    importlib.reload(K)

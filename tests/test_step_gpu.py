@@ -432,3 +432,23 @@ def test_bench_contract_line_with_roofline_pass():
     assert any(k.startswith("resblock_kernel<false") for k in fam) and any(k.startswith("conv_rgb_kernel") for k in fam)
     assert all(v["launches"] > 0 and v["ms"] > 0 for v in fam.values())
     assert rf["hbm_kernels"] and all(0.0 < v["frac_of_8TBps"] < 1.0 for v in rf["hbm_kernels"].values())
+
+
+def test_persistent_workgroup_cap_is_a_scheduling_knob_only():
+    """kernels.PERSIST_WGS (workgroups of the persistent launches) changes how the pixel tiles are dealt out and how many
+    weight-gradient slabs are summed - i.e. fp32 summation order - and nothing else: the benchmarked step with one workgroup per
+    CU and with the shipped caps ends at the same losses"""
+    import json
+    import subprocess
+    res = []
+    for cap in ("256", None):
+        env = dict(os.environ)
+        env.pop("TECOGAN_PERSIST_WGS", None)
+        if cap:
+            env["TECOGAN_PERSIST_WGS"] = cap
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+                            "--no-roofline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["final_losses"])
+    np.testing.assert_allclose(res[0]["gen_loss"], res[1]["gen_loss"], rtol=2e-3)
+    np.testing.assert_allclose(res[0]["d_loss"], res[1]["d_loss"], rtol=5e-2, atol=2e-3)
