@@ -1,7 +1,12 @@
 """Throughput bench of the TecoGAN training step (BASELINE.json config 2: B=4 sequences per GPU, T=10, 32x32 -> 128x128,
 bf16 compute / fp32 master weights, full G + pseudo-flow/warp + D + losses + two Adam updates per step).
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched once per rank by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched once per rank by torch.distributed.run (RANK / WORLD_SIZE in the environment; WORLD_SIZE must equal
+--gpus), or - with no RANK in the environment - this process starts the N ranks itself as children (before it touches the
+GPU) and exits with their code.  It refuses to run when fewer than N GPUs are visible: a silent 1-GPU "dp1" line is never
+printed for --gpus N.  --dry: the launch logic only (gloo rendezvous on the CPU, no GPU, no kernels) - tests/test_host_cpu.py.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
   roofline      the dominant kernel family (every family of one eager step is replayed inside one event bracket), the
@@ -42,7 +47,56 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--dry", action="store_true", help="launch logic only: gloo rendezvous on the CPU, no GPU work")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(a):
+    """--gpus N without RANK in the environment: start N child ranks with torch.distributed.run.  Runs BEFORE anything
+    in this process initialises the GPU (device_count() does not), and the children are fresh processes - a process
+    that has touched the GPU is never re-executed."""
+    import subprocess
+    if not a.dry:
+        vis = torch.cuda.device_count()
+        if vis < a.gpus:
+            raise SystemExit(f"bench.py: {a.gpus} GPUs requested, {vis} visible - refusing to print a {a.gpus}-GPU line")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(a, rank, world):
+    """--dry: rendezvous (gloo, CPU), barrier, max-over-ranks timing and the line's parallelism fields - everything of the
+    N-rank launch except the GPU work."""
+    import torch.distributed as dist
+    n = 1
+    if "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo")
+        n = dist.get_world_size()
+        if n != a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but the process group has {n} ranks")
+        dist.barrier()
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == float(n)
+    if rank == 0:
+        print(json.dumps({"dry": True, "n_gpus": n, "pg_world_size": n, "pg_backend": "gloo" if n > 1 or "RANK" in os.environ else None,
+                          "config": {"parallelism": f"dp{n}", "global_batch": n * WORKLOADS[a.config]["batch"]}}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def default_args(dtype, T=10, cs=32, extend=False):
@@ -259,18 +313,32 @@ def cpu_baseline(B, n_steps):
 
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "RANK" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a))      # this process never touches the GPU; it exits with the ranks' code
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:   # a launcher that started another number of ranks than the line would claim
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.dry:
+        return dry_run(a, rank, world)
+    vis = torch.cuda.device_count()
+    if vis < 1 or local >= vis:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local}, {vis} visible ({a.gpus} GPUs requested)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    pg_backend = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=dev)
+        pg_backend = dist.get_backend()
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but the process group has {dist.get_world_size()} ranks")
+        world = dist.get_world_size()   # the line reports what the process group says, not the environment
     os.environ["TECOGAN_GRAPH"] = "0" if a.no_graph else "1"
 
     import pytorch_tecogan_amd  # noqa: F401
@@ -323,7 +391,8 @@ def main():
         ms = dt / a.steps * 1e3
         value = world * B * T * a.steps / dt
         res = {"metric": f"HR frames/sec per train step, 4x {cs}->{4 * cs} seq-{T}", "value": round(value, 2),
-               "unit": "HR-frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "unit": "HR-frames/s", "n_gpus": world, "pg_world_size": world if pg_backend else None,
+               "pg_backend": pg_backend, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": f"{wl['name']}, B={B} sequences/GPU, T={T}, {cs}x{cs}->{4 * cs}x{4 * cs}",

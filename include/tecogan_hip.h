@@ -296,16 +296,19 @@ int tg_dlogit_real(const float* prob, float* dlogit, int tb, const float* cfg, c
 int tg_reduce_replicas(const float* src, int replicas, int stride, int n, float* dst, int accumulate, void* stream);
 
 /* ---- optimiser (torch.optim.Adam as built at main.py:239-243) ------------------------------------------- */
-/* hyper_dev (device floats): lr, beta1, beta2, eps, 1-beta1^t, 1-beta2^t, grad_scale - in memory so that a captured
- * hipGraph picks up each step's values. */
+/* hyper_dev (8 device floats): lr, beta1, beta2, eps, 1-beta1^t, 1-beta2^t, grad_scale, t (the caller's step count) - in
+ * memory so that a captured hipGraph picks up each step's values. */
 int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, void* stream);
 
 /* ---- dynamic loss scaling of the fp16 mode (torch.cuda.amp.GradScaler as used at code/train.py:9,335-342) ---------- */
 /* `loss_scale` (device float, nullable) of tg_content_loss / tg_loss_finalize / tg_dlogit_real / tg_cosine_loss multiplies
  * every backward seed, so all gradient tensors and both flat gradient buffers carry the scale.  scaler_state (device
- * floats): 0 scale, 1 growth tracker, 2 found_inf of the generator, 3 of the discriminator, 4 1/scale.
+ * floats, 8): 0 scale, 1 growth tracker, 2 found_inf of the generator, 3 of the discriminator, 4 1/scale, 5 / 6 updates of
+ * the generator / discriminator skipped so far (tg_scaler_update counts them; optimizer.step() is not called on overflow,
+ * code/train.py:337,341, so torch's Adam step count does not advance there: tg_adam_scaled uses t - skipped).
  * tg_check_finite: *flag = 1 if any g[i] is inf/NaN (flag = scaler_state + 2 + which).
- * tg_adam_scaled: tg_adam on g / scale, skipped entirely when found_inf[which] is set (GradScaler.step).
+ * tg_adam_scaled: tg_adam on g / scale, skipped entirely when found_inf[which] is set (GradScaler.step); bias corrections
+ *   for step hyper[7] - scaler_state[5 + which] (hyper[4], hyper[5] as given while nothing has been skipped).
  * tg_scaler_update: the two GradScaler.update() calls of one training step (generator's first), then clears the flags. */
 int tg_check_finite(const float* g, int64_t n, float* flag, void* stream);
 int tg_adam_scaled(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev,

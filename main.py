@@ -81,13 +81,18 @@ def main(argv=None):
     from train import FRVSR_Train
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    # one GPU per rank; ranks beyond the visible devices wrap around (only the gloo test backend can share a device)
-    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    # one GPU per rank.  Only the gloo test backend can share a device (ranks beyond the visible devices wrap around there);
+    # RCCL fails obscurely with two ranks on one GPU, so that is refused here
+    backend = os.environ.get("TECOGAN_DIST_BACKEND", "nccl")  # "nccl" is RCCL here; gloo: ranks sharing one GPU (tests)
+    local, ndev = int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.device_count()
+    if local >= max(1, ndev):
+        if world > 1 and backend == "nccl":
+            raise RuntimeError(f"LOCAL_RANK {local} but only {ndev} GPU(s) visible: RCCL needs one GPU per rank")
+        local %= max(1, ndev)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("TECOGAN_DIST_BACKEND", "nccl")  # "nccl" is RCCL here; gloo: ranks sharing one GPU (tests)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -200,7 +205,8 @@ def main(argv=None):
             save_image(targets.reshape(n, 3, cs * 4, cs * 4), "real_image.jpg")
             save_image(inputs.reshape(n, 3, cs, cs), "original_image.jpg")
             print("\nSaving model...")
-            from pytorch_tecogan_amd.train import loss_scaler_state
+            from pytorch_tecogan_amd.train import loss_scaler_state, sync_optimizer_steps
+            sync_optimizer_steps(opt_g, opt_d)   # fp16: Adam's step count without the updates skipped on overflow
             g_state = {"epoch": e, "model_state_dict": G.state_dict(), "optimizer_state_dict": opt_g.state_dict()}
             if loss_scaler_state() is not None:
                 g_state["tg_scaler"] = loss_scaler_state()

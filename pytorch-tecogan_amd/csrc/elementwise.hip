@@ -535,7 +535,7 @@ __global__ void loss_finalize_kernel(const float* __restrict__ prob, const float
   sc[15] = (float)n;
 }
 
-// hyper (device): 0 lr, 1 beta1, 2 beta2, 3 eps, 4 1-beta1^t, 5 1-beta2^t, 6 grad scale (1/world for data parallel).
+// hyper (device): 0 lr, 1 beta1, 2 beta2, 3 eps, 4 1-beta1^t, 5 1-beta2^t, 6 grad scale (1/world for data parallel), 7 t.
 // Read from memory, not kernel arguments, so that a captured hipGraph replays with the current step's values.
 // scaler (fp16 mode, else null): the dynamic loss-scale state of tg_scaler_update; found_inf[which] != 0 skips the whole
 // update (torch.cuda.amp.GradScaler.step, code/train.py:336-341) and the gradients are divided by the scale.
@@ -543,8 +543,17 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
                             float* __restrict__ v, long long n, const float* __restrict__ hyper,
                             const float* __restrict__ scaler, int which) {
   if (scaler && scaler[2 + which] != 0.f) return;
-  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], bc2 = hyper[5],
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3],
               gscale = scaler ? hyper[6] * scaler[4] : hyper[6];
+  float bc1 = hyper[4], bc2 = hyper[5];
+  // fp16 mode: GradScaler.step() does not call optimizer.step() on overflow, so torch's step count - and with it the bias
+  // corrections - does not advance on a skipped update.  The host counts calls (hyper[7]); the skips are counted on the
+  // device (scaler[5 + which], tg_scaler_update), and the corrections are re-derived here for the steps actually taken.
+  if (scaler && scaler[5 + which] != 0.f) {
+    const double t = (double)hyper[7] - (double)scaler[5 + which];
+    bc1 = (float)(1.0 - pow((double)b1, t));
+    bc2 = (float)(1.0 - pow((double)b2, t));
+  }
   const float step = lr / bc1, sq2 = sqrtf(bc2);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
@@ -709,7 +718,8 @@ __global__ void check_finite_kernel(const float* __restrict__ g, long long n, fl
   if (__any(bad) && (threadIdx.x & 63) == 0) *flag = 1.f;  // benign race: every writer stores the same value
 }
 
-// state: 0 scale, 1 growth tracker, 2 found_inf (generator), 3 found_inf (discriminator), 4 1/scale.  The reference shares
+// state: 0 scale, 1 growth tracker, 2 found_inf (generator), 3 found_inf (discriminator), 4 1/scale, 5 / 6 skipped updates of
+// the generator / discriminator (subtracted from the host's call count in adam_kernel).  The reference shares
 // ONE GradScaler between both optimisers and calls update() after each step() (code/train.py:9,337-341): two updates per
 // training step, the generator's first.  update(): found_inf -> scale *= backoff, tracker = 0; else tracker += 1 and at
 // `interval` scale *= growth, tracker = 0.
@@ -720,6 +730,7 @@ __global__ void scaler_update_kernel(float* __restrict__ s, float growth, float 
     if (s[2 + which] != 0.f) {
       scale *= backoff;
       tracker = 0.f;
+      s[5 + which] += 1.f;  // updates this network has skipped so far (adam_kernel's step count)
     } else {
       tracker += 1.f;
       if (tracker >= (float)interval) {

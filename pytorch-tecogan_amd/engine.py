@@ -106,6 +106,11 @@ class ShapeSets:
     def unpin(self, shape):
         self.pinned.discard(shape)
 
+    def drop(self, shape):
+        """forgets an unpinned set at once (TecoGANStep.close: the configuration it served is gone)"""
+        if shape not in self.pinned:
+            self.sets.pop(shape, None)
+
 
 _SUBPIX_CT = os.environ.get("TECOGAN_SUBPIX_CT", "1") != "0"
 _FAST_C4S2 = os.environ.get("TECOGAN_FAST_C4S2", "1") != "0"

@@ -516,7 +516,7 @@ def loss_finalize(prob, acc, scalars, dlogit, tb, cfg, loss_scale=None):
 
 
 def adam_hyper(lr, beta1, beta2, eps, step, grad_scale=1.0):
-    return [lr, beta1, beta2, eps, 1.0 - beta1 ** step, 1.0 - beta2 ** step, grad_scale, 0.0]
+    return [lr, beta1, beta2, eps, 1.0 - beta1 ** step, 1.0 - beta2 ** step, grad_scale, float(step)]
 
 
 def adam(p, g, m, v, hyper_dev, scaler=None, which=0):

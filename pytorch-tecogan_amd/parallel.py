@@ -18,7 +18,7 @@ import torch.distributed as dist
 def dist_info():
     """(process_group or None, world_size)."""
     if dist.is_available() and dist.is_initialized():
-        if dist.get_world_size() > 1 or os.environ.get("TECOGAN_FORCE_DP_SEGMENTS", "0") == "1":
+        if dist.get_world_size() > 1 or os.environ.get("TECOGAN_FORCE_COLLECTIVES", "0") == "1":
             return dist.group.WORLD, dist.get_world_size()
     return None, 1
 
@@ -31,17 +31,60 @@ def shard_bounds(n, world, rank):
     return rank * per, (rank + 1) * per
 
 
+class _StagedWork:
+    """all-reduce of a DEVICE buffer over a gloo group (the tests' rendezvous when several ranks share one GPU; RCCL
+    refuses that).  Issued like an RCCL collective - nothing blocks at issue: the device-to-host copy is enqueued on the
+    issuing stream, a worker thread (ONE per process, FIFO, so every rank runs its collectives in issue order) waits for
+    the copy's event and reduces the pinned host buffer; wait() joins that job and enqueues the copy back on the
+    caller's current stream.  The step's launches issued between all-reduce and wait() run meanwhile, which is the
+    interleave the RCCL path has."""
+    _queue, _thread, _pinned = None, None, {}
+
+    def __init__(self, buf, group):
+        import queue
+        import threading
+        cls = _StagedWork
+        if cls._thread is None or not cls._thread.is_alive():
+            cls._queue = queue.Queue()
+            cls._thread = threading.Thread(target=cls._serve, args=(cls._queue,), daemon=True)
+            cls._thread.start()
+        key = (buf.data_ptr(), buf.numel())
+        host = cls._pinned.get(key)
+        if host is None:
+            host = cls._pinned[key] = torch.empty(buf.numel(), dtype=buf.dtype).pin_memory()
+        self.buf, self.host, self.group = buf, host, group
+        self.done, self.error = threading.Event(), None
+        host.copy_(buf.view(-1), non_blocking=True)
+        self.copied = torch.cuda.Event()
+        self.copied.record()
+        cls._queue.put(self)
+
+    @staticmethod
+    def _serve(q):
+        while True:
+            w = q.get()
+            try:
+                w.copied.synchronize()
+                dist.all_reduce(w.host, op=dist.ReduceOp.SUM, group=w.group)
+            except Exception as e:  # noqa: BLE001  (re-raised by wait())
+                w.error = e
+            w.done.set()
+
+    def wait(self):
+        self.done.wait()
+        if self.error is not None:
+            raise self.error
+        self.buf.view(-1).copy_(self.host, non_blocking=True)
+
+
 def allreduce_sum_async(buf, group, world):
-    """launches the all-reduce of one flat gradient buffer; returns a work handle (None when single process, and None
-    on a gloo group: gloo is the CPU rendezvous used by the tests, device buffers are staged through the host there,
-    synchronously on the current stream)."""
+    """launches the all-reduce of one flat gradient buffer on the current stream's data; returns a work handle with
+    .wait() (None when single process).  RCCL: Work.wait() makes the current STREAM wait.  gloo with a device buffer (the
+    tests' two-ranks-on-one-GPU rendezvous): _StagedWork - asynchronous at issue, host-joined at wait()."""
     if group is None or world == 1:
         return None
     if buf.is_cuda and dist.get_backend(group) == "gloo":
-        host = buf.cpu()                       # synchronises with the current stream: the gradients are final
-        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-        buf.copy_(host)
-        return None
+        return _StagedWork(buf, group)
     return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
 

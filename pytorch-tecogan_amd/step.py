@@ -7,9 +7,9 @@ buffers - which is what makes it hipGraph-capturable - plus the generator-only r
   * fake D input reuses the TARGET frames as its first 9 channels; both D inputs detached from G;
   * reported gen_loss = content + 2*ratio*t_adv + layer_sum*dt_ratio (aliased tensor), gradient of G = content only;
   * BN running statistics updated twice per step (real pass, then fake pass).
-Data parallel: sequences are sharded over ranks; the flat G and D gradient buffers are all-reduced over RCCL, the G
-all-reduce issued behind the G backward so that it runs while the fake half of the D backward is still in flight
-(TecoGANStep._run_lanes)."""
+Data parallel: sequences are sharded over ranks; the flat G and D gradient buffers are all-reduced over RCCL, each
+issued where its inputs become final - the D all-reduce behind lane B's last backward launch, the G all-reduce behind
+lane A's (TecoGANStep._run_lanes)."""
 import os
 
 import torch
@@ -228,12 +228,21 @@ class TecoGANStep:
         """releases the pins on the engines' buffer sets (train.get_step calls it when another configuration replaces
         this one); the graphs of a closed step must not be replayed"""
         self.graphs = None
-        self.G.sets.unpin((self.T * self.B, self.h, self.h))
-        self.D.sets.unpin((2 * self.tb, self.H))
-        if self.F is not None:
-            self.F.sets.unpin((self.B * self.T, self.h, self.h))
-        if self.V is not None:
-            self.V.sets.unpin((self.T * self.B, self.H, self.H))
+        for eng, shape in ((self.G, (self.T * self.B, self.h, self.h)), (self.D, (2 * self.tb, self.H)),
+                           (self.F, (self.B * self.T, self.h, self.h)), (self.V, (self.T * self.B, self.H, self.H))):
+            if eng is not None:
+                eng.sets.unpin(shape)
+                eng.sets.drop(shape)      # the step's activation / gradient buffers go with it
+                if eng.shape == shape:    # the engine re-selects (re-creates) a set at its next alloc()
+                    eng.shape = None
+                    for attr in ("cur", "act", "grad", "gbuf", "g_c0", "prob", "dlogit"):
+                        if hasattr(eng, attr):
+                            setattr(eng, attr, None)
+        if self.sBm is not self.sB:       # the CU-masked stream was created through the C ABI (lane_stream)
+            import ctypes
+            torch.cuda.synchronize(self.dev)
+            L.check(L.load().tg_stream_destroy(ctypes.c_void_p(self.sBm.cuda_stream)), "tg_stream_destroy")
+            self.sBm = self.sB
 
     # ----------------------------------------------------------------------------------------------------------
     def _host_params(self, global_step, lr_g, lr_d, betas_g, betas_d, eps_g, eps_d):
@@ -429,7 +438,7 @@ class TecoGANStep:
 
     # ---------------------------------------------------------------------------------------------------------- schedule
     def _allreduce(self, buf):
-        if self.pg is not None and os.environ.get("TECOGAN_FORCE_DP_SEGMENTS", "0") == "1":
+        if self.pg is not None and os.environ.get("TECOGAN_FORCE_COLLECTIVES", "0") == "1":
             import torch.distributed as dist  # test hook: exercise the collective's call path even with one rank
             return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         return parallel.allreduce_sum_async(buf, self.pg, self.world)
@@ -466,10 +475,13 @@ class TecoGANStep:
         sB.wait_event(ev["tail"])
         with torch.cuda.stream(sB):
             fn["d_fake_bwd"]()
+            # RCCL runs a process group's collectives on ONE internal stream in issue order (the same on every rank): the
+            # D all-reduce goes first - lane B ends before lane A - so it never queues behind the G all-reduce, which cannot
+            # start before the G backward is done
+            w2 = self._allreduce(self.D.flat.g)
         fn["g_bwd"]()
         w1 = self._allreduce(self.G.flat.g)
         with torch.cuda.stream(sB):
-            w2 = self._allreduce(self.D.flat.g)
             if w2 is not None:
                 w2.wait()          # (RCCL: makes lane B's stream wait, no host block)
             fn["update_d"]()

@@ -88,14 +88,29 @@ def get_step(generator_F, discriminator_F, B, T, h, args, device, dtype_t=None, 
            id(getattr(args, "tg_vgg", None)) if float(getattr(args, "vgg_scaling", -1.0)) > 0.0 else None)
     st = _STEPS.get(key)
     if st is None:
+        for old in _STEPS.values():  # one live configuration: activation buffers are large - the old step's buffer sets are
+            old.close()              # released BEFORE the new step allocates its own
+        _STEPS.clear()
         pg, world = parallel.dist_info()
         st = TecoGANStep(Ge, De, B, T, h, args, device, use_graph=use_graph, process_group=pg, world_size=world)
-        for old in _STEPS.values():  # one live configuration: activation buffers are large
-            old.close()
-        _STEPS.clear()
         _STEPS[key] = st
         _apply_scaler(st)
     return st
+
+
+def sync_optimizer_steps(optimizer_g, optimizer_d):
+    """fp16 mode: Adam's `step` as torch counts it.  The host counts calls; an update skipped on overflow is counted on the
+    device (tg_scaler_update) and subtracted inside tg_adam_scaled, because GradScaler.step() does not call
+    optimizer.step() then (code/train.py:337,341).  Before optimizer.state_dict() is written the two are merged: the skip
+    counts move from the device into the optimisers' step tensors.  Synchronises; no-op outside fp16 mode."""
+    for st in _STEPS.values():
+        if st.scaler is None:
+            continue
+        skipped = st.scaler[5:7].cpu()
+        for opt, k in ((optimizer_g, 0), (optimizer_d, 1)):
+            if getattr(opt, "_tg_step", None) is not None and float(skipped[k]) != 0.0:
+                opt._tg_step -= float(skipped[k])
+        st.scaler[5:7].zero_()
 
 
 def TecoGAN(r_inputs, r_targets, discriminator_F, generator_F, args, Global_step, counter1, counter2, optimizer_g,

@@ -1,7 +1,8 @@
 """Data-parallel step with TWO ranks on the one GPU of the test box (gloo rendezvous, device buffers staged through the
 host; RCCL refuses two ranks per device).  This is the first place where world_size > 1 meets the real step: 1/world in
-tg_adam (hyper[6] = 0.5), the collectives between the per-lane hipGraphs, replica bit-equality, and main.py's broadcast /
-DistributedSampler path."""
+tg_adam (hyper[6] = 0.5), the collectives between the per-lane hipGraphs - issued ASYNCHRONOUSLY between the replays
+(parallel._StagedWork: device-to-host copy on the issuing stream, host reduction on a worker thread, joined at wait()), the
+interleave RCCL's async_op has with 8 ranks -, replica bit-equality, and main.py's broadcast / DistributedSampler path."""
 import json
 import os
 import subprocess
@@ -12,6 +13,15 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def _launch(script_args, port, env_extra, cwd, timeout=900):
@@ -28,7 +38,7 @@ def _launch(script_args, port, env_extra, cwd, timeout=900):
 @pytest.mark.timeout(1200)
 def test_two_rank_step_equals_two_shards_with_local_bn_and_averaged_gradients(tmp_path):
     out = tmp_path / "dp"
-    r = _launch([os.path.join(ROOT, "tests", "dp_worker.py"), str(out)], 29541, {}, ROOT)
+    r = _launch([os.path.join(ROOT, "tests", "dp_worker.py"), str(out)], _free_port(), {}, ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     res = [json.load(open(f"{out}.{k}")) for k in range(2)]
     for x in res:
@@ -51,7 +61,7 @@ def test_main_py_two_ranks_broadcast_sampler_and_replica_check(tmp_path):
     broadcast, the DistributedSampler halves the 16 synthetic sequences (2 steps of 4 per rank), rank 0 writes the
     checkpoints and the end-of-epoch replica check passes."""
     r = _launch([os.path.join(ROOT, "main.py"), "--synthetic", "16", "--max_epochs", "1", "--tg_dtype", "bf16",
-                 "--num_resblock", "2", "--discrim_resblocks", "1"], 29543, {"TECOGAN_DIST_BACKEND": "gloo"}, str(tmp_path))
+                 "--num_resblock", "2", "--discrim_resblocks", "1"], _free_port(), {"TECOGAN_DIST_BACKEND": "gloo"}, str(tmp_path))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "replica check ok (2 ranks)" in r.stdout, r.stdout[-1500:]
     g_ck = torch.load(tmp_path / "generator.pt")

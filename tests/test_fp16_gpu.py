@@ -186,7 +186,47 @@ def test_fp16_overflow_skips_both_updates_and_backs_the_scale_off(monkeypatch):
     assert not torch.equal(torch.cat([p.detach().flatten() for p in G.parameters()]), w0)   # and training resumed
     assert bool(torch.isfinite(torch.cat([p.detach().flatten() for p in D.parameters()])).all())
     assert np.isfinite(float(out.gen_loss)) and np.isfinite(float(out.d_loss))
+    # Adam's step count is torch's: GradScaler.step() does not call optimizer.step() on overflow (code/train.py:337,341).
+    # 41 calls; the skipped ones were counted on the device and are merged into optimizer.state['step'] for the checkpoint
+    skipped = st.scaler[5:7].cpu()
+    assert float(skipped[0]) >= 1.0 and float(skipped[1]) >= 1.0, skipped
+    assert float(og._tg_step) == 41.0 and float(od._tg_step) == 41.0
+    hip_train.sync_optimizer_steps(og, od)
+    assert float(og.state_dict()["state"][0]["step"]) == 41.0 - float(skipped[0])
+    assert float(od.state_dict()["state"][0]["step"]) == 41.0 - float(skipped[1])
+    assert float(st.scaler[5:7].abs().sum()) == 0.0      # merged: the device counters start again at zero
     hip_train._STEPS.clear()
+
+
+def test_adam_scaled_bias_correction_counts_only_the_updates_taken():
+    """tg_adam_scaled with `skipped` updates on the device counter: the host says t = 2 + skipped calls, the update must be
+    torch.optim.Adam's step 2 (bias corrections 1 - beta^2), and a set found_inf flag leaves everything untouched."""
+    rng = np.random.default_rng(3)
+    p0 = torch.from_numpy(rng.standard_normal(2051).astype(np.float32))
+    g = torch.from_numpy(rng.standard_normal((2, 2051)).astype(np.float32))
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], 1e-3, betas=(0.9, 0.999), eps=1e-8)
+    pd, m, v = p0.to(DEV), torch.zeros(2051, device=DEV), torch.zeros(2051, device=DEV)
+    S = 1024.0
+    sc = torch.tensor([S, 0.0, 0.0, 0.0, 1.0 / S, 0.0, 0.0, 0.0], device=DEV)
+    hy = lambda t: torch.tensor(K.adam_hyper(1e-3, 0.9, 0.999, 1e-8, t), device=DEV)  # noqa: E731
+    pt.grad = g[0]
+    opt.step()
+    K.adam(pd, (g[0] * S).to(DEV), m, v, hy(1), scaler=sc, which=0)            # call 1: taken
+    sc[2] = 1.0
+    before = pd.clone()
+    for t in (2, 3, 4):                                                          # calls 2-4: overflow, skipped
+        K.adam(pd, torch.full((2051,), float("inf"), device=DEV), m, v, hy(t), scaler=sc, which=0)
+    assert torch.equal(pd, before)
+    sc[2], sc[5] = 0.0, 3.0                                                      # (what three tg_scaler_update calls leave)
+    pt.grad = g[1]
+    opt.step()
+    K.adam(pd, (g[1] * S).to(DEV), m, v, hy(5), scaler=sc, which=0)            # call 5 = torch's step 2
+    torch.testing.assert_close(pd.cpu(), pt.detach(), rtol=1e-5, atol=5e-7)
+    # and the counter itself: update() of a step whose generator overflowed
+    st = torch.tensor([S, 5.0, 1.0, 0.0, 1.0 / S, 3.0, 0.0, 0.0], device=DEV)
+    K.scaler_update(st)
+    assert st.cpu().tolist() == [S / 2, 1.0, 0.0, 0.0, 2.0 / S, 4.0, 0.0, 0.0]
 
 
 def test_fp16_generator_inference_matches_fp32_oracle():

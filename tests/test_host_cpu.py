@@ -374,3 +374,27 @@ def test_persistent_workgroup_caps_defaults_and_overrides(monkeypatch):
     assert K.wgrad_plan(1, 8, 8, 1, 9, 64, 64, cap=160)[0] >= 1            # never zero splits
     monkeypatch.delenv("TECOGAN_PERSIST_WGS")
     importlib.reload(K)
+
+
+def test_bench_launch_logic_spawns_its_ranks_and_refuses_mismatches():
+    """bench.py --gpus N with no RANK in the environment starts N ranks itself (torch.distributed.run children, before any
+    GPU call) - here with --dry: gloo rendezvous on the CPU, barrier, max-over-ranks reduce, the line's n_gpus taken from the
+    process group.  Without --dry this box has no GPU: `--gpus 2` must fail loudly instead of printing a 1-GPU line, and so
+    must a launcher whose WORLD_SIZE differs from --gpus."""
+    import json
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["pg_world_size"] == 2 and line["config"] == {"parallelism": "dp2", "global_batch": 8}
+    r = subprocess.run([sys.executable, bench, "--dry"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode != 0 and "2 GPUs requested" in r.stderr and "{" not in r.stdout, (r.stdout, r.stderr[-500:])
+    r = subprocess.run([sys.executable, bench, "--gpus", "1", "--dry"], capture_output=True, text=True, timeout=120,
+                       env=dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in r.stderr

@@ -389,15 +389,39 @@ def test_main_entry_point_synthetic_train_and_resume(tmp_path, monkeypatch):
     assert float(g2["optimizer_state_dict"]["state"][0]["step"]) == 3.0
 
 
-def test_data_parallel_segments_on_one_gpu(tmp_path):
-    """The 8-GPU run is the driver's; here the same code path (torch.distributed.run, RCCL process group, the three
-    graph segments with the all-reduces between them) is exercised with ONE rank and must reproduce the single-process
-    losses."""
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_refuses_more_gpus_than_are_visible():
+    """`python bench.py --gpus 2` on a one-GPU box must fail loudly - not print a dp1 line; a launcher
+    that started another number of ranks than --gpus says is refused as well."""
+    import subprocess
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "2 GPUs requested, 1 visible" in r.stderr, (r.returncode, r.stderr[-500:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in r.stderr, (r.returncode, r.stderr[-500:])
+
+
+def test_data_parallel_collectives_on_one_gpu(tmp_path):
+    """The 8-GPU run is the driver's; here the same code path (torch.distributed.run, RCCL process group, the two
+    asynchronous all-reduces issued between the per-lane graph replays - TecoGANStep._run_lanes) is exercised with ONE rank
+    (TECOGAN_FORCE_COLLECTIVES=1 issues them although world == 1) and must reproduce the single-process losses."""
     import json
     import subprocess
-    env = dict(os.environ, TECOGAN_FORCE_DP_SEGMENTS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, TECOGAN_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
            "--warmup", "2", "--no-cpu-baseline", "--no-roofline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -406,7 +430,8 @@ def test_data_parallel_segments_on_one_gpu(tmp_path):
                          "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r2.returncode == 0, r2.stderr[-2000:]
     sp = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
-    assert dp["n_gpus"] == 1 and dp["config"]["parallelism"] == "dp1"
+    assert dp["n_gpus"] == 1 and dp["config"]["parallelism"] == "dp1" and dp["pg_world_size"] == 1 and dp["pg_backend"] == "nccl"
+    assert sp["pg_backend"] is None
     np.testing.assert_allclose(dp["final_losses"]["gen_loss"], sp["final_losses"]["gen_loss"], rtol=2e-3)
     np.testing.assert_allclose(dp["final_losses"]["d_loss"], sp["final_losses"]["d_loss"], rtol=5e-2, atol=2e-3)
 
