@@ -185,22 +185,26 @@ def roofline_pass(st, dtype):
     rb_fl = lambda x, *a, **k: 2 * 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * 9 * x.shape[3] * x.shape[3]  # noqa: E731
     wrap(K, "resblock_fwd", lambda *a, **k: "resblock_kernel<false>", rb_fl, "mfma")
     wrap(K, "resblock_bwd", lambda *a, **k: "resblock_kernel<true>", rb_fl, "mfma")
-    orig_group = E.WgradGroup.launch
-    saved.append((E.WgradGroup, "launch", orig_group))
+    def time_group(cls, label):
+        orig_group = cls.launch
+        saved.append((cls, "launch", orig_group))
 
-    def group_timed(self):
-        items = list(self.items)
-        orig_group(self)
-        if not items:
-            return
-        fl = sum(conv_flops(c.spec, x.shape[0], x.shape[1], x.shape[2]) for c, x, _, _ in items)
-
-        def again():
-            for it in items:
-                self.add(*it)
+        def group_timed(self):
+            items = list(self.items)
             orig_group(self)
-        record(f"wgrad_kernel<{T16}, 9, 9, ..> (tg_wgrad_multi, {len(items)} layers)", fl, again, "mfma")
-    E.WgradGroup.launch = group_timed
+            if not items:
+                return
+            fl = sum(conv_flops(c.spec, x.shape[0], x.shape[1], x.shape[2]) for c, x, _, _ in items)
+
+            def again():
+                self.items = list(items)
+                orig_group(self)
+            record(label(items), fl, again, "mfma")
+        cls.launch = group_timed
+    time_group(E.WgradGroup, lambda items: f"wgrad_kernel<{T16}, 9, 9, ..> (tg_wgrad_multi, {len(items)} layers)")
+    # the work-list launch (csrc/wgrad_group.hip): one rocprofv3 row per tile width; bracketed per call site
+    time_group(E.WgradList, lambda items: f"wgrad_group_kernel<{T16}, {32 if max(x.shape[2] for _, x, _, _ in items) > 16 else 16}> "
+                                          f"(tg_wgrad_group, {len(items)} layers of {items[0][1].shape[1]}x{items[0][1].shape[2]}..)")
 
     # ---- HBM-bound launches: algorithmic bytes = every tensor the op must read + write once
     wrap(K, "bn_apply", lambda *a, **k: f"bn_apply_kernel<{T16}>",
@@ -223,7 +227,10 @@ def roofline_pass(st, dtype):
     wrap(K, "absdiff_sum", lambda *a, **k: f"absdiff_sum_kernel<{T16}>", lambda a_, b_, *r, **k: nb(a_, b_), "hbm")
 
     def fold_bytes(self):
-        jobs = [c.fin_job for c in self.convs if c.fin_job is not None]
+        jobs = []
+        for c in self.convs:
+            if c.fin_job is not None:  # one fold job per conv, or one per 64 x 64 channel block (engine.WgradList)
+                jobs += c.fin_job if isinstance(c.fin_job[0], list) else [c.fin_job]
         return float(sum(j[4] * j[11] * 4 + j[5] * j[8] * j[9] * 4 for j in jobs))  # slabs read + gradient written
     wrap(E.Finalizer, "run", lambda self: "wgrad_finalize_multi_kernel", fold_bytes, "hbm")
     try:
@@ -424,13 +431,14 @@ def main():
                                "avg_launch_gflop": round(d["work"] / d["launches"] / 1e9, 3),
                                # rocprofv3 lists the 9-tap weight-gradient kernel as ONE row (single-layer and grouped launches
                                # are the same instantiation); bracketed here as three families - their sum, for comparison
-                               "also": (lambda ws: {"kernel": "wgrad_kernel<.., 9, 9, ..> (single-layer + grouped launches)",
+                               "also": (lambda ws: {"kernel": "9-tap weight gradients: wgrad_group_kernel (work-list launches) + wgrad_kernel<.., 9, 9, ..>",
                                                     "launches_per_step": sum(v["launches"] for v in ws),
                                                     "ms": round(sum(v["ms"] for v in ws), 3),
                                                     "achieved": round(sum(v["work"] for v in ws) / (sum(v["ms"] for v in ws) * 1e-3) / 1e12, 2),
                                                     "frac": round(sum(v["work"] for v in ws) / (sum(v["ms"] for v in ws) * 1e-3) / 1e12
                                                                   / MFMA_PEAK_TFLOPS[a.dtype], 5)} if ws else None)(
-                                   [v for k, v in fam.items() if k.startswith("wgrad_kernel<") and ", 9, " in k]),
+                                   [v for k, v in fam.items() if (k.startswith("wgrad_kernel<") and ", 9, " in k) or
+                                    k.startswith("wgrad_group_kernel<")]),
                                "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                                 "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
                                                 "mfma_busy_pct": busy(k)}

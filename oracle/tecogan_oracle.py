@@ -495,10 +495,21 @@ def tecogan_forward(gp, dp, dbufs, x, y, args, global_step, counter1=0.0, counte
     B = x.shape[0]
     h = args.crop_size
     H = 4 * h
-    flow = pseudo_flow(x, getattr(args, "tg_fnet_params", None))
     lr_prev = x[:, :-1].reshape(B * (T - 1), 3, h, h)
     lr_next = x[:, 1:].reshape(B * (T - 1), 3, h, h)
-    lr_warp = warp(lr_prev, x[:, 1:, 0:2].reshape(B * (T - 1), h, h, 2))
+    fnet_params = getattr(args, "tg_fnet_params", None)
+    if fnet_params is not None and bool(getattr(args, "tg_fnet_train", False)):
+        # Opt-in, parity unpinned (DESIGN.md "FNet training"): the estimator is TRAINED, wired the way the
+        # reference's dead code hints (main.py:231,244-245; code/train.py:343-346: a third optimiser stepping on fnet_loss).
+        # Every generator input is detached (code/train.py:90,108), so the only term of fnet_loss that reaches the estimator
+        # is the LR warp loss of code/train.py:78-84,247-249 - with the estimator's output in the place of the raw next frame
+        # as the sampling grid (the same (2,h,w) -> (h,w,2) reinterpretation the reference applies to every flow block).
+        fx = fnet_forward(fnet_params, lr_prev)
+        flow = up4(fx.detach() * 4.0).reshape(B, T - 1, 2, H, H)
+        lr_warp = warp(lr_prev, as_grid(fx))
+    else:
+        flow = pseudo_flow(x, fnet_params)
+        lr_warp = warp(lr_prev, x[:, 1:, 0:2].reshape(B * (T - 1), h, h, 2))
     gen = recurrent_generator(gp, x, flow, int(args.num_resblock))
     s_gen = gen.reshape(B * T, 3, H, H)
     s_tgt = y.reshape(B * T, 3, H, H)
@@ -575,25 +586,31 @@ def tecogan_forward(gp, dp, dbufs, x, y, args, global_step, counter1=0.0, counte
     return dict(gen=gen, flow=flow, lr_warp=lr_warp, t_vel=t_vel, real_in=real_in, fake_in=fake_in,
                 p_real=p_real, p_fake=p_fake, L_real=L_real, L_fake=L_fake, content=content, gen_loss=total,
                 d_loss=d_loss, tb=tb, update_list=vals, update_list_name=names_avg, update_list_avg=avg,
-                global_step=global_step, pp=pp)
+                global_step=global_step, pp=pp, warp_loss=warp_loss)
 
 
 def tecogan_step(gp, dp, dbufs, opt_g, opt_d, x, y, args, global_step, counter1=0.0, counter2=0.0,
-                 return_grads=False):
-    """One full step (forward, both backward passes, both Adam updates), in place on gp/dp/dbufs/opt_*."""
-    for t in list(gp.values()) + list(dp.values()):
+                 return_grads=False, opt_f=None):
+    """One full step (forward, both backward passes, both Adam updates), in place on gp/dp/dbufs/opt_*.
+    opt_f (with args.tg_fnet_params and args.tg_fnet_train): the estimator's Adam, stepping on the LR warp loss."""
+    fp = getattr(args, "tg_fnet_params", None) if (opt_f is not None and getattr(args, "tg_fnet_train", False)) else None
+    for t in list(gp.values()) + list(dp.values()) + (list(fp.values()) if fp else []):
         t.requires_grad_(True)
         t.grad = None
     f = tecogan_forward(gp, dp, dbufs, x, y, args, global_step, counter1, counter2)
     g_grads = torch.autograd.grad(f["gen_loss"], list(gp.values()), retain_graph=True, allow_unused=True)
-    d_grads = torch.autograd.grad(f["d_loss"], list(dp.values()), allow_unused=True)
-    for t in list(gp.values()) + list(dp.values()):
+    d_grads = torch.autograd.grad(f["d_loss"], list(dp.values()), allow_unused=True, retain_graph=fp is not None)
+    f_grads = torch.autograd.grad(f["warp_loss"], list(fp.values()), allow_unused=True) if fp else None
+    for t in list(gp.values()) + list(dp.values()) + (list(fp.values()) if fp else []):
         t.requires_grad_(False)
     gg = dict(zip(gp.keys(), g_grads))
     dg = dict(zip(dp.keys(), d_grads))
     with torch.no_grad():
         opt_g.step(gp, gg)
         opt_d.step(dp, dg)
+        if fp:
+            f["fnet_grads"] = dict(zip(fp.keys(), f_grads))
+            opt_f.step(fp, f["fnet_grads"])
     net = Network(gen_output=f["gen"].detach(), learning_rate=args.learning_rate,
                   update_list=[v.detach() for v in f["update_list"]], update_list_name=f["update_list_name"],
                   update_list_avg=f["update_list_avg"], global_step=f["global_step"], d_loss=f["d_loss"].detach(),

@@ -55,6 +55,8 @@ _PROTOS = {
     "tg_wgrad_slab_floats": (_L, [C.POINTER(WgradDesc)]),
     "tg_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P]),
     "tg_wgrad_multi": (_I, [C.POINTER(WgradDesc), _P, _I, _P]),
+    "tg_wgrad_group_slot_floats": (_L, []),
+    "tg_wgrad_group": (_I, [_I, _I, _P, _I, _I, _I, _P, _P]),
     "tg_wgrad_finalize": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _L, _L, _P, _I, _P, _L, _P]),
     "tg_wgrad_finalize_multi": (_I, [_P, _I, _I, _P]),
     "tg_nchw_to_nhwc": (_I, [_I, _P, _L, _P, _I, _I, _I, _I, _I, _P]),

@@ -4,11 +4,11 @@ set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-for f in conv_mfma wgrad_mfma warp elementwise fnet resblock convt_mfma conv4s2_mfma runtime conv3_rw vgg conv_rgb; do
+for f in conv_mfma wgrad_mfma wgrad_group warp elementwise fnet resblock convt_mfma conv4s2_mfma runtime conv3_rw vgg conv_rgb; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ ../../include/tecogan_hip.h -nt $f.o ]; then
     $HIPCC $FLAGS "$@" -c $f.hip -o $f.o &
   fi
 done
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libtecogan_hip.so conv_mfma.o wgrad_mfma.o warp.o elementwise.o fnet.o resblock.o convt_mfma.o conv4s2_mfma.o runtime.o conv3_rw.o vgg.o conv_rgb.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libtecogan_hip.so conv_mfma.o wgrad_mfma.o wgrad_group.o warp.o elementwise.o fnet.o resblock.o convt_mfma.o conv4s2_mfma.o runtime.o conv3_rw.o vgg.o conv_rgb.o
 echo "built $(pwd)/libtecogan_hip.so"

@@ -1,0 +1,310 @@
+// Weight gradients of MANY 3x3 stride-1 convolutions in ONE persistent launch (16-bit element types):
+//
+//   dW_j[t][a][b] = sum over (n, y, x) of  X_j[n, y + dy[t], x + dx[t]][a] * Y_j[n, y, x][b]        (zero padding)
+//
+// for a list of jobs j of possibly different image size and channel counts (the generator's 39 plain 3x3 layers, the
+// 8 residual convs of a discriminator stage ...).  The unit of work is (job, 64x64 channel block, 128-pixel tile); the
+// units of all jobs form one list, and workgroup w takes the contiguous range [w * per, (w + 1) * per) of it.  A
+// workgroup keeps the partial dW of its current (job, block) in accumulators and writes one fp32 slab whenever its
+// range leaves that block - so the number of slabs is  workgroups + channel blocks  instead of
+// launches x workgroups (tg_wgrad writes one slab per workgroup and LAUNCH: 23.5 MB per layer at 160 workgroups;
+// 10 generator layers wrote - and the fold read back - 235 MB per step, this launch 47 MB).  Slab slot of a
+// segment = workgroup index + global ordinal of the channel block, so the slots of one block are contiguous and
+// tg_wgrad_finalize_multi folds them unchanged (one fold job per channel block).
+//
+// Inside a tile the structure follows wgrad_mfma.hip - both MFMA operands are transposed reads
+// (ds_read_b64_tr_b16) of [pixel][channel] LDS images - with the staging rebuilt around it:
+//   * LDS-DMA (global_load_lds_dwordx4) fills the images: no staging registers, no ds_write pass (930 of 7440 cycles
+//     per tile in the register-staged kernel, tools/stamp_wgrad.py), and the loads of tile i+1 are issued into the
+//     second LDS buffer at the head of tile i's k-loop: ONE barrier per tile, the matrix pipe never waits for a store
+//     pass.  Out-of-image pixels read a 16-byte page of zeros.
+//   * the images are unpadded 128-byte rows (DMA writes 1 KiB per wave-instruction, lane-linear) whose 32-byte
+//     segment index is XOR-ed with bits 1-2 of the pixel's COLUMN (X) / row (Y): a 32-lane group of a transposed read
+//     takes 32 bytes of each of 8 consecutive pixels -> 8 distinct segments of the 256-byte bank window at any tap
+//     shift.  The swizzle lives on the DMA's per-lane SOURCE address.
+//   * the key depends on the column only and every tile geometry is a template parameter, so the whole k-loop reads
+//     through 3 (X: one per column tap) + 2 (Y) lane addresses with immediate offsets: no address arithmetic in the
+//     loop (the old k-loop spent 4 v_mad_u64 + 26 v_add per 18 MFMAs and waited lgkmcnt(0) in front of every pair).
+//
+// Replaces aten::convolution_backward (weight path) behind code/train.py:336,340 for the layers of
+// code/models.py:54-58,68-76 (generator) and :90-94 (discriminator residual blocks).
+#include "common.h"
+
+namespace {
+
+constexpr int GJ = 12;  // int64 per job row (include/tecogan_hip.h, tg_wgrad_group)
+
+struct WgGroupK {
+  const long long* jobs;
+  float* slab;
+  int njobs, units_total, per_wg;
+};
+
+// 16 bytes of zeros: the DMA source of every out-of-image piece
+__device__ __attribute__((aligned(16))) unsigned int tg_wg_zero_page[4];
+
+// One LDS-DMA wave-instruction: lane l's 16 bytes at `gsrc` land at LDS byte address lds_dst + 16 * l (lds_dst wave-uniform,
+// in M0).  Inline asm on purpose: hipcc orders every ds_read behind ALL outstanding LDS-DMA it knows of (s_waitcnt vmcnt(0)
+// in front of the k-loop, which drains the prefetch of the next tile); an asm load is absent from its bookkeeping, so the
+// kernel counts it itself - dma_wait() in front of the barrier that precedes the reads.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+constexpr int kSlot = 9 * 64 * 64 + 64;  // floats per slab slot: [9][64][64] + channel sums of Y
+
+template <typename T, int TW>
+__global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
+  constexpr int TH = 128 / TW, IW = TW + 2, IH = TH + 2, XROWS = IW * IH;
+  constexpr int XCH = (XROWS * 128 + 1023) / 1024;  // 1-KiB chunks of the X image (26 for 34 x 6, 23 for 18 x 10)
+  constexpr int YCH = 16;                           // Y image: 128 pixels x 128 bytes
+  constexpr int XCW = (XCH + 7) / 8;                // chunks per wave
+  constexpr int XBYTES = XCH * 1024, BUF = XBYTES + YCH * 1024;
+  constexpr int HI = (TW == 32) ? 16 * 128 : IW * 128;  // pixel k + 16: 16 columns further (TW 32) / one patch row down (TW 16)
+  constexpr int SROW = (TW == 32) ? 1 : 2;              // patch rows per 32-pixel k-step
+  static_assert(IW % 2 == 0, "the swizzle key needs an even patch pitch");
+
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // two buffers of BUF bytes
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wa = wid & 3, wb = wid >> 2;
+  const int idx = lane & 15, g = lane >> 4, q = idx >> 2, pp = idx & 3;
+
+  int u = blockIdx.x * p.per_wg;
+  const int u_end = min(u + p.per_wg, p.units_total);
+  if (u >= u_end) return;
+
+  // ---- lane constants of the fragment reads (tile- and job-independent)
+  // X: pixel (ty, tx) of the tile under tap (dy', dx') sits in patch row (ty + dy') * IW + tx + dx'; lane k = 4g + q
+  int xa[3], ya[2];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int px = 4 * g + q + d;
+    xa[d] = px * 128 + ((wa ^ ((px >> 1) & 3)) * 32) + 8 * pp;
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int k = 4 * g + q;
+    ya[b] = XBYTES + k * 128 + (((wb * 2 + b) ^ ((k >> 1) & 3)) * 32) + 8 * pp;
+  }
+  // ---- lane constants of the DMA: chunk c of a wave covers image rows 8 * chunk + lane / 8, physical piece lane % 8
+  const int jp = lane & 7, r8 = lane >> 3;
+  int xpy[XCW], xpx[XCW], xch[XCW];  // patch row / column of my piece, byte offset of its channels in the pixel
+#pragma unroll
+  for (int c = 0; c < XCW; ++c) {
+    const int row = (wid + 8 * c) * 8 + r8;
+    const int py = row / IW, px = row - py * IW;
+    xpy[c] = row < XROWS ? py : -100000;  // rows behind the image (last chunk) load zeros
+    xpx[c] = px;
+    xch[c] = ((((jp >> 1) ^ ((px >> 1) & 3)) * 2) + (jp & 1)) * 16;
+  }
+  int yty[2], ytx[2], ych[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int k = (wid + 8 * c) * 8 + r8;
+    yty[c] = k / TW;
+    ytx[c] = k - yty[c] * TW;
+    ych[c] = ((((jp >> 1) ^ ((k >> 1) & 3)) * 2) + (jp & 1)) * 16;
+  }
+  const char* zero = reinterpret_cast<const char*>(tg_wg_zero_page);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+
+  f32x4 acc[9][2];
+  constexpr int E = 8;
+  float bsum[E];
+
+  // ---- job lookup
+  int job = 0;
+  while (job + 1 < p.njobs && (int)p.jobs[GJ * (job + 1) + 2] <= u) ++job;
+
+  while (u < u_end) {
+    const long long* jr = p.jobs + GJ * job;
+    const char* xbase = reinterpret_cast<const char*>(jr[0]);
+    const char* ybase = reinterpret_cast<const char*>(jr[1]);
+    const int ubeg = (int)jr[2], N = (int)jr[3], H = (int)jr[4], W = (int)jr[5], Cx = (int)jr[6], Cy = (int)jr[7];
+    const int tiles_x = (int)jr[8], tiles_y = (int)jr[9], want_ysum = (int)jr[10], gb0 = (int)jr[11];
+    const int tiles = tiles_x * tiles_y * N;
+    const int b_blocks = Cy >> 6, blocks = (Cx >> 6) * b_blocks;
+    const int local = u - ubeg;
+    const int blk = local / tiles;
+    int tile = local - blk * tiles;
+    const int seg_n = min(u_end - u, tiles - tile);  // tiles of this segment
+    const int a0 = (blk / b_blocks) * 64, b0 = (blk % b_blocks) * 64;
+    const bool ysum = want_ysum && a0 == 0;
+    const int xpixb = Cx * 2, ypixb = Cy * 2;
+
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) bsum[e] = 0.f;
+
+    // per-segment DMA constants: byte offset of my pieces relative to the patch / tile origin (32-bit: patch-relative)
+    int xrel[XCW], yrel[2];
+#pragma unroll
+    for (int c = 0; c < XCW; ++c) xrel[c] = (max(xpy[c], 0) * W + xpx[c]) * xpixb + xch[c];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) yrel[c] = (yty[c] * W + ytx[c]) * ypixb + ych[c];
+    // coordinates of the next tile to issue, advanced incrementally (no division per tile)
+    int i_txb, i_tyb, i_n;
+    {
+      int r = tile;
+      i_txb = r % tiles_x;
+      r /= tiles_x;
+      i_tyb = r % tiles_y;
+      i_n = r / tiles_y;
+    }
+
+    auto issue = [&](int bufoff) {
+      const int ty0 = i_tyb * TH, tx0 = i_txb * TW;
+      const long long npix = (long long)i_n * H * W;
+      const char* xo = xbase + (npix + (long long)(ty0 - 1) * W + (tx0 - 1)) * xpixb + a0 * 2;
+      const unsigned lx = lds0 + bufoff;
+#pragma unroll
+      for (int c = 0; c < XCW; ++c) {
+        if (wid_u + 8 * c < XCH) {  // wave-uniform
+          const int iy = ty0 - 1 + xpy[c], ix = tx0 - 1 + xpx[c];
+          const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+          glds16(ok ? xo + xrel[c] : zero, lx + (wid_u + 8 * c) * 1024);
+        }
+      }
+      const char* yo = ybase + (npix + (long long)ty0 * W + tx0) * ypixb + b0 * 2;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const bool ok = ty0 + yty[c] < H && tx0 + ytx[c] < W;
+        glds16(ok ? yo + yrel[c] : zero, lx + XBYTES + (wid_u + 8 * c) * 1024);
+      }
+      if (++i_txb == tiles_x) {
+        i_txb = 0;
+        if (++i_tyb == tiles_y) {
+          i_tyb = 0;
+          ++i_n;
+        }
+      }
+    };
+
+    int buf = 0;
+    issue(0);
+    for (int i = 0; i < seg_n; ++i, ++tile) {
+      // my DMA pieces of this tile have landed (vmcnt) and every wave is past the previous tile's reads (barrier)
+      dma_wait();
+      __syncthreads();
+      const int bo = buf * BUF;
+      if (i + 1 < seg_n) issue(BUF - bo);
+      if (ysum) {
+        // bias gradient = sum over pixels of Y: thread (row r0 = tid / 8 [+ 64], logical piece tid % 8) adds its 8 channels
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int k = (tid >> 3) + 64 * h, lp = tid & 7;
+          const int phys = ((((lp >> 1) ^ ((k >> 1) & 3)) * 2) + (lp & 1)) * 16;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(smem + bo + XBYTES + k * 128 + phys);
+          float f[8];
+          Vec<T>::load(&v, f);
+#pragma unroll
+          for (int e = 0; e < E; ++e) bsum[e] += f[e];
+        }
+      }
+      const char* base = smem + bo;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 bfr[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const char* yp = base + ya[b] + s * 32 * 128;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(yp));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(yp + 16 * 128));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 cat = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          bfr[b] = __builtin_bit_cast(bf16x8, cat);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int dy = t / 3, dx = t % 3;
+          const char* xp = base + xa[dx] + (s * SROW + dy) * IW * 128;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xp));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xp + HI));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 cat = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const bf16x8 af = __builtin_bit_cast(bf16x8, cat);
+          acc[t][0] = Mma16<T>::run(af, bfr[0], acc[t][0]);
+          acc[t][1] = Mma16<T>::run(af, bfr[1], acc[t][1]);
+        }
+      }
+      buf ^= 1;
+    }
+
+    // ---- the segment's partial dW -> slab slot (workgroup + global ordinal of the channel block)
+    float* slab = p.slab + (size_t)(blockIdx.x + gb0 + blk) * kSlot;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int bch = (wb * 2 + b) * 16 + idx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) slab[(t * 64 + wa * 16 + 4 * g + j) * 64 + bch] = acc[t][b][j];
+      }
+    __syncthreads();  // every wave is done with the LDS images (the next segment's DMA, or the sums below, overwrite them)
+    if (want_ysum) {
+      float* red = reinterpret_cast<float*>(smem);  // [64 rows][64 channels]
+      if (ysum) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) red[(tid >> 3) * 64 + (tid & 7) * 8 + e] = bsum[e];
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float s = 0.f;
+        if (ysum)
+          for (int r = 0; r < 64; ++r) s += red[r * 64 + tid];
+        slab[9 * 64 * 64 + tid] = s;  // blocks with a0 != 0 write zeros: the fold reads the sums of block row 0 only
+      }
+      __syncthreads();
+    }
+    u += seg_n;
+    if (u < u_end && u >= ubeg + blocks * tiles) ++job;  // (a segment never crosses a job; ranges may)
+  }
+}
+
+template <typename T, int TW>
+int launch_group(const WgGroupK& k, int nwg, hipStream_t st) {
+  auto fn = wgrad_group_kernel<T, TW>;
+  constexpr int IW = TW + 2, IH = 128 / TW + 2;
+  constexpr int lds = 2 * (((IW * IH * 128 + 1023) / 1024) * 1024 + 16 * 1024);
+  static std::atomic<bool> attr_done{false};
+  if (!attr_done) {
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(512), lds, st, k);
+  return tg_launch_status();
+}
+
+}  // namespace
+
+extern "C" int64_t tg_wgrad_group_slot_floats(void) { return kSlot; }
+
+extern "C" int tg_wgrad_group(int dtype, int tile_w, const int64_t* jobs_dev, int njobs, int units_total, int workgroups,
+                              float* slab, void* stream) {
+  if (!jobs_dev || !slab || njobs <= 0 || units_total <= 0 || workgroups <= 0) return TG_E_BADARG;
+  if (!tg_aligned16(slab)) return TG_E_ALIGN;
+  if (dtype != TG_BF16 && dtype != TG_F16) return TG_E_UNSUPPORTED;
+  if (tile_w != 32 && tile_w != 16) return TG_E_UNSUPPORTED;
+  WgGroupK k;
+  k.jobs = reinterpret_cast<const long long*>(jobs_dev);
+  k.slab = slab;
+  k.njobs = njobs;
+  k.units_total = units_total;
+  k.per_wg = (units_total + workgroups - 1) / workgroups;
+  const int nwg = (units_total + k.per_wg - 1) / k.per_wg;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TG_BF16) return tile_w == 32 ? launch_group<BF16, 32>(k, nwg, st) : launch_group<BF16, 16>(k, nwg, st);
+  return tile_w == 32 ? launch_group<F16, 32>(k, nwg, st) : launch_group<F16, 16>(k, nwg, st);
+}

@@ -344,6 +344,94 @@ class WgradGroup:
         K.wgrad_multi(desc, jobs, len(fin))
 
 
+class WgradList:
+    """Weight gradients of several plain 3x3 layers - ANY mix of image sizes and channel counts - in ONE persistent launch
+    (tg_wgrad_group, csrc/wgrad_group.hip): the (layer, 64 x 64 channel block, 128-pixel tile) units of all layers form one
+    list that `cap` workgroups share evenly, so a step writes  workgroups + channel blocks  slabs per launch instead of
+    workgroups slabs per LAYER.  Same calling pattern as WgradGroup (add ... launch, deferred fold); layers the kernel
+    does not take (other kinds, channel counts not multiples of 64, fp32) run their own tg_wgrad launch at add()."""
+
+    def __init__(self, cap):
+        self.items, self.cache, self.cap = [], {}, cap
+
+    @staticmethod
+    def takes(conv):
+        return conv.spec.kind == "c3" and conv.dt in (torch.bfloat16, torch.float16) and conv.cin_p % 64 == 0 and \
+            conv.cout_p % 64 == 0 and conv.defer_finalize
+
+    def add(self, conv, x_in, dout, bias_sum=False):
+        if not self.takes(conv):
+            conv.wgrad(x_in, dout, bias_sum=bias_sum)
+            return
+        self.items.append((conv, x_in, dout, bias_sum))
+
+    @staticmethod
+    def plan(shapes, cap, slot):
+        """pure host logic (unit-tested on the CPU).  shapes: [(N, H, W, cx_p, cy_p)] -> (tile_w, job rows without the two
+        pointers, units_total, workgroups, [(job, a0, b0, first_slot, count)] per channel block, slots)"""
+        tw = 32 if max(s[2] for s in shapes) > 16 else 16
+        th = 128 // tw
+        rows, units, gb = [], 0, 0
+        spans = []
+        for j, (N, H, W, cx, cy) in enumerate(shapes):
+            tx, ty = (W + tw - 1) // tw, (H + th - 1) // th
+            tiles = N * tx * ty
+            blocks = (cx // 64) * (cy // 64)
+            rows.append([units, N, H, W, cx, cy, tx, ty, 0, gb])
+            for blk in range(blocks):
+                spans.append((j, (blk // (cy // 64)) * 64, (blk % (cy // 64)) * 64, units + blk * tiles, units + (blk + 1) * tiles))
+            units += blocks * tiles
+            gb += blocks
+        per = (units + cap - 1) // cap
+        nwg = (units + per - 1) // per
+        fold = []
+        for g, (j, a0, b0, beg, end) in enumerate(spans):
+            w0, w1 = beg // per, (end - 1) // per
+            fold.append((j, a0, b0, w0 + g, w1 - w0 + 1))
+        return tw, rows, units, nwg, fold, nwg + gb
+
+    def launch(self):
+        items, self.items = self.items, []
+        if not items:
+            return
+        key = tuple((id(c), x.data_ptr(), y.data_ptr(), tuple(x.shape), tuple(y.shape), b) for c, x, y, b in items)
+        ent = self.cache.get(key)
+        if ent is None:
+            if items[0][0].ws.frozen:
+                raise L.TecoganHipError("new wgrad shape after graph capture")
+            lib = L.load()
+            slot = int(lib.tg_wgrad_group_slot_floats())
+            shapes = [(x.shape[0], x.shape[1], x.shape[2], x.shape[3], y.shape[3]) for _, x, y, _ in items]
+            tw, rows, units, nwg, fold, slots = self.plan(shapes, self.cap, slot)
+            dev = items[0][1].device
+            slab = torch.empty(slots * slot, dtype=torch.float32, device=dev)
+            jobs = []
+            for (c, x, y, b), r in zip(items, rows):
+                if x.shape[:3] != y.shape[:3]:
+                    raise L.TecoganHipError("tg_wgrad_group needs stride-1 layers (X and Y of one size)")
+                r[8] = 1 if b else 0
+                jobs.append([x.data_ptr(), y.data_ptr()] + r)
+            fin = {}
+            for j, a0, b0, first, count in fold:
+                c, _, _, b = items[j]
+                _, _, taps, ca, cb, s_a, s_b = c.spec.wgrad_info()
+                bias = c.gbias.data_ptr() + 4 * b0 if (b and a0 == 0) else 0
+                fin.setdefault(j, []).append([slab.data_ptr() + 4 * slot * first, c.gw.data_ptr() + 4 * (a0 * s_a + b0 * s_b),
+                                              s_a, s_b, count, 9, 64, 64, min(64, ca - a0), min(64, cb - b0), bias, slot])
+            ent = (tw, torch.tensor(jobs, dtype=torch.int64, device=dev), units, nwg, slab, fin, K.tg_dtype(items[0][0].dt))
+            self.cache[key] = ent
+        tw, jobs, units, nwg, slab, fin, tg = ent
+        for j, (c, _, _, _) in enumerate(items):
+            c.fin_job = fin[j]   # a LIST of fold jobs (one per channel block): Finalizer.run flattens
+        L.check(L.load().tg_wgrad_group(tg, tw, jobs.data_ptr(), jobs.shape[0], units, nwg, slab.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), "tg_wgrad_group")
+
+
+def _wgrad_lists():
+    """TECOGAN_WGRAD_LIST=0: the per-layer / same-shape launches (tg_wgrad, tg_wgrad_multi) instead of tg_wgrad_group"""
+    return os.environ.get("TECOGAN_WGRAD_LIST", "1") != "0"
+
+
 class Repacker:
     """fp32 master weights -> packed compute copies (forward + dgrad) of every conv of a network in one launch."""
 
@@ -385,7 +473,10 @@ class Finalizer:
         """folds the slabs of the launches issued since the previous run (a network whose backward pass runs in two
         parts - the discriminator's real and fake halves - folds after each part; every distinct job set keeps its own
         device table, so nothing is rebuilt under graph capture)"""
-        jobs = [c.fin_job for c in self.convs if c.fin_job is not None]
+        jobs = []
+        for c in self.convs:
+            if c.fin_job is not None:  # one job, or one per channel block (WgradList)
+                jobs += c.fin_job if isinstance(c.fin_job[0], list) else [c.fin_job]
         key = tuple(tuple(j) for j in jobs)
         table = self.tables.get(key)
         if table is None:
@@ -499,6 +590,11 @@ class GeneratorEngine:
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
         self.trunk_group = WgradGroup() if os.environ.get("TECOGAN_WGRAD_GROUPS", "1") != "0" else None
+        # 16-bit modes: ONE work-list launch for the plain 3x3 layers of the up-sampling stage and one for the trunk
+        self.hr_list = None
+        if self.finalizer is not None and self.trunk_group is not None and _wgrad_lists() and \
+                dtype_t in (torch.bfloat16, torch.float16):
+            self.hr_list, self.trunk_group = WgradList(K.persist_wgs("G")), WgradList(K.persist_wgs("G"))
         self.fused_rb = dtype_t in (torch.bfloat16, torch.float16) and os.environ.get("TECOGAN_FUSED_RESBLOCK", "1") != "0"
         # the fused input-gradient launch (tg_resblock_bwd) is numerically identical and was measured EQUAL in time on the
         # batched backward (15 x 28.2 us vs 30 x 14.9 us at 40 samples: 640 workgroups each re-read 147 KB of weights), so
@@ -576,25 +672,32 @@ class GeneratorEngine:
         if dpre is not None:
             g["dpre"] = dpre
         RELU = L.MASK_RELU
+        # the plain 3x3 layers of the up-sampling stage share one work-list launch behind its input-gradient chain
+        # (hr_list; every gradient tensor has its own buffer); the other kinds launch where they stand
+        hr = self.hr_list
+        wh = (lambda c, x, y, b=False: hr.add(c, x, y, b)) if hr is not None else \
+            (lambda c, x, y, b=False: c.wgrad(x, y, bias_sum=b))
         self.cout.wgrad(a["u4"], g["dpre"])                         # output bias grad: see TecoGANStep
         # bias gradients of plain convs come out of their own wgrad launch (bias_sum): the output gradient is that
         # launch's Y operand, so its channel sums cost a few VALU adds there instead of an atomics epilogue here
         self.cout.dgrad(g["dpre"], g["hr64"], mask=a["u4"], mask_mode=RELU)
-        self.c6.wgrad(a["u3"], g["hr64"], bias_sum=True)
+        wh(self.c6, a["u3"], g["hr64"], True)
         self.c6.dgrad(g["hr64"], g["hr128"], mask=a["u3"], mask_mode=RELU, bias_grad_of=self.ct4)
         self.ct4.wgrad(a["u2"], g["hr128"])
         self.ct4.dgrad(g["hr128"], g["m128a"])
-        self.c32.wgrad(a["h2"], g["m128a"])
+        wh(self.c32, a["h2"], g["m128a"])
         self.c32.dgrad(g["m128a"], g["m128b"], mask=a["h2"], mask_mode=RELU)
-        self.c30.wgrad(a["u1"], g["m128b"], bias_sum=True)
+        wh(self.c30, a["u1"], g["m128b"], True)
         self.c30.dgrad(g["m128b"], g["m64a"])
-        self.c22.wgrad(a["hh"], g["m64a"])
+        wh(self.c22, a["hh"], g["m64a"])
         self.c22.dgrad(g["m64a"], g["m64b"], mask=a["hh"], mask_mode=RELU)
-        self.c20.wgrad(a["u0"], g["m64b"], bias_sum=True)
+        wh(self.c20, a["u0"], g["m64b"], True)
         self.c20.dgrad(g["m64b"], g["m64c"], mask=a["u0"], mask_mode=RELU, bias_grad_of=self.ct0)
         self.ct0.wgrad(a["a"][self.nrb], g["m64c"])
         dA, dH = g["dA"], g["dH"]
         self.ct0.dgrad(g["m64c"], dA[self.nrb])
+        if hr is not None:
+            hr.launch()
         grouped = self.finalizer is not None and self.trunk_group is not None
         wg = (lambda c, x, y, b=False: self.trunk_group.add(c, x, y, b)) if grouped else \
             (lambda c, x, y, b=False: c.wgrad(x, y, bias_sum=b))
@@ -874,6 +977,9 @@ class DiscriminatorEngine:
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
         self.res_group = WgradGroup() if os.environ.get("TECOGAN_WGRAD_GROUPS", "1") != "0" else None
+        if self.finalizer is not None and self.res_group is not None and _wgrad_lists() and \
+                dtype_t in (torch.bfloat16, torch.float16):
+            self.res_group = WgradList(K.persist_wgs("D"))
 
     def repack(self):
         self.repacker.run()

@@ -398,3 +398,33 @@ def test_bench_launch_logic_spawns_its_ranks_and_refuses_mismatches():
     r = subprocess.run([sys.executable, bench, "--gpus", "1", "--dry"], capture_output=True, text=True, timeout=120,
                        env=dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"))
     assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in r.stderr
+
+
+def test_wgrad_work_list_plan_covers_every_unit_once_and_slots_are_disjoint():
+    """engine.WgradList.plan (host logic of tg_wgrad_group): the unit ranges of the workgroups tile the work list, every channel
+    block's slab slots [first, first + count) are exactly the slots `workgroup + block ordinal` of the workgroups whose range
+    meets the block, and no two blocks share a slot."""
+    from pytorch_tecogan_amd import engine as E
+    shapes = [(40, 128, 128, 128, 64), (40, 64, 64, 128, 128), (40, 64, 64, 64, 128), (40, 64, 64, 64, 64)] + [(40, 32, 32, 64, 64)] * 5
+    for cap in (1, 7, 96, 160, 100000):
+        tw, rows, units, nwg, fold, slots = E.WgradList.plan(shapes, cap, 36928)
+        assert tw == 32 and nwg <= cap and slots == nwg + sum((s[3] // 64) * (s[4] // 64) for s in shapes)
+        per = (units + cap - 1) // cap
+        assert (nwg - 1) * per < units <= nwg * per
+        # units of job j: [rows[j][0], next); blocks in order
+        used = set()
+        g = 0
+        for j, s in enumerate(shapes):
+            tiles = s[0] * rows[j][6] * rows[j][7]
+            assert rows[j][6] == (s[2] + 31) // 32 and rows[j][7] == (s[1] + 3) // 4 and rows[j][9] == g
+            for blk in range((s[3] // 64) * (s[4] // 64)):
+                beg, end = rows[j][0] + blk * tiles, rows[j][0] + (blk + 1) * tiles
+                wgs = [w for w in range(nwg) if w * per < end and (w + 1) * per > beg]
+                fj, a0, b0, first, count = fold[g]
+                assert fj == j and (a0, b0) == ((blk // (s[4] // 64)) * 64, (blk % (s[4] // 64)) * 64)
+                assert [w + g for w in wgs] == list(range(first, first + count))
+                assert not (used & set(range(first, first + count)))
+                used |= set(range(first, first + count))
+                g += 1
+        assert max(used) < slots
+    assert E.WgradList.plan([(12, 16, 16, 128, 128)], 96, 36928)[0] == 16

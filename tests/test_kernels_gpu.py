@@ -333,6 +333,58 @@ def test_conv_wgrad_multi_same_shape_layers(dt):
             assert float(gbs[i].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cap,shapes", [
+    (7, [(2, 32, 32, 64, 64, True), (1, 64, 64, 64, 128, True), (2, 32, 32, 128, 64, False), (1, 64, 32, 128, 128, True)]),
+    (160, [(3, 32, 32, 51, 64, True)] + [(3, 32, 32, 64, 64, i % 2 == 0) for i in range(6)]),   # more workgroups than a layer's tiles
+    (5, [(2, 16, 16, 128, 128, True), (3, 8, 16, 64, 64, False), (1, 24, 12, 64, 128, True)]),   # 16 x 8 tiles, ragged edges
+    (3, [(1, 20, 40, 64, 64, True), (2, 36, 72, 64, 64, False)]),                                 # 32 x 4 tiles, ragged edges
+])
+def test_wgrad_group_work_list_vs_torch(cap, shapes, dt):
+    """tg_wgrad_group: layers of different image sizes / channel counts in ONE work-list launch (LDS-DMA staged, two LDS
+    buffers), slabs folded by tg_wgrad_finalize_multi with one job per 64 x 64 channel block - against torch autograd on
+    the rounded operands.  Covers workgroup ranges that cross blocks and layers, ranges inside one block, image edges that
+    cut tiles, real channel counts below the padded ones, bias sums on some layers only."""
+    from pytorch_tecogan_amd import engine as E
+    lib = L.load()
+    slot = int(lib.tg_wgrad_group_slot_floats())
+    specs = [K.ConvSpec("c3", cin, cout) for (_, _, _, cin, cout, _) in shapes]
+    xs = [q(rnd((N, cin, H, W), 300 + i), dt) for i, (N, H, W, cin, cout, _) in enumerate(shapes)]
+    ds = [q(rnd((N, cout, H, W), 400 + i), dt) for i, (N, H, W, cin, cout, _) in enumerate(shapes)]
+    Xs, Ys = [K.to_nhwc(t.to(DEV), dt) for t in xs], [K.to_nhwc(t.to(DEV), dt) for t in ds]
+    tw, rows, units, nwg, fold, slots = E.WgradList.plan([(X.shape[0], X.shape[1], X.shape[2], X.shape[3], Y.shape[3])
+                                                          for X, Y in zip(Xs, Ys)], cap, slot)
+    slab = torch.full((slots * slot,), float("nan"), device=DEV)
+    jobs = []
+    for X, Y, r, sh in zip(Xs, Ys, rows, shapes):
+        r[8] = 1 if sh[5] else 0
+        jobs.append([X.data_ptr(), Y.data_ptr()] + r)
+    jt = torch.tensor(jobs, dtype=torch.int64, device=DEV)
+    L.check(lib.tg_wgrad_group(K.tg_dtype(dt), tw, jt.data_ptr(), len(jobs), units, nwg, slab.data_ptr(), None), "tg_wgrad_group")
+    grads = [torch.zeros(sp.weight_shape, device=DEV) for sp in specs]
+    gbs = [torch.zeros(K.pad32(sp.cout), device=DEV) for sp in specs]
+    fin = []
+    for j, a0, b0, first, count in fold:
+        _, _, taps, ca, cb, s_a, s_b = specs[j].wgrad_info()
+        bias = gbs[j].data_ptr() + 4 * b0 if (shapes[j][5] and a0 == 0) else 0
+        fin.append([slab.data_ptr() + 4 * slot * first, grads[j].data_ptr() + 4 * (a0 * s_a + b0 * s_b), s_a, s_b, count, 9, 64, 64,
+                    min(64, ca - a0), min(64, cb - b0), bias, slot])
+    ft = torch.tensor(fin, dtype=torch.int64, device=DEV)
+    L.check(lib.tg_wgrad_finalize_multi(ft.data_ptr(), len(fin), 8, None), "tg_wgrad_finalize_multi")
+    torch.cuda.synchronize()
+    for i, sp in enumerate(specs):
+        w = torch.zeros(sp.weight_shape, requires_grad=True)
+        b = torch.zeros(sp.cout, requires_grad=True)
+        F.conv2d(xs[i], w, b, 1, 1).backward(ds[i])
+        scale = float(w.grad.abs().max())
+        torch.testing.assert_close(grads[i].cpu(), w.grad, rtol=2e-2, atol=scale * 1e-2)
+        assert rel_err(grads[i].cpu(), w.grad) < 2e-3, (i, rel_err(grads[i].cpu(), w.grad))   # fp32 accumulation of exact products
+        if shapes[i][5]:
+            torch.testing.assert_close(gbs[i][:sp.cout].cpu(), b.grad, rtol=1e-4, atol=1e-3)
+        else:
+            assert float(gbs[i].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("C_,act,skip", [(64, L.ACT_NONE, True), (128, L.ACT_LRELU, False), (32, L.ACT_LRELU, False)])
 def test_batchnorm_train_fwd_bwd(C_, act, skip, dt):
