@@ -19,8 +19,10 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts: pytorch-tecogan_amd/__init__.py says why
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -226,13 +228,13 @@ def roofline_pass(st, dtype):
          lambda src, so, dst, do, n, h, w, **k: 4.0 * n * h * w * 17, "hbm")
     wrap(K, "absdiff_sum", lambda *a, **k: f"absdiff_sum_kernel<{T16}>", lambda a_, b_, *r, **k: nb(a_, b_), "hbm")
 
-    def fold_bytes(self):
+    def fold_bytes(self, only=None):
         jobs = []
-        for c in self.convs:
+        for c in (self.convs if only is None else only):
             if c.fin_job is not None:  # one fold job per conv, or one per 64 x 64 channel block (engine.WgradList)
                 jobs += c.fin_job if isinstance(c.fin_job[0], list) else [c.fin_job]
         return float(sum(j[4] * j[11] * 4 + j[5] * j[8] * j[9] * 4 for j in jobs))  # slabs read + gradient written
-    wrap(E.Finalizer, "run", lambda self: "wgrad_finalize_multi_kernel", fold_bytes, "hbm")
+    wrap(E.Finalizer, "run", lambda self, **k: "wgrad_finalize_multi_kernel", lambda self, **k: fold_bytes(self, **k), "hbm")
     try:
         torch.cuda.synchronize()
         st._forward_backward(True)

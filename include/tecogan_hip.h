@@ -295,12 +295,14 @@ int tg_absdiff_sum(int dtype, const void* a, const void* b, float* acc, int64_t 
 int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const float* b, const int64_t* b_off_dev, float* acc,
                     int nblocks, int64_t len, void* stream);
 /* content loss partial sum and d(pre-sigmoid) for the generator output (code/train.py:239-241):
- * acc (>= 16 floats): acc[0] += sum (gen-y)^2 ; dpre[nhwc] = gscale * 2*(gen-y) * gen*(1-gen) ; acc[8+c] += sum dpre[c] (output bias grad).  gen/y are NCHW fp32 (B,T,3,H,W);
+ * acc (>= 16 floats): acc[0] += sum (gen-y)^2 ; dpre[nhwc] = gscale * 2*(gen-y) * gen*(1-gen) ; bias_acc[c] += sum dpre[c], c < 3
+ * (the output layer's bias gradient; bias_acc null: acc + 8).  gen/y are NCHW fp32 (B,T,3,H,W);
  * dpre is NHWC [(t1-t0)*B][H][W][32] in (t,b) order and covers frames t0 <= t < t1 only.
  * pp_T > 0 (ping-pong, T == 2*pp_T-1): acc[6] += sum |gen_t - gen_{2(pp_T-1)-t}| over t < pp_T-1 and the gradient
  * pp_coef*sign(gen_t - gen_partner) is added before the sigmoid derivative (code/train.py:275-283). */
 int tg_content_loss(int dtype, const float* gen, const float* y, void* dpre, float* acc, int B, int T, int H, int W,
-                    float gscale, int t0, int t1, int pp_T, float pp_coef, const float* loss_scale, void* stream);
+                    float gscale, int t0, int t1, int pp_T, float pp_coef, const float* loss_scale, float* bias_acc,
+                    void* stream);
 /* All step scalars on device + d(logit) for the discriminator loss (code/train.py:287-333). */
 int tg_loss_finalize(const float* prob, const float* acc, float* scalars, float* dlogit, int tb, const float* cfg,
                      const float* loss_scale, void* stream);
@@ -333,6 +335,22 @@ int tg_adam_scaled(float* p, const float* g, float* m, float* v, int64_t n, cons
                    const float* scaler_state, int which, void* stream);
 int tg_scaler_update(float* scaler_state, float growth, float backoff, int interval, void* stream);
 
+/* ---- FNet training, opt-in (the reference defines f_net, code/models.py:22-50, and leaves its optimiser commented out:
+ * main.py:231,244-245, code/train.py:343-346; DESIGN.md "FNet training" fixes the semantics; parity unpinned) -------------
+ * tg_warp_grid_grad: the LR warp loss of code/train.py:78-84,247-249 with the estimator's output as the sampling grid, and its
+ *   gradient w.r.t. that grid (aten::grid_sampler_2d_backward, bilinear / zeros / align_corners=False, grid part):
+ *   v = sample of img block n (C planes of IH x IW at img_off[n]) at grid (the (2,GH,GW) block at grid_off[n] read as (GH,GW,2));
+ *   *loss_acc (nullable) += sum (ref - v)^2;  dgrid block n (same layout as the grid block, at dgrid_off[n]) =
+ *   coef [* *loss_scale] * d/dgrid sum_c (ref - v)^2.  All buffers fp32.
+ * tg_tanh24_bwd: dpre[n][y][x][c] = dout[n][c][y][x] * (24 - out[n][c][y][x]^2 / 24), c < 2 (d/dp of 24 tanh(p)); NHWC, 32 channels.
+ * tg_up2_bilinear_bwd: backward of tg_up2_bilinear (nn.Upsample(scale_factor=2, bilinear)): ddst [N][2H][2W][C] ->
+ *   dsrc [N][H][W][C], multiplied by LeakyReLU(0.2)'(lrelu_mask) when lrelu_mask [N][H][W][C] is given. */
+int tg_warp_grid_grad(const float* img, const int64_t* img_off_dev, const float* grid, const int64_t* grid_off_dev,
+                      const float* ref, const int64_t* ref_off_dev, float* dgrid, const int64_t* dgrid_off_dev, float* loss_acc,
+                      int N, int C, int IH, int IW, int GH, int GW, float coef, const float* loss_scale, void* stream);
+int tg_tanh24_bwd(int dtype, const float* dout_nchw, const float* out_nchw, void* dpre_nhwc32, int N, int H, int W, void* stream);
+int tg_up2_bilinear_bwd(int dtype, const void* ddst, const void* lrelu_mask, void* dsrc, int N, int H, int W, int C, void* stream);
+
 /* ---- opt-in VGG feature loss (code/train.py:30-45,124-127,253-273; code/ops.py:144-213) ----------------- */
 /* The reference's VGG path cannot execute; DESIGN.md fixes its semantics.  The VGG-19 convolutions run
  * on tg_conv / tg_conv3x3_rw; these are the HBM-bound pieces between them.
@@ -346,7 +364,8 @@ int tg_vgg_input(int dtype, const float* src_nchw, void* dst_nhwc32, int N, int 
 int tg_cosine_loss(int dtype, const void* fg, const void* ft, void* dg, int64_t npix, int C, float coef, int relu_mask,
                    float* acc, const float* loss_scale, void* stream);
 /* backward of nn.MaxPool2d((2,2), stride=2) (code/ops.py:149): out[n][y][x][c] = (res ? res : 0) + (dpool of the window
- * if (y,x) is the window's first maximum of `a`), zeroed where a <= 0 when relu_mask.  a, res, out [N][H][W][C],
+ * if (y,x) is the window's first maximum of `a`), zeroed where a <= 0 when relu_mask == 1, times 0.2 there when relu_mask == 2
+ * (LeakyReLU(0.2): f_net's encoder blocks, code/models.py:6-11).  a, res, out [N][H][W][C],
  * dpool [N][H/2][W/2][C]. */
 int tg_maxpool2_bwd(int dtype, const void* a, const void* dpool, const void* res, void* out, int N, int H, int W, int C,
                     int relu_mask, void* stream);

@@ -14,6 +14,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts: pytorch-tecogan_amd/__init__.py says why
 sys.path.insert(1, os.path.join(os.path.dirname(os.path.abspath(__file__)), "code"))
 
 
@@ -59,6 +60,13 @@ def build_parser():
     a("--tg_gpu_resize", default=False, type=str2bool,
       help="data ingest: the workers only decode the PNGs; the PIL-bilinear resize to the LR / HR sizes runs on the GPU "
            "(bit-exact restatement of PIL's resize; frames of one dataset must share a size)")
+    a("--tg_fnet", default=False, type=str2bool,
+      help="opt-in (not reference behaviour): the flow comes from the f_net estimator the reference defines and never calls "
+           "(main.py:231): gen_flow = up4(4 * f_net(previous LR frame)) instead of the raw-frame pseudo-flow")
+    a("--tg_fnet_train", default=False, type=str2bool,
+      help="opt-in, with --tg_fnet: train the estimator with its own Adam (the optimiser main.py:244-245 leaves commented out) on "
+           "the LR warp loss; fnet.pt is written next to generator.pt (--f_checkpoint to resume)")
+    a("--f_checkpoint", default=None, type=str, help="fnet.pt to load with --pre_trained_model (main.py:259-261, commented out there)")
     a("--tg_extend", default=False, type=str2bool,
       help="opt-in extension beyond what the reference can execute: RNN_N outside 9..11 and crop_size != 32 "
            "(discriminator fc sized from crop_size); parity with the reference is undefined there")
@@ -151,6 +159,17 @@ def main(argv=None):
     opt_g = torch.optim.Adam(G.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
     sch_d = torch.optim.lr_scheduler.StepLR(opt_d, args.decay_step, args.decay_rate)
     sch_g = torch.optim.lr_scheduler.StepLR(opt_g, args.decay_step, args.decay_rate)
+    Fn = opt_f = sch_f = None
+    if args.tg_fnet or args.tg_fnet_train:   # the estimator the reference leaves commented out (main.py:231,244-245,249)
+        from models import f_net
+        Fn = f_net().to(dev)
+        args.tg_fnet = Fn
+        if args.tg_fnet_train:
+            opt_f = torch.optim.Adam(Fn.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
+            sch_f = torch.optim.lr_scheduler.StepLR(opt_f, args.decay_step, args.decay_rate)
+            args.tg_fnet_optimizer = opt_f
+    else:
+        args.tg_fnet = None
     epoch0 = 0
     if args.pre_trained_model:
         g_ck = torch.load(args.g_checkpoint, map_location=dev)
@@ -160,12 +179,17 @@ def main(argv=None):
         d_ck = torch.load(args.d_checkpoint, map_location=dev)
         D.load_state_dict(d_ck["model_state_dict"])
         opt_d.load_state_dict(d_ck["optimizer_state_dict"])
+        if Fn is not None and args.f_checkpoint:
+            f_ck = torch.load(args.f_checkpoint, map_location=dev)
+            Fn.load_state_dict(f_ck["model_state_dict"])
+            if opt_f is not None and "optimizer_state_dict" in f_ck:
+                opt_f.load_state_dict(f_ck["optimizer_state_dict"])
         if g_ck.get("tg_scaler"):  # fp16 mode: the dynamic loss scale is part of the training state (extra key)
             from pytorch_tecogan_amd.train import load_loss_scaler_state
             load_loss_scaler_state(g_ck["tg_scaler"])
     if world > 1:  # replicas start equal: every rank drew its own initial weights above
         from pytorch_tecogan_amd import parallel
-        parallel.broadcast_state((G, D), (opt_g, opt_d))
+        parallel.broadcast_state((G, D) + ((Fn,) if Fn is not None else ()), (opt_g, opt_d) + ((opt_f,) if opt_f else ()))
 
     since = time.time()
     for e in range(epoch0, args.max_epochs):
@@ -185,6 +209,8 @@ def main(argv=None):
             d_loss = d_loss + (output.d_loss.data - d_loss) / (batch_idx + 1)
         sch_d.step()
         sch_g.step()
+        if sch_f is not None:
+            sch_f.step()
         if world > 1:
             from pytorch_tecogan_amd import parallel
             if not parallel.replicas_equal((G, D)):
@@ -212,6 +238,8 @@ def main(argv=None):
                 g_state["tg_scaler"] = loss_scaler_state()
             torch.save(g_state, "generator.pt")
             torch.save({"model_state_dict": D.state_dict(), "optimizer_state_dict": opt_d.state_dict()}, "discrim.pt")
+            if opt_f is not None:
+                torch.save({"model_state_dict": Fn.state_dict(), "optimizer_state_dict": opt_f.state_dict()}, "fnet.pt")
             el = time.time() - since
             print("\nTraining complete in {:.0f}m {:.0f}s".format(el // 60, el % 60))
 

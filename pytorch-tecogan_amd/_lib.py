@@ -70,6 +70,9 @@ _PROTOS = {
     "tg_resblock_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "tg_maxpool2": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "tg_up2_bilinear": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
+    "tg_up2_bilinear_bwd": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "tg_tanh24_bwd": (_I, [_I, _P, _P, _P, _I, _I, _I, _P]),
+    "tg_warp_grid_grad": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "tg_up4_planes": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P]),
     "tg_copy_blocks": (_I, [_P, _P, _P, _P, _I, _L, _P]),
     "tg_warp_nchw": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -82,7 +85,7 @@ _PROTOS = {
     "tg_fc_head_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tg_absdiff_sum": (_I, [_I, _P, _P, _P, _L, _I, _I, _P]),
     "tg_absdiff_nchw": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
-    "tg_content_loss": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _I, _F, _P, _P]),
+    "tg_content_loss": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _I, _F, _P, _P, _P]),
     "tg_loss_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P, _P]),
     "tg_dlogit_real": (_I, [_P, _P, _I, _P, _P, _P]),
     "tg_reduce_replicas": (_I, [_P, _I, _I, _I, _P, _I, _P]),

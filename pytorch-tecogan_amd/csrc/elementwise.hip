@@ -375,7 +375,8 @@ template <typename T>
 __global__ __launch_bounds__(kClThreads) void content_loss_kernel(const float* __restrict__ gen, const float* __restrict__ y,
                                                           char* __restrict__ dpre, float* __restrict__ acc, int B,
                                                           int T_, int H, int W, float gscale, int t0, int t1, int pp_T,
-                                                          float pp_coef, const float* __restrict__ loss_scale) {
+                                                          float pp_coef, const float* __restrict__ loss_scale,
+                                                          float* __restrict__ bias_acc) {
   using TR = ElemTraits<T>;
   constexpr int NW = kClThreads / 64;
   if (loss_scale) {  // fp16 mode: every backward seed carries the dynamic loss scale (tg_adam_scaled divides it out)
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(kClThreads) void content_loss_kernel(const float* _
     for (int w = 0; w < NW; ++w) t += shc[threadIdx.x][w];
     if (threadIdx.x == 4) atomicAdd(acc, t);
     else if (threadIdx.x == 3) { if (pp_T > 0) atomicAdd(acc + 6, t); }
-    else atomicAdd(acc + 8 + threadIdx.x, t);  // output-layer bias gradient
+    else atomicAdd(bias_acc + threadIdx.x, t);  // output-layer bias gradient
   }
 }
 
@@ -664,12 +665,12 @@ extern "C" int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const f
 
 extern "C" int tg_content_loss(int dtype, const float* gen, const float* y, void* dpre, float* acc, int B, int T,
                                int H, int W, float gscale, int t0, int t1, int pp_T, float pp_coef,
-                               const float* loss_scale, void* stream) {
+                               const float* loss_scale, float* bias_acc, void* stream) {
   if (!gen || !y || !acc || B <= 0 || T <= 0 || H <= 0 || W <= 0 || t0 < 0 || t1 > T || t0 >= t1) return TG_E_BADARG;
   if (pp_T != 0 && T != 2 * pp_T - 1) return TG_E_BADARG;  // ping-pong: the sequence is x followed by reverse(x)[1:]
   const long long total = (long long)B * (t1 - t0) * H * W;
   TG_DISPATCH(dtype, content_loss_kernel, dim3(grid_for(total, kClThreads, 256)), dim3(kClThreads), (hipStream_t)stream, gen, y,
-              (char*)dpre, acc, B, T, H, W, gscale, t0, t1, pp_T, pp_coef, loss_scale);
+              (char*)dpre, acc, B, T, H, W, gscale, t0, t1, pp_T, pp_coef, loss_scale, bias_acc ? bias_acc : acc + 8);
   return tg_launch_status();
 }
 

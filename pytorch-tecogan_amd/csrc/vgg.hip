@@ -137,7 +137,7 @@ __global__ void maxpool2_bwd_kernel(const char* __restrict__ a, const char* __re
 #pragma unroll
       for (int e = 0; e < TR::kVec; ++e) {
         float g = (res ? o[e] : 0.f) + (arg[e] == q ? d[e] : 0.f);
-        if (relu_mask && !(v[q][e] > 0.f)) g = 0.f;
+        if (relu_mask && !(v[q][e] > 0.f)) g = relu_mask == 2 ? 0.2f * g : 0.f;  // 1: ReLU, 2: LeakyReLU(0.2)
         o[e] = g;
       }
       Vec<T>::store(out + off, o);

@@ -139,6 +139,52 @@ __global__ void warp_nchw_kernel(const float* __restrict__ img, const long long*
   }
 }
 
+// LR warp loss of code/train.py:78-84,247-249 and its gradient w.r.t. the SAMPLING GRID (FNet training, opt-in):
+//   L = coef * sum_{n,c,p} (ref[n][c][p] - v)^2,  v = bilinear sample of img[n][c] at grid[n][p]   (zeros padding)
+//   dgrid[n][2p + 0] = coef * scale * sum_c -2 (ref - v) * dv/d(ix) * IW/2,   [2p + 1]: d(iy), IH/2
+// dv/d(ix) = (ne - nw)(1 - n) + (se - sw) n with out-of-image corners contributing 0 (aten grid_sampler_2d_backward);
+// the (2,GH,GW) grid block is the (GH,GW,2) reinterpretation the forward uses, so dgrid has the layout of the block
+// that produced the grid (f_net's [N,2,h,w] output).  loss_acc (nullable) += sum (ref - v)^2.
+__global__ void warp_grid_grad_kernel(const float* __restrict__ img, const long long* __restrict__ img_off,
+                                      const float* __restrict__ grid, const long long* __restrict__ grid_off,
+                                      const float* __restrict__ ref, const long long* __restrict__ ref_off,
+                                      float* __restrict__ dgrid, const long long* __restrict__ dgrid_off,
+                                      float* __restrict__ loss_acc, int N, int C, int IH, int IW, int GH, int GW, float coef,
+                                      const float* __restrict__ loss_scale) {
+  __shared__ float sh[8];
+  const long long total = (long long)N * GH * GW;
+  const float k = -2.f * coef * (loss_scale ? *loss_scale : 1.f);
+  float lsum = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long pos = i % ((long long)GH * GW);
+    const int n = (int)(i / ((long long)GH * GW));
+    const float* gb = grid + grid_off[n] + 2 * pos;
+    const Bilin b = bilin_setup(gb[0], gb[1], IW, IH);
+    // east / south weights recovered from the corner weights: w = ne + se, nn = sw + se (nw + ne + sw + se == 1)
+    const float w = b.ne + b.se, nn = b.sw + b.se;
+    float gx = 0.f, gy = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float* pl = img + img_off[n] + (long long)c * IH * IW;
+      const float vnw = (b.vy0 && b.vx0) ? pl[b.y0 * IW + b.x0] : 0.f;
+      const float vne = (b.vy0 && b.vx1) ? pl[b.y0 * IW + b.x0 + 1] : 0.f;
+      const float vsw = (b.vy1 && b.vx0) ? pl[(b.y0 + 1) * IW + b.x0] : 0.f;
+      const float vse = (b.vy1 && b.vx1) ? pl[(b.y0 + 1) * IW + b.x0 + 1] : 0.f;
+      const float v = vnw * b.nw + vne * b.ne + vsw * b.sw + vse * b.se;
+      const float d = ref[ref_off[n] + (long long)c * GH * GW + pos] - v;
+      lsum += d * d;
+      gx += d * ((vne - vnw) * (1.f - nn) + (vse - vsw) * nn);
+      gy += d * ((vsw - vnw) * (1.f - w) + (vse - vne) * w);
+    }
+    float* o = dgrid + dgrid_off[n] + 2 * pos;
+    o[0] = k * gx * (0.5f * (float)IW);
+    o[1] = k * gy * (0.5f * (float)IH);
+  }
+  if (loss_acc) {  // uniform
+    const float t = block_sum(lsum, sh);
+    if (threadIdx.x == 0) atomicAdd(loss_acc, t);
+  }
+}
+
 // One thread per HR pixel (16 per LR pixel): this kernel sits on the serial recurrent path between two generator
 // passes, so it is organised for latency (3 bilinear samples per thread, HR-row-major thread order so that the grid and
 // image reads of a wave are contiguous) rather than for wide stores.
@@ -298,6 +344,20 @@ extern "C" int tg_warp_nchw(const float* img, const int64_t* img_off_dev, const 
   hipLaunchKernelGGL(warp_nchw_kernel, dim3(grid_for((long long)N * GH * GW, 256, 1024)), dim3(256), 0,
                      (hipStream_t)stream, img, (const long long*)img_off_dev, grid, (const long long*)grid_off_dev, out,
                      corner_idx, sq_ref, (const long long*)sq_off_dev, loss_acc, N, C, IH, IW, GH, GW, fp16_grid);
+  return tg_launch_status();
+}
+
+extern "C" int tg_warp_grid_grad(const float* img, const int64_t* img_off_dev, const float* grid, const int64_t* grid_off_dev,
+                                 const float* ref, const int64_t* ref_off_dev, float* dgrid, const int64_t* dgrid_off_dev,
+                                 float* loss_acc, int N, int C, int IH, int IW, int GH, int GW, float coef,
+                                 const float* loss_scale, void* stream) {
+  if (!img || !img_off_dev || !grid || !grid_off_dev || !ref || !ref_off_dev || !dgrid || !dgrid_off_dev || N <= 0 || C <= 0 ||
+      IH <= 0 || IW <= 0 || GH <= 0 || GW <= 0)
+    return TG_E_BADARG;
+  hipLaunchKernelGGL(warp_grid_grad_kernel, dim3(grid_for((long long)N * GH * GW, 256, 1024)), dim3(256), 0,
+                     (hipStream_t)stream, img, (const long long*)img_off_dev, grid, (const long long*)grid_off_dev, ref,
+                     (const long long*)ref_off_dev, dgrid, (const long long*)dgrid_off_dev, loss_acc, N, C, IH, IW, GH, GW, coef,
+                     loss_scale);
   return tg_launch_status();
 }
 

@@ -491,7 +491,11 @@ int pick_cfg(const tg_wgrad_desc* d, WgCfg* c) {  // returns config id
   }
   if (d->ntaps != 9) return -1;
   if (d->Cx % 64) {
-    if (d->Cx % 32 || d->Cy % 64) return -1;
+    if (d->Cx % 32 || d->Cy % 32) return -1;
+    if (d->Cy % 64) {  // 32 x 32 blocks (f_net's 3 -> 32, 32 -> 32 and 32 -> 2 layers, padded to 32 channels)
+      *c = {32, 32};
+      return 4;
+    }
     *c = {32, 64};
     return 1;
   }
@@ -590,6 +594,7 @@ int wgrad_launch(const tg_wgrad_desc* d, const void* x, const void* y, float* sl
       case 1: if (split) TG_WG(BF16, 9, 3, 2, 2); else TG_WG(BF16, 9, 9, 2, 2);
       case 2: if (split) TG_WG(BF16, 9, 3, 4, 2); else return launch_wgrad<BF16, 9, 9, 4, 1, 8>(k, grid, lds, st);
       case 3: if (split) TG_WG(BF16, 16, 4, 4, 2); else return launch_wgrad<BF16, 16, 16, 4, 1, 8>(k, grid, lds, st);
+      case 4: if (split) TG_WG(BF16, 9, 3, 2, 1); else TG_WG(BF16, 9, 9, 2, 1);
     }
   } else if (d->dtype == TG_F16) {
     switch (cfg) {
@@ -599,6 +604,7 @@ int wgrad_launch(const tg_wgrad_desc* d, const void* x, const void* y, float* sl
       case 1: if (split) TG_WG(F16, 9, 3, 2, 2); else TG_WG(F16, 9, 9, 2, 2);
       case 2: if (split) TG_WG(F16, 9, 3, 4, 2); else return launch_wgrad<F16, 9, 9, 4, 1, 8>(k, grid, lds, st);
       case 3: if (split) TG_WG(F16, 16, 4, 4, 2); else return launch_wgrad<F16, 16, 16, 4, 1, 8>(k, grid, lds, st);
+      case 4: if (split) TG_WG(F16, 9, 3, 2, 1); else TG_WG(F16, 9, 9, 2, 1);
     }
   } else {
     switch (cfg) {
@@ -606,6 +612,7 @@ int wgrad_launch(const tg_wgrad_desc* d, const void* x, const void* y, float* sl
       case 1: if (split) TG_WG(F32, 9, 3, 2, 2); else TG_WG(F32, 9, 9, 2, 2);
       case 2: if (split) TG_WG(F32, 9, 3, 4, 2); else TG_WG(F32, 9, 9, 4, 2);
       case 3: if (split) TG_WG(F32, 16, 4, 4, 2); else TG_WG(F32, 16, 16, 4, 2);
+      case 4: if (split) TG_WG(F32, 9, 3, 2, 1); else TG_WG(F32, 9, 9, 2, 1);
     }
   }
 #undef TG_WG

@@ -469,14 +469,17 @@ class Finalizer:
         for c in self.convs:
             c.defer_finalize = False
 
-    def run(self):
-        """folds the slabs of the launches issued since the previous run (a network whose backward pass runs in two
-        parts - the discriminator's real and fake halves - folds after each part; every distinct job set keeps its own
-        device table, so nothing is rebuilt under graph capture)"""
+    def run(self, only=None):
+        """folds the slabs of the launches issued since the previous run (a network whose backward pass runs in several
+        parts - the discriminator's real and fake halves, the gradient buckets of data-parallel mode - folds after each
+        part; every distinct job set keeps its own device table, so nothing is rebuilt under graph capture).
+        only: the convs of this part (default: all)."""
         jobs = []
-        for c in self.convs:
+        for c in (self.convs if only is None else only):
             if c.fin_job is not None:  # one job, or one per channel block (WgradList)
                 jobs += c.fin_job if isinstance(c.fin_job[0], list) else [c.fin_job]
+        if not jobs:
+            return
         key = tuple(tuple(j) for j in jobs)
         table = self.tables.get(key)
         if table is None:
@@ -660,10 +663,18 @@ class GeneratorEngine:
                      "m64b": e(2 * h, 2 * w, 64), "m64c": e(2 * h, 2 * w, 64),
                      "dA": [e(h, w, 64) for _ in range(self.nrb + 1)], "dH": [e(h, w, 64) for _ in range(self.nrb)]}
 
-    def backward(self, s0=0, s1=None, dpre=None):
+    def bucket_split(self):
+        """element offset in the flat gradient buffer where the up-sampling stage's parameters (conv_trans.*, output.*)
+        begin: [split, total) is final after backward(part='hr'), [0, split) after part='trunk' (data-parallel buckets)"""
+        return self.flat.offsets["conv_trans.0.weight"][0]
+
+    def backward(self, s0=0, s1=None, dpre=None, part=None):
         """consumes grad['dpre'][:s1-s0] (d loss / d pre-sigmoid of samples [s0,s1)) and ACCUMULATES every weight/bias
         gradient.  The T passes are independent in backward (inputs are detached, code/train.py:90,108), so any
-        sample range may be processed as one batch; ranges must not run concurrently (they add into the same grads)."""
+        sample range may be processed as one batch; ranges must not run concurrently (they add into the same grads).
+        part: None = the whole pass; 'hr' = the up-sampling stage (output layer ... conv_trans.0) including the fold of its
+        weight gradients, 'trunk' = the rest - two launch sequences, so that data-parallel mode can all-reduce the first
+        bucket while the second is still being computed."""
         NS = self.shape[0]
         s1 = NS if s1 is None else s1
         n = s1 - s0
@@ -677,6 +688,20 @@ class GeneratorEngine:
         hr = self.hr_list
         wh = (lambda c, x, y, b=False: hr.add(c, x, y, b)) if hr is not None else \
             (lambda c, x, y, b=False: c.wgrad(x, y, bias_sum=b))
+        dA, dH = g["dA"], g["dH"]
+        hr_convs = [self.cout, self.c6, self.ct4, self.c32, self.c30, self.c22, self.c20, self.ct0]
+        if part != "trunk":
+            self._backward_hr(a, g, wh, hr, RELU)
+            if part == "hr":
+                if self.finalizer is not None:
+                    self.finalizer.run(only=hr_convs)
+                return
+        self._backward_trunk(a, g, dA, dH, RELU)
+        if self.finalizer is not None and s1 == NS:  # last (or only) sample range of the step
+            self.finalizer.run(only=None if part is None else [c for c in self.convs if all(c is not x for x in hr_convs)])
+
+    def _backward_hr(self, a, g, wh, hr, RELU):
+        dA = g["dA"]
         self.cout.wgrad(a["u4"], g["dpre"])                         # output bias grad: see TecoGANStep
         # bias gradients of plain convs come out of their own wgrad launch (bias_sum): the output gradient is that
         # launch's Y operand, so its channel sums cost a few VALU adds there instead of an atomics epilogue here
@@ -694,10 +719,11 @@ class GeneratorEngine:
         wh(self.c20, a["u0"], g["m64b"], True)
         self.c20.dgrad(g["m64b"], g["m64c"], mask=a["u0"], mask_mode=RELU, bias_grad_of=self.ct0)
         self.ct0.wgrad(a["a"][self.nrb], g["m64c"])
-        dA, dH = g["dA"], g["dH"]
         self.ct0.dgrad(g["m64c"], dA[self.nrb])
         if hr is not None:
             hr.launch()
+
+    def _backward_trunk(self, a, g, dA, dH, RELU):
         grouped = self.finalizer is not None and self.trunk_group is not None
         wg = (lambda c, x, y, b=False: self.trunk_group.add(c, x, y, b)) if grouped else \
             (lambda c, x, y, b=False: c.wgrad(x, y, bias_sum=b))
@@ -718,8 +744,6 @@ class GeneratorEngine:
         wg(self.conv0, a["in0"], dA[0], True)
         if grouped:
             self.trunk_group.launch()  # 2*nrb+1 layers of one shape (64 -> 64 channels, 3x3, h x w): one grid
-        if self.finalizer is not None and s1 == NS:  # last (or only) sample range of the step
-            self.finalizer.run()
 
 
 # =============================================================================================================
@@ -738,21 +762,28 @@ def fnet_shapes():
 
 
 class FNetEngine:
-    """code/models.py:9-50, forward only: four (conv-lrelu-conv-lrelu-maxpool) encoder blocks, four
-    (conv-lrelu-conv-lrelu-bilinear x2) decoder blocks, conv-lrelu-conv, 24*tanh.  The reference never instantiates f_net
-    (main.py:231 is commented out), so there is no training path for it to mirror."""
+    """code/models.py:9-50: four (conv-lrelu-conv-lrelu-maxpool) encoder blocks, four (conv-lrelu-conv-lrelu-bilinear x2)
+    decoder blocks, conv-lrelu-conv, 24*tanh.  The reference never instantiates f_net (main.py:231 is commented out) and
+    leaves its optimiser dead (main.py:244-245, code/train.py:343-346); forward() serves inference and the opt-in flow
+    option, backward() the opt-in FNet training (parity unpinned): hand-derived, same kernels as G / D."""
 
     def __init__(self, flat, dtype_t):
         self.flat, self.dt = flat, dtype_t
         self.ws = Workspace(flat.device)
-        mk = lambda pre, ci, co: Conv(flat, pre + ".weight", pre + ".bias", ConvSpec("c3", ci, co), dtype_t, self.ws,
-                                      need_dgrad=False)
-        self.blocks = [(name, mk(name + ".0", ci, co), mk(name + ".2", co, co), co) for name, ci, co in FNET_BLOCKS]
+        train = flat.g is not None
+        mk = lambda pre, ci, co, dg=True: Conv(flat, pre + ".weight", pre + ".bias", ConvSpec("c3", ci, co), dtype_t, self.ws,
+                                               need_dgrad=train and dg)
+        self.blocks = [(name, mk(name + ".0", ci, co, name != "down1"), mk(name + ".2", co, co), co) for name, ci, co in FNET_BLOCKS]
         self.o0, self.o2 = mk("output_block.0", 64, 32), mk("output_block.2", 32, 2)
         self.convs = [c for _, a, b, _ in self.blocks for c in (a, b)] + [self.o0, self.o2]
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
-        self.shape, self.act = None, None
+        self.shape, self.act, self.grad = None, None, None
         self.sets = ShapeSets()
+        self.finalizer = Finalizer(self.convs, flat.device) if (train and _defer_finalize()) else None
+        self.wlist = WgradList(K.persist_wgs("D")) if (self.finalizer is not None and _wgrad_lists() and
+                                                      dtype_t in (torch.bfloat16, torch.float16)) else None
+        for c in self.convs:
+            c.persist_wgs = K.persist_wgs("D")   # (runs at the head of lane B, beside the generator chain)
 
     def repack(self):
         self.repacker.run()
@@ -771,16 +802,22 @@ class FNetEngine:
                 a, b = e(hh, ww, co), e(hh, ww, co)
                 hh, ww = (hh // 2, ww // 2) if i < 4 else (hh * 2, ww * 2)
                 bufs.append((a, b, e(hh, ww, co)))
-            return {"in": e(h, w, 3), "blocks": bufs, "o0": e(h, w, 32)}
+            return {"in": e(h, w, 3), "blocks": bufs, "o0": e(h, w, 32), "grad": None}
 
         self.act = self.sets.get((N, h, w), make)
-        self.shape = (N, h, w)
+        self.shape, self.grad = (N, h, w), self.act["grad"]
+
+    def _alloc_grad(self):
+        """one gradient buffer per activation (the grouped weight-gradient launch at the end reads all of them)"""
+        if self.grad is None:
+            z = torch.empty_like
+            self.act["grad"] = self.grad = {"blocks": [(z(a), z(b), z(r)) for a, b, r in self.act["blocks"]],
+                                            "o0": z(self.act["o0"]), "o2": z(self.act["in"])}
 
     def forward(self, out):
         """act['in'] -> out [N,2,h,w] fp32 NCHW"""
         N, h, w = self.shape
         x = self.act["in"]
-        tg = K.tg_dtype(self.dt)
         for i, (_, c0, c2, _) in enumerate(self.blocks):
             a, b, r = self.act["blocks"][i]
             c0.fwd(x, a, act=L.ACT_LRELU)
@@ -789,6 +826,41 @@ class FNetEngine:
             x = r
         self.o0.fwd(x, self.act["o0"], act=L.ACT_LRELU)
         self.o2.fwd(self.act["o0"], None, act=L.ACT_TANH24, nchw=(out, 0, 2 * h * w, 2))
+
+    def backward(self, dout, out):
+        """dout = d(loss)/d(result), out = the result of forward() (both fp32 [N,2,h,w]); ACCUMULATES every weight / bias
+        gradient of the estimator into the flat gradient buffer (which the caller zeroes).  Chain: 24 tanh' -> output block
+        -> decoder (bilinear x2 backward, LeakyReLU') -> encoder (max-pool routing, LeakyReLU')."""
+        if self.flat.g is None:
+            raise L.TecoganHipError("this f_net engine was built without gradient buffers")
+        self._alloc_grad()
+        a_, g_ = self.act, self.grad
+        LR = L.MASK_LRELU
+        wl = self.wlist
+        wg = (lambda c, x, y: wl.add(c, x, y, True)) if wl is not None else (lambda c, x, y: c.wgrad(x, y, bias_sum=True))
+        K.tanh24_bwd(dout, out, g_["o2"])
+        wg(self.o2, a_["o0"], g_["o2"])
+        self.o2.dgrad(g_["o2"], g_["o0"], mask=a_["o0"], mask_mode=LR)
+        wg(self.o0, a_["blocks"][-1][2], g_["o0"])
+        self.o0.dgrad(g_["o0"], g_["blocks"][-1][2])
+        for i in range(len(self.blocks) - 1, -1, -1):
+            _, c0, c2, _ = self.blocks[i]
+            a, b, r = a_["blocks"][i]
+            ga, gb, gr = g_["blocks"][i]
+            if i >= 4:
+                K.up2_bilinear_bwd(gr, gb, lrelu_mask=b)
+            else:
+                K.maxpool2_bwd(b, gr, gb, relu_mask=2)
+            x_in = a_["in"] if i == 0 else a_["blocks"][i - 1][2]
+            wg(c2, a, gb)
+            c2.dgrad(gb, ga, mask=a, mask_mode=LR)
+            wg(c0, x_in, ga)
+            if i > 0:  # (the pooled / up-sampled tensor below carries no activation of its own)
+                c0.dgrad(ga, g_["blocks"][i - 1][2])
+        if wl is not None:
+            wl.launch()
+        if self.finalizer is not None:
+            self.finalizer.run()
 
 
 # =============================================================================================================
@@ -1055,11 +1127,18 @@ class DiscriminatorEngine:
             prev = net
         K.fc_head_fwd(v(a["n"][5]), self.fc_w, self.fc_b, self.prob[sl], sl.stop - sl.start, self.fc_hw, 3, 32)
 
-    def backward(self, groups=2, half=None):
+    def bucket_split(self):
+        """element offset in the flat gradient buffer where block2 begins: [0, split) = conv.0, block1, resids1 - the
+        layers whose gradients come LAST in backward - is final after backward(part='lo'), [split, total) after 'hi'"""
+        return self.flat.offsets["block2.0.weight"][0]
+
+    def backward(self, groups=2, half=None, part=None):
         """consumes self.dlogit; accumulates all D gradients (everything on the current stream).
         half=0/1: only the real / fake half of the 2-group batch (the loss is a mean of per-half terms and BN statistics
         are per half, code/train.py:199-203,304-307, so the halves are independent in backward): the real half's backward
-        can run before the generator has produced the frames the fake half needs."""
+        can run before the generator has produced the frames the fake half needs.
+        part: None = the whole pass; 'hi' = fc, block5 ... block2 (with the fold of their weight gradients), 'lo' = stage 1
+        and conv.0 - the gradient buckets of data-parallel mode."""
         N = self.act["in"].shape[0]
         if half is None:
             sl = slice(0, N)
@@ -1069,14 +1148,18 @@ class DiscriminatorEngine:
                          [x[sl] for x in v] if isinstance(v, list) else v[sl])
         a, g = cut(self.act), cut(self.gbuf)
         n = sl.stop - sl.start
-        K.fc_head_bwd(a["n"][5], self.fc_w, self.dlogit[sl], g["dn"][5], self.g_fc_w, self.g_fc_b, n, self.fc_hw, 3, 32)
-        d_net = g["dn"][5]  # gradient w.r.t. the current stage's output
+        lo_convs = [self.conv0, self.blk[1][0]] + [c for (c1, c2, _) in self.res[1] for c in (c1, c2)]
+        if part != "lo":
+            K.fc_head_bwd(a["n"][5], self.fc_w, self.dlogit[sl], g["dn"][5], self.g_fc_w, self.g_fc_b, n, self.fc_hw, 3, 32)
+            d_net = g["dn"][5]  # gradient w.r.t. the current stage's output
+        else:
+            d_net = g["dnet"][1][self.nrb - 1] if self.nrb > 0 else g["dn"][1]   # what part 'hi' left behind
         grouped = self.finalizer is not None and self.res_group is not None
         wg = (lambda c, x, y, b=False: self.res_group.add(c, x, y, b)) if grouped else \
             (lambda c, x, y, b=False: c.wgrad(x, y, bias_sum=b))
         stage_out = lambda k: a["net"][k][self.nrb - 1] if (k <= 3 and self.nrb > 0) else a["n"][k]
         g_c0 = self.g_c0[sl]
-        for k in range(5, 0, -1):
+        for k in (range(5, 1, -1) if part == "hi" else (1,) if part == "lo" else range(5, 0, -1)):
             if k <= 3:
                 for j in range(self.nrb - 1, -1, -1):
                     c1, c2, bnj = self.res[k][j]
@@ -1104,4 +1187,5 @@ class DiscriminatorEngine:
                 conv.dgrad(d_z, g_c0, mask=a["c0"], mask_mode=L.MASK_LRELU)
                 self.conv0.wgrad(a["in"], g_c0, bias_sum=True)
         if self.finalizer is not None:
-            self.finalizer.run()
+            self.finalizer.run(only=None if part is None else lo_convs if part == "lo" else
+                               [c for c in self.convs if all(c is not x for x in lo_convs)])

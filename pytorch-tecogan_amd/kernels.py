@@ -294,7 +294,7 @@ def wgrad_blocks(ntaps, cx_p, cy_p):
     if ntaps == 16:
         return (cx_p // 64) * (cy_p // 32)
     if cx_p % 64:
-        return (cx_p // 32) * (cy_p // 64)
+        return (cx_p // 32) * (cy_p // 64 if cy_p % 64 == 0 else cy_p // 32)
     if cy_p % 64:
         return (cx_p // 64) * (cy_p // 32)
     return (cx_p // 64) * (cy_p // 64)
@@ -389,9 +389,10 @@ def cosine_loss(fg, ft, dg, coef, relu_mask, acc, loss_scale=None):
 
 
 def maxpool2_bwd(a, dpool, out, res=None, relu_mask=True):
+    """relu_mask: False / 0 none, True / 1 ReLU'(a), 2 LeakyReLU(0.2)'(a)"""
     N, H, W, C_ = a.shape
     L.check(L.load().tg_maxpool2_bwd(tg_dtype(a.dtype), _ptr(a), _ptr(dpool), _ptr(res), _ptr(out), N, H, W, C_,
-                                     int(bool(relu_mask)), _stream()), "tg_maxpool2_bwd")
+                                     int(relu_mask), _stream()), "tg_maxpool2_bwd")
 
 
 def vgg_input_grad(dx, gen_nchw, dpre, scale, bias_acc=None):
@@ -412,6 +413,27 @@ def resample_u8(frames_u8, plan, out):
 def up2_bilinear(src, dst):
     N, H, W, C_ = src.shape
     L.check(L.load().tg_up2_bilinear(tg_dtype(src.dtype), _ptr(src), _ptr(dst), N, H, W, C_, _stream()), "tg_up2_bilinear")
+
+
+def up2_bilinear_bwd(ddst, dsrc, lrelu_mask=None):
+    """backward of tg_up2_bilinear: ddst [N,2H,2W,C] -> dsrc [N,H,W,C] (x LeakyReLU(0.2)'(lrelu_mask) when given)"""
+    N, H, W, C_ = dsrc.shape
+    L.check(L.load().tg_up2_bilinear_bwd(tg_dtype(dsrc.dtype), _ptr(ddst), _ptr(lrelu_mask), _ptr(dsrc), N, H, W, C_, _stream()),
+            "tg_up2_bilinear_bwd")
+
+
+def tanh24_bwd(dout, out, dpre):
+    """dout / out fp32 [N,2,H,W] (f_net's result and its gradient) -> dpre NHWC [N,H,W,32] = dout * (24 - out^2 / 24)"""
+    N, H, W, _ = dpre.shape
+    L.check(L.load().tg_tanh24_bwd(tg_dtype(dpre.dtype), _ptr(dout), _ptr(out), _ptr(dpre), N, H, W, _stream()), "tg_tanh24_bwd")
+
+
+def warp_grid_grad(img, img_off, grid, grid_off, ref, ref_off, dgrid, dgrid_off, N, C_, IH, IW, GH, GW, coef, loss_acc=None,
+                   loss_scale=None):
+    """LR warp loss and its gradient w.r.t. the sampling grid (include/tecogan_hip.h, tg_warp_grid_grad)"""
+    L.check(L.load().tg_warp_grid_grad(_ptr(img), _ptr(img_off), _ptr(grid), _ptr(grid_off), _ptr(ref), _ptr(ref_off), _ptr(dgrid),
+                                       _ptr(dgrid_off), _ptr(loss_acc), N, C_, IH, IW, GH, GW, float(coef), _ptr(loss_scale),
+                                       _stream()), "tg_warp_grid_grad")
 
 
 def to_nhwc(x, dtype_t):
@@ -499,11 +521,13 @@ def absdiff_sum(a, b, acc, acc_idx, npix, C_, Cp):
                                     _stream()), "tg_absdiff_sum")
 
 
-def content_loss(gen, y, dpre, acc, B, T, H, W, gscale, t0=0, t1=None, pp_T=0, pp_coef=0.0, loss_scale=None):
-    """loss_scale: device float (fp16 mode) multiplied into every backward seed - here d(loss)/d(pre-sigmoid)"""
+def content_loss(gen, y, dpre, acc, B, T, H, W, gscale, t0=0, t1=None, pp_T=0, pp_coef=0.0, loss_scale=None, bias_acc=None):
+    """loss_scale: device float (fp16 mode) multiplied into every backward seed - here d(loss)/d(pre-sigmoid);
+    bias_acc: 3 floats that receive the channel sums of dpre (the output layer's bias gradient); default acc[8:11]"""
     dt = tg_dtype(dpre.dtype) if dpre is not None else L.TG_F32
     L.check(L.load().tg_content_loss(dt, _ptr(gen), _ptr(y), _ptr(dpre), _ptr(acc), B, T, H, W, gscale, t0,
-                                     T if t1 is None else t1, pp_T, pp_coef, _ptr(loss_scale), _stream()), "tg_content_loss")
+                                     T if t1 is None else t1, pp_T, pp_coef, _ptr(loss_scale), _ptr(bias_acc), _stream()),
+            "tg_content_loss")
 
 
 def dlogit_real(prob, dlogit, tb, cfg, loss_scale=None):

@@ -149,9 +149,10 @@ class TecoGANStep:
         self.scalars = torch.zeros(64, **f32)
         # per-step host parameters (loss config, Adam bias corrections, lr) travel through ONE small async copy from a
         # ring of pinned slots, so the CPU may run many steps ahead of the GPU without overwriting a pending copy
-        self.params_dev = torch.zeros(48, **f32)   # [0:16] loss config, [16:32] two Adam rows, [32:48] VGG loss config
-        self.cfg = self.params_dev                  # tg_loss_finalize reads cfg[32..35] when the VGG flag is set
-        self.hyper = self.params_dev[16:32].view(2, 8)
+        self.params_dev = torch.zeros(48, **f32)   # [0:16] loss config, [16:32] two Adam rows, [32:40] VGG loss config,
+        self.cfg = self.params_dev                  # [40:48] the estimator's Adam row (opt-in FNet training)
+        self.hyper = self.params_dev[16:32].view(2, 8)   # (tg_loss_finalize reads cfg[32..35] when the VGG flag is set)
+        self.hyper_f = self.params_dev[40:48]
         self.ring = torch.zeros(256, 48, dtype=torch.float32).pin_memory()
         # fp16 element type: dynamic loss scaling, state on the device (scale, growth tracker, found_inf G / D, 1/scale) so
         # that the captured graphs read the current scale and a skipped update needs no host round trip.  The reference
@@ -173,6 +174,8 @@ class TecoGANStep:
         # TECOGAN_LANES=0: the whole forward/backward as ONE forked capture (lane B's stream is then an ordinary one:
         # a CU mask is lost inside a forked graph)
         self.lanes = os.environ.get("TECOGAN_LANES", "1") != "0"
+        # data-parallel mode: two gradient buckets per network, all-reduced where they become final (TecoGANStep._run_lanes)
+        self.buckets = self.lanes and process_group is not None and os.environ.get("TECOGAN_DP_BUCKETS", "1") != "0"
         # measured (tools/lane_matrix.sh, profiles/r02_b_lane_matrix.log): reserving CUs for the chain does not pay - the dense
         # lane loses more on 192 CUs than the chain gains - so the default is an unmasked lane B
         self.reserve = int(os.environ.get("TECOGAN_CU_RESERVE", "0")) if self.lanes else 0
@@ -196,7 +199,7 @@ class TecoGANStep:
             self.V.alloc(T * B, H, H)
         self._tables()
         self.graphs = None
-        self.adam_t = [0, 0]
+        self.adam_t = [0, 0, 0]
         self.border = (H - int(H * args.crop_dt)) // 2 if args.crop_dt < 1.0 else 0
 
     # ----------------------------------------------------------------------------------------------------------
@@ -204,10 +207,19 @@ class TecoGANStep:
         # opt-in (not reference behaviour): args.tg_fnet = an f_net module -> flow = up4(4 * f_net(previous LR frame))
         fn = getattr(self.args, "tg_fnet", None)
         self.F = fn.engine(self.G.dt) if fn is not None else None
+        # opt-in on top of it: args.tg_fnet_train -> the estimator is trained on the LR warp loss (DESIGN.md "FNet training")
+        self.F_train = self.F is not None and bool(getattr(self.args, "tg_fnet_train", False))
+        if self.F_train and self.G.dt == torch.float16:
+            raise ValueError("tg_fnet_train runs in bf16 / fp32 (the fp16 loss scaler tracks two optimisers, code/train.py:9)")
         if self.F is not None:
             self.F.sets.pin((self.B * self.T, self.h, self.h))
             self.F.alloc(self.B * self.T, self.h, self.h)
             self.fx = torch.empty(self.B * self.T, 2, self.h, self.h, dtype=torch.float32, device=self.dev)
+            if self.F_train:
+                self.F._alloc_grad()
+                self.dfx = torch.zeros_like(self.fx)   # blocks of the last frame of a sequence are never written: zero
+                hh, T = self.h * self.h, self.T
+                self.fx_off = _i64([(b * T + t) * 2 * hh for b in range(self.B) for t in range(T - 1)], self.dev)
         t = build_tables(self.B, self.T, self.h, self.K, self.pingpang, fnet_flow=self.F is not None)
         dev = self.dev
         self.flow_src, self.flow_dst, self.n_flow = _i64(t["flow_src"], dev), _i64(t["flow_dst"], dev), len(t["flow_src"])
@@ -245,7 +257,7 @@ class TecoGANStep:
             self.sBm = self.sB
 
     # ----------------------------------------------------------------------------------------------------------
-    def _host_params(self, global_step, lr_g, lr_d, betas_g, betas_d, eps_g, eps_d):
+    def _host_params(self, global_step, lr_g, lr_d, betas_g, betas_d, eps_g, eps_d, f_hyper=None):
         a = self.args
         B, T, h, H = self.B, self.T, self.h, self.H
         slot = self.ring[self.ring_i % self.ring.shape[0]]
@@ -270,6 +282,9 @@ class TecoGANStep:
         gs = 1.0 / self.world
         c[16:24] = K.adam_hyper(lr_g, betas_g[0], betas_g[1], eps_g, self.adam_t[0] + 1, gs)
         c[24:32] = K.adam_hyper(lr_d, betas_d[0], betas_d[1], eps_d, self.adam_t[1] + 1, gs)
+        if self.F_train:
+            lr_f, betas_f, eps_f = f_hyper or (lr_g, betas_g, eps_g)   # main.py:244-245: the generator's settings
+            c[40:48] = K.adam_hyper(lr_f, betas_f[0], betas_f[1], eps_f, self.adam_t[2] + 1, gs)
         slot.copy_(torch.tensor(c, dtype=torch.float32))
         self._params_slot = slot   # copied to the device at the head of lane B (_stage_inputs_b)
 
@@ -301,11 +316,28 @@ class TecoGANStep:
             K.up4_planes(self.fx, self.flow_src, self.flow, self.flow_dst, self.n_flow, h, h, pre=4.0)
         else:
             K.up4_planes(self.x, self.flow_src, self.flow, self.flow_dst, self.n_flow, h, h, pre=4.0)
-        K.warp_nchw(self.x, self.lrw_img, self.x, self.lrw_grid, B * (T - 1), 3, h, h, h, h, False, sq_ref=self.x,
-                    sq_off=self.lrw_grid, loss_acc=self.acc[1:2])
+        if not self.F_train:  # (with FNet training the warp loss is the estimator's: _fnet_bwd)
+            K.warp_nchw(self.x, self.lrw_img, self.x, self.lrw_grid, B * (T - 1), 3, h, h, h, h, False, sq_ref=self.x,
+                        sq_off=self.lrw_grid, loss_acc=self.acc[1:2])
         K.copy_blocks(self.flow, self.tv_csrc, self.tvel, self.tv_cdst, self.n_tvc, 2 * HH)
         if self.n_tvb:
             K.up4_planes(self.x, self.tv_bsrc, self.tvel, self.tv_bdst, self.n_tvb, h, h, pre=4.0, post_a=2.0, post_b=-1.0)
+
+    def _fnet_bwd(self):
+        """opt-in FNet training: the LR warp loss of code/train.py:78-84,247-249 with the estimator's output as the
+        sampling grid, its gradient w.r.t. that grid, and the estimator's backward pass.  Lane B, behind the prologue:
+        lane A only waits for the flow, not for this."""
+        B, T, h = self.B, self.T, self.h
+        self.F.flat.g.zero_()
+        K.warp_grid_grad(self.x, self.lrw_img, self.fx, self.fx_off, self.x, self.lrw_grid, self.dfx, self.fx_off, B * (T - 1),
+                         3, h, h, h, h, 1.0 / (B * (T - 1) * 3 * h), loss_acc=self.acc[1:2], loss_scale=self.loss_scale)
+        self.F.backward(self.dfx, self.fx)
+
+    def _update_f(self):
+        """the estimator's Adam (the third optimiser the reference leaves commented out, main.py:244-245) + repack"""
+        F = self.F
+        K.adam(F.flat.p, F.flat.g, F.flat.m, F.flat.v, self.hyper_f)
+        F.repack()
 
     def _d_real(self, backward=None):
         """real half of the discriminator: input assembly, forward (BN statistics of this half, first running-stat
@@ -339,20 +371,20 @@ class TecoGANStep:
             return
         pp_T = self.T_in if self.pingpang else 0
         pp_coef = (2.0 * self.args.pp_scaling / (B * (self.T_in - 1) * 3 * H * H)) if (self.pingpang and self.args.pp_scaling > 0) else 0.0
+        # the output layer's bias gradient is the channel sum of d(loss)/d(pre-sigmoid): added straight into its slot of the
+        # flat gradient buffer (zeroed by the prologue, which lane A has picked up before pass 1)
         K.content_loss(self.gen, self.y, self.dpre, self.acc, B, T, H, H, 1.0 / (B * T * 3 * H), 0, T, pp_T, pp_coef,
-                       loss_scale=self.loss_scale)
+                       loss_scale=self.loss_scale, bias_acc=G.cout.gbias)
         if self.V is not None:  # VGG features of all generated and target frames; its input-gradient is added to dpre
             gen, tgt = self.gen.view(B * T, 3, H, H), self.y.view(B * T, 3, H, H)
             self.V.forward(gen, tgt)
             self.V.loss_backward(self.acc[11:14], self.vgg_scaling, gen, self.dpre, loss_scale=self.loss_scale,
-                                 bias_acc=self.acc[8:11])
+                                 bias_acc=G.cout.gbias)
 
-    def _g_backward(self):
+    def _g_backward(self, part=None):
         """G backward for all T*B samples as ONE batch (the passes are independent in backward: every generator input is
-        detached, code/train.py:90,108); the output bias gradient comes from the content-loss kernel's channel sums"""
-        G = self.G
-        G.backward(0, self.T * self.B, dpre=self.dpre)
-        G.cout.gbias[:3] += self.acc[8:11]
+        detached, code/train.py:90,108); the output bias gradient came from the content-loss kernel's channel sums"""
+        self.G.backward(0, self.T * self.B, dpre=self.dpre, part=part)
 
     def _d_fake(self):
         """fake half, forward: input assembly from the generated frames the discriminator sees, forward, layer losses"""
@@ -364,16 +396,18 @@ class TecoGANStep:
                 n = tb * l.shape[1] * l.shape[2]
                 K.absdiff_sum(l[:tb], l[tb:], self.acc, 2 + i, n, l.shape[3], l.shape[3])
 
-    def _d_fake_bwd(self, backward=True):
+    def _d_fake_bwd(self, backward=True, part=None):
         """every loss scalar (needs the content loss of lane A's tail) and d(logit), then the backward pass of the fake
-        half (or of both halves when the real half has not run its own yet)"""
+        half (or of both halves when the real half has not run its own yet).  part 'hi' / 'lo': the two gradient buckets
+        of data-parallel mode (fc ... block2, then stage 1 and conv.0) as separate launch sequences."""
         D, tb = self.D, self.tb
-        K.loss_finalize(D.prob, self.acc, self.scalars, D.dlogit, tb, self.cfg, self.loss_scale)
+        if part != "lo":
+            K.loss_finalize(D.prob, self.acc, self.scalars, D.dlogit, tb, self.cfg, self.loss_scale)
         if backward:
             if self.dreal_bwd_early:
-                D.backward(groups=2, half=1)
+                D.backward(groups=2, half=1, part=part)
             else:
-                D.backward(groups=2)
+                D.backward(groups=2, part=part)
 
     def _update_d(self):
         """discriminator: Adam + repack.  Runs at the tail of lane B, as soon as D's gradients are final - lane B is done
@@ -393,6 +427,8 @@ class TecoGANStep:
         K.adam(G.flat.p, G.flat.g, G.flat.m, G.flat.v, self.hyper[0], scaler=sc, which=0)
         if with_d:
             self._update_d()
+            if self.F_train:
+                self._update_f()
         if sc is not None:
             K.scaler_update(sc)
         G.repack()
@@ -417,18 +453,29 @@ class TecoGANStep:
         self._chain(1, self.tsize)
 
     PIECES = ("prep", "d_real", "chain0", "chain", "chain_tail", "d_fake", "d_fake_bwd", "g_bwd", "update_d", "update")
-    LANE_B = ("prep", "d_real", "d_fake", "d_fake_bwd", "update_d")
+    # data-parallel mode: both backward passes are cut where their first gradient bucket is final
+    PIECES_DP = ("prep", "d_real", "chain0", "chain", "chain_tail", "d_fake", "d_fake_bwd_hi", "d_fake_bwd_lo", "g_bwd_hr",
+                 "g_bwd_trunk", "update_d", "update")
+    LANE_B = ("prep", "d_real", "d_fake", "d_fake_bwd", "d_fake_bwd_hi", "d_fake_bwd_lo", "update_d")
 
     def _piece_fns(self):
-        return {"prep": self._prep, "d_real": self._d_real, "chain0": self._chain0, "chain": self._chain_rest,
-                "chain_tail": self._chain_tail,
-                "d_fake": self._d_fake, "d_fake_bwd": self._d_fake_bwd, "g_bwd": self._g_backward,
-                "update_d": self._update_d, "update": self._update}
+        fns = {"prep": self._prep, "d_real": self._d_real, "chain0": self._chain0, "chain": self._chain_rest,
+               "chain_tail": self._chain_tail,
+               "d_fake": self._d_fake, "d_fake_bwd": self._d_fake_bwd, "g_bwd": self._g_backward,
+               "update_d": self._update_d, "update": self._update}
+        if self.F_train:
+            fns.update({"fnet_bwd": self._fnet_bwd, "update_f": self._update_f})
+        if self.buckets:
+            fns.update({"d_fake_bwd_hi": lambda: self._d_fake_bwd(part="hi"), "d_fake_bwd_lo": lambda: self._d_fake_bwd(part="lo"),
+                        "g_bwd_hr": lambda: self._g_backward(part="hr"), "g_bwd_trunk": lambda: self._g_backward(part="trunk")})
+        return fns
 
     def _forward_backward(self, include_d_backward=True):
         """everything up to the update on the CURRENT stream alone, in dependency order (serial; tools and bench.py's
         per-launch roofline pass use this)"""
         self._prep()
+        if self.F_train:
+            self._fnet_bwd()
         self._d_real()
         self._chain()
         self._chain_tail()
@@ -445,9 +492,8 @@ class TecoGANStep:
 
     def _run_lanes(self, fn):
         """fn: piece name -> callable (the eager pieces or their graphs' replay).  Cross-lane dependencies are events
-        recorded between the pieces; the collectives of data-parallel mode are issued where their inputs become final: the
-        G all-reduce behind lane A's G backward - it then runs while lane B is still in the fake half's backward - and the
-        D all-reduce behind lane B.  Work.wait() of the RCCL backend makes the current STREAM wait (no host block)."""
+        recorded between the pieces; the collectives of data-parallel mode are issued where their inputs become final (see
+        below: two buckets per network).  Work.wait() of the RCCL backend makes the current STREAM wait (no host block)."""
         main, sB, sBm, ev = torch.cuda.current_stream(), self.sB, self.sBm, self.ev
         # the step's prologue (zeroing, pseudo-flow, T_vel: 8 small launches, ~60 us) runs at the head of lane B while lane A
         # is already in the first generator pass - frame 0 has no previous frame, so it needs neither the flow nor any of
@@ -459,6 +505,12 @@ class TecoGANStep:
             self._stage_inputs_b()
             fn["prep"]()
             ev["prep"].record(sBm)
+            if self.F_train:   # estimator: loss, backward, [all-reduce,] Adam - its weights are next read by the NEXT step's prologue
+                fn["fnet_bwd"]()
+                w_f = self._allreduce(self.F.flat.g)
+                if w_f is not None:
+                    w_f.wait()
+                fn["update_f"]()
             fn["d_real"]()
         if sBm is not sB:
             ev["dreal"].record(sBm)
@@ -473,21 +525,42 @@ class TecoGANStep:
         fn["chain_tail"]()
         ev["tail"].record(main)
         sB.wait_event(ev["tail"])
+        if not self.buckets:
+            # one all-reduce per network (TECOGAN_DP_BUCKETS=0, or no process group: _allreduce returns None); the D one is
+            # issued first - lane B ends before lane A
+            with torch.cuda.stream(sB):
+                fn["d_fake_bwd"]()
+                works_d = (self._allreduce(self.D.flat.g),)
+            fn["g_bwd"]()
+            works_g = (self._allreduce(self.G.flat.g),)
+        else:
+            # Data parallel.  RCCL runs a process group's collectives on ONE internal stream in issue order (the same on every
+            # rank), so they are issued in the order their inputs become final: the generator's up-sampling stage (its weight
+            # gradients are folded ~0.8 ms before the G backward ends: the 32 trunk input-gradients and the trunk's weight
+            # gradients are still to come), the discriminator's upper stages (stage 1, the largest tensors, is still to come),
+            # then the two remainders.  Each is enqueued behind the piece that completes it, on that piece's lane.
+            G, D = self.G, self.D
+            gs, ds = G.bucket_split(), D.bucket_split()
+            with torch.cuda.stream(sB):
+                fn["d_fake_bwd_hi"]()
+            fn["g_bwd_hr"]()
+            w_g1 = self._allreduce(G.flat.g[gs:])
+            with torch.cuda.stream(sB):
+                w_d1 = self._allreduce(D.flat.g[ds:])
+                fn["d_fake_bwd_lo"]()
+                w_d2 = self._allreduce(D.flat.g[:ds])
+            fn["g_bwd_trunk"]()
+            w_g2 = self._allreduce(G.flat.g[:gs])
+            works_d, works_g = (w_d1, w_d2), (w_g1, w_g2)
         with torch.cuda.stream(sB):
-            fn["d_fake_bwd"]()
-            # RCCL runs a process group's collectives on ONE internal stream in issue order (the same on every rank): the
-            # D all-reduce goes first - lane B ends before lane A - so it never queues behind the G all-reduce, which cannot
-            # start before the G backward is done
-            w2 = self._allreduce(self.D.flat.g)
-        fn["g_bwd"]()
-        w1 = self._allreduce(self.G.flat.g)
-        with torch.cuda.stream(sB):
-            if w2 is not None:
-                w2.wait()          # (RCCL: makes lane B's stream wait, no host block)
+            for w in works_d:
+                if w is not None:
+                    w.wait()       # (RCCL: makes lane B's stream wait, no host block)
             fn["update_d"]()
             ev["d"].record(sB)
-        if w1 is not None:
-            w1.wait()
+        for w in works_g:
+            if w is not None:
+                w.wait()
         main.wait_event(ev["d"])
         fn["update"]()
 
@@ -496,6 +569,8 @@ class TecoGANStep:
         capture segfaults when a non-origin captured stream joins a side stream, tools/capture_probe.py)"""
         main, sB = torch.cuda.current_stream(), self.sB
         self._prep()
+        if self.F_train:
+            self._fnet_bwd()
         sB.wait_stream(main)
         with torch.cuda.stream(sB):
             self._d_real()
@@ -512,9 +587,10 @@ class TecoGANStep:
 
     def _run_single(self, fwd_bwd, update):
         fwd_bwd()
-        w1 = self._allreduce(self.G.flat.g)
-        w2 = self._allreduce(self.D.flat.g)
-        for w in (w1, w2):
+        works = [self._allreduce(self.G.flat.g), self._allreduce(self.D.flat.g)]
+        if self.F_train:
+            works.append(self._allreduce(self.F.flat.g))
+        for w in works:
             if w is not None:
                 w.wait()
         update()
@@ -533,13 +609,15 @@ class TecoGANStep:
 
         if self.lanes:
             fns = self._piece_fns()
-            lane = lambda k: self.sBm if k in ("prep", "d_real") else (self.sB if k in self.LANE_B else None)  # noqa: E731
-            self.graphs = {k: cap(fns[k], lane(k)) for k in self.PIECES}
+            names = (self.PIECES_DP if self.buckets else self.PIECES) + (("fnet_bwd", "update_f") if self.F_train else ())
+            lane = lambda k: self.sBm if k in ("prep", "d_real", "fnet_bwd", "update_f") else (self.sB if k in self.LANE_B else None)  # noqa: E731
+            self.graphs = {k: cap(fns[k], lane(k)) for k in names}
         else:
             self.graphs = (cap(self._fork_join), cap(self._update_all))
 
     # ----------------------------------------------------------------------------------------------------------
-    def run(self, x, y, global_step, lr_g, lr_d, betas_g=(0.9, 0.999), betas_d=(0.9, 0.999), eps_g=1e-8, eps_d=1e-8):
+    def run(self, x, y, global_step, lr_g, lr_d, betas_g=(0.9, 0.999), betas_d=(0.9, 0.999), eps_g=1e-8, eps_d=1e-8,
+            f_hyper=None):
         """x (B,T,3,h,h), y (B,T,3,H,H) fp32 device tensors.  Returns nothing; results live in self.gen / self.scalars /
         self.target and the parameter / optimiser buffers are updated in place."""
         Ti = self.T_in
@@ -552,7 +630,7 @@ class TecoGANStep:
         if self.pingpang:  # reverse(x)[1:] appended (data movement only)
             self.x[:, Ti:].copy_(torch.flip(x, dims=[1])[:, 1:])
         self._y_src = y
-        self._host_params(global_step + 1, lr_g, lr_d, betas_g, betas_d, eps_g, eps_d)
+        self._host_params(global_step + 1, lr_g, lr_d, betas_g, betas_d, eps_g, eps_d, f_hyper)
         if not self.lanes:
             self._stage_inputs_b()
         eager = (lambda: self._run_lanes(self._piece_fns())) if self.lanes else \
@@ -574,7 +652,7 @@ class TecoGANStep:
                 eager()
         if laneA is not caller:
             caller.wait_stream(laneA)
-        self.adam_t = [self.adam_t[0] + 1, self.adam_t[1] + 1]
+        self.adam_t = [t + 1 for t in self.adam_t]
 
 
 class RecurrentGenerator:

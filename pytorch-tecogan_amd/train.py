@@ -85,6 +85,7 @@ def get_step(generator_F, discriminator_F, B, T, h, args, device, dtype_t=None, 
         from .models import VGG19          # the frozen feature extractor is built ONCE and kept on args
         args.tg_vgg = VGG19(args).to(device)
     key = (id(Ge), id(De), B, T, h, use_graph, bool(getattr(args, "pingpang", False)), id(getattr(args, "tg_fnet", None)),
+           bool(getattr(args, "tg_fnet_train", False)),
            id(getattr(args, "tg_vgg", None)) if float(getattr(args, "vgg_scaling", -1.0)) > 0.0 else None)
     st = _STEPS.get(key)
     if st is None:
@@ -131,11 +132,24 @@ def TecoGAN(r_inputs, r_targets, discriminator_F, generator_F, args, Global_step
     _bind_optimizer(optimizer_g, generator_F)
     _bind_optimizer(optimizer_d, discriminator_F)
     gg, gd = optimizer_g.param_groups[0], optimizer_d.param_groups[0]
-    st.adam_t = [int(optimizer_g._tg_step), int(optimizer_d._tg_step)]
+    st.adam_t = [int(optimizer_g._tg_step), int(optimizer_d._tg_step), 0]
+    f_hyper, opt_f = None, None
+    if st.F_train:
+        # the third optimiser of main.py:244-245 (commented out there): args.tg_fnet_optimizer, a torch.optim.Adam over
+        # args.tg_fnet.parameters(); FRVSR_Train's signature (code/train.py:374-377) has no slot for it
+        opt_f = getattr(args, "tg_fnet_optimizer", None)
+        if opt_f is None:
+            raise ValueError("args.tg_fnet_train needs args.tg_fnet_optimizer (torch.optim.Adam over args.tg_fnet.parameters())")
+        _bind_optimizer(opt_f, args.tg_fnet)
+        gf = opt_f.param_groups[0]
+        f_hyper = (gf["lr"], gf["betas"], gf["eps"])
+        st.adam_t[2] = int(opt_f._tg_step)
     st.run(r_inputs.float(), r_targets.float(), Global_step, gg["lr"], gd["lr"], gg["betas"], gd["betas"], gg["eps"],
-           gd["eps"])
+           gd["eps"], f_hyper=f_hyper)
     optimizer_g._tg_step += 1
     optimizer_d._tg_step += 1
+    if opt_f is not None:
+        opt_f._tg_step += 1
     return _network(st, args, Global_step + 1, counter1, counter2)
 
 

@@ -432,6 +432,9 @@ def test_data_parallel_collectives_on_one_gpu(tmp_path):
     sp = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
     assert dp["n_gpus"] == 1 and dp["config"]["parallelism"] == "dp1" and dp["pg_world_size"] == 1 and dp["pg_backend"] == "nccl"
     assert sp["pg_backend"] is None
+    # the two lanes must still overlap beside RCCL's own streams (they shared one hardware queue with the runtime's default
+    # of 4 queues: 7.1 vs 4.5 ms per step; pytorch-tecogan_amd/__init__.py).  4 collectives of 1 rank cost ~0.1 ms of host time
+    assert dp["ms_per_step"] < 1.2 * sp["ms_per_step"], (dp["ms_per_step"], sp["ms_per_step"])
     np.testing.assert_allclose(dp["final_losses"]["gen_loss"], sp["final_losses"]["gen_loss"], rtol=2e-3)
     np.testing.assert_allclose(dp["final_losses"]["d_loss"], sp["final_losses"]["d_loss"], rtol=5e-2, atol=2e-3)
 
