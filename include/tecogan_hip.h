@@ -180,18 +180,24 @@ int tg_wgrad_finalize(const float* slab, int nsplit, int ntaps, int ca_p, int cb
  * jobs_dev: njobs x 12 int64 = {slab ptr, grad ptr, s_a, s_b, nsplit, ntaps, ca_p, cb_p, ca, cb, bias-grad ptr or 0,
  * slab stride in floats}. */
 int tg_wgrad_finalize_multi(const int64_t* jobs_dev, int njobs, int blocks_per_job, void* stream);
+/* The same fold with one workgroup per work item instead of blocks_per_job workgroups per job.  A job's items are its
+ * (16 x BB)-channel tiles x chunks of 8 slabs: (ca_p / (1024 / BB)) * (cb_p / BB) * ceil(nsplit / 8), BB = 64 if cb_p % 64 == 0
+ * else 32.  jobs_dev: njobs x 13 int64 = the 12 entries above + the job's first item index (prefix sum, ascending);
+ * nitems = their total; max_taps = 9 or 16 (the largest ntaps among the jobs: sizes the LDS image). */
+int tg_wgrad_fold_items(const int64_t* jobs_dev, int njobs, int nitems, int max_taps, void* stream);
 
 /* ---- grouped weight gradients of 3x3 stride-1 convolutions (16-bit element types; csrc/wgrad_group.hip) -----------------
  * ONE persistent launch for a list of layers of possibly different image size / channel counts (the weight path of
  * aten::convolution_backward behind code/train.py:336,340 for the plain 3x3 layers of code/models.py:54-58,68-76,90-94).
  * Work unit = (job, 64 x 64 channel block, 128-pixel tile of tile_w x 128/tile_w pixels); the units of all jobs form one
- * list (job-major, then block = a_block * (Cy/64) + b_block, then tile = (n * tiles_y + ty) * tiles_x + tx) and workgroup
+ * list (job-major, then block = a_block * b_blocks + b_block, then tile = (n * tiles_y + ty) * tiles_x + tx) and workgroup
  * w of W' = ceil(units_total / per), per = ceil(units_total / workgroups), takes units [w * per, (w + 1) * per).
  * jobs_dev: njobs x 12 int64 = {x ptr, y ptr, first unit of the job, N, H, W, Cx, Cy, tiles_x = ceil(W / tile_w),
  * tiles_y = ceil(H / (128 / tile_w)), y_sum (0/1), ordinal of the job's first channel block among all blocks of the list};
- * x [N,H,W,Cx], y [N,H,W,Cy] NHWC, Cx % 64 == Cy % 64 == 0.
+ * x [N,H,W,Cx], y [N,H,W,Cy] NHWC, Cx % 32 == Cy % 32 == 0; channel blocks are 64 x 64, a_blocks = ceil(Cx / 64),
+ * b_blocks = ceil(Cy / 64) (a 32-channel remainder is a block whose upper half holds don't-care values: fold real channels only).
  * slab: slots of tg_wgrad_group_slot_floats() floats = [9 taps][64 a][64 b] partial dW + [64] channel sums of Y (the conv's
- * bias gradient; zeros unless y_sum and a_block == 0).  The segment of workgroup w inside channel block g (global ordinal)
+ * bias gradient; zeros unless y_sum and a_block == 0; entries of padded channels are don't-care).  The segment of workgroup w inside channel block g (global ordinal)
  * goes to slot w + g: block g owns slots [w_first(g) + g, w_last(g) + g], at most W' + (number of blocks) slots in all,
  * and tg_wgrad_finalize_multi folds them with one job per block (ca_p = cb_p = 64, stride = the slot size).
  * tile_w: 32 (tiles of 32 x 4 pixels) or 16 (16 x 8).  TG_E_UNSUPPORTED for fp32: use tg_wgrad. */

@@ -59,6 +59,7 @@ _PROTOS = {
     "tg_wgrad_group": (_I, [_I, _I, _P, _I, _I, _I, _P, _P]),
     "tg_wgrad_finalize": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _L, _L, _P, _I, _P, _L, _P]),
     "tg_wgrad_finalize_multi": (_I, [_P, _I, _I, _P]),
+    "tg_wgrad_fold_items": (_I, [_P, _I, _I, _I, _P]),
     "tg_nchw_to_nhwc": (_I, [_I, _P, _L, _P, _I, _I, _I, _I, _I, _P]),
     "tg_nhwc_to_nchw": (_I, [_I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "tg_resblock_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),

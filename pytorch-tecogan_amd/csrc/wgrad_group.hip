@@ -2,8 +2,9 @@
 //
 //   dW_j[t][a][b] = sum over (n, y, x) of  X_j[n, y + dy[t], x + dx[t]][a] * Y_j[n, y, x][b]        (zero padding)
 //
-// for a list of jobs j of possibly different image size and channel counts (the generator's 39 plain 3x3 layers, the
-// 8 residual convs of a discriminator stage ...).  The unit of work is (job, 64x64 channel block, 128-pixel tile); the
+// for a list of jobs j of possibly different image size and channel counts (the generator's 40 plain 3x3 layers, the
+// 8 residual convs of a discriminator stage ...; channel counts are multiples of 32, a 32-channel remainder runs as a
+// half-empty 64-channel block whose missing channels hold don't-care values the fold never reads).  The unit of work is (job, 64x64 channel block, 128-pixel tile); the
 // units of all jobs form one list, and workgroup w takes the contiguous range [w * per, (w + 1) * per) of it.  A
 // workgroup keeps the partial dW of its current (job, block) in accumulators and writes one fp32 slab whenever its
 // range leaves that block - so the number of slabs is  workgroups + channel blocks  instead of
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
     const int ubeg = (int)jr[2], N = (int)jr[3], H = (int)jr[4], W = (int)jr[5], Cx = (int)jr[6], Cy = (int)jr[7];
     const int tiles_x = (int)jr[8], tiles_y = (int)jr[9], want_ysum = (int)jr[10], gb0 = (int)jr[11];
     const int tiles = tiles_x * tiles_y * N;
-    const int b_blocks = Cy >> 6, blocks = (Cx >> 6) * b_blocks;
+    const int b_blocks = (Cy + 63) >> 6, blocks = ((Cx + 63) >> 6) * b_blocks;  // a 32-channel remainder is a half-empty block
     const int local = u - ubeg;
     const int blk = local / tiles;
     int tile = local - blk * tiles;
@@ -150,10 +151,14 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
 
     // per-segment DMA constants: byte offset of my pieces relative to the patch / tile origin (32-bit: patch-relative)
     int xrel[XCW], yrel[2];
+    // A 32-channel remainder runs as a half-empty block: the pieces of its missing channels are CLAMPED onto the pixel's last
+    // real 16 bytes instead of being masked off.  What they produce - rows a >= Cx - a0 / columns b >= Cy - b0 of the slab -
+    // is never read (the fold takes real channels only) and cannot reach a real entry: dW[a][b] involves channels a, b alone.
+    const int xlast = xpixb - a0 * 2 - 16, ylast = ypixb - b0 * 2 - 16;
 #pragma unroll
-    for (int c = 0; c < XCW; ++c) xrel[c] = (max(xpy[c], 0) * W + xpx[c]) * xpixb + xch[c];
+    for (int c = 0; c < XCW; ++c) xrel[c] = (max(xpy[c], 0) * W + xpx[c]) * xpixb + min(xch[c], xlast);
 #pragma unroll
-    for (int c = 0; c < 2; ++c) yrel[c] = (yty[c] * W + ytx[c]) * ypixb + ych[c];
+    for (int c = 0; c < 2; ++c) yrel[c] = (yty[c] * W + ytx[c]) * ypixb + min(ych[c], ylast);
     // coordinates of the next tile to issue, advanced incrementally (no division per tile)
     int i_txb, i_tyb, i_n;
     {

@@ -399,12 +399,12 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
 template <int NT, int BB>
 __device__ __forceinline__ void fold2_job(const float* __restrict__ slab, float* __restrict__ grad, long long s_a, long long s_b,
                                           int nsplit, int ca_p, int cb_p, int ca, int cb, float* __restrict__ bias_grad,
-                                          size_t slab_sz, float* __restrict__ sh) {
+                                          size_t slab_sz, float* __restrict__ sh, int u0, int ustep) {
   constexpr int AB = 1024 / BB, NB4 = BB / 4, KC = 8, ROW = AB * NT, PITCH = ROW + 1;
   const int tid = threadIdx.x, ai = tid / NB4, bj = tid % NB4;
   const int tiles_b = cb_p / BB, tiles = (ca_p / AB) * tiles_b;
   const int nchunks = (nsplit + KC - 1) / KC;
-  for (int u = blockIdx.x; u < tiles * nchunks; u += gridDim.x) {
+  for (int u = u0; u < tiles * nchunks; u += ustep) {
     const int chunk = u % nchunks, tile = u / nchunks;
     const int tb = tile % tiles_b, ta = tile / tiles_b;
     const int a = ta * AB + ai, b = tb * BB + 4 * bj;
@@ -448,9 +448,7 @@ __device__ __forceinline__ void fold2_job(const float* __restrict__ slab, float*
 
 constexpr int kFold2Lds = (64 * (16 * 16 + 1)) * 4;  // the largest image: 16 taps, BB = 64 -> 65792 bytes
 
-__global__ __launch_bounds__(256) void wgrad_finalize_multi_kernel(const long long* __restrict__ jobs) {
-  extern __shared__ __attribute__((aligned(16))) float fold_sh[];
-  const long long* j = jobs + 12 * blockIdx.y;
+__device__ __forceinline__ void fold2_dispatch(const long long* __restrict__ j, float* fold_sh, int u0, int ustep) {
   const float* slab = reinterpret_cast<const float*>(j[0]);
   float* grad = reinterpret_cast<float*>(j[1]);
   const int nsplit = (int)j[4], ntaps = (int)j[5], ca_p = (int)j[6], cb_p = (int)j[7], ca = (int)j[8], cb = (int)j[9];
@@ -458,12 +456,32 @@ __global__ __launch_bounds__(256) void wgrad_finalize_multi_kernel(const long lo
   const size_t sz = (size_t)j[11];
   const bool wide = (cb_p % 64) == 0;
   if (ntaps == 9) {
-    if (wide) fold2_job<9, 64>(slab, grad, j[2], j[3], nsplit, ca_p, cb_p, ca, cb, bias, sz, fold_sh);
-    else fold2_job<9, 32>(slab, grad, j[2], j[3], nsplit, ca_p, cb_p, ca, cb, bias, sz, fold_sh);
+    if (wide) fold2_job<9, 64>(slab, grad, j[2], j[3], nsplit, ca_p, cb_p, ca, cb, bias, sz, fold_sh, u0, ustep);
+    else fold2_job<9, 32>(slab, grad, j[2], j[3], nsplit, ca_p, cb_p, ca, cb, bias, sz, fold_sh, u0, ustep);
   } else if (ntaps == 16) {
-    if (wide) fold2_job<16, 64>(slab, grad, j[2], j[3], nsplit, ca_p, cb_p, ca, cb, bias, sz, fold_sh);
-    else fold2_job<16, 32>(slab, grad, j[2], j[3], nsplit, ca_p, cb_p, ca, cb, bias, sz, fold_sh);
+    if (wide) fold2_job<16, 64>(slab, grad, j[2], j[3], nsplit, ca_p, cb_p, ca, cb, bias, sz, fold_sh, u0, ustep);
+    else fold2_job<16, 32>(slab, grad, j[2], j[3], nsplit, ca_p, cb_p, ca, cb, bias, sz, fold_sh, u0, ustep);
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_finalize_multi_kernel(const long long* __restrict__ jobs) {
+  extern __shared__ __attribute__((aligned(16))) float fold_sh[];
+  fold2_dispatch(jobs + 12 * blockIdx.y, fold_sh, blockIdx.x, gridDim.x);
+}
+
+// The same fold with ONE workgroup per work item (16-row tile x 8-slab chunk) over all jobs: the grid above is
+// blocks_per_job x jobs, and a job of a few slabs has 4-8 items - with ~80 jobs per discriminator pass, 4500 of 5000
+// workgroups (each reserving the 66-KB transposition image) were dispatched only to exit (103-147 us for 123 MB of slabs).
+// Job rows carry a 13th entry here: the job's first item index in the launch.
+__global__ __launch_bounds__(256) void wgrad_fold_items_kernel(const long long* __restrict__ jobs, int njobs) {
+  extern __shared__ __attribute__((aligned(16))) float fold_sh[];
+  const int it = blockIdx.x;
+  int lo = 0, hi = njobs - 1;  // last job whose first item is <= it
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)jobs[13 * mid + 12] <= it) lo = mid; else hi = mid - 1;
+  }
+  fold2_dispatch(jobs + 13 * lo, fold_sh, it - (int)jobs[13 * lo + 12], 1 << 30);
 }
 
 struct WgCfg {
@@ -645,5 +663,19 @@ extern "C" int tg_wgrad_finalize_multi(const int64_t* jobs_dev, int njobs, int b
   }
   hipLaunchKernelGGL(wgrad_finalize_multi_kernel, dim3((unsigned)blocks_per_job, (unsigned)njobs), dim3(256), kFold2Lds,
                      (hipStream_t)stream, (const long long*)jobs_dev);
+  return tg_launch_status();
+}
+
+extern "C" int tg_wgrad_fold_items(const int64_t* jobs_dev, int njobs, int nitems, int max_taps, void* stream) {
+  if (!jobs_dev || njobs <= 0 || nitems <= 0 || (max_taps != 9 && max_taps != 16)) return TG_E_BADARG;
+  const int lds = (64 * (16 * max_taps + 1)) * 4;
+  static std::atomic<bool> attr_done{false};  // one-time function attribute (benign race: idempotent)
+  if (!attr_done) {
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_fold_items_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kFold2Lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wgrad_fold_items_kernel, dim3((unsigned)nitems), dim3(256), lds, (hipStream_t)stream,
+                     (const long long*)jobs_dev, njobs);
   return tg_launch_status();
 }

@@ -356,8 +356,8 @@ class WgradList:
 
     @staticmethod
     def takes(conv):
-        return conv.spec.kind == "c3" and conv.dt in (torch.bfloat16, torch.float16) and conv.cin_p % 64 == 0 and \
-            conv.cout_p % 64 == 0 and conv.defer_finalize
+        return conv.spec.kind == "c3" and conv.dt in (torch.bfloat16, torch.float16) and conv.defer_finalize and \
+            (conv.cin_p >= 64 or conv.cout_p >= 64)   # (32 -> 32 layers would run quarter-full blocks: tg_wgrad's 32 x 32 config)
 
     def add(self, conv, x_in, dout, bias_sum=False):
         if not self.takes(conv):
@@ -368,7 +368,8 @@ class WgradList:
     @staticmethod
     def plan(shapes, cap, slot):
         """pure host logic (unit-tested on the CPU).  shapes: [(N, H, W, cx_p, cy_p)] -> (tile_w, job rows without the two
-        pointers, units_total, workgroups, [(job, a0, b0, first_slot, count)] per channel block, slots)"""
+        pointers, units_total, the `workgroups` argument of tg_wgrad_group (it launches ceil(units / ceil(units / workgroups))
+        of them), [(job, a0, b0, first_slot, count)] per channel block, slots)"""
         tw = 32 if max(s[2] for s in shapes) > 16 else 16
         th = 128 // tw
         rows, units, gb = [], 0, 0
@@ -376,19 +377,21 @@ class WgradList:
         for j, (N, H, W, cx, cy) in enumerate(shapes):
             tx, ty = (W + tw - 1) // tw, (H + th - 1) // th
             tiles = N * tx * ty
-            blocks = (cx // 64) * (cy // 64)
+            ab, bb = (cx + 63) // 64, (cy + 63) // 64   # a 32-channel remainder is a half-empty 64 block
+            blocks = ab * bb
             rows.append([units, N, H, W, cx, cy, tx, ty, 0, gb])
             for blk in range(blocks):
-                spans.append((j, (blk // (cy // 64)) * 64, (blk % (cy // 64)) * 64, units + blk * tiles, units + (blk + 1) * tiles))
+                spans.append((j, (blk // bb) * 64, (blk % bb) * 64, units + blk * tiles, units + (blk + 1) * tiles))
             units += blocks * tiles
             gb += blocks
-        per = (units + cap - 1) // cap
+        cap = max(1, min(cap, units))
+        per = (units + cap - 1) // cap     # what tg_wgrad_group derives from (units, cap) - pass `cap`, not the launch's grid
         nwg = (units + per - 1) // per
         fold = []
         for g, (j, a0, b0, beg, end) in enumerate(spans):
             w0, w1 = beg // per, (end - 1) // per
             fold.append((j, a0, b0, w0 + g, w1 - w0 + 1))
-        return tw, rows, units, nwg, fold, nwg + gb
+        return tw, rows, units, cap, fold, nwg + gb
 
     def launch(self):
         items, self.items = self.items, []
@@ -456,6 +459,21 @@ def _defer_finalize():
     return os.environ.get("TECOGAN_DEFER_FINALIZE", "1") != "0"
 
 
+_FOLD_ITEMS = os.environ.get("TECOGAN_FOLD_ITEMS", "1") != "0"
+
+
+def fold_items(jobs):
+    """host side of tg_wgrad_fold_items: appends each 12-entry fold job's first item index (pure logic, CPU-tested).
+    A job has (ca_p / AB) * (cb_p / BB) tiles x ceil(nsplit / 8) chunks, BB = 64 or 32, AB = 1024 / BB."""
+    rows, n = [], 0
+    for j in jobs:
+        nsplit, ca_p, cb_p = j[4], j[6], j[7]
+        bb = 64 if cb_p % 64 == 0 else 32
+        rows.append(list(j) + [n])
+        n += (ca_p // (1024 // bb)) * (cb_p // bb) * ((nsplit + 7) // 8)
+    return rows, n
+
+
 class Finalizer:
     """folds the weight-gradient slabs of every conv of a network into the flat gradient buffer with ONE launch (instead
     of one ~9 us launch per conv).  The job table is rebuilt only when a conv's launch shape changed."""
@@ -481,11 +499,20 @@ class Finalizer:
         if not jobs:
             return
         key = tuple(tuple(j) for j in jobs)
-        table = self.tables.get(key)
-        if table is None:
-            table = self.tables[key] = torch.tensor(jobs, dtype=torch.int64, device=self.dev)
-        L.check(L.load().tg_wgrad_finalize_multi(table.data_ptr(), len(jobs), 64,
-                                                 torch.cuda.current_stream().cuda_stream), "tg_wgrad_finalize_multi")
+        ent = self.tables.get(key)
+        if ent is None:
+            rows, n = fold_items(jobs)
+            ent = self.tables[key] = (torch.tensor(rows, dtype=torch.int64, device=self.dev), n, max(j[5] for j in jobs))
+        table, nitems, max_taps = ent
+        if _FOLD_ITEMS:  # one workgroup per (tile, 8-slab chunk) item of any job
+            L.check(L.load().tg_wgrad_fold_items(table.data_ptr(), len(jobs), nitems, max_taps,
+                                                 torch.cuda.current_stream().cuda_stream), "tg_wgrad_fold_items")
+        else:
+            t12 = self.tables.get(("t12", key))
+            if t12 is None:
+                t12 = self.tables[("t12", key)] = torch.tensor(jobs, dtype=torch.int64, device=self.dev)
+            L.check(L.load().tg_wgrad_finalize_multi(t12.data_ptr(), len(jobs), 64,
+                                                     torch.cuda.current_stream().cuda_stream), "tg_wgrad_finalize_multi")
 
 
 class BatchNorm:
@@ -702,7 +729,7 @@ class GeneratorEngine:
 
     def _backward_hr(self, a, g, wh, hr, RELU):
         dA = g["dA"]
-        self.cout.wgrad(a["u4"], g["dpre"])                         # output bias grad: see TecoGANStep
+        wh(self.cout, a["u4"], g["dpre"])                           # output bias grad: see TecoGANStep
         # bias gradients of plain convs come out of their own wgrad launch (bias_sum): the output gradient is that
         # launch's Y operand, so its channel sums cost a few VALU adds there instead of an atomics epilogue here
         self.cout.dgrad(g["dpre"], g["hr64"], mask=a["u4"], mask_mode=RELU)
@@ -1172,8 +1199,9 @@ class DiscriminatorEngine:
                     wg(c1, net_in, d_h, True)
                     c1.dgrad(d_h, d_in, res=d_net)
                     d_net = d_in
-                if grouped:
+                if grouped and (k > 1 or not isinstance(self.res_group, WgradList)):
                     self.res_group.launch()  # the 2*nrb same-shaped residual convs of this stage in one grid
+                # (stage 1 of a work-list engine waits for conv.0 below: one launch for both)
             conv, bn = self.blk[k]
             d_z = g["dz"][k]
             bn.backward(d_net, a["n"][k], a["z"][k], d_z, L.ACT_LRELU, groups, half=half)
@@ -1185,7 +1213,11 @@ class DiscriminatorEngine:
                 d_net = d_prev
             else:
                 conv.dgrad(d_z, g_c0, mask=a["c0"], mask_mode=L.MASK_LRELU)
-                self.conv0.wgrad(a["in"], g_c0, bias_sum=True)
+                if grouped and isinstance(self.res_group, WgradList):   # conv.0 (27 -> 64, full resolution) shares stage 1's work list
+                    wg(self.conv0, a["in"], g_c0, True)
+                    self.res_group.launch()
+                else:
+                    self.conv0.wgrad(a["in"], g_c0, bias_sum=True)
         if self.finalizer is not None:
             self.finalizer.run(only=None if part is None else lo_convs if part == "lo" else
                                [c for c in self.convs if all(c is not x for x in lo_convs)])

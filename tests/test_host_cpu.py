@@ -406,10 +406,11 @@ def test_wgrad_work_list_plan_covers_every_unit_once_and_slots_are_disjoint():
     meets the block, and no two blocks share a slot."""
     from pytorch_tecogan_amd import engine as E
     shapes = [(40, 128, 128, 128, 64), (40, 64, 64, 128, 128), (40, 64, 64, 64, 128), (40, 64, 64, 64, 64)] + [(40, 32, 32, 64, 64)] * 5
-    for cap in (1, 7, 96, 160, 100000):
-        tw, rows, units, nwg, fold, slots = E.WgradList.plan(shapes, cap, 36928)
-        assert tw == 32 and nwg <= cap and slots == nwg + sum((s[3] // 64) * (s[4] // 64) for s in shapes)
-        per = (units + cap - 1) // cap
+    for cap in (1, 2, 5, 7, 96, 160, 100000):
+        tw, rows, units, wgs, fold, slots = E.WgradList.plan(shapes, cap, 36928)
+        per = (units + wgs - 1) // wgs           # the C side's rule
+        nwg = (units + per - 1) // per
+        assert tw == 32 and wgs == min(cap, units) and nwg <= cap and slots == nwg + sum((s[3] // 64) * (s[4] // 64) for s in shapes)
         assert (nwg - 1) * per < units <= nwg * per
         # units of job j: [rows[j][0], next); blocks in order
         used = set()
@@ -428,3 +429,17 @@ def test_wgrad_work_list_plan_covers_every_unit_once_and_slots_are_disjoint():
                 g += 1
         assert max(used) < slots
     assert E.WgradList.plan([(12, 16, 16, 128, 128)], 96, 36928)[0] == 16
+    # 32-channel remainders are half-empty 64 blocks
+    _, rows, units, _, fold, slots = E.WgradList.plan([(1, 32, 32, 32, 96)], 3, 36928)
+    assert units == 2 * 8 and [(f[1], f[2]) for f in fold] == [(0, 0), (0, 64)]
+
+
+def test_fold_items_prefix_table():
+    """engine.fold_items (host side of tg_wgrad_fold_items): item counts per job = tiles x chunks of 8 slabs"""
+    from pytorch_tecogan_amd import engine as E
+    jobs = [[0, 0, 9, 576, 5, 9, 64, 64, 64, 64, 0, 36928],       # 4 tiles x 1 chunk
+            [0, 0, 9, 576, 26, 9, 64, 64, 51, 64, 0, 36928],      # 4 x 4
+            [0, 0, 16, 1024, 12, 16, 128, 128, 128, 128, 0, 262144],   # (128/16) * (128/64) = 16 tiles x 2
+            [0, 0, 9, 576, 96, 9, 64, 32, 64, 3, 0, 18432]]       # BB = 32: AB = 32 -> 2 tiles x 12
+    rows, n = E.fold_items(jobs)
+    assert [r[12] for r in rows] == [0, 4, 20, 52] and n == 76 and all(r[:12] == j for r, j in zip(rows, jobs))

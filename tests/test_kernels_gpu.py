@@ -339,6 +339,7 @@ def test_conv_wgrad_multi_same_shape_layers(dt):
     (160, [(3, 32, 32, 51, 64, True)] + [(3, 32, 32, 64, 64, i % 2 == 0) for i in range(6)]),   # more workgroups than a layer's tiles
     (5, [(2, 16, 16, 128, 128, True), (3, 8, 16, 64, 64, False), (1, 24, 12, 64, 128, True)]),   # 16 x 8 tiles, ragged edges
     (3, [(1, 20, 40, 64, 64, True), (2, 36, 72, 64, 64, False)]),                                 # 32 x 4 tiles, ragged edges
+    (6, [(2, 32, 32, 27, 64, True), (1, 32, 64, 64, 3, False), (2, 16, 32, 96, 64, True), (1, 32, 32, 64, 96, True)]),  # 32-channel remainders
 ])
 def test_wgrad_group_work_list_vs_torch(cap, shapes, dt):
     """tg_wgrad_group: layers of different image sizes / channel counts in ONE work-list launch (LDS-DMA staged, two LDS
