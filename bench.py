@@ -255,6 +255,28 @@ def roofline_pass(st, dtype):
         recs[label]["ms"] = e0.elapsed_time(e1)
     mf = {k: v for k, v in recs.items() if v["kind"] == "mfma"}
     hb = {k: v for k, v in recs.items() if v["kind"] == "hbm"}
+    # The dominant family once more, this time IN THE STEP'S CONDITIONS: the other lane's real work (the discriminator's real
+    # half, the piece that runs beside the generator chain) replays on lane B's stream while the family is bracketed on this
+    # one.  A latency-bound chain of small launches pays for its neighbour ("what slows the chain"); the
+    # stand-alone bracket above does not see that, rocprofv3's per-kernel average of the whole step does.
+    dom = max(mf, key=lambda k: mf[k]["ms"])
+    if st.graphs is not None and st.lanes and "d_real" in st.graphs:
+        calls = replays[dom]
+        torch.cuda.synchronize()
+        neighbour_ms = 1.7                                       # d_real alone (tools/step_breakdown.py)
+        reps = max(1, int(mf[dom]["ms"] * 1.5 / neighbour_ms) + 1)
+        torch.cuda._sleep(int(0.008 * 2.0e9))
+        with torch.cuda.stream(st.sBm):
+            torch.cuda._sleep(int(0.008 * 2.0e9))
+            for _ in range(reps):
+                st.graphs["d_real"]()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for call in calls:
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        mf[dom]["ms_in_step"] = e0.elapsed_time(e1)
     return mf, hb
 
 
@@ -274,7 +296,7 @@ def usable_cores():
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are separate
     runs of this same command; they cannot be collected live).  gfx950 correction: FETCH_SIZE counts 64 B per 128-B request."""
-    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         try:
             tab = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
         except (OSError, ValueError, KeyError):
@@ -416,7 +438,10 @@ def main():
             fam, hbm = roofline_pass(st, a.dtype)
             dom = max(fam, key=lambda k: fam[k]["ms"])
             d = fam[dom]
-            ach = d["work"] / (d["ms"] * 1e-3) / 1e12
+            ach_alone = d["work"] / (d["ms"] * 1e-3) / 1e12
+            # `achieved` / `frac` are quoted from the bracket taken beside the other lane's work (what rocprofv3 reports for the
+            # kernel inside the overlapped step); the stand-alone bracket is kept as frac_standalone
+            ach = d["work"] / (d.get("ms_in_step", d["ms"]) * 1e-3) / 1e12
             pmc, pmc_src = pmc_traffic(dom)
 
             def busy(label):  # MFMA-pipe busy share of the kernel's SQ busy cycles, from the committed counter passes
@@ -428,8 +453,13 @@ def main():
                                "traffic": int(pmc["hbm_bytes_per_launch"]) if pmc else None,
                                "traffic_source": pmc_src, "mfma_busy_pct": busy(dom),
                                "rocprof_names": pmc["rocprof_names"] if pmc else None,
+                               "frac_standalone": round(ach_alone / MFMA_PEAK_TFLOPS[a.dtype], 5),
+                               "achieved_standalone": round(ach_alone, 2),
+                               "frac_basis": "family bracketed with HIP events on its stream while the discriminator's real half "
+                                             "replays on the other lane (in-step conditions); *_standalone: the family alone",
                                "launches_per_step": d["launches"],
-                               "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+                               "avg_launch_us": round(d.get("ms_in_step", d["ms"]) * 1e3 / d["launches"], 2),
+                               "avg_launch_us_standalone": round(d["ms"] * 1e3 / d["launches"], 2),
                                "avg_launch_gflop": round(d["work"] / d["launches"] / 1e9, 3),
                                # rocprofv3 lists the 9-tap weight-gradient kernel as ONE row (single-layer and grouped launches
                                # are the same instantiation); bracketed here as three families - their sum, for comparison
@@ -449,7 +479,12 @@ def main():
                                "hbm_kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                                    "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
                                                    "GBps": round(v["work"] / (v["ms"] * 1e-3) / 1e9, 1),
-                                                   "frac_of_8TBps": round(v["work"] / (v["ms"] * 1e-3) / 8e12, 4)}
+                                                   "frac_of_8TBps": round(v["work"] / (v["ms"] * 1e-3) / 8e12, 4),
+                                                   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE)
+                                                   # beside the algorithmic bytes per launch
+                                                   "algorithmic_bytes_per_launch": int(v["work"] / v["launches"]),
+                                                   "pmc_hbm_bytes_per_launch": (lambda e: int(e["hbm_bytes_per_launch"]) if e and
+                                                                                "hbm_bytes_per_launch" in e else None)(pmc_traffic(k)[0])}
                                                for k, v in sorted(hbm.items(), key=lambda kv: -kv[1]["ms"])}}
         if not a.no_cpu_baseline and a.config == 2:
             log(f"cpu baseline: oracle, {a.cpu_steps}+1 steps on {usable_cores()} usable host cores")

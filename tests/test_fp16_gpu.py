@@ -160,6 +160,63 @@ def test_fp16_step_config4_shape_vs_oracle_extension(monkeypatch):
         assert 1e-5 < rel(w, w0) < 2e-2      # the update happened, at Adam's scale
 
 
+def test_config4_full_depth_shard_fp32_vs_oracle_extension(monkeypatch):
+    """configs[3] per-GPU shard at FULL depth (16 generator / 4 discriminator residual blocks, B = 2, T = 16, 64x64 -> 256x256,
+    tg_extend): the fp32 HIP step against the oracle extension - every loss scalar, gen_output, and the generator's whole
+    gradient vector."""
+    monkeypatch.setenv("TECOGAN_GRAPH", "0")
+    hip_train._STEPS.clear()
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    over = dict(RNN_N=16, crop_size=64, tg_extend=True)
+    args, G, D, og, od, gp, dp = build(21, "fp32", **over)
+    assert args.num_resblock == 16 and args.discrim_resblocks == 4
+    x, y = synth(2, 16, 64, 21)
+    out = train.FRVSR_Train(x.cuda(), y.cuda(), args, D, G, 0, 0.0, 0.0, og, od)
+    torch.cuda.synchronize()
+    g = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    f = orc.tecogan_forward(g, dp, orc.init_bn_buffers(dp), x, y, orc.default_args(**over), 0)
+    got = np.array([float(v) for v in out.update_list])
+    exp = np.array([float(v) for v in f["update_list"]])
+    np.testing.assert_allclose(got, exp, rtol=1e-3, atol=1e-6)
+    assert rel(out.gen_output, f["gen"].detach()) < 1e-4
+    assert tuple(out.gen_output.shape) == (2, 16, 3, 256, 256) and tuple(out.target.shape) == (2 * 5, 27, 256, 256)
+    gg = torch.autograd.grad(f["gen_loss"], list(g.values()))
+    gvec = torch.cat([p.grad.flatten() for _, p in G.named_parameters()])
+    assert rel(gvec, torch.cat([t.flatten() for t in gg])) < 1e-3
+    hip_train._STEPS.clear()
+
+
+def test_config4_full_depth_shard_fp16_graph_replay_properties(monkeypatch):
+    """the same shard in its benchmarked form (fp16 + dynamic loss scaling, per-lane hipGraphs; `bench.py --config 4`): three
+    steps replayed from graphs and three eager steps from the same start - finite losses and weights, a loss-scale state
+    the GradScaler rule can produce, and graph == eager on every reported loss."""
+    over = dict(RNN_N=16, crop_size=64, tg_extend=True)
+    x, y = synth(2, 16, 64, 22)
+    x, y = x.cuda(), y.cuda()
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TECOGAN_GRAPH", mode)
+        hip_train._STEPS.clear()
+        args, G, D, og, od, gp, dp = build(22, "fp16", **over)
+        args.tg_loss_scale = 4096.0     # (a start the first steps do not overflow from: both modes take the same updates)
+        losses = []
+        for s in range(3):
+            out = train.FRVSR_Train(x, y, args, D, G, s, 0.0, 0.0, og, od)
+            losses.append(np.array([float(v) for v in out.update_list]))
+        st = next(iter(hip_train._STEPS.values()))
+        assert (st.graphs is not None) == (mode == "1") and st.G.dt == torch.float16 and st.G.nrb == 16 and st.D.nrb == 4
+        state = st.scaler_state()
+        res[mode] = (losses, state, torch.cat([p.detach().flatten() for p in G.parameters()]).cpu())
+        assert all(np.isfinite(l).all() for l in losses) and bool(torch.isfinite(res[mode][2]).all())
+        assert state["scale"] in (4096.0, 2048.0, 1024.0, 512.0) and 0 <= state["growth_tracker"] <= 6, state
+        assert float(st.scaler[2:4].abs().sum()) == 0.0      # found_inf flags cleared by the step's two update() calls
+    assert res["0"][1] == res["1"][1]
+    for a, b in zip(res["0"][0], res["1"][0]):
+        np.testing.assert_allclose(a, b, rtol=2e-2, atol=2e-3)     # fp16 activations + order-dependent float atomics
+    assert rel(res["1"][2], res["0"][2]) < 1e-3
+    hip_train._STEPS.clear()
+
+
 def test_fp16_overflow_skips_both_updates_and_backs_the_scale_off(monkeypatch):
     """a loss scale that overflows fp16 everywhere: both networks keep their weights, the scale is halved twice (the two
     update() calls of a step), and training proceeds once the scale has come down; hipGraph replay reads the new scale."""

@@ -456,6 +456,23 @@ def test_bench_contract_line_with_roofline_pass():
     rf = line["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0.0 < rf["frac"] < 1.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    # frac is quoted from the bracket taken beside the other lane's work; the stand-alone bracket is a second field and can
+    # only be better
+    assert 0.0 < rf["frac"] <= rf["frac_standalone"] * 1.05 and rf["avg_launch_us"] >= rf["avg_launch_us_standalone"] * 0.95
+    # the kernel the roofline object describes is the largest row of the committed rocprofv3 --kernel-trace --stats summary
+    # of this same command, and the in-step launch time agrees with that summary's average
+    import csv
+    import glob
+    stats = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*kernel_stats*.csv")))
+    assert stats, "profiles/r03_*kernel_stats*.csv (rocprofv3 --kernel-trace --stats of bench.py) is missing"
+    rows = list(csv.DictReader(open(stats[-1])))
+    top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+    assert "resblock_kernel<false" in top["Name"] and rf["kernel"].startswith("resblock_kernel<false"), (top["Name"], rf["kernel"])
+    prof_us = sum(float(r["TotalDurationNs"]) for r in rows if "resblock_kernel<false" in r["Name"]) / \
+        sum(float(r["Calls"]) for r in rows if "resblock_kernel<false" in r["Name"]) / 1e3
+    # (rocprofv3's kernel trace dispatches the two lanes' kernels almost serially - profiles/r03_overlap.json: 12 % of the
+    # profiled step has both lanes busy, 84 % of the unprofiled one - so its per-kernel average is the STAND-ALONE launch time)
+    assert abs(rf["avg_launch_us_standalone"] / prof_us - 1.0) < 0.15, (rf["avg_launch_us_standalone"], prof_us)
     fam = rf["families"]
     assert any(k.startswith("resblock_kernel<false") for k in fam) and any(k.startswith("conv_rgb_kernel") for k in fam)
     assert all(v["launches"] > 0 and v["ms"] > 0 for v in fam.values())
