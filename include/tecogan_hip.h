@@ -204,6 +204,19 @@ int tg_wgrad_fold_items(const int64_t* jobs_dev, int njobs, int nitems, int max_
 int64_t tg_wgrad_group_slot_floats(void);
 int tg_wgrad_group(int dtype, int tile_w, const int64_t* jobs_dev, int njobs, int units_total, int workgroups, float* slab,
                    void* stream);
+/* The same work-list launch for the two stride-2 layer kinds (tile_w = 16: tiles of 16 x 4 pixels of y; H, W of a job row
+ * are y's, x lives on the 2H x 2W grid; 64-pixel tiles, so tiles_x = ceil(W / 16), tiles_y = ceil(H / 4)):
+ *   TG_WGROUP_CT    conv-transpose k3 s2 p1 op1 (code/ops.py:45-54): x = the output gradient [N,2H,2W,Cx], y = the layer input
+ *                   [N,H,W,Cy]; dW[t][a][b] = sum x[n, 2y + dy[t], 2x + dx[t]][a] * y[n, y, x][b], 9 taps (dy, dx) in -1..1;
+ *   TG_WGROUP_C4S2  conv k4 s2 p1 (code/models.py:90-94): x = the layer input [N,2H,2W,Cx], y = the output gradient [N,H,W,Cy];
+ *                   16 taps (dy, dx) in -1..2.
+ * TG_WGROUP_C3 is tg_wgrad_group.  Slot size: tg_wgrad_group_slot_floats_v(variant) = [taps][64][64] + [64]. */
+#define TG_WGROUP_C3 0
+#define TG_WGROUP_CT 1
+#define TG_WGROUP_C4S2 2
+int64_t tg_wgrad_group_slot_floats_v(int variant);
+int tg_wgrad_group_v(int dtype, int variant, int tile_w, const int64_t* jobs_dev, int njobs, int units_total, int workgroups,
+                     float* slab, void* stream);
 
 /* ---- output layer of the generator (code/models.py:77-79 conv 64 -> 3 + sigmoid; the store replaces the permute + float()
  * of code/train.py:97-99) --------------------------------------------------------------------------------------------

@@ -18,6 +18,7 @@ OUT_NHWC, OUT_NCHW_F32 = 0, 1
 TILE_AUTO, TILE_64x256, TILE_64x64, TILE_128x128, TILE_32x128 = 0, 1, 2, 3, 4
 TILE_32x64, TILE_64x128, TILE_64x128_8W, TILE_64x64_8W = 5, 6, 7, 8
 MAX_TAPS, MAX_CLASSES = 16, 4
+WGROUP_C3, WGROUP_CT, WGROUP_C4S2 = 0, 1, 2
 
 
 class ConvClass(C.Structure):
@@ -57,6 +58,8 @@ _PROTOS = {
     "tg_wgrad_multi": (_I, [C.POINTER(WgradDesc), _P, _I, _P]),
     "tg_wgrad_group_slot_floats": (_L, []),
     "tg_wgrad_group": (_I, [_I, _I, _P, _I, _I, _I, _P, _P]),
+    "tg_wgrad_group_slot_floats_v": (_L, [_I]),
+    "tg_wgrad_group_v": (_I, [_I, _I, _I, _P, _I, _I, _I, _P, _P]),
     "tg_wgrad_finalize": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _L, _L, _P, _I, _P, _L, _P]),
     "tg_wgrad_finalize_multi": (_I, [_P, _I, _I, _P]),
     "tg_wgrad_fold_items": (_I, [_P, _I, _I, _I, _P]),

@@ -58,18 +58,66 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-constexpr int kSlot = 9 * 64 * 64 + 64;  // floats per slab slot: [9][64][64] + channel sums of Y
+// Tile geometry.  S = 1 (3x3 stride-1 convs): tile TW x 128/TW output pixels, X patch (TW + 2) x (TH + 2) of pitch TW + 2.
+// S = 2 (NTS = 3: conv-transpose k3 s2, X = the output gradient on the 2h grid; NTS = 4: conv k4 s2, X = the input): tile
+// 16 x 4 pixels of Y, X patch rows 2 ty + dy, columns 2 tx + dx - the columns are DE-INTERLEAVED by parity into two sub-images
+// of pitch 18, so that the 8 pixels a 32-lane group of a transposed read takes (consecutive tx under one tap) are 8 consecutive
+// rows of one sub-image again and the column-keyed swizzle stays conflict-free.
+template <int TW, int S, int NTS>
+struct WgGeom {
+  static constexpr int TH = S == 1 ? 128 / TW : 4;
+  static constexpr int TPIX = TW * TH, KSTEPS = TPIX / 32;
+  static constexpr int PITCH = S == 1 ? TW + 2 : 18;            // rows of the X image per patch row (even: swizzle parity)
+  static constexpr int NR = S * (TH - 1) + NTS;                 // patch rows
+  static constexpr int NC = S * (TW - 1) + NTS;                 // patch columns
+  static constexpr int SUB = NR * PITCH;                        // rows of one sub-image
+  static constexpr int XROWS = S * SUB;
+  static constexpr int XCH = (XROWS * 128 + 1023) / 1024, YCH = TPIX / 8;
+  static constexpr int XCW = (XCH + 7) / 8, YCW = (YCH + 7) / 8;
+  static constexpr int XBYTES = XCH * 1024, BUF = XBYTES + YCH * 1024;
+  // pixel k + 16 of the tile: 16 columns further (TW 32), else the next tile row = S patch rows down
+  static constexpr int HI = (TW == 32) ? 16 * 128 : S * PITCH * 128;
+  static constexpr int KROW = (TW == 32) ? 1 : 2;               // tile rows per 32-pixel k-step
+  static_assert(PITCH % 2 == 0 && SUB % 2 == 0, "the swizzle key needs even pitches");
+  static_assert(S == 1 || TW == 16, "stride-2 tiles are 16 x 4");
+  // image row -> patch (row, column), swizzle key, validity
+  __device__ static void decode(int row, int& py, int& px, int& key, bool& valid) {
+    if constexpr (S == 1) {
+      py = row / PITCH;
+      px = row - py * PITCH;
+      key = (px >> 1) & 3;
+      valid = row < XROWS;
+    } else {
+      const int sub = row / SUB, rr = row - sub * SUB;
+      py = rr / PITCH;
+      const int c = rr - py * PITCH;
+      px = 2 * c + sub;
+      key = (c >> 1) & 3;
+      valid = row < XROWS && px < NC;
+    }
+  }
+  // lane address (bytes into the X image, without the 32-byte segment) of tile column tx under column tap d, and its key
+  __device__ static void lane_col(int tx, int d, int& rowbytes, int& key) {
+    if constexpr (S == 1) {
+      const int px = tx + d;
+      rowbytes = px * 128;
+      key = (px >> 1) & 3;
+    } else {
+      const int c = tx + (d >> 1);
+      rowbytes = ((d & 1) * SUB + c) * 128;
+      key = (c >> 1) & 3;
+    }
+  }
+  // byte offset of k-step s, row tap dy
+  __device__ static constexpr int tap_row(int s, int dy) { return (S * KROW * s + dy) * PITCH * 128; }
+};
 
-template <typename T, int TW>
+template <typename T, int TW, int S, int NTS>
 __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
-  constexpr int TH = 128 / TW, IW = TW + 2, IH = TH + 2, XROWS = IW * IH;
-  constexpr int XCH = (XROWS * 128 + 1023) / 1024;  // 1-KiB chunks of the X image (26 for 34 x 6, 23 for 18 x 10)
-  constexpr int YCH = 16;                           // Y image: 128 pixels x 128 bytes
-  constexpr int XCW = (XCH + 7) / 8;                // chunks per wave
-  constexpr int XBYTES = XCH * 1024, BUF = XBYTES + YCH * 1024;
-  constexpr int HI = (TW == 32) ? 16 * 128 : IW * 128;  // pixel k + 16: 16 columns further (TW 32) / one patch row down (TW 16)
-  constexpr int SROW = (TW == 32) ? 1 : 2;              // patch rows per 32-pixel k-step
-  static_assert(IW % 2 == 0, "the swizzle key needs an even patch pitch");
+  using Gm = WgGeom<TW, S, NTS>;
+  constexpr int TH = Gm::TH, NT = NTS * NTS, XCH = Gm::XCH, YCH = Gm::YCH, XCW = Gm::XCW, YCW = Gm::YCW;
+  constexpr int XBYTES = Gm::XBYTES, BUF = Gm::BUF, HI = Gm::HI, TPIX = Gm::TPIX;
+  constexpr int kSlot = NT * 64 * 64 + 64;  // floats per slab slot: [NT][64][64] + channel sums of Y
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // two buffers of BUF bytes
 
@@ -81,13 +129,13 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
   const int u_end = min(u + p.per_wg, p.units_total);
   if (u >= u_end) return;
 
-  // ---- lane constants of the fragment reads (tile- and job-independent)
-  // X: pixel (ty, tx) of the tile under tap (dy', dx') sits in patch row (ty + dy') * IW + tx + dx'; lane k = 4g + q
-  int xa[3], ya[2];
+  // ---- lane constants of the fragment reads (tile- and job-independent): one X address per column tap, two Y addresses
+  int xa[NTS], ya[2];
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const int px = 4 * g + q + d;
-    xa[d] = px * 128 + ((wa ^ ((px >> 1) & 3)) * 32) + 8 * pp;
+  for (int d = 0; d < NTS; ++d) {
+    int rb, key;
+    Gm::lane_col(4 * g + q, d, rb, key);
+    xa[d] = rb + ((wa ^ key) * 32) + 8 * pp;
   }
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
@@ -99,15 +147,16 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
   int xpy[XCW], xpx[XCW], xch[XCW];  // patch row / column of my piece, byte offset of its channels in the pixel
 #pragma unroll
   for (int c = 0; c < XCW; ++c) {
-    const int row = (wid + 8 * c) * 8 + r8;
-    const int py = row / IW, px = row - py * IW;
-    xpy[c] = row < XROWS ? py : -100000;  // rows behind the image (last chunk) load zeros
+    int py, px, key;
+    bool valid;
+    Gm::decode((wid + 8 * c) * 8 + r8, py, px, key, valid);
+    xpy[c] = valid ? py : -100000;  // rows behind the image (last chunk, pitch padding) load zeros
     xpx[c] = px;
-    xch[c] = ((((jp >> 1) ^ ((px >> 1) & 3)) * 2) + (jp & 1)) * 16;
+    xch[c] = ((((jp >> 1) ^ key) * 2) + (jp & 1)) * 16;
   }
-  int yty[2], ytx[2], ych[2];
+  int yty[YCW], ytx[YCW], ych[YCW];
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
+  for (int c = 0; c < YCW; ++c) {
     const int k = (wid + 8 * c) * 8 + r8;
     yty[c] = k / TW;
     ytx[c] = k - yty[c] * TW;
@@ -117,7 +166,7 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int wid_u = __builtin_amdgcn_readfirstlane(wid);
 
-  f32x4 acc[9][2];
+  f32x4 acc[NT][2];
   constexpr int E = 8;
   float bsum[E];
 
@@ -129,8 +178,10 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
     const long long* jr = p.jobs + GJ * job;
     const char* xbase = reinterpret_cast<const char*>(jr[0]);
     const char* ybase = reinterpret_cast<const char*>(jr[1]);
+    // H x W: the grid of Y (and of the tiles); X lives on the S*H x S*W grid
     const int ubeg = (int)jr[2], N = (int)jr[3], H = (int)jr[4], W = (int)jr[5], Cx = (int)jr[6], Cy = (int)jr[7];
     const int tiles_x = (int)jr[8], tiles_y = (int)jr[9], want_ysum = (int)jr[10], gb0 = (int)jr[11];
+    const int XH = S * H, XW = S * W;
     const int tiles = tiles_x * tiles_y * N;
     const int b_blocks = (Cy + 63) >> 6, blocks = ((Cx + 63) >> 6) * b_blocks;  // a 32-channel remainder is a half-empty block
     const int local = u - ubeg;
@@ -142,7 +193,7 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
     const int xpixb = Cx * 2, ypixb = Cy * 2;
 
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < NT; ++t) {
       acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
       acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -150,15 +201,15 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
     for (int e = 0; e < E; ++e) bsum[e] = 0.f;
 
     // per-segment DMA constants: byte offset of my pieces relative to the patch / tile origin (32-bit: patch-relative)
-    int xrel[XCW], yrel[2];
+    int xrel[XCW], yrel[YCW];
     // A 32-channel remainder runs as a half-empty block: the pieces of its missing channels are CLAMPED onto the pixel's last
     // real 16 bytes instead of being masked off.  What they produce - rows a >= Cx - a0 / columns b >= Cy - b0 of the slab -
     // is never read (the fold takes real channels only) and cannot reach a real entry: dW[a][b] involves channels a, b alone.
     const int xlast = xpixb - a0 * 2 - 16, ylast = ypixb - b0 * 2 - 16;
 #pragma unroll
-    for (int c = 0; c < XCW; ++c) xrel[c] = (max(xpy[c], 0) * W + xpx[c]) * xpixb + min(xch[c], xlast);
+    for (int c = 0; c < XCW; ++c) xrel[c] = (max(xpy[c], 0) * XW + xpx[c]) * xpixb + min(xch[c], xlast);
 #pragma unroll
-    for (int c = 0; c < 2; ++c) yrel[c] = (yty[c] * W + ytx[c]) * ypixb + min(ych[c], ylast);
+    for (int c = 0; c < YCW; ++c) yrel[c] = (yty[c] * W + ytx[c]) * ypixb + min(ych[c], ylast);
     // coordinates of the next tile to issue, advanced incrementally (no division per tile)
     int i_txb, i_tyb, i_n;
     {
@@ -171,22 +222,23 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
 
     auto issue = [&](int bufoff) {
       const int ty0 = i_tyb * TH, tx0 = i_txb * TW;
-      const long long npix = (long long)i_n * H * W;
-      const char* xo = xbase + (npix + (long long)(ty0 - 1) * W + (tx0 - 1)) * xpixb + a0 * 2;
+      const char* xo = xbase + ((long long)i_n * XH * XW + (long long)(S * ty0 - 1) * XW + (S * tx0 - 1)) * xpixb + a0 * 2;
       const unsigned lx = lds0 + bufoff;
 #pragma unroll
       for (int c = 0; c < XCW; ++c) {
         if (wid_u + 8 * c < XCH) {  // wave-uniform
-          const int iy = ty0 - 1 + xpy[c], ix = tx0 - 1 + xpx[c];
-          const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+          const int iy = S * ty0 - 1 + xpy[c], ix = S * tx0 - 1 + xpx[c];
+          const bool ok = (unsigned)iy < (unsigned)XH && (unsigned)ix < (unsigned)XW;
           glds16(ok ? xo + xrel[c] : zero, lx + (wid_u + 8 * c) * 1024);
         }
       }
-      const char* yo = ybase + (npix + (long long)ty0 * W + tx0) * ypixb + b0 * 2;
+      const char* yo = ybase + ((long long)i_n * H * W + (long long)ty0 * W + tx0) * ypixb + b0 * 2;
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const bool ok = ty0 + yty[c] < H && tx0 + ytx[c] < W;
-        glds16(ok ? yo + yrel[c] : zero, lx + XBYTES + (wid_u + 8 * c) * 1024);
+      for (int c = 0; c < YCW; ++c) {
+        if (wid_u + 8 * c < YCH) {  // wave-uniform
+          const bool ok = ty0 + yty[c] < H && tx0 + ytx[c] < W;
+          glds16(ok ? yo + yrel[c] : zero, lx + XBYTES + (wid_u + 8 * c) * 1024);
+        }
       }
       if (++i_txb == tiles_x) {
         i_txb = 0;
@@ -206,9 +258,9 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
       const int bo = buf * BUF;
       if (i + 1 < seg_n) issue(BUF - bo);
       if (ysum) {
-        // bias gradient = sum over pixels of Y: thread (row r0 = tid / 8 [+ 64], logical piece tid % 8) adds its 8 channels
+        // bias gradient = sum over pixels of Y: thread (row tid / 8 [+ 64], logical piece tid % 8) adds its 8 channels
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < TPIX / 64; ++h) {
           const int k = (tid >> 3) + 64 * h, lp = tid & 7;
           const int phys = ((((lp >> 1) ^ ((k >> 1) & 3)) * 2) + (lp & 1)) * 16;
           const u32x4 v = *reinterpret_cast<const u32x4*>(smem + bo + XBYTES + k * 128 + phys);
@@ -220,7 +272,7 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
       }
       const char* base = smem + bo;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < Gm::KSTEPS; ++s) {
         bf16x8 bfr[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -232,9 +284,9 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
           bfr[b] = __builtin_bit_cast(bf16x8, cat);
         }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int dy = t / 3, dx = t % 3;
-          const char* xp = base + xa[dx] + (s * SROW + dy) * IW * 128;
+        for (int t = 0; t < NT; ++t) {
+          const int dy = t / NTS, dx = t % NTS;
+          const char* xp = base + xa[dx] + Gm::tap_row(s, dy);
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xp));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xp + HI));
           typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -250,7 +302,7 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
     // ---- the segment's partial dW -> slab slot (workgroup + global ordinal of the channel block)
     float* slab = p.slab + (size_t)(blockIdx.x + gb0 + blk) * kSlot;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const int bch = (wb * 2 + b) * 16 + idx;
@@ -269,7 +321,7 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
         float s = 0.f;
         if (ysum)
           for (int r = 0; r < 64; ++r) s += red[r * 64 + tid];
-        slab[9 * 64 * 64 + tid] = s;  // blocks with a0 != 0 write zeros: the fold reads the sums of block row 0 only
+        slab[NT * 64 * 64 + tid] = s;  // blocks with a0 != 0 write zeros: the fold reads the sums of block row 0 only
       }
       __syncthreads();
     }
@@ -278,11 +330,11 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
   }
 }
 
-template <typename T, int TW>
+template <typename T, int TW, int S, int NTS>
 int launch_group(const WgGroupK& k, int nwg, hipStream_t st) {
-  auto fn = wgrad_group_kernel<T, TW>;
-  constexpr int IW = TW + 2, IH = 128 / TW + 2;
-  constexpr int lds = 2 * (((IW * IH * 128 + 1023) / 1024) * 1024 + 16 * 1024);
+  auto fn = wgrad_group_kernel<T, TW, S, NTS>;
+  constexpr int lds = 2 * WgGeom<TW, S, NTS>::BUF;
+  static_assert(lds <= 160 * 1024, "two LDS buffers must fit");
   static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -292,16 +344,36 @@ int launch_group(const WgGroupK& k, int nwg, hipStream_t st) {
   return tg_launch_status();
 }
 
+template <typename T>
+int dispatch_group(int variant, int tile_w, const WgGroupK& k, int nwg, hipStream_t st) {
+  if (variant == TG_WGROUP_C3) return tile_w == 32 ? launch_group<T, 32, 1, 3>(k, nwg, st) : launch_group<T, 16, 1, 3>(k, nwg, st);
+  if (variant == TG_WGROUP_CT) return launch_group<T, 16, 2, 3>(k, nwg, st);
+  return launch_group<T, 16, 2, 4>(k, nwg, st);
+}
+
 }  // namespace
 
-extern "C" int64_t tg_wgrad_group_slot_floats(void) { return kSlot; }
+extern "C" int64_t tg_wgrad_group_slot_floats(void) { return 9 * 64 * 64 + 64; }
 
-extern "C" int tg_wgrad_group(int dtype, int tile_w, const int64_t* jobs_dev, int njobs, int units_total, int workgroups,
-                              float* slab, void* stream) {
+extern "C" int64_t tg_wgrad_group_slot_floats_v(int variant) {
+  if (variant == TG_WGROUP_C3 || variant == TG_WGROUP_CT) return 9 * 64 * 64 + 64;
+  if (variant == TG_WGROUP_C4S2) return 16 * 64 * 64 + 64;
+  return TG_E_BADARG;
+}
+
+namespace {
+int group_launch(int dtype, int variant, int tile_w, const int64_t* jobs_dev, int njobs, int units_total, int workgroups,
+                 float* slab, void* stream) {
   if (!jobs_dev || !slab || njobs <= 0 || units_total <= 0 || workgroups <= 0) return TG_E_BADARG;
   if (!tg_aligned16(slab)) return TG_E_ALIGN;
   if (dtype != TG_BF16 && dtype != TG_F16) return TG_E_UNSUPPORTED;
-  if (tile_w != 32 && tile_w != 16) return TG_E_UNSUPPORTED;
+  if (variant == TG_WGROUP_C3) {
+    if (tile_w != 32 && tile_w != 16) return TG_E_UNSUPPORTED;
+  } else if (variant == TG_WGROUP_CT || variant == TG_WGROUP_C4S2) {
+    if (tile_w != 16) return TG_E_UNSUPPORTED;
+  } else {
+    return TG_E_BADARG;
+  }
   WgGroupK k;
   k.jobs = reinterpret_cast<const long long*>(jobs_dev);
   k.slab = slab;
@@ -310,6 +382,16 @@ extern "C" int tg_wgrad_group(int dtype, int tile_w, const int64_t* jobs_dev, in
   k.per_wg = (units_total + workgroups - 1) / workgroups;
   const int nwg = (units_total + k.per_wg - 1) / k.per_wg;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TG_BF16) return tile_w == 32 ? launch_group<BF16, 32>(k, nwg, st) : launch_group<BF16, 16>(k, nwg, st);
-  return tile_w == 32 ? launch_group<F16, 32>(k, nwg, st) : launch_group<F16, 16>(k, nwg, st);
+  return dtype == TG_BF16 ? dispatch_group<BF16>(variant, tile_w, k, nwg, st) : dispatch_group<F16>(variant, tile_w, k, nwg, st);
+}
+}  // namespace
+
+extern "C" int tg_wgrad_group(int dtype, int tile_w, const int64_t* jobs_dev, int njobs, int units_total, int workgroups,
+                              float* slab, void* stream) {
+  return group_launch(dtype, TG_WGROUP_C3, tile_w, jobs_dev, njobs, units_total, workgroups, slab, stream);
+}
+
+extern "C" int tg_wgrad_group_v(int dtype, int variant, int tile_w, const int64_t* jobs_dev, int njobs, int units_total,
+                                int workgroups, float* slab, void* stream) {
+  return group_launch(dtype, variant, tile_w, jobs_dev, njobs, units_total, workgroups, slab, stream);
 }

@@ -345,18 +345,20 @@ class WgradGroup:
 
 
 class WgradList:
-    """Weight gradients of several plain 3x3 layers - ANY mix of image sizes and channel counts - in ONE persistent launch
-    (tg_wgrad_group, csrc/wgrad_group.hip): the (layer, 64 x 64 channel block, 128-pixel tile) units of all layers form one
-    list that `cap` workgroups share evenly, so a step writes  workgroups + channel blocks  slabs per launch instead of
-    workgroups slabs per LAYER.  Same calling pattern as WgradGroup (add ... launch, deferred fold); layers the kernel
-    does not take (other kinds, channel counts not multiples of 64, fp32) run their own tg_wgrad launch at add()."""
+    """Weight gradients of several layers - ANY mix of image sizes and channel counts - in ONE persistent launch per layer
+    kind (tg_wgrad_group_v, csrc/wgrad_group.hip: 3x3 stride-1 convs, conv-transposes k3 s2, convs k4 s2): the (layer, 64 x 64
+    channel block, pixel tile) units of all layers form one list that `cap` workgroups share evenly, so a step writes
+    workgroups + channel blocks  slabs per launch instead of  workgroups  slabs per LAYER.  Same calling pattern as
+    WgradGroup (add ... launch, deferred fold); layers the kernel does not take (fp32, 32 -> 32 channels) run their own
+    tg_wgrad launch at add()."""
+    VARIANT = {"c3": L.WGROUP_C3, "ct": L.WGROUP_CT, "c4s2": L.WGROUP_C4S2}
 
     def __init__(self, cap):
         self.items, self.cache, self.cap = [], {}, cap
 
     @staticmethod
     def takes(conv):
-        return conv.spec.kind == "c3" and conv.dt in (torch.bfloat16, torch.float16) and conv.defer_finalize and \
+        return conv.spec.kind in WgradList.VARIANT and conv.dt in (torch.bfloat16, torch.float16) and conv.defer_finalize and \
             (conv.cin_p >= 64 or conv.cout_p >= 64)   # (32 -> 32 layers would run quarter-full blocks: tg_wgrad's 32 x 32 config)
 
     def add(self, conv, x_in, dout, bias_sum=False):
@@ -366,12 +368,15 @@ class WgradList:
         self.items.append((conv, x_in, dout, bias_sum))
 
     @staticmethod
-    def plan(shapes, cap, slot):
-        """pure host logic (unit-tested on the CPU).  shapes: [(N, H, W, cx_p, cy_p)] -> (tile_w, job rows without the two
-        pointers, units_total, the `workgroups` argument of tg_wgrad_group (it launches ceil(units / ceil(units / workgroups))
-        of them), [(job, a0, b0, first_slot, count)] per channel block, slots)"""
-        tw = 32 if max(s[2] for s in shapes) > 16 else 16
-        th = 128 // tw
+    def plan(shapes, cap, slot, variant=L.WGROUP_C3):
+        """pure host logic (unit-tested on the CPU).  shapes: [(N, H, W, cx_p, cy_p)] with H x W the grid of the Y operand ->
+        (tile_w, job rows without the two pointers, units_total, the `workgroups` argument of tg_wgrad_group_v (it launches
+        ceil(units / ceil(units / workgroups)) of them), [(job, a0, b0, first_slot, count)] per channel block, slots)"""
+        if variant == L.WGROUP_C3:
+            tw = 32 if max(s[2] for s in shapes) > 16 else 16
+            th = 128 // tw
+        else:
+            tw, th = 16, 4
         rows, units, gb = [], 0, 0
         spans = []
         for j, (N, H, W, cx, cy) in enumerate(shapes):
@@ -393,41 +398,52 @@ class WgradList:
             fold.append((j, a0, b0, w0 + g, w1 - w0 + 1))
         return tw, rows, units, cap, fold, nwg + gb
 
-    def launch(self):
-        items, self.items = self.items, []
-        if not items:
-            return
+    def launch(self, only=None):
+        """launches the queued layers, one work list per layer kind; only: the kinds (L.WGROUP_*) to launch now - the
+        others stay queued (the discriminator queues its five k4 s2 layers across the whole backward pass)"""
+        now = [it for it in self.items if only is None or self.VARIANT[it[0].spec.kind] in only]
+        self.items = [it for it in self.items if not (only is None or self.VARIANT[it[0].spec.kind] in only)]
+        for variant in sorted({self.VARIANT[it[0].spec.kind] for it in now}):
+            self._launch([it for it in now if self.VARIANT[it[0].spec.kind] == variant], variant)
+
+    def _launch(self, items, variant):
         key = tuple((id(c), x.data_ptr(), y.data_ptr(), tuple(x.shape), tuple(y.shape), b) for c, x, y, b in items)
         ent = self.cache.get(key)
         if ent is None:
             if items[0][0].ws.frozen:
                 raise L.TecoganHipError("new wgrad shape after graph capture")
             lib = L.load()
-            slot = int(lib.tg_wgrad_group_slot_floats())
-            shapes = [(x.shape[0], x.shape[1], x.shape[2], x.shape[3], y.shape[3]) for _, x, y, _ in items]
-            tw, rows, units, nwg, fold, slots = self.plan(shapes, self.cap, slot)
-            dev = items[0][1].device
+            slot = int(lib.tg_wgrad_group_slot_floats_v(variant))
+            ops = []
+            for c, x_in, dout, b in items:   # X: the operand the taps shift (on the S-times finer grid), Y: the other one
+                x_is_in = c.spec.wgrad_info()[0]
+                ops.append((x_in, dout) if x_is_in else (dout, x_in))
+            S = 1 if variant == L.WGROUP_C3 else 2
+            for X, Y in ops:
+                if (X.shape[0], X.shape[1], X.shape[2]) != (Y.shape[0], S * Y.shape[1], S * Y.shape[2]):
+                    raise L.TecoganHipError("tg_wgrad_group: operand grids do not match the layer kind")
+            shapes = [(Y.shape[0], Y.shape[1], Y.shape[2], X.shape[3], Y.shape[3]) for X, Y in ops]
+            tw, rows, units, wgs, fold, slots = self.plan(shapes, self.cap, slot, variant)
+            dev = ops[0][0].device
             slab = torch.empty(slots * slot, dtype=torch.float32, device=dev)
             jobs = []
-            for (c, x, y, b), r in zip(items, rows):
-                if x.shape[:3] != y.shape[:3]:
-                    raise L.TecoganHipError("tg_wgrad_group needs stride-1 layers (X and Y of one size)")
+            for (c, _, _, b), (X, Y), r in zip(items, ops, rows):
                 r[8] = 1 if b else 0
-                jobs.append([x.data_ptr(), y.data_ptr()] + r)
+                jobs.append([X.data_ptr(), Y.data_ptr()] + r)
             fin = {}
             for j, a0, b0, first, count in fold:
                 c, _, _, b = items[j]
                 _, _, taps, ca, cb, s_a, s_b = c.spec.wgrad_info()
                 bias = c.gbias.data_ptr() + 4 * b0 if (b and a0 == 0) else 0
                 fin.setdefault(j, []).append([slab.data_ptr() + 4 * slot * first, c.gw.data_ptr() + 4 * (a0 * s_a + b0 * s_b),
-                                              s_a, s_b, count, 9, 64, 64, min(64, ca - a0), min(64, cb - b0), bias, slot])
-            ent = (tw, torch.tensor(jobs, dtype=torch.int64, device=dev), units, nwg, slab, fin, K.tg_dtype(items[0][0].dt))
+                                              s_a, s_b, count, len(taps), 64, 64, min(64, ca - a0), min(64, cb - b0), bias, slot])
+            ent = (tw, torch.tensor(jobs, dtype=torch.int64, device=dev), units, wgs, slab, fin, K.tg_dtype(items[0][0].dt))
             self.cache[key] = ent
-        tw, jobs, units, nwg, slab, fin, tg = ent
+        tw, jobs, units, wgs, slab, fin, tg = ent
         for j, (c, _, _, _) in enumerate(items):
             c.fin_job = fin[j]   # a LIST of fold jobs (one per channel block): Finalizer.run flattens
-        L.check(L.load().tg_wgrad_group(tg, tw, jobs.data_ptr(), jobs.shape[0], units, nwg, slab.data_ptr(),
-                                        torch.cuda.current_stream().cuda_stream), "tg_wgrad_group")
+        L.check(L.load().tg_wgrad_group_v(tg, variant, tw, jobs.data_ptr(), jobs.shape[0], units, wgs, slab.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "tg_wgrad_group_v")
 
 
 def _wgrad_lists():
@@ -735,7 +751,7 @@ class GeneratorEngine:
         self.cout.dgrad(g["dpre"], g["hr64"], mask=a["u4"], mask_mode=RELU)
         wh(self.c6, a["u3"], g["hr64"], True)
         self.c6.dgrad(g["hr64"], g["hr128"], mask=a["u3"], mask_mode=RELU, bias_grad_of=self.ct4)
-        self.ct4.wgrad(a["u2"], g["hr128"])
+        wh(self.ct4, a["u2"], g["hr128"])
         self.ct4.dgrad(g["hr128"], g["m128a"])
         wh(self.c32, a["h2"], g["m128a"])
         self.c32.dgrad(g["m128a"], g["m128b"], mask=a["h2"], mask_mode=RELU)
@@ -745,7 +761,7 @@ class GeneratorEngine:
         self.c22.dgrad(g["m64a"], g["m64b"], mask=a["hh"], mask_mode=RELU)
         wh(self.c20, a["u0"], g["m64b"], True)
         self.c20.dgrad(g["m64b"], g["m64c"], mask=a["u0"], mask_mode=RELU, bias_grad_of=self.ct0)
-        self.ct0.wgrad(a["a"][self.nrb], g["m64c"])
+        wh(self.ct0, a["a"][self.nrb], g["m64c"])
         self.ct0.dgrad(g["m64c"], dA[self.nrb])
         if hr is not None:
             hr.launch()
@@ -1182,6 +1198,7 @@ class DiscriminatorEngine:
         else:
             d_net = g["dnet"][1][self.nrb - 1] if self.nrb > 0 else g["dn"][1]   # what part 'hi' left behind
         grouped = self.finalizer is not None and self.res_group is not None
+        lists = grouped and isinstance(self.res_group, WgradList)
         wg = (lambda c, x, y, b=False: self.res_group.add(c, x, y, b)) if grouped else \
             (lambda c, x, y, b=False: c.wgrad(x, y, bias_sum=b))
         stage_out = lambda k: a["net"][k][self.nrb - 1] if (k <= 3 and self.nrb > 0) else a["n"][k]
@@ -1199,25 +1216,31 @@ class DiscriminatorEngine:
                     wg(c1, net_in, d_h, True)
                     c1.dgrad(d_h, d_in, res=d_net)
                     d_net = d_in
-                if grouped and (k > 1 or not isinstance(self.res_group, WgradList)):
+                if grouped and not lists:
                     self.res_group.launch()  # the 2*nrb same-shaped residual convs of this stage in one grid
-                # (stage 1 of a work-list engine waits for conv.0 below: one launch for both)
+                elif grouped and k > 1:
+                    self.res_group.launch(only=(L.WGROUP_C3,))
+                # (work lists: stage 1 waits for conv.0 below - one launch for both; the k4 s2 layers stay queued to the end)
             conv, bn = self.blk[k]
             d_z = g["dz"][k]
             bn.backward(d_net, a["n"][k], a["z"][k], d_z, L.ACT_LRELU, groups, half=half)
             prev = stage_out(k - 1) if k > 1 else a["c0"]
-            conv.wgrad(prev, d_z)
+            if lists:
+                wg(conv, prev, d_z)
+            else:
+                conv.wgrad(prev, d_z)
             if k > 1:
                 d_prev = g["dnet"][k - 1][self.nrb - 1] if (k - 1 <= 3 and self.nrb > 0) else g["dn"][k - 1]
                 conv.dgrad(d_z, d_prev)
                 d_net = d_prev
             else:
                 conv.dgrad(d_z, g_c0, mask=a["c0"], mask_mode=L.MASK_LRELU)
-                if grouped and isinstance(self.res_group, WgradList):   # conv.0 (27 -> 64, full resolution) shares stage 1's work list
+                if lists:   # conv.0 (27 -> 64, full resolution) shares stage 1's work list
                     wg(self.conv0, a["in"], g_c0, True)
-                    self.res_group.launch()
                 else:
                     self.conv0.wgrad(a["in"], g_c0, bias_sum=True)
+        if lists:
+            self.res_group.launch()   # whatever is still queued: the k4 s2 layers of this part, stage 1 + conv.0
         if self.finalizer is not None:
             self.finalizer.run(only=None if part is None else lo_convs if part == "lo" else
                                [c for c in self.convs if all(c is not x for x in lo_convs)])

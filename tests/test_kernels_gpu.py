@@ -386,6 +386,55 @@ def test_wgrad_group_work_list_vs_torch(cap, shapes, dt):
             assert float(gbs[i].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kind,cap,layers", [
+    # (N, h, w of the COARSE grid, cin, cout)
+    ("ct", 5, [(2, 16, 16, 64, 64), (1, 32, 32, 128, 128), (2, 8, 20, 64, 128)]),
+    ("ct", 160, [(3, 32, 32, 64, 64), (3, 64, 64, 128, 128)]),
+    ("c4s2", 7, [(2, 32, 32, 64, 64), (1, 16, 16, 128, 128), (3, 4, 4, 64, 3), (2, 8, 8, 128, 64), (1, 10, 6, 64, 64)]),
+    ("c4s2", 96, [(3, 64, 64, 64, 64), (3, 32, 32, 64, 128)]),
+])
+def test_wgrad_group_stride2_kinds_vs_torch(kind, cap, layers, dt):
+    """tg_wgrad_group_v for the two stride-2 layer kinds (conv-transpose k3 s2: X = the output gradient on the fine grid;
+    conv k4 s2: X = the input on the fine grid; the patch columns are de-interleaved by parity in LDS): work lists of
+    several layers, folded by tg_wgrad_finalize_multi, against torch autograd of the module ops (code/ops.py:45-63)."""
+    from pytorch_tecogan_amd import engine as E
+    lib = L.load()
+    variant = E.WgradList.VARIANT[kind]
+    slot = int(lib.tg_wgrad_group_slot_floats_v(variant))
+    specs = [K.ConvSpec(kind, cin, cout) for (_, _, _, cin, cout) in layers]
+    ops, refs = [], []
+    for i, ((N, h, w, cin, cout), sp) in enumerate(zip(layers, specs)):
+        if kind == "ct":     # input on the coarse grid, output gradient on the fine one
+            x, d = q(rnd((N, cin, h, w), 500 + i), dt), q(rnd((N, cout, 2 * h, 2 * w), 600 + i), dt)
+        else:                # input on the fine grid, output gradient on the coarse one
+            x, d = q(rnd((N, cin, 2 * h, 2 * w), 500 + i), dt), q(rnd((N, cout, h, w), 600 + i), dt)
+        wt = torch.zeros(sp.weight_shape, requires_grad=True)
+        ref_conv(sp, x, wt, None).backward(d)
+        refs.append(wt.grad)
+        xd, dd = K.to_nhwc(x.to(DEV), dt), K.to_nhwc(d.to(DEV), dt)
+        ops.append((xd, dd) if sp.wgrad_info()[0] else (dd, xd))
+    tw, rows, units, wgs, fold, slots = E.WgradList.plan([(Y.shape[0], Y.shape[1], Y.shape[2], X.shape[3], Y.shape[3])
+                                                          for X, Y in ops], cap, slot, variant)
+    assert tw == 16
+    slab = torch.full((slots * slot,), float("nan"), device=DEV)
+    jt = torch.tensor([[X.data_ptr(), Y.data_ptr()] + r for (X, Y), r in zip(ops, rows)], dtype=torch.int64, device=DEV)
+    L.check(lib.tg_wgrad_group_v(K.tg_dtype(dt), variant, tw, jt.data_ptr(), len(rows), units, wgs, slab.data_ptr(), None),
+            "tg_wgrad_group_v")
+    grads = [torch.zeros(sp.weight_shape, device=DEV) for sp in specs]
+    fin = []
+    for j, a0, b0, first, count in fold:
+        _, _, taps, ca, cb, s_a, s_b = specs[j].wgrad_info()
+        fin.append([slab.data_ptr() + 4 * slot * first, grads[j].data_ptr() + 4 * (a0 * s_a + b0 * s_b), s_a, s_b, count, len(taps),
+                    64, 64, min(64, ca - a0), min(64, cb - b0), 0, slot])
+    ft = torch.tensor(fin, dtype=torch.int64, device=DEV)
+    L.check(lib.tg_wgrad_finalize_multi(ft.data_ptr(), len(fin), 8, None), "tg_wgrad_finalize_multi")
+    torch.cuda.synchronize()
+    for i in range(len(layers)):
+        assert rel_err(grads[i].cpu(), refs[i]) < 2e-3, (i, layers[i], rel_err(grads[i].cpu(), refs[i]))
+        torch.testing.assert_close(grads[i].cpu(), refs[i], rtol=2e-2, atol=float(refs[i].abs().max()) * 1e-2)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("C_,act,skip", [(64, L.ACT_NONE, True), (128, L.ACT_LRELU, False), (32, L.ACT_LRELU, False)])
 def test_batchnorm_train_fwd_bwd(C_, act, skip, dt):
