@@ -38,7 +38,7 @@ enum {
 };
 
 enum { TG_ACT_NONE = 0, TG_ACT_RELU = 1, TG_ACT_LRELU = 2, TG_ACT_SIGMOID = 3, TG_ACT_TANH24 = 4 /* 24*tanh, code/models.py:50 */ };
-enum { TG_MASK_NONE = 0, TG_MASK_RELU = 1, TG_MASK_LRELU = 2 };
+enum { TG_MASK_NONE = 0, TG_MASK_RELU = 1, TG_MASK_LRELU = 2, TG_MASK_BNZ = 3 /* tg_conv stats_mode 3: `mask` is z */ };
 enum { TG_OUT_NHWC = 0, TG_OUT_NCHW_F32 = 1 };
 
 #define TG_MAX_TAPS 16
@@ -65,7 +65,8 @@ typedef struct {
   /* epilogue, applied in this order: +bias, +res, act, *mask, store, per-channel stats */
   int32_t act;                  /* TG_ACT_* */
   int32_t mask_mode;            /* TG_MASK_*: multiply by act'(mask) where mask is the saved activation */
-  int32_t stats_mode;           /* 0 none, 1 per-channel sum, 2 sum and sum of squares */
+  int32_t stats_mode;           /* 0 none, 1 per-channel sum, 2 sum and sum of squares, 3 (with TG_MASK_BNZ) sum out and sum out * z:
+                                 * the batch-norm backward sums of the layer whose output gradient this launch produces */
   int32_t stats_groups;         /* batch is split into this many equal groups with separate statistics */
   int32_t out_mode;             /* TG_OUT_* */
   int32_t c_real;               /* TG_OUT_NCHW_F32: number of real channels stored (<=4) */
@@ -298,10 +299,12 @@ int tg_bn_apply(int dtype, const void* z, const float* stats, int stats_replicas
 /* red (red_replicas blocks of [groups][2][C]) += (sum dyp, sum dyp*xhat) where dyp = dy * act'(yact). */
 int tg_bn_bwd_reduce(int dtype, const void* dy, const void* yact, const void* z, const float* save, float* red,
                      int red_replicas, int N, int HW, int C, int groups, int act, void* stream);
-/* dz = gamma*invstd*(dyp - mean(dyp) - xhat*mean(dyp*xhat)); block 0 accumulates dgamma/dbeta. */
+/* dz = gamma*invstd*(dyp - mean(dyp) - xhat*mean(dyp*xhat)); block 0 accumulates dgamma/dbeta.
+ * red_raw = 1: red holds (sum dy, sum dy*z) as the epilogue of the tg_conv launch that PRODUCED dy left them (stats_mode 3,
+ * TG_MASK_BNZ; act must be TG_ACT_NONE then) instead of tg_bn_bwd_reduce's (sum dyp, sum dyp*xhat): converted here. */
 int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, const void* z, const float* save, const float* red,
                     int red_replicas, const float* gamma, void* dz, float* dgamma, float* dbeta, int N, int HW, int C,
-                    int groups, int act, void* stream);
+                    int groups, int act, int red_raw, void* stream);
 
 /* ---- heads and losses (code/models.py:143-145; code/train.py:205-333) ----------------------------------- */
 int tg_fc_head_fwd(int dtype, const void* feat, const float* w, const float* b, float* prob, int N, int HW, int C,

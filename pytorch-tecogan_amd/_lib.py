@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("TECOGAN_LIB") or os.path.join(_HERE, "csrc", "libteco
 
 TG_F32, TG_BF16, TG_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_TANH24 = 0, 1, 2, 3, 4
-MASK_NONE, MASK_RELU, MASK_LRELU = 0, 1, 2
+MASK_NONE, MASK_RELU, MASK_LRELU, MASK_BNZ = 0, 1, 2, 3
 OUT_NHWC, OUT_NCHW_F32 = 0, 1
 TILE_AUTO, TILE_64x256, TILE_64x64, TILE_128x128, TILE_32x128 = 0, 1, 2, 3, 4
 TILE_32x64, TILE_64x128, TILE_64x128_8W, TILE_64x64_8W = 5, 6, 7, 8
@@ -84,7 +84,7 @@ _PROTOS = {
     "tg_d_assemble": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "tg_bn_apply": (_I, [_I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
     "tg_bn_bwd_reduce": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "tg_bn_bwd_apply": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "tg_bn_bwd_apply": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "tg_fc_head_fwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tg_fc_head_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tg_absdiff_sum": (_I, [_I, _P, _P, _P, _L, _I, _I, _P]),

@@ -484,7 +484,7 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gather_kernel(const ConvK p
 #pragma unroll
           for (int e = 0; e < E; ++e) v[e] = apply_act(v[e], p.act);
         }
-        if (p.mask_mode != TG_MASK_NONE) {
+        if (p.mask_mode == TG_MASK_RELU || p.mask_mode == TG_MASK_LRELU) {
           float m[E];
           Vec<T>::load(&pre[b][a], m);
           const float neg = p.mask_mode == TG_MASK_LRELU ? 0.2f : 0.f;
@@ -497,7 +497,21 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gather_kernel(const ConvK p
           float* o = reinterpret_cast<float*>(p.out) + (size_t)n * p.out_n_stride + (size_t)oy * p.OW + ox;
           for (int e = 0; e < p.c_real; ++e) o[(size_t)e * p.OH * p.OW] = v[e];
         }
-        if (!SLIM && p.stats_mode) {
+        if (!SLIM && p.stats_mode == 3) {
+          // batch-norm backward sums for the layer this output is the gradient of (TG_MASK_BNZ: `mask` is that layer's
+          // pre-normalisation tensor z): sum dy and sum dy * z per channel, of the values as STORED (what tg_bn_bwd_reduce,
+          // which this replaces, would read back)
+          float zz[E], vr[E];
+          Vec<T>::load(&pre[b][a], zz);
+          u32x4 rt;
+          Vec<T>::store(&rt, v);
+          Vec<T>::load(&rt, vr);
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            s1[a][e] += vr[e];
+            s2[a][e] += vr[e] * zz[e];
+          }
+        } else if (!SLIM && p.stats_mode) {
 #pragma unroll
           for (int e = 0; e < E; ++e) {
             s1[a][e] += v[e];
@@ -535,7 +549,7 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gather_kernel(const ConvK p
     }
     __syncthreads();
     const int grp = n / (p.N / p.stats_groups);
-    for (int i = tid; i < p.stats_mode * CO_TILE; i += NTHR) {
+    for (int i = tid; i < (p.stats_mode == 1 ? 1 : 2) * CO_TILE; i += NTHR) {
       const int which = i / CO_TILE, chn = i - which * CO_TILE;
       float s = 0.f;
 #pragma unroll
@@ -702,7 +716,9 @@ static int prepare_conv(const tg_conv_desc* d, const void* in, const void* w_pac
     if (d->mask_mode != TG_MASK_NONE && !mask) return TG_E_BADARG;
     if (d->stats_mode && !stats) return TG_E_BADARG;
   }
-  if (d->stats_mode < 0 || d->stats_mode > 2) return TG_E_BADARG;
+  if (d->stats_mode < 0 || d->stats_mode > 3) return TG_E_BADARG;
+  if ((d->stats_mode == 3) != (d->mask_mode == TG_MASK_BNZ)) return TG_E_BADARG;  // the BN sums need z in the mask slot
+  if (d->mask_mode == TG_MASK_BNZ && !mask && check_ptrs) return TG_E_BADARG;
   if (d->stats_mode && (d->stats_groups <= 0 || d->N % d->stats_groups)) return TG_E_BADARG;
   if (d->out_mode == TG_OUT_NCHW_F32 && (d->c_real <= 0 || d->c_real > 4 || d->out_n_stride <= 0)) return TG_E_BADARG;
   if (d->out_mode != TG_OUT_NHWC && d->out_mode != TG_OUT_NCHW_F32) return TG_E_BADARG;

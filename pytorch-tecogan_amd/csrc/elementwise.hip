@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
                                                           const float* __restrict__ red_rep, int R, const float* __restrict__ gamma,
                                                           char* __restrict__ dz, float* __restrict__ dgamma,
                                                           float* __restrict__ dbeta, int N, int HW, int C, int groups,
-                                                          int act) {
+                                                          int act, int red_raw) {
   using TR = ElemTraits<T>;
   constexpr int E = TR::kVec;
   const int vpp = C / E;
@@ -256,6 +256,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
     mean[e] = save[(grp * 2 + 0) * C + c];
     invstd[e] = save[(grp * 2 + 1) * C + c];
     k0[e] = gamma[c] * invstd[e];
+    // red_raw: the second sum is sum dy * z as the producing conv's epilogue left it (tg_conv, stats_mode 3), not yet
+    // sum dy * (z - mean) * invstd
+    if (red_raw) m2[e] = (m2[e] - mean[e] * m1[e]) * invstd[e];
     m1[e] *= inv_cnt;
     m2[e] *= inv_cnt;
   }
@@ -263,8 +266,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
     const int c = threadIdx.x;
     float dg = 0.f, db = 0.f;
     for (int g2 = 0; g2 < groups; ++g2) {
-      db += load_folded1(red_rep + (g2 * 2 + 0) * C + c, R, rblock);
-      dg += load_folded1(red_rep + (g2 * 2 + 1) * C + c, R, rblock);
+      const float b1 = load_folded1(red_rep + (g2 * 2 + 0) * C + c, R, rblock);
+      float g1 = load_folded1(red_rep + (g2 * 2 + 1) * C + c, R, rblock);
+      if (red_raw) g1 = (g1 - save[(g2 * 2 + 0) * C + c] * b1) * save[(g2 * 2 + 1) * C + c];
+      db += b1;
+      dg += g1;
     }
     dgamma[c] += dg;
     dbeta[c] += db;
@@ -616,7 +622,7 @@ extern "C" int tg_bn_bwd_reduce(int dtype, const void* dy, const void* yact, con
 
 extern "C" int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, const void* z, const float* save,
                                const float* red, int red_replicas, const float* gamma, void* dz, float* dgamma, float* dbeta,
-                               int N, int HW, int C, int groups, int act, void* stream) {
+                               int N, int HW, int C, int groups, int act, int red_raw, void* stream) {
   if (!dy || !z || !save || !red || !gamma || !dz || !dgamma || !dbeta || N <= 0 || HW <= 0 || groups <= 0 || N % groups)
     return TG_E_BADARG;
   if (act == TG_ACT_LRELU && !yact) return TG_E_BADARG;
@@ -625,7 +631,7 @@ extern "C" int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, cons
   const int rows = 256 / (C / (dtype == TG_F32 ? 4 : 8));
   dim3 grid(grid_for((long long)(N / groups) * HW, rows * 4, 1024), groups);
   TG_DISPATCH(dtype, bn_bwd_apply_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)dy, (const char*)yact,
-              (const char*)z, save, red, red_replicas, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act);
+              (const char*)z, save, red, red_replicas, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act, red_raw);
   return tg_launch_status();
 }
 

@@ -214,11 +214,26 @@ class Conv:
         else:
             K.conv(d, x, self.wf, out, bias=self.bias, res=res, stats=stats)
 
-    def dgrad(self, dout, out, mask=None, mask_mode=L.MASK_NONE, res=None, bias_grad_of=None):
+    def dgrad(self, dout, out, mask=None, mask_mode=L.MASK_NONE, res=None, bias_grad_of=None, bn_sums=None):
         """dout [N,OH,OW,cout_p] -> out [N,H,W,cin_p] = (dgrad + res) * act'(mask); bias_grad_of: Conv whose bias
-        gradient is the per-channel sum of `out` (accumulated straight into its grad slot)."""
+        gradient is the per-channel sum of `out` (accumulated straight into its grad slot).
+        bn_sums = (red, z, groups, replicas): `out` is the output gradient of a BatchNorm without activation whose
+        pre-normalisation tensor is z - the epilogue also adds (sum out, sum out * z) per channel into red (the layout of
+        tg_bn_bwd_reduce, raw second sum: BatchNorm.backward(reduced=True) converts), which saves that reduction launch."""
         N, OH, OW, _ = dout.shape
         _, H, W, _ = out.shape
+        if bn_sums is not None:
+            if self.spec.kind != "c3" or mask is not None or bias_grad_of is not None:
+                raise L.TecoganHipError("bn_sums: plain 3x3 input-gradient without mask / bias sums only")
+            red, z, groups, R = bn_sums
+            key = ("dbn", N, OH, OW, res is not None, groups, R)
+            d = self._desc.get(key)
+            if d is None:
+                d = self._desc[key] = K.make_conv_desc(self.spec.dgrad_geom(), self.tg, N, OH, OW, self.cout_p, H, W, self.cin_p,
+                                                       mask_mode=L.MASK_BNZ, stats_mode=3, stats_groups=groups, stats_replicas=R)
+            self.last_desc = d
+            K.conv(d, dout, self.wb, out, res=res, mask=z, stats=red)
+            return
         if self.spec.kind == "ct" and self.cin_p % 64 == 0 and mask is None and res is None and bias_grad_of is None and \
                 _FAST_C4S2 and OH == 2 * H and OW == 2 * W:
             self.last_desc = "ctd"  # 3x3-window stride-2 gather (csrc/conv4s2_mfma.hip, KS = 3)
@@ -476,6 +491,12 @@ def _defer_finalize():
 
 
 _FOLD_ITEMS = os.environ.get("TECOGAN_FOLD_ITEMS", "1") != "0"
+# Batch-norm backward sums in the epilogue of the input-gradient launch that produces dy (9 of the 17 BN layers per pass):
+# built, parity-tested (tests/test_kernels_gpu.py::test_bn_backward_sums_in_the_dgrad_epilogue) and measured SLOWER in the step
+# - 18 tg_bn_bwd_reduce launches fewer, but the sums need the general conv epilogue (the plain launch takes the slim one) and
+# stage 2 leaves the register-weights kernel: D real 1.589 -> 1.574 ms alone, step 4.43 -> 4.46 ms on one box
+# (profiles/r03_g_bn_fuse_ab.log).  Off by default.
+_BN_FUSE = os.environ.get("TECOGAN_BN_FUSE", "0") == "1"
 
 
 def fold_items(jobs):
@@ -563,14 +584,22 @@ class BatchNorm:
                    running_mean=self.rm if update else None, running_var=self.rv if update else None,
                    nbt=self.nbt if update else None, replicas=self.R)
 
-    def backward(self, dy, yact, z, dz, act, groups, half=None):
-        """half=g: the tensors hold only group g of 2 (see apply); that group's saved statistics / reduction slots are used"""
+    def red_slot(self, half=None):
+        """what a producing input-gradient launch adds the backward sums into (Conv.dgrad(bn_sums=...))"""
+        return self._slot(self.red, half)
+
+    def backward(self, dy, yact, z, dz, act, groups, half=None, reduced=False):
+        """half=g: the tensors hold only group g of 2 (see apply); that group's saved statistics / reduction slots are used.
+        reduced: the launch that produced dy has already left (sum dy, sum dy * z) in red_slot(half) (act must be none)"""
         N, H, W, C_ = z.shape
         save, red = (self.save if half is None else self.save[half]), self._slot(self.red, half)
         g = groups if half is None else 1
-        K.bn_bwd_reduce(dy, yact, z, save, red, N, H * W, C_, g, act, replicas=self.R)
+        if not reduced:
+            K.bn_bwd_reduce(dy, yact, z, save, red, N, H * W, C_, g, act, replicas=self.R)
+        elif act != L.ACT_NONE:
+            raise L.TecoganHipError("BatchNorm.backward(reduced=True) needs a BatchNorm without activation")
         K.bn_bwd_apply(dy, yact, z, save, red, self.gamma, dz, self.dgamma, self.dbeta, N, H * W, C_, g, act,
-                       replicas=self.R)
+                       replicas=self.R, red_raw=reduced)
 
 
 class Arena:
@@ -1205,16 +1234,25 @@ class DiscriminatorEngine:
         g_c0 = self.g_c0[sl]
         for k in (range(5, 1, -1) if part == "hi" else (1,) if part == "lo" else range(5, 0, -1)):
             if k <= 3:
+                fused = False   # the stage's last block gets its output gradient from the next stage's k4 s2 input-gradient
                 for j in range(self.nrb - 1, -1, -1):
                     c1, c2, bnj = self.res[k][j]
                     net_in = a["net"][k][j - 1] if j > 0 else a["n"][k]
                     d_r, d_h = g["dr"][k][j], g["dh"][k][j]
                     d_in = g["dnet"][k][j - 1] if j > 0 else g["dn"][k]
-                    bnj.backward(d_net, None, a["r"][k][j], d_r, L.ACT_NONE, groups, half=half)
+                    bnj.backward(d_net, None, a["r"][k][j], d_r, L.ACT_NONE, groups, half=half, reduced=fused)
                     wg(c2, a["h"][k][j], d_r)
                     c2.dgrad(d_r, d_h, mask=a["h"][k][j], mask_mode=L.MASK_RELU)
                     wg(c1, net_in, d_h, True)
-                    c1.dgrad(d_h, d_in, res=d_net)
+                    # d_in is the output gradient of the previous block's BatchNorm (no activation): its backward sums ride
+                    # in this launch's epilogue instead of a tg_bn_bwd_reduce launch
+                    fused = _BN_FUSE and j > 0
+                    if fused:
+                        bnp = self.res[k][j - 1][2]
+                        c1.dgrad(d_h, d_in, res=d_net, bn_sums=(bnp.red_slot(half), a["r"][k][j - 1],
+                                                                groups if half is None else 1, bnp.R))
+                    else:
+                        c1.dgrad(d_h, d_in, res=d_net)
                     d_net = d_in
                 if grouped and not lists:
                     self.res_group.launch()  # the 2*nrb same-shaped residual convs of this stage in one grid

@@ -500,9 +500,10 @@ def bn_bwd_reduce(dy, yact, z, save, red, N, HW, C_, groups, act, replicas=1):
                                       C_, groups, act, _stream()), "tg_bn_bwd_reduce")
 
 
-def bn_bwd_apply(dy, yact, z, save, red, gamma, dz, dgamma, dbeta, N, HW, C_, groups, act, replicas=1):
+def bn_bwd_apply(dy, yact, z, save, red, gamma, dz, dgamma, dbeta, N, HW, C_, groups, act, replicas=1, red_raw=False):
+    """red_raw: `red` holds (sum dy, sum dy * z) from the epilogue of the conv launch that produced dy (Conv.dgrad bn_sums)"""
     L.check(L.load().tg_bn_bwd_apply(tg_dtype(z.dtype), _ptr(dy), _ptr(yact), _ptr(z), _ptr(save), _ptr(red), replicas,
-                                     _ptr(gamma), _ptr(dz), _ptr(dgamma), _ptr(dbeta), N, HW, C_, groups, act,
+                                     _ptr(gamma), _ptr(dz), _ptr(dgamma), _ptr(dbeta), N, HW, C_, groups, act, int(red_raw),
                                      _stream()), "tg_bn_bwd_apply")
 
 

@@ -493,6 +493,66 @@ def test_batchnorm_train_fwd_bwd(C_, act, skip, dt):
         torch.testing.assert_close(dbet.cpu(), bet.grad, rtol=1e-2, atol=1e-2 if dt != torch.float32 else 1e-4)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C_,N,H,G", [(64, 4, 16, 1), (128, 4, 8, 2), (64, 2, 24, 1)])
+def test_bn_backward_sums_in_the_dgrad_epilogue(C_, N, H, G, dt):
+    """Conv.dgrad(bn_sums=...) + BatchNorm.backward(reduced=True): the input-gradient launch that produces dy (3x3 conv, plus
+    residual) leaves (sum dy, sum dy * z) of the BatchNorm below in its replica blocks, and tg_bn_bwd_apply(red_raw) finishes
+    from them - against the unfused pair (tg_bn_bwd_reduce + tg_bn_bwd_apply on the same dy) and torch autograd."""
+    from pytorch_tecogan_amd import engine as E
+    R = 4
+    spec = K.ConvSpec("c3", C_, C_)
+    flat = E.FlatParams({"w": spec.weight_shape, "bn.weight": (C_,), "bn.bias": (C_,)}, torch.device(DEV))
+    flat.load({"w": rnd(spec.weight_shape, 31, -0.05, 0.05), "bn.weight": rnd((C_,), 32, 0.5, 1.5), "bn.bias": rnd((C_,), 33)})
+    conv = E.Conv(flat, "w", None, spec, dt, E.Workspace(torch.device(DEV)))
+    conv.repack()
+    dout, res, z = (q(rnd((N, C_, H, H), 34 + i), dt) for i in range(3))
+    doutd, resd, zd = (K.to_nhwc(t.to(DEV), dt) for t in (dout, res, z))
+    # statistics of z (forward), then the fused backward
+    stats = torch.zeros(R, G, 2, C_, device=DEV)
+    for g in range(G):
+        zz = zd[g * N // G:(g + 1) * N // G].float()
+        stats[0, g, 0], stats[0, g, 1] = zz.sum(dim=(0, 1, 2)), (zz * zz).sum(dim=(0, 1, 2))
+    y, save = torch.empty_like(zd), torch.empty(G, 2, C_, device=DEV)
+    gam, bet = flat.padded(flat.p, "bn.weight"), flat.padded(flat.p, "bn.bias")
+    K.bn_apply(zd, stats, gam, bet, y, save, N, H * H, C_, G, L.ACT_NONE, replicas=R)
+    dy = torch.empty_like(zd)
+    red = torch.zeros(R, G, 2, C_, device=DEV)
+    conv.dgrad(doutd, dy, res=resd, bn_sums=(red, zd, G, R))
+    dz, dg, db = torch.empty_like(zd), torch.zeros(C_, device=DEV), torch.zeros(C_, device=DEV)
+    K.bn_bwd_apply(dy, None, zd, save, red, gam, dz, dg, db, N, H * H, C_, G, L.ACT_NONE, replicas=R, red_raw=True)
+    # unfused pair on the same dy
+    dy2 = torch.empty_like(zd)
+    conv.dgrad(doutd, dy2, res=resd)
+    assert torch.equal(dy, dy2)
+    red2 = torch.zeros(R, G, 2, C_, device=DEV)
+    K.bn_bwd_reduce(dy2, None, zd, save, red2, N, H * H, C_, G, L.ACT_NONE, replicas=R)
+    dz2, dg2, db2 = torch.empty_like(zd), torch.zeros(C_, device=DEV), torch.zeros(C_, device=DEV)
+    K.bn_bwd_apply(dy2, None, zd, save, red2, gam, dz2, dg2, db2, N, H * H, C_, G, L.ACT_NONE, replicas=R)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(red.sum(0)[:, 0], red2.sum(0)[:, 0], rtol=1e-4, atol=1e-3)
+    big = 16 if dt != torch.float32 else 1
+    torch.testing.assert_close(db, db2, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dg, dg2, rtol=1e-3, atol=2e-3 * big)
+    assert float((dz.float() - dz2.float()).abs().max()) <= (1e-5 if dt == torch.float32 else 2e-2) * float(dz2.float().abs().max())
+    # and torch: dy from autograd of the conv, BatchNorm in training mode per group
+    w = flat.view(flat.p, "w").cpu()
+    xin = torch.zeros(N, C_, H, H, requires_grad=True)
+    F.conv2d(xin, q(w, dt), None, 1, 1).backward(dout)
+    dy_ref = q(xin.grad + res, dt)
+    zt = z.clone().requires_grad_(True)
+    gt, bt = gam[:C_].cpu().clone().requires_grad_(True), bet[:C_].cpu().clone().requires_grad_(True)
+    for g in range(G):
+        sl = slice(g * N // G, (g + 1) * N // G)
+        F.batch_norm(zt[sl], None, None, gt, bt, True, 0.1, 1e-3).backward(dy_ref[sl])
+    t = tol(dt)
+    torch.testing.assert_close(K.to_nchw(dy, C_).cpu(), dy_ref, **t)
+    if dt == torch.float32:
+        torch.testing.assert_close(K.to_nchw(dz, C_).cpu(), zt.grad, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(dg.cpu(), gt.grad, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(db.cpu(), bt.grad, rtol=1e-3, atol=1e-3)
+
+
 def test_up4_matches_golden_and_torch(golden_dir):
     u = np.load(os.path.join(golden_dir, "units.npz"))
     src = torch.from_numpy(u["up4_in"]).to(DEV)
