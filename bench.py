@@ -239,7 +239,8 @@ def roofline_pass(st, dtype):
             if c.fin_job is not None:  # one fold job per conv, or one per 64 x 64 channel block (engine.WgradList)
                 jobs += c.fin_job if isinstance(c.fin_job[0], list) else [c.fin_job]
         return float(sum(j[4] * j[11] * 4 + j[5] * j[8] * j[9] * 4 for j in jobs))  # slabs read + gradient written
-    wrap(E.Finalizer, "run", lambda self, **k: "wgrad_finalize_multi_kernel", lambda self, **k: fold_bytes(self, **k), "hbm")
+    wrap(E.Finalizer, "run", lambda self, **k: "wgrad_fold_items_kernel" if E._FOLD_ITEMS else "wgrad_finalize_multi_kernel",
+         lambda self, **k: fold_bytes(self, **k), "hbm")
     try:
         torch.cuda.synchronize()
         st._forward_backward(True)
