@@ -82,7 +82,7 @@ struct ResblockK {
   char* out_a;
   const char* pf1;  // packed weights the NEXT launch will stream (or null): pulled into this XCD's L2 ahead of time
   const char* pf2;
-  int N, H, W, tiles_x, tiles_y;
+  int N, H, W, tiles_x, tiles_y, xcd_blocks;
   int skip;  // 1: out_a = in + conv2(h) (residual block); 0: out_a = conv2(h) (the conv-relu-conv pair of conv_trans.2)
   const char* hmask;  // BWD: the block's saved forward activation h (relu mask of the first stage)
 };
@@ -130,6 +130,10 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
   const int w = wid & 3, kc = wid >> 2;                      // MFMA row tile, channel chunk (K half)
   const int idx = lane & 15, g = lane >> 4;
   int bx = blockIdx.x;
+  // XCD-aware tile order (TECOGAN_RB_XCD=1, A/B knob): workgroups go to the 8 XCDs round-robin, so with the plain order the eight
+  // neighbours of a tile sit on other XCDs; this gives XCD x (blockIdx % 8 == x) a contiguous run of tiles (half an image at
+  // 4 x 32 x 32) and keeps a tile's halo mostly inside its own XCD's L2
+  if (p.xcd_blocks) bx = (bx & 7) * p.xcd_blocks + (bx >> 3);
   const int txb = bx % p.tiles_x;
   bx /= p.tiles_x;
   const int tyb = bx % p.tiles_y;
@@ -393,6 +397,8 @@ int resblock_launch(bool bwd, const void* in, const void* wa, const float* b1, c
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::kLdsTotal));
     attr_done = true;
   }
+  static const int xcd = [] { const char* e = getenv("TECOGAN_RB_XCD"); return e ? atoi(e) : 0; }();
+  k.xcd_blocks = (xcd && blocks % 8 == 0) ? (int)(blocks / 8) : 0;
   const dim3 grid((unsigned)blocks), blk(512);
   hipStream_t st = (hipStream_t)stream;
   if (th == 4) {
