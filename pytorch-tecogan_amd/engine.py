@@ -1124,6 +1124,17 @@ class DiscriminatorEngine:
         if self.finalizer is not None and self.res_group is not None and _wgrad_lists() and \
                 dtype_t in (torch.bfloat16, torch.float16):
             self.res_group = WgradList(K.persist_wgs("D"))
+        # workgroups of the persistent launches per half: the REAL half runs beside the latency-bound generator chain and
+        # lane B has slack there (it waits for the chain's last frame), the fake half is on the step's critical path
+        self.cap = {None: K.persist_wgs("D"), 1: K.persist_wgs("D"),
+                    0: int(os.environ.get("TECOGAN_PERSIST_WGS_DREAL", K.persist_wgs("D")))}
+
+    def _set_cap(self, half):
+        cap = self.cap[half]
+        for c in self.convs:
+            c.persist_wgs = cap
+        if isinstance(self.res_group, WgradList):
+            self.res_group.cap = cap
 
     def repack(self):
         self.repacker.run()
@@ -1175,6 +1186,7 @@ class DiscriminatorEngine:
         the real half run while the generator is still producing the frames the fake half needs)."""
         a = self.act
         N = a["in"].shape[0]
+        self._set_cap(half)
         if half is None:
             sl, st_of = slice(0, N), (lambda bn: bn.stats_slot())
         else:
@@ -1212,6 +1224,7 @@ class DiscriminatorEngine:
         part: None = the whole pass; 'hi' = fc, block5 ... block2 (with the fold of their weight gradients), 'lo' = stage 1
         and conv.0 - the gradient buckets of data-parallel mode."""
         N = self.act["in"].shape[0]
+        self._set_cap(half)
         if half is None:
             sl = slice(0, N)
         else:

@@ -216,3 +216,32 @@ def test_fnet_training_bf16_follows_the_oracle_trajectory_and_moves_only_when_as
         else:
             assert torch.equal(w0, w1) and max(losses) - min(losses) < 1e-6 * losses[0]
     hip_train._STEPS.clear()
+
+
+def test_main_py_trains_the_estimator_and_resumes_from_fnet_pt(tmp_path, monkeypatch):
+    """main.py --tg_fnet true --tg_fnet_train true: the third optimiser / scheduler / checkpoint the reference leaves commented out
+    (main.py:231,244-245,249,259-261): fnet.pt with the reference module's keys, resumed with --f_checkpoint."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tg_main_f", os.path.join(ROOT, "main.py"))
+    tg_main = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tg_main)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("TECOGAN_GRAPH", "1")
+    hip_train._STEPS.clear()
+    common = ["--synthetic", "8", "--max_epochs", "1", "--tg_dtype", "bf16", "--num_resblock", "2", "--discrim_resblocks", "1",
+              "--tg_fnet", "true", "--tg_fnet_train", "true"]
+    tg_main.main(common)
+    f_ck = torch.load(tmp_path / "fnet.pt")
+    assert set(f_ck) == {"model_state_dict", "optimizer_state_dict"}
+    assert list(f_ck["model_state_dict"].keys()) == list(orc.fnet_param_shapes().keys())
+    assert len(f_ck["optimizer_state_dict"]["state"]) == 36 and float(f_ck["optimizer_state_dict"]["state"][0]["step"]) == 2.0
+    w1 = f_ck["model_state_dict"]["up1.2.weight"].clone()
+    hip_train._STEPS.clear()
+    tg_main.main(["--synthetic", "4", "--max_epochs", "1", "--tg_dtype", "bf16", "--num_resblock", "2", "--discrim_resblocks", "1",
+                  "--tg_fnet", "true", "--tg_fnet_train", "true", "--pre_trained_model", "true", "--g_checkpoint",
+                  str(tmp_path / "generator.pt"), "--d_checkpoint", str(tmp_path / "discrim.pt"), "--f_checkpoint",
+                  str(tmp_path / "fnet.pt")])
+    f2 = torch.load(tmp_path / "fnet.pt")
+    assert float(f2["optimizer_state_dict"]["state"][0]["step"]) == 3.0
+    assert not torch.equal(f2["model_state_dict"]["up1.2.weight"], w1)
+    hip_train._STEPS.clear()
