@@ -232,6 +232,9 @@ def roofline_pass(st, dtype):
     wrap(K, "up4_planes", lambda *a, **k: "up4_planes_kernel",
          lambda src, so, dst, do, n, h, w, **k: 4.0 * n * h * w * 17, "hbm")
     wrap(K, "absdiff_sum", lambda *a, **k: f"absdiff_sum_kernel<{T16}>", lambda a_, b_, *r, **k: nb(a_, b_), "hbm")
+    wrap(K, "absdiff_sum_multi", lambda *a, **k: f"absdiff_sum_multi_kernel<{T16}>",
+         lambda dt, jobs, n, *r, **k: float(sum(2 * int(row[3]) * int(row[5]) * (4 if dt == torch.float32 else 2) for row in jobs.cpu().tolist())),
+         "hbm")
 
     def fold_bytes(self, only=None):
         jobs = []

@@ -313,6 +313,9 @@ int tg_fc_head_bwd(int dtype, const void* feat, const float* w, const float* dlo
                    float* db, int N, int HW, int C, int Cp, void* stream);
 /* acc[0] += sum |a-b| over real channels (layer loss, code/train.py:219-220). */
 int tg_absdiff_sum(int dtype, const void* a, const void* b, float* acc, int64_t npix, int C, int Cp, void* stream);
+/* The same for njobs tensor pairs in one launch (the four D layer losses of code/train.py:205-226): jobs_dev = njobs x 6 int64
+ * {a ptr, b ptr, acc ptr, npix, C, Cp}; blocks_per_job workgroups walk each pair. */
+int tg_absdiff_sum_multi(int dtype, const int64_t* jobs_dev, int njobs, int blocks_per_job, void* stream);
 /* acc[0] += sum |a[a_off[k]+e] - b[b_off[k]+e]| (ping-pong loss, code/train.py:275-279). */
 int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const float* b, const int64_t* b_off_dev, float* acc,
                     int nblocks, int64_t len, void* stream);

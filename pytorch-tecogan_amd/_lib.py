@@ -88,6 +88,7 @@ _PROTOS = {
     "tg_fc_head_fwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tg_fc_head_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tg_absdiff_sum": (_I, [_I, _P, _P, _P, _L, _I, _I, _P]),
+    "tg_absdiff_sum_multi": (_I, [_I, _P, _I, _I, _P]),
     "tg_absdiff_nchw": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
     "tg_content_loss": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _I, _F, _P, _P, _P]),
     "tg_loss_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P, _P]),

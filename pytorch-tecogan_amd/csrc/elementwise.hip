@@ -374,6 +374,35 @@ __global__ __launch_bounds__(256) void absdiff_sum_kernel(const char* __restrict
   if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+// Several absdiff sums in ONE launch (the four layer losses at the end of the discriminator's fake-half forward, which sits on
+// the step's critical path: four 7-us launches for 5 MB each).  blockIdx.y selects the job: 6 x int64 = a, b, acc, npix, C, Cp.
+template <typename T>
+__global__ __launch_bounds__(256) void absdiff_sum_multi_kernel(const long long* __restrict__ jobs) {
+  using TR = ElemTraits<T>;
+  constexpr int E = TR::kVec;
+  __shared__ float sh[4];
+  const long long* j = jobs + 6 * blockIdx.y;
+  const char* a = reinterpret_cast<const char*>(j[0]);
+  const char* b = reinterpret_cast<const char*>(j[1]);
+  float* acc = reinterpret_cast<float*>(j[2]);
+  const int C = (int)j[4], vpp = (int)j[5] / E;
+  const long long total = j[3] * vpp;
+  float s = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += 256LL * gridDim.x) {
+    const int vec = (int)(i % vpp);
+    float x[E], y[E];
+    Vec<T>::load(a + i * 16, x);
+    Vec<T>::load(b + i * 16, y);
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (vec * E + e < C) s += fabsf(x[e] - y[e]);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
 // 1024 threads per block: the block count - and with it the number of atomics that serialise on the same four words at the
 // end - is a quarter of what 256-thread blocks give for the same number of threads in flight
 constexpr int kClThreads = 1024;
@@ -657,6 +686,13 @@ extern "C" int tg_absdiff_sum(int dtype, const void* a, const void* b, float* ac
   const long long total = npix * (Cp / (dtype == TG_F32 ? 4 : 8));
   TG_DISPATCH(dtype, absdiff_sum_kernel, dim3(grid_for(total, 1024, 512)), dim3(256), (hipStream_t)stream,
               (const char*)a, (const char*)b, acc, (long long)npix, C, Cp);
+  return tg_launch_status();
+}
+
+extern "C" int tg_absdiff_sum_multi(int dtype, const int64_t* jobs_dev, int njobs, int blocks_per_job, void* stream) {
+  if (!jobs_dev || njobs <= 0 || blocks_per_job <= 0) return TG_E_BADARG;
+  TG_DISPATCH(dtype, absdiff_sum_multi_kernel, dim3((unsigned)blocks_per_job, (unsigned)njobs), dim3(256), (hipStream_t)stream,
+              (const long long*)jobs_dev);
   return tg_launch_status();
 }
 

@@ -522,6 +522,11 @@ def absdiff_sum(a, b, acc, acc_idx, npix, C_, Cp):
                                     _stream()), "tg_absdiff_sum")
 
 
+def absdiff_sum_multi(dtype_t, jobs, njobs, blocks_per_job=128):
+    """jobs: int64 device table, njobs x {a ptr, b ptr, acc ptr, npix, C, Cp} (include/tecogan_hip.h)"""
+    L.check(L.load().tg_absdiff_sum_multi(tg_dtype(dtype_t), _ptr(jobs), njobs, blocks_per_job, _stream()), "tg_absdiff_sum_multi")
+
+
 def content_loss(gen, y, dpre, acc, B, T, H, W, gscale, t0=0, t1=None, pp_T=0, pp_coef=0.0, loss_scale=None, bias_acc=None):
     """loss_scale: device float (fp16 mode) multiplied into every backward seed - here d(loss)/d(pre-sigmoid);
     bias_acc: 3 floats that receive the channel sums of dpre (the output layer's bias gradient); default acc[8:11]"""

@@ -391,10 +391,13 @@ class TecoGANStep:
         D, B, T, h, tb = self.D, self.B, self.T, self.h, self.tb
         K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"][tb:], B, T, self.K, h, self.border, half=1)
         D.forward(update_stats=True, half=1)
-        if self.args.D_LAYERLOSS:
-            for i, l in enumerate(D.layers()):
-                n = tb * l.shape[1] * l.shape[2]
-                K.absdiff_sum(l[:tb], l[tb:], self.acc, 2 + i, n, l.shape[3], l.shape[3])
+        if self.args.D_LAYERLOSS:   # the four layer losses in one launch (they sit on the step's critical path)
+            key = tuple(l.data_ptr() for l in D.layers())
+            if getattr(self, "_ll_key", None) != key:
+                rows = [[l[:tb].data_ptr(), l[tb:].data_ptr(), self.acc.data_ptr() + 4 * (2 + i), tb * l.shape[1] * l.shape[2],
+                         l.shape[3], l.shape[3]] for i, l in enumerate(D.layers())]
+                self._ll_jobs, self._ll_key = _i64(rows, self.dev), key
+            K.absdiff_sum_multi(D.dt, self._ll_jobs, self._ll_jobs.shape[0])
 
     def _d_fake_bwd(self, backward=True, part=None):
         """every loss scalar (needs the content loss of lane A's tail) and d(logit), then the backward pass of the fake

@@ -729,6 +729,15 @@ def test_content_loss_and_absdiff(dt):
     a, b2 = q(rnd((4, 64, 8, 8), 40), dt), q(rnd((4, 64, 8, 8), 41), dt)
     K.absdiff_sum(K.to_nhwc(a.to(DEV), dt), K.to_nhwc(b2.to(DEV), dt), acc, 3, 4 * 64, 64, 64)
     torch.testing.assert_close(acc[3].cpu(), (a - b2).abs().sum(), rtol=1e-5, atol=1e-3)
+    # several pairs in one launch (the four layer losses of the step): different sizes, padded channels
+    pairs = [(q(rnd((3, c, h, h), 50 + i), dt), q(rnd((3, c, h, h), 60 + i), dt)) for i, (c, h) in enumerate([(64, 8), (128, 4), (3, 6), (64, 2)])]
+    dev = [(K.to_nhwc(x.to(DEV), dt), K.to_nhwc(y_.to(DEV), dt)) for x, y_ in pairs]
+    acc2 = torch.zeros(16, device=DEV)
+    jobs = torch.tensor([[x.data_ptr(), y_.data_ptr(), acc2.data_ptr() + 4 * (2 + i), x.shape[0] * x.shape[1] * x.shape[2], p[0].shape[1],
+                          x.shape[3]] for i, ((x, y_), p) in enumerate(zip(dev, pairs))], dtype=torch.int64, device=DEV)
+    K.absdiff_sum_multi(dt, jobs, len(pairs), blocks_per_job=8)
+    for i, (x, y_) in enumerate(pairs):
+        torch.testing.assert_close(acc2[2 + i].cpu(), (x - y_).abs().sum(), rtol=1e-5, atol=1e-3)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
