@@ -564,8 +564,14 @@ class TecoGANStep:
         for w in works_g:
             if w is not None:
                 w.wait()
-        main.wait_event(ev["d"])
-        fn["update"]()
+        if self.scaler is None:
+            # the generator's Adam + repack need nothing of lane B: they run beside lane B's tail (the fake half's last weight
+            # gradients, fold, D update); the caller's stream then picks lane B up (its results are read next)
+            fn["update"]()
+            main.wait_event(ev["d"])
+        else:  # fp16: the shared loss scaler's two update() calls sit in this piece and need both networks' found_inf flags
+            main.wait_event(ev["d"])
+            fn["update"]()
 
     def _fork_join(self):
         """TECOGAN_LANES=0: the same schedule as ONE capturable fork/join (all joins go into the origin stream: HIP stream
