@@ -306,6 +306,14 @@ int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, const void* z, 
                     int red_replicas, const float* gamma, void* dz, float* dgamma, float* dbeta, int N, int HW, int C,
                     int groups, int act, int red_raw, void* stream);
 
+/* The same backward pass (reduce + apply) as ONE launch for a tensor of at most tg_bn_bwd_fused_max_pixels() pixels per group
+ * (the discriminator's 16x16 ... 4x4 layers): one workgroup per 16-byte channel piece keeps its share of the tensors in registers
+ * between the sums and dz and is the only writer of its channels' dgamma / dbeta (+=).  act: TG_ACT_NONE or TG_ACT_LRELU.
+ * TG_E_UNSUPPORTED above the pixel limit (callers take the two-launch path). */
+int tg_bn_bwd_fused(int dtype, const void* dy, const void* yact, const void* z, const float* save, const float* gamma,
+                    void* dz, float* dgamma, float* dbeta, int N, int HW, int C, int groups, int act, void* stream);
+int tg_bn_bwd_fused_max_pixels(void);
+
 /* ---- heads and losses (code/models.py:143-145; code/train.py:205-333) ----------------------------------- */
 int tg_fc_head_fwd(int dtype, const void* feat, const float* w, const float* b, float* prob, int N, int HW, int C,
                    int Cp, void* stream);

@@ -317,6 +317,91 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
   }
 }
 
+// Batch-norm backward of a SMALL tensor (<= kBfThreads * kBfTrips pixels per group) in ONE launch: workgroup v owns the E
+// channels of 16-byte piece v of every pixel, keeps its share of dy / z (/ yact) in registers between the reduction and the
+// apply, and is the only writer of those channels' dgamma / dbeta.  The two-launch path (tg_bn_bwd_reduce + tg_bn_bwd_apply)
+// costs two ~6 us launches on the discriminator's 16x16 ... 4x4 layers whatever the tensor size (<= 0.8 MB: all of it latency);
+// here the tensors are read once (16-byte pieces, one 2*C-byte row apart: L2-resident) and nothing goes through atomics.
+constexpr int kBfThreads = 1024, kBfTrips = 4;
+template <typename T>
+__global__ __launch_bounds__(kBfThreads) void bn_bwd_fused_kernel(const char* __restrict__ dy, const char* __restrict__ yact,
+                                                                  const char* __restrict__ z, const float* __restrict__ save,
+                                                                  const float* __restrict__ gamma, char* __restrict__ dz,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int N,
+                                                                  int HW, int C, int groups, int act) {
+  using TR = ElemTraits<T>;
+  constexpr int E = TR::kVec, NW = kBfThreads / 64;
+  __shared__ float sh[NW][2 * E];
+  __shared__ float tot[2 * E];
+  const int vec = blockIdx.x, grp = blockIdx.y;
+  const int npix = (N / groups) * HW;
+  const long long base = (long long)grp * npix;
+  u32x4 rd[kBfTrips], rz[kBfTrips], ra[kBfTrips];
+#pragma unroll
+  for (int u = 0; u < kBfTrips; ++u) {  // every load of the launch goes out before anything is used
+    const int pix = threadIdx.x + u * kBfThreads;
+    const long long off = ((base + (pix < npix ? pix : npix - 1)) * C + vec * E) * TR::kBytes;
+    rd[u] = *reinterpret_cast<const u32x4*>(dy + off);
+    rz[u] = *reinterpret_cast<const u32x4*>(z + off);
+    if (act == TG_ACT_LRELU) ra[u] = *reinterpret_cast<const u32x4*>(yact + off);
+  }
+  float mean[E], invstd[E], k0[E], s[2 * E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int c = vec * E + e;
+    mean[e] = save[(grp * 2 + 0) * C + c];
+    invstd[e] = save[(grp * 2 + 1) * C + c];
+    k0[e] = gamma[c] * invstd[e];
+    s[e] = s[E + e] = 0.f;
+  }
+  float dd[kBfTrips][E], xh[kBfTrips][E];
+#pragma unroll
+  for (int u = 0; u < kBfTrips; ++u) {
+    float zz[E], a[E];
+    Vec<T>::load(&rd[u], dd[u]);
+    Vec<T>::load(&rz[u], zz);
+    if (act == TG_ACT_LRELU) Vec<T>::load(&ra[u], a);
+    const bool live = threadIdx.x + u * kBfThreads < npix;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      if (act == TG_ACT_LRELU) dd[u][e] *= (a[e] > 0.f ? 1.f : 0.2f);
+      xh[u][e] = (zz[e] - mean[e]) * invstd[e];
+      if (live) {
+        s[e] += dd[u][e];
+        s[E + e] += dd[u][e] * xh[u][e];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * E; ++i) s[i] = wave_sum(s[i]);
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 2 * E; ++i) sh[threadIdx.x >> 6][i] = s[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * E) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += sh[w][threadIdx.x];
+    tot[threadIdx.x] = t;
+    // sole owner of these channels; the groups (the reference's D calls) of one launch add in turn
+    float* dst = (threadIdx.x < E ? dbeta : dgamma) + vec * E + (threadIdx.x < E ? threadIdx.x : threadIdx.x - E);
+    if (groups == 1) *dst += t; else atomicAdd(dst, t);
+  }
+  __syncthreads();
+  const float inv_cnt = 1.f / (float)npix;
+#pragma unroll
+  for (int u = 0; u < kBfTrips; ++u) {
+    const int pix = threadIdx.x + u * kBfThreads;
+    if (pix < npix) {
+      float o[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] = k0[e] * (dd[u][e] - tot[e] * inv_cnt - xh[u][e] * tot[E + e] * inv_cnt);
+      Vec<T>::store(dz + ((base + pix) * C + vec * E) * TR::kBytes, o);
+    }
+  }
+}
+
 template <typename T>
 __global__ void fc_head_fwd_kernel(const char* __restrict__ feat, const float* __restrict__ w,
                                    const float* __restrict__ b, float* __restrict__ prob, int N, int HW, int C, int Cp) {
@@ -661,6 +746,23 @@ extern "C" int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, cons
   dim3 grid(grid_for((long long)(N / groups) * HW, rows * 4, 1024), groups);
   TG_DISPATCH(dtype, bn_bwd_apply_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)dy, (const char*)yact,
               (const char*)z, save, red, red_replicas, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act, red_raw);
+  return tg_launch_status();
+}
+
+extern "C" int tg_bn_bwd_fused_max_pixels(void) { return kBfThreads * kBfTrips; }
+
+extern "C" int tg_bn_bwd_fused(int dtype, const void* dy, const void* yact, const void* z, const float* save,
+                               const float* gamma, void* dz, float* dgamma, float* dbeta, int N, int HW, int C, int groups,
+                               int act, void* stream) {
+  if (!dy || !z || !save || !gamma || !dz || !dgamma || !dbeta || N <= 0 || HW <= 0 || groups <= 0 || N % groups)
+    return TG_E_BADARG;
+  if (act == TG_ACT_LRELU && !yact) return TG_E_BADARG;
+  if (act != TG_ACT_NONE && act != TG_ACT_LRELU) return TG_E_UNSUPPORTED;
+  if (!bn_shape_ok(dtype, C)) return TG_E_UNSUPPORTED;
+  if ((long long)(N / groups) * HW > (long long)kBfThreads * kBfTrips) return TG_E_UNSUPPORTED;
+  dim3 grid(C / (dtype == TG_F32 ? 4 : 8), groups);
+  TG_DISPATCH(dtype, bn_bwd_fused_kernel, grid, dim3(kBfThreads), (hipStream_t)stream, (const char*)dy, (const char*)yact,
+              (const char*)z, save, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act);
   return tg_launch_status();
 }
 

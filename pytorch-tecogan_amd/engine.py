@@ -499,6 +499,13 @@ _FOLD_ITEMS = os.environ.get("TECOGAN_FOLD_ITEMS", "1") != "0"
 _BN_FUSE = os.environ.get("TECOGAN_BN_FUSE", "0") == "1"
 
 
+# Backward pass of a batch norm on a small tensor (the discriminator's 16x16 ... 4x4 layers: 7 of 17 per pass) as one launch
+# (tg_bn_bwd_fused) instead of tg_bn_bwd_reduce + tg_bn_bwd_apply: built, parity-tested and measured SLOWER - a workgroup per
+# 16-byte channel piece reads 16 B of every 256-byte pixel row (64 cache lines per wave-load; 16 workgroups instead of ~50):
+# d_fake_bwd alone 0.936 -> 0.963 ms, D real 1.596 -> 1.608, step 4.405 -> 4.42 ms (profiles/r03_l_bn_bwd_fused_ab.log).  Off.
+_BN_BWD_FUSED = os.environ.get("TECOGAN_BN_BWD_FUSED", "0") == "1"
+
+
 def fold_items(jobs):
     """host side of tg_wgrad_fold_items: appends each 12-entry fold job's first item index (pure logic, CPU-tested).
     A job has (ca_p / AB) * (cb_p / BB) tiles x ceil(nsplit / 8) chunks, BB = 64 or 32, AB = 1024 / BB."""
@@ -594,6 +601,9 @@ class BatchNorm:
         N, H, W, C_ = z.shape
         save, red = (self.save if half is None else self.save[half]), self._slot(self.red, half)
         g = groups if half is None else 1
+        if not reduced and _BN_BWD_FUSED and (N // g) * H * W <= K.bn_bwd_fused_max_pixels():
+            K.bn_bwd_fused(dy, yact, z, save, self.gamma, dz, self.dgamma, self.dbeta, N, H * W, C_, g, act)
+            return
         if not reduced:
             K.bn_bwd_reduce(dy, yact, z, save, red, N, H * W, C_, g, act, replicas=self.R)
         elif act != L.ACT_NONE:

@@ -507,6 +507,23 @@ def bn_bwd_apply(dy, yact, z, save, red, gamma, dz, dgamma, dbeta, N, HW, C_, gr
                                      _stream()), "tg_bn_bwd_apply")
 
 
+_BN_FUSED_MAX = None
+
+
+def bn_bwd_fused_max_pixels():
+    """pixels per group up to which tg_bn_bwd_fused runs the whole backward pass of a batch norm in one launch"""
+    global _BN_FUSED_MAX
+    if _BN_FUSED_MAX is None:
+        _BN_FUSED_MAX = int(L.load().tg_bn_bwd_fused_max_pixels())
+    return _BN_FUSED_MAX
+
+
+def bn_bwd_fused(dy, yact, z, save, gamma, dz, dgamma, dbeta, N, HW, C_, groups, act):
+    """reduce + apply of a small tensor in one launch (csrc/elementwise.hip: bn_bwd_fused_kernel)"""
+    L.check(L.load().tg_bn_bwd_fused(tg_dtype(z.dtype), _ptr(dy), _ptr(yact), _ptr(z), _ptr(save), _ptr(gamma), _ptr(dz),
+                                     _ptr(dgamma), _ptr(dbeta), N, HW, C_, groups, act, _stream()), "tg_bn_bwd_fused")
+
+
 def fc_head_fwd(feat, w, b, prob, N, HW, C_, Cp):
     L.check(L.load().tg_fc_head_fwd(tg_dtype(feat.dtype), _ptr(feat), _ptr(w), _ptr(b), _ptr(prob), N, HW, C_, Cp,
                                     _stream()), "tg_fc_head_fwd")

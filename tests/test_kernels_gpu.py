@@ -553,6 +553,48 @@ def test_bn_backward_sums_in_the_dgrad_epilogue(C_, N, H, G, dt):
         torch.testing.assert_close(db.cpu(), bt.grad, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C_,N,H,G,act", [(128, 12, 16, 1, "none"), (128, 12, 16, 1, "lrelu"), (64, 12, 8, 1, "lrelu"),
+                                          (32, 12, 4, 1, "lrelu"), (64, 6, 16, 2, "none"), (128, 16, 16, 1, "none"), (64, 3, 5, 1, "lrelu")])
+def test_bn_backward_small_tensor_single_launch(C_, N, H, G, act, dt):
+    """tg_bn_bwd_fused (reduce + apply of a tensor of <= 4096 pixels per group in one launch, dgamma / dbeta accumulated on top of
+    what is there) against the two-launch pair on the same tensors and torch autograd of training-mode batch_norm (+ LeakyReLU);
+    above the pixel limit the entry point refuses."""
+    R, act_i = 4, (L.ACT_LRELU if act == "lrelu" else L.ACT_NONE)
+    z, dy = q(rnd((N, C_, H, H), 51), dt), q(rnd((N, C_, H, H), 52), dt)
+    gam, bet = rnd((C_,), 53, 0.5, 1.5).to(DEV), rnd((C_,), 54).to(DEV)
+    zd, dyd = K.to_nhwc(z.to(DEV), dt), K.to_nhwc(dy.to(DEV), dt)
+    stats = torch.zeros(R, G, 2, C_, device=DEV)
+    for g in range(G):
+        zz = zd[g * N // G:(g + 1) * N // G].float()
+        stats[0, g, 0], stats[0, g, 1] = zz.sum(dim=(0, 1, 2)), (zz * zz).sum(dim=(0, 1, 2))
+    y, save = torch.empty_like(zd), torch.empty(G, 2, C_, device=DEV)
+    K.bn_apply(zd, stats, gam, bet, y, save, N, H * H, C_, G, act_i, replicas=R)
+    assert (N // G) * H * H <= K.bn_bwd_fused_max_pixels()
+    dz, dg, db = torch.empty_like(zd), torch.full((C_,), 0.5, device=DEV), torch.full((C_,), -0.25, device=DEV)
+    K.bn_bwd_fused(dyd, y, zd, save, gam, dz, dg, db, N, H * H, C_, G, act_i)
+    red = torch.zeros(R, G, 2, C_, device=DEV)
+    dz2, dg2, db2 = torch.empty_like(zd), torch.full((C_,), 0.5, device=DEV), torch.full((C_,), -0.25, device=DEV)
+    K.bn_bwd_reduce(dyd, y, zd, save, red, N, H * H, C_, G, act_i, replicas=R)
+    K.bn_bwd_apply(dyd, y, zd, save, red, gam, dz2, dg2, db2, N, H * H, C_, G, act_i, replicas=R)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(db, db2, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dg, dg2, rtol=1e-4, atol=1e-3)
+    assert float((dz.float() - dz2.float()).abs().max()) <= (1e-5 if dt == torch.float32 else 8e-3) * float(dz2.float().abs().max())
+    if dt == torch.float32:
+        zt, gt, bt = z.clone().requires_grad_(True), gam.cpu().clone().requires_grad_(True), bet.cpu().clone().requires_grad_(True)
+        for g in range(G):
+            sl = slice(g * N // G, (g + 1) * N // G)
+            o = F.batch_norm(zt[sl], None, None, gt, bt, True, 0.1, 1e-3)
+            (F.leaky_relu(o, 0.2) if act == "lrelu" else o).backward(dy[sl])
+        torch.testing.assert_close(K.to_nchw(dz, C_).cpu(), zt.grad, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(dg.cpu() - 0.5, gt.grad, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(db.cpu() + 0.25, bt.grad, rtol=1e-3, atol=1e-3)
+    big = K.to_nhwc(torch.zeros(2 * G, C_, 64, 64, device=DEV), dt)   # 8192 pixels per group: the two-launch path's job
+    with pytest.raises(L.TecoganHipError):
+        K.bn_bwd_fused(big, big, big, save, gam, torch.empty_like(big), dg, db, 2 * G, 64 * 64, C_, G, act_i)
+
+
 def test_up4_matches_golden_and_torch(golden_dir):
     u = np.load(os.path.join(golden_dir, "units.npz"))
     src = torch.from_numpy(u["up4_in"]).to(DEV)
