@@ -211,10 +211,15 @@ int tg_wgrad_group(int dtype, int tile_w, const int64_t* jobs_dev, int njobs, in
  *                   [N,H,W,Cy]; dW[t][a][b] = sum x[n, 2y + dy[t], 2x + dx[t]][a] * y[n, y, x][b], 9 taps (dy, dx) in -1..1;
  *   TG_WGROUP_C4S2  conv k4 s2 p1 (code/models.py:90-94): x = the layer input [N,2H,2W,Cx], y = the output gradient [N,H,W,Cy];
  *                   16 taps (dy, dx) in -1..2.
- * TG_WGROUP_C3 is tg_wgrad_group.  Slot size: tg_wgrad_group_slot_floats_v(variant) = [taps][64][64] + [64]. */
+ * TG_WGROUP_C3 is tg_wgrad_group.  Slot size: tg_wgrad_group_slot_floats_v(variant) = [taps][64][64] + [64].
+ *   TG_WGROUP_C3_B128 / TG_WGROUP_CT_B128: the same two kinds with 64 x 128 channel blocks (b_blocks = ceil(Cy / 128), slot =
+ *                   [9][64][128] + [128]; fold jobs with cb_p = 128): for layers with >= 128 y channels - x is fetched once per
+ *                   128 of them and a 32-pixel k-step is 26 transposed LDS reads per 36 MFMAs instead of 22 per 18. */
 #define TG_WGROUP_C3 0
 #define TG_WGROUP_CT 1
 #define TG_WGROUP_C4S2 2
+#define TG_WGROUP_C3_B128 3
+#define TG_WGROUP_CT_B128 4
 int64_t tg_wgrad_group_slot_floats_v(int variant);
 int tg_wgrad_group_v(int dtype, int variant, int tile_w, const int64_t* jobs_dev, int njobs, int units_total, int workgroups,
                      float* slab, void* stream);

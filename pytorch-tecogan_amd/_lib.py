@@ -18,7 +18,7 @@ OUT_NHWC, OUT_NCHW_F32 = 0, 1
 TILE_AUTO, TILE_64x256, TILE_64x64, TILE_128x128, TILE_32x128 = 0, 1, 2, 3, 4
 TILE_32x64, TILE_64x128, TILE_64x128_8W, TILE_64x64_8W = 5, 6, 7, 8
 MAX_TAPS, MAX_CLASSES = 16, 4
-WGROUP_C3, WGROUP_CT, WGROUP_C4S2 = 0, 1, 2
+WGROUP_C3, WGROUP_CT, WGROUP_C4S2, WGROUP_C3_B128, WGROUP_CT_B128 = 0, 1, 2, 3, 4
 
 
 class ConvClass(C.Structure):

@@ -112,12 +112,20 @@ struct WgGeom {
   __device__ static constexpr int tap_row(int s, int dy) { return (S * KROW * s + dy) * PITCH * 128; }
 };
 
-template <typename T, int TW, int S, int NTS>
+// NB = 64-channel sub-blocks of Y per workgroup.  NB = 2 (64 x 128 channel blocks, layers with >= 128 Y channels): a wave owns
+// 16 x 64 of the block (144 accumulator registers with 9 taps), a 32-pixel k-step is 8 Y + 18 X transposed reads for 36 MFMAs
+// instead of 4 + 18 for 18, and X is fetched once per 128 Y channels instead of once per 64.  The Y image has 256-byte rows
+// then: 8 segments, swizzle key = the pixel's low 3 bits (8 consecutive pixels -> 8 distinct segments of the bank window).
+template <typename T, int TW, int S, int NTS, int NB>
 __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
   using Gm = WgGeom<TW, S, NTS>;
-  constexpr int TH = Gm::TH, NT = NTS * NTS, XCH = Gm::XCH, YCH = Gm::YCH, XCW = Gm::XCW, YCW = Gm::YCW;
-  constexpr int XBYTES = Gm::XBYTES, BUF = Gm::BUF, HI = Gm::HI, TPIX = Gm::TPIX;
-  constexpr int kSlot = NT * 64 * 64 + 64;  // floats per slab slot: [NT][64][64] + channel sums of Y
+  constexpr int TH = Gm::TH, NT = NTS * NTS, XCH = Gm::XCH, XCW = Gm::XCW;
+  constexpr int XBYTES = Gm::XBYTES, HI = Gm::HI, TPIX = Gm::TPIX;
+  constexpr int CB = 64 * NB, YROW = 128 * NB, NF = 2 * NB;       // Y channels per block, bytes per Y image row, B fragments per wave
+  constexpr int YCH = TPIX * NB / 8, YCW = (YCH + 7) / 8, BUF = XBYTES + YCH * 1024;
+  constexpr int YPR = 8 * NB, YRC = 64 / YPR;                     // 16-byte pieces per Y row, rows per 1-KiB DMA chunk
+  constexpr int kSlot = NT * 64 * CB + CB;  // floats per slab slot: [NT][64][CB] + channel sums of Y
+  auto ykey = [](int k) { return NB == 1 ? (k >> 1) & 3 : k & 7; };
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // two buffers of BUF bytes
 
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
   if (u >= u_end) return;
 
   // ---- lane constants of the fragment reads (tile- and job-independent): one X address per column tap, two Y addresses
-  int xa[NTS], ya[2];
+  int xa[NTS], ya[NF];
 #pragma unroll
   for (int d = 0; d < NTS; ++d) {
     int rb, key;
@@ -138,9 +146,9 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
     xa[d] = rb + ((wa ^ key) * 32) + 8 * pp;
   }
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < NF; ++b) {
     const int k = 4 * g + q;
-    ya[b] = XBYTES + k * 128 + (((wb * 2 + b) ^ ((k >> 1) & 3)) * 32) + 8 * pp;
+    ya[b] = XBYTES + k * YROW + (((wb * NF + b) ^ ykey(k)) * 32) + 8 * pp;
   }
   // ---- lane constants of the DMA: chunk c of a wave covers image rows 8 * chunk + lane / 8, physical piece lane % 8
   const int jp = lane & 7, r8 = lane >> 3;
@@ -157,16 +165,16 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
   int yty[YCW], ytx[YCW], ych[YCW];
 #pragma unroll
   for (int c = 0; c < YCW; ++c) {
-    const int k = (wid + 8 * c) * 8 + r8;
+    const int k = (wid + 8 * c) * YRC + lane / YPR, yp = lane % YPR;
     yty[c] = k / TW;
     ytx[c] = k - yty[c] * TW;
-    ych[c] = ((((jp >> 1) ^ ((k >> 1) & 3)) * 2) + (jp & 1)) * 16;
+    ych[c] = ((((yp >> 1) ^ ykey(k)) * 2) + (yp & 1)) * 16;
   }
   const char* zero = reinterpret_cast<const char*>(tg_wg_zero_page);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int wid_u = __builtin_amdgcn_readfirstlane(wid);
 
-  f32x4 acc[NT][2];
+  f32x4 acc[NT][NF];
   constexpr int E = 8;
   float bsum[E];
 
@@ -183,20 +191,19 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
     const int tiles_x = (int)jr[8], tiles_y = (int)jr[9], want_ysum = (int)jr[10], gb0 = (int)jr[11];
     const int XH = S * H, XW = S * W;
     const int tiles = tiles_x * tiles_y * N;
-    const int b_blocks = (Cy + 63) >> 6, blocks = ((Cx + 63) >> 6) * b_blocks;  // a 32-channel remainder is a half-empty block
+    const int b_blocks = (Cy + CB - 1) / CB, blocks = ((Cx + 63) >> 6) * b_blocks;  // a channel remainder is a part-empty block
     const int local = u - ubeg;
     const int blk = local / tiles;
     int tile = local - blk * tiles;
     const int seg_n = min(u_end - u, tiles - tile);  // tiles of this segment
-    const int a0 = (blk / b_blocks) * 64, b0 = (blk % b_blocks) * 64;
+    const int a0 = (blk / b_blocks) * 64, b0 = (blk % b_blocks) * CB;
     const bool ysum = want_ysum && a0 == 0;
     const int xpixb = Cx * 2, ypixb = Cy * 2;
 
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int b = 0; b < NF; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < E; ++e) bsum[e] = 0.f;
 
@@ -258,12 +265,12 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
       const int bo = buf * BUF;
       if (i + 1 < seg_n) issue(BUF - bo);
       if (ysum) {
-        // bias gradient = sum over pixels of Y: thread (row tid / 8 [+ 64], logical piece tid % 8) adds its 8 channels
+        // bias gradient = sum over pixels of Y: thread (row tid / YPR [+ 512 / YPR ...], logical piece tid % YPR) adds its 8 channels
 #pragma unroll
-        for (int h = 0; h < TPIX / 64; ++h) {
-          const int k = (tid >> 3) + 64 * h, lp = tid & 7;
-          const int phys = ((((lp >> 1) ^ ((k >> 1) & 3)) * 2) + (lp & 1)) * 16;
-          const u32x4 v = *reinterpret_cast<const u32x4*>(smem + bo + XBYTES + k * 128 + phys);
+        for (int h = 0; h < TPIX / (512 / YPR); ++h) {
+          const int k = tid / YPR + (512 / YPR) * h, lp = tid % YPR;
+          const int phys = ((((lp >> 1) ^ ykey(k)) * 2) + (lp & 1)) * 16;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(smem + bo + XBYTES + k * YROW + phys);
           float f[8];
           Vec<T>::load(&v, f);
 #pragma unroll
@@ -273,12 +280,12 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
       const char* base = smem + bo;
 #pragma unroll
       for (int s = 0; s < Gm::KSTEPS; ++s) {
-        bf16x8 bfr[2];
+        bf16x8 bfr[NF];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const char* yp = base + ya[b] + s * 32 * 128;
+        for (int b = 0; b < NF; ++b) {
+          const char* yp = base + ya[b] + s * 32 * YROW;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(yp));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(yp + 16 * 128));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(yp + 16 * YROW));
           typedef __attribute__((ext_vector_type(8))) short s16x8;
           const s16x8 cat = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           bfr[b] = __builtin_bit_cast(bf16x8, cat);
@@ -292,8 +299,8 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
           typedef __attribute__((ext_vector_type(8))) short s16x8;
           const s16x8 cat = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           const bf16x8 af = __builtin_bit_cast(bf16x8, cat);
-          acc[t][0] = Mma16<T>::run(af, bfr[0], acc[t][0]);
-          acc[t][1] = Mma16<T>::run(af, bfr[1], acc[t][1]);
+#pragma unroll
+          for (int b = 0; b < NF; ++b) acc[t][b] = Mma16<T>::run(af, bfr[b], acc[t][b]);
         }
       }
       buf ^= 1;
@@ -304,24 +311,24 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int bch = (wb * 2 + b) * 16 + idx;
+      for (int b = 0; b < NF; ++b) {
+        const int bch = (wb * NF + b) * 16 + idx;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) slab[(t * 64 + wa * 16 + 4 * g + j) * 64 + bch] = acc[t][b][j];
+        for (int j = 0; j < 4; ++j) slab[(t * 64 + wa * 16 + 4 * g + j) * CB + bch] = acc[t][b][j];
       }
     __syncthreads();  // every wave is done with the LDS images (the next segment's DMA, or the sums below, overwrite them)
     if (want_ysum) {
-      float* red = reinterpret_cast<float*>(smem);  // [64 rows][64 channels]
+      float* red = reinterpret_cast<float*>(smem);  // [512 / YPR rows][CB channels]
       if (ysum) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) red[(tid >> 3) * 64 + (tid & 7) * 8 + e] = bsum[e];
+        for (int e = 0; e < E; ++e) red[(tid / YPR) * CB + (tid % YPR) * 8 + e] = bsum[e];
       }
       __syncthreads();
-      if (tid < 64) {
+      if (tid < CB) {
         float s = 0.f;
         if (ysum)
-          for (int r = 0; r < 64; ++r) s += red[r * 64 + tid];
-        slab[NT * 64 * 64 + tid] = s;  // blocks with a0 != 0 write zeros: the fold reads the sums of block row 0 only
+          for (int r = 0; r < 512 / YPR; ++r) s += red[r * CB + tid];
+        slab[NT * 64 * CB + tid] = s;  // blocks with a0 != 0 write zeros: the fold reads the sums of block row 0 only
       }
       __syncthreads();
     }
@@ -330,10 +337,10 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
   }
 }
 
-template <typename T, int TW, int S, int NTS>
+template <typename T, int TW, int S, int NTS, int NB = 1>
 int launch_group(const WgGroupK& k, int nwg, hipStream_t st) {
-  auto fn = wgrad_group_kernel<T, TW, S, NTS>;
-  constexpr int lds = 2 * WgGeom<TW, S, NTS>::BUF;
+  auto fn = wgrad_group_kernel<T, TW, S, NTS, NB>;
+  constexpr int lds = 2 * (WgGeom<TW, S, NTS>::XBYTES + WgGeom<TW, S, NTS>::TPIX * NB * 128);
   static_assert(lds <= 160 * 1024, "two LDS buffers must fit");
   static std::atomic<bool> attr_done{false};
   if (!attr_done) {
@@ -347,7 +354,10 @@ int launch_group(const WgGroupK& k, int nwg, hipStream_t st) {
 template <typename T>
 int dispatch_group(int variant, int tile_w, const WgGroupK& k, int nwg, hipStream_t st) {
   if (variant == TG_WGROUP_C3) return tile_w == 32 ? launch_group<T, 32, 1, 3>(k, nwg, st) : launch_group<T, 16, 1, 3>(k, nwg, st);
+  if (variant == TG_WGROUP_C3_B128)
+    return tile_w == 32 ? launch_group<T, 32, 1, 3, 2>(k, nwg, st) : launch_group<T, 16, 1, 3, 2>(k, nwg, st);
   if (variant == TG_WGROUP_CT) return launch_group<T, 16, 2, 3>(k, nwg, st);
+  if (variant == TG_WGROUP_CT_B128) return launch_group<T, 16, 2, 3, 2>(k, nwg, st);
   return launch_group<T, 16, 2, 4>(k, nwg, st);
 }
 
@@ -357,6 +367,7 @@ extern "C" int64_t tg_wgrad_group_slot_floats(void) { return 9 * 64 * 64 + 64; }
 
 extern "C" int64_t tg_wgrad_group_slot_floats_v(int variant) {
   if (variant == TG_WGROUP_C3 || variant == TG_WGROUP_CT) return 9 * 64 * 64 + 64;
+  if (variant == TG_WGROUP_C3_B128 || variant == TG_WGROUP_CT_B128) return 9 * 64 * 128 + 128;
   if (variant == TG_WGROUP_C4S2) return 16 * 64 * 64 + 64;
   return TG_E_BADARG;
 }
@@ -367,9 +378,9 @@ int group_launch(int dtype, int variant, int tile_w, const int64_t* jobs_dev, in
   if (!jobs_dev || !slab || njobs <= 0 || units_total <= 0 || workgroups <= 0) return TG_E_BADARG;
   if (!tg_aligned16(slab)) return TG_E_ALIGN;
   if (dtype != TG_BF16 && dtype != TG_F16) return TG_E_UNSUPPORTED;
-  if (variant == TG_WGROUP_C3) {
+  if (variant == TG_WGROUP_C3 || variant == TG_WGROUP_C3_B128) {
     if (tile_w != 32 && tile_w != 16) return TG_E_UNSUPPORTED;
-  } else if (variant == TG_WGROUP_CT || variant == TG_WGROUP_C4S2) {
+  } else if (variant == TG_WGROUP_CT || variant == TG_WGROUP_C4S2 || variant == TG_WGROUP_CT_B128) {
     if (tile_w != 16) return TG_E_UNSUPPORTED;
   } else {
     return TG_E_BADARG;

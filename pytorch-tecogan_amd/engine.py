@@ -367,9 +367,26 @@ class WgradList:
     WgradGroup (add ... launch, deferred fold); layers the kernel does not take (fp32, 32 -> 32 channels) run their own
     tg_wgrad launch at add()."""
     VARIANT = {"c3": L.WGROUP_C3, "ct": L.WGROUP_CT, "c4s2": L.WGROUP_C4S2}
+    WIDE = {L.WGROUP_C3: L.WGROUP_C3_B128, L.WGROUP_CT: L.WGROUP_CT_B128}   # the same kinds with 64 x 128 channel blocks
+    # 64 x 128 blocks for layers whose Y operand has a multiple of 128 channels and at least this many pixels; 0 = never (default).
+    # Built, parity-tested and measured SLOWER: 144 accumulator registers + the kernel's ~120 other live registers do not fit the 256
+    # of a two-waves-per-SIMD workgroup (139-157 VGPRs spilled for the 3x3 kind, 67 for the conv-transpose kind): c32 + c30 of the
+    # generator 89 -> 230 us at 160 workgroups, ct4 79 -> 87 us, the discriminator's stage 2 62 -> 126 us
+    # (profiles/r03_m_wgrad_b128.log; the 64 x 64 lists run these layers at 700-1050 TFLOP/s alone).
+    WIDE_MIN_PIXELS = int(os.environ.get("TECOGAN_WGRAD_B128_PIXELS", "0"))
 
     def __init__(self, cap):
         self.items, self.cache, self.cap = [], {}, cap
+
+    @classmethod
+    def variant_of(cls, conv, x_in, dout):
+        """the work list (L.WGROUP_*) a layer's weight gradient runs in"""
+        v = cls.VARIANT[conv.spec.kind]
+        if v in cls.WIDE and cls.WIDE_MIN_PIXELS > 0:
+            y = dout if conv.spec.wgrad_info()[0] else x_in
+            if y.shape[3] % 128 == 0 and y.shape[0] * y.shape[1] * y.shape[2] >= cls.WIDE_MIN_PIXELS:
+                return cls.WIDE[v]
+        return v
 
     @staticmethod
     def takes(conv):
@@ -383,25 +400,31 @@ class WgradList:
         self.items.append((conv, x_in, dout, bias_sum))
 
     @staticmethod
+    def block_b(variant):
+        """Y channels per channel block of a work list"""
+        return 128 if variant in (L.WGROUP_C3_B128, L.WGROUP_CT_B128) else 64
+
+    @staticmethod
     def plan(shapes, cap, slot, variant=L.WGROUP_C3):
         """pure host logic (unit-tested on the CPU).  shapes: [(N, H, W, cx_p, cy_p)] with H x W the grid of the Y operand ->
         (tile_w, job rows without the two pointers, units_total, the `workgroups` argument of tg_wgrad_group_v (it launches
         ceil(units / ceil(units / workgroups)) of them), [(job, a0, b0, first_slot, count)] per channel block, slots)"""
-        if variant == L.WGROUP_C3:
+        if variant in (L.WGROUP_C3, L.WGROUP_C3_B128):
             tw = 32 if max(s[2] for s in shapes) > 16 else 16
             th = 128 // tw
         else:
             tw, th = 16, 4
+        cbw = WgradList.block_b(variant)
         rows, units, gb = [], 0, 0
         spans = []
         for j, (N, H, W, cx, cy) in enumerate(shapes):
             tx, ty = (W + tw - 1) // tw, (H + th - 1) // th
             tiles = N * tx * ty
-            ab, bb = (cx + 63) // 64, (cy + 63) // 64   # a 32-channel remainder is a half-empty 64 block
+            ab, bb = (cx + 63) // 64, (cy + cbw - 1) // cbw   # a channel remainder is a part-empty block
             blocks = ab * bb
             rows.append([units, N, H, W, cx, cy, tx, ty, 0, gb])
             for blk in range(blocks):
-                spans.append((j, (blk // bb) * 64, (blk % bb) * 64, units + blk * tiles, units + (blk + 1) * tiles))
+                spans.append((j, (blk // bb) * 64, (blk % bb) * cbw, units + blk * tiles, units + (blk + 1) * tiles))
             units += blocks * tiles
             gb += blocks
         cap = max(1, min(cap, units))
@@ -418,8 +441,9 @@ class WgradList:
         others stay queued (the discriminator queues its five k4 s2 layers across the whole backward pass)"""
         now = [it for it in self.items if only is None or self.VARIANT[it[0].spec.kind] in only]
         self.items = [it for it in self.items if not (only is None or self.VARIANT[it[0].spec.kind] in only)]
-        for variant in sorted({self.VARIANT[it[0].spec.kind] for it in now}):
-            self._launch([it for it in now if self.VARIANT[it[0].spec.kind] == variant], variant)
+        var = [self.variant_of(c, x, y) for c, x, y, _ in now]
+        for variant in sorted(set(var)):
+            self._launch([it for it, v in zip(now, var) if v == variant], variant)
 
     def _launch(self, items, variant):
         key = tuple((id(c), x.data_ptr(), y.data_ptr(), tuple(x.shape), tuple(y.shape), b) for c, x, y, b in items)
@@ -433,7 +457,7 @@ class WgradList:
             for c, x_in, dout, b in items:   # X: the operand the taps shift (on the S-times finer grid), Y: the other one
                 x_is_in = c.spec.wgrad_info()[0]
                 ops.append((x_in, dout) if x_is_in else (dout, x_in))
-            S = 1 if variant == L.WGROUP_C3 else 2
+            S = 1 if variant in (L.WGROUP_C3, L.WGROUP_C3_B128) else 2
             for X, Y in ops:
                 if (X.shape[0], X.shape[1], X.shape[2]) != (Y.shape[0], S * Y.shape[1], S * Y.shape[2]):
                     raise L.TecoganHipError("tg_wgrad_group: operand grids do not match the layer kind")
@@ -445,13 +469,13 @@ class WgradList:
             for (c, _, _, b), (X, Y), r in zip(items, ops, rows):
                 r[8] = 1 if b else 0
                 jobs.append([X.data_ptr(), Y.data_ptr()] + r)
-            fin = {}
+            fin, cbw = {}, self.block_b(variant)
             for j, a0, b0, first, count in fold:
                 c, _, _, b = items[j]
                 _, _, taps, ca, cb, s_a, s_b = c.spec.wgrad_info()
                 bias = c.gbias.data_ptr() + 4 * b0 if (b and a0 == 0) else 0
                 fin.setdefault(j, []).append([slab.data_ptr() + 4 * slot * first, c.gw.data_ptr() + 4 * (a0 * s_a + b0 * s_b),
-                                              s_a, s_b, count, len(taps), 64, 64, min(64, ca - a0), min(64, cb - b0), bias, slot])
+                                              s_a, s_b, count, len(taps), 64, cbw, min(64, ca - a0), min(cbw, cb - b0), bias, slot])
             ent = (tw, torch.tensor(jobs, dtype=torch.int64, device=dev), units, wgs, slab, fin, K.tg_dtype(items[0][0].dt))
             self.cache[key] = ent
         tw, jobs, units, wgs, slab, fin, tg = ent

@@ -435,6 +435,67 @@ def test_wgrad_group_stride2_kinds_vs_torch(kind, cap, layers, dt):
         torch.testing.assert_close(grads[i].cpu(), refs[i], rtol=2e-2, atol=float(refs[i].abs().max()) * 1e-2)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kind,cap,layers", [
+    # (N, h, w of the COARSE grid, cin, cout, bias sums)
+    ("c3", 7, [(2, 32, 32, 64, 128, True), (1, 64, 64, 128, 128, False), (2, 20, 40, 64, 256, True)]),
+    ("c3", 160, [(3, 32, 32, 128, 128, True), (2, 16, 16, 64, 128, True)]),
+    ("c3", 5, [(2, 16, 16, 128, 160, True), (1, 24, 12, 64, 32, True), (1, 16, 16, 96, 224, False)]),   # part-empty 128 blocks
+    ("ct", 5, [(2, 16, 16, 128, 64, False), (1, 32, 32, 128, 128, False), (2, 8, 20, 256, 64, False)]),
+    ("ct", 160, [(3, 64, 64, 128, 128, False)]),
+])
+def test_wgrad_group_wide_channel_blocks_vs_torch(kind, cap, layers, dt):
+    """TG_WGROUP_C3_B128 / TG_WGROUP_CT_B128: the work-list launch with 64 x 128 channel blocks (256-byte Y rows in LDS, four B
+    fragments per wave), folded with cb_p = 128 jobs - against torch autograd; Y channel counts that are not multiples of 128 run
+    as part-empty blocks, bias sums cover all 128 columns."""
+    from pytorch_tecogan_amd import engine as E
+    lib = L.load()
+    variant = E.WgradList.WIDE[E.WgradList.VARIANT[kind]]
+    slot = int(lib.tg_wgrad_group_slot_floats_v(variant))
+    assert slot == 9 * 64 * 128 + 128
+    specs = [K.ConvSpec(kind, cin, cout) for (_, _, _, cin, cout, _) in layers]
+    ops, refs, brefs = [], [], []
+    for i, ((N, h, w, cin, cout, bsum), sp) in enumerate(zip(layers, specs)):
+        if kind == "ct":     # input on the coarse grid, output gradient on the fine one
+            x, d = q(rnd((N, cin, h, w), 700 + i), dt), q(rnd((N, cout, 2 * h, 2 * w), 800 + i), dt)
+        else:
+            x, d = q(rnd((N, cin, h, w), 700 + i), dt), q(rnd((N, cout, h, w), 800 + i), dt)
+        wt = torch.zeros(sp.weight_shape, requires_grad=True)
+        ref_conv(sp, x, wt, None).backward(d)
+        refs.append(wt.grad)
+        brefs.append(d.sum(dim=(0, 2, 3)))
+        xd, dd = K.to_nhwc(x.to(DEV), dt), K.to_nhwc(d.to(DEV), dt)
+        ops.append((xd, dd) if sp.wgrad_info()[0] else (dd, xd))
+    tw, rows, units, wgs, fold, slots = E.WgradList.plan([(Y.shape[0], Y.shape[1], Y.shape[2], X.shape[3], Y.shape[3])
+                                                          for X, Y in ops], cap, slot, variant)
+    slab = torch.full((slots * slot,), float("nan"), device=DEV)
+    jobs = []
+    for (X, Y), r, ly in zip(ops, rows, layers):
+        r[8] = 1 if ly[5] else 0
+        jobs.append([X.data_ptr(), Y.data_ptr()] + r)
+    jt = torch.tensor(jobs, dtype=torch.int64, device=DEV)
+    L.check(lib.tg_wgrad_group_v(K.tg_dtype(dt), variant, tw, jt.data_ptr(), len(rows), units, wgs, slab.data_ptr(), None),
+            "tg_wgrad_group_v")
+    grads = [torch.zeros(sp.weight_shape, device=DEV) for sp in specs]
+    gbs = [torch.zeros(K.pad32(sp.cout), device=DEV) for sp in specs]
+    fin = []
+    for j, a0, b0, first, count in fold:
+        _, _, taps, ca, cb, s_a, s_b = specs[j].wgrad_info()
+        assert b0 % 128 == 0
+        bias = gbs[j].data_ptr() + 4 * b0 if (layers[j][5] and a0 == 0) else 0
+        fin.append([slab.data_ptr() + 4 * slot * first, grads[j].data_ptr() + 4 * (a0 * s_a + b0 * s_b), s_a, s_b, count, len(taps),
+                    64, 128, min(64, ca - a0), min(128, cb - b0), bias, slot])
+    rows13, nitems = E.fold_items(fin)
+    ft = torch.tensor(rows13, dtype=torch.int64, device=DEV)
+    L.check(lib.tg_wgrad_fold_items(ft.data_ptr(), len(fin), nitems, 9, None), "tg_wgrad_fold_items")
+    torch.cuda.synchronize()
+    for i in range(len(layers)):
+        assert rel_err(grads[i].cpu(), refs[i]) < 2e-3, (i, layers[i], rel_err(grads[i].cpu(), refs[i]))
+        torch.testing.assert_close(grads[i].cpu(), refs[i], rtol=2e-2, atol=float(refs[i].abs().max()) * 1e-2)
+        if layers[i][5]:
+            torch.testing.assert_close(gbs[i][:specs[i].cout].cpu(), brefs[i], rtol=1e-4, atol=1e-3)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("C_,act,skip", [(64, L.ACT_NONE, True), (128, L.ACT_LRELU, False), (32, L.ACT_LRELU, False)])
 def test_batchnorm_train_fwd_bwd(C_, act, skip, dt):
