@@ -229,6 +229,8 @@ def roofline_pass(st, dtype):
          "hbm")  # reads: 9 target ch + 9 warped-source ch + 3 x 2 velocity ch per HR pixel, 9 LR ch
     wrap(K, "content_loss", lambda *a, **k: f"content_loss_kernel<{T16}>",
          lambda gen, y, dpre, *a, **k: nb(gen, y, dpre), "hbm")
+    wrap(K, "conv3x3_rgb_bwd", lambda *a, **k: f"rgb_bwd_kernel<{T16}>",
+         lambda dpre4, x, w, dx, slab, cap: nb(dpre4, x, dx), "hbm")  # output layer backward: x in, dx out, 8 B/pixel of dpre
     wrap(K, "up4_planes", lambda *a, **k: "up4_planes_kernel",
          lambda src, so, dst, do, n, h, w, **k: 4.0 * n * h * w * 17, "hbm")
     wrap(K, "absdiff_sum", lambda *a, **k: f"absdiff_sum_kernel<{T16}>", lambda a_, b_, *r, **k: nb(a_, b_), "hbm")

@@ -233,6 +233,17 @@ int tg_wgrad_group_v(int dtype, int variant, int tile_w, const int64_t* jobs_dev
 int tg_conv3x3_rgb(int dtype, const void* in, const void* w_packed, const float* bias, float* out, long long out_n_stride,
                    int c_real, int N, int H, int W, int Cin, int act, void* stream);
 
+/* Backward of that layer for the batched generator backward (autograd of code/models.py:77-79 behind code/train.py:336), one pass:
+ *   dx[n][y][x][ci] = (x > 0) * sum_{t, co} dpre4[p - off(t)][co] * w[co][ci][t]      (input gradient under the ReLU mask of x)
+ *   slab slot of workgroup g: partial dW in tg_wgrad's slab layout [9 taps][64 ci][32] fp32, columns co < 3 (column 3 zero, the
+ *   rest unwritten): fold with ONE job {slab, gw, s_a = 9, s_b = 576, nsplit = workgroups, 9, 64, 32, 64, 3, 0, slot}.
+ * dpre4 [N][H][W][4] 16-bit (tg_content_loss with dpre_channels = 4), x / dx [N][H][W][64], w = the fp32 master weight
+ * [3][64][3][3].  workgroups = min(N * ceil(H / 16) * ceil(W / 16), max_workgroups) persistent workgroups; slab must hold that
+ * many slots of tg_conv3x3_rgb_bwd_slot_floats() floats.  TG_E_UNSUPPORTED for fp32 or Cin != 64 (tg_conv + tg_wgrad then). */
+int64_t tg_conv3x3_rgb_bwd_slot_floats(void);
+int tg_conv3x3_rgb_bwd(int dtype, const void* dpre4, const void* x, const float* w, void* dx, float* slab, int N, int H, int W,
+                       int Cin, int max_workgroups, void* stream);
+
 /* ---- fused residual block (code/ops.py:45-54; code/models.py:66-69), bf16, C == 64 ------------------------------
  * out_h = relu(conv3x3(in, w1) + b1), out_a = (add_skip ? in : 0) + conv3x3(out_h, w2) in ONE launch (add_skip = 0: the
  * conv-relu-conv pair of conv_trans.2, code/models.py:73); tensors NHWC [N][H][W][64]; w1 / w2 are
@@ -335,12 +346,13 @@ int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const float* b, co
 /* content loss partial sum and d(pre-sigmoid) for the generator output (code/train.py:239-241):
  * acc (>= 16 floats): acc[0] += sum (gen-y)^2 ; dpre[nhwc] = gscale * 2*(gen-y) * gen*(1-gen) ; bias_acc[c] += sum dpre[c], c < 3
  * (the output layer's bias gradient; bias_acc null: acc + 8).  gen/y are NCHW fp32 (B,T,3,H,W);
- * dpre is NHWC [(t1-t0)*B][H][W][32] in (t,b) order and covers frames t0 <= t < t1 only.
+ * dpre is NHWC [(t1-t0)*B][H][W][dpre_channels] in (t,b) order and covers frames t0 <= t < t1 only; dpre_channels = 32 (the
+ * padded operand of tg_conv / tg_wgrad) or, 16-bit types only, 4 (3 + 1 pad: the compact operand of tg_conv3x3_rgb_bwd).
  * pp_T > 0 (ping-pong, T == 2*pp_T-1): acc[6] += sum |gen_t - gen_{2(pp_T-1)-t}| over t < pp_T-1 and the gradient
  * pp_coef*sign(gen_t - gen_partner) is added before the sigmoid derivative (code/train.py:275-283). */
 int tg_content_loss(int dtype, const float* gen, const float* y, void* dpre, float* acc, int B, int T, int H, int W,
                     float gscale, int t0, int t1, int pp_T, float pp_coef, const float* loss_scale, float* bias_acc,
-                    void* stream);
+                    int dpre_channels, void* stream);
 /* All step scalars on device + d(logit) for the discriminator loss (code/train.py:287-333). */
 int tg_loss_finalize(const float* prob, const float* acc, float* scalars, float* dlogit, int tb, const float* cfg,
                      const float* loss_scale, void* stream);

@@ -67,6 +67,8 @@ _PROTOS = {
     "tg_nhwc_to_nchw": (_I, [_I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "tg_resblock_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "tg_conv3x3_rgb": (_I, [_I, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "tg_conv3x3_rgb_bwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "tg_conv3x3_rgb_bwd_slot_floats": (_L, []),
     "tg_conv4s2_fwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "tg_conv4s2_dgrad": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "tg_convt_dgrad": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -92,7 +94,7 @@ _PROTOS = {
     "tg_absdiff_sum": (_I, [_I, _P, _P, _P, _L, _I, _I, _P]),
     "tg_absdiff_sum_multi": (_I, [_I, _P, _I, _I, _P]),
     "tg_absdiff_nchw": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
-    "tg_content_loss": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _I, _F, _P, _P, _P]),
+    "tg_content_loss": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _I, _F, _P, _P, _I, _P]),
     "tg_loss_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P, _P]),
     "tg_dlogit_real": (_I, [_P, _P, _I, _P, _P, _P]),
     "tg_reduce_replicas": (_I, [_P, _I, _I, _I, _P, _I, _P]),

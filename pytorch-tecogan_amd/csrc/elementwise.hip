@@ -3,6 +3,7 @@
 // All kernels move 16 bytes per lane per access; per-channel quantities are kept in registers because a thread's
 // channel vector is fixed for its whole grid-stride loop.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(kClThreads) void content_loss_kernel(const float* _
                                                           char* __restrict__ dpre, float* __restrict__ acc, int B,
                                                           int T_, int H, int W, float gscale, int t0, int t1, int pp_T,
                                                           float pp_coef, const float* __restrict__ loss_scale,
-                                                          float* __restrict__ bias_acc) {
+                                                          float* __restrict__ bias_acc, int dpre_c) {
   using TR = ElemTraits<T>;
   constexpr int NW = kClThreads / 64;
   if (loss_scale) {  // fp16 mode: every backward seed carries the dynamic loss scale (tg_adam_scaled divides it out)
@@ -532,7 +533,14 @@ __global__ __launch_bounds__(kClThreads) void content_loss_kernel(const float* _
       v[c] = dg * g * (1.f - g);
       cs[c] += v[c];
     }
-    if (dpre) {
+    if (dpre && dpre_c == 4) {  // compact rows for tg_conv3x3_rgb_bwd: 3 channels + 1 pad, 16-bit
+      if constexpr (!std::is_same<T, F32>::value) {
+        uint2 pk;
+        pk.x = (unsigned)f32_to_bits16<T>(v[0]) | ((unsigned)f32_to_bits16<T>(v[1]) << 16);
+        pk.y = (unsigned)f32_to_bits16<T>(v[2]);
+        *reinterpret_cast<uint2*>(dpre + i * 8) = pk;
+      }
+    } else if (dpre) {
       char* o = dpre + i * 32 * TR::kBytes;
 #pragma unroll
       for (int k = 0; k < 32 / TR::kVec; ++k) Vec<T>::store(o + k * 16, v + k * TR::kVec);
@@ -809,12 +817,14 @@ extern "C" int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const f
 
 extern "C" int tg_content_loss(int dtype, const float* gen, const float* y, void* dpre, float* acc, int B, int T,
                                int H, int W, float gscale, int t0, int t1, int pp_T, float pp_coef,
-                               const float* loss_scale, float* bias_acc, void* stream) {
+                               const float* loss_scale, float* bias_acc, int dpre_channels, void* stream) {
   if (!gen || !y || !acc || B <= 0 || T <= 0 || H <= 0 || W <= 0 || t0 < 0 || t1 > T || t0 >= t1) return TG_E_BADARG;
+  if (dpre_channels != 32 && !(dpre_channels == 4 && dtype != TG_F32)) return TG_E_UNSUPPORTED;
   if (pp_T != 0 && T != 2 * pp_T - 1) return TG_E_BADARG;  // ping-pong: the sequence is x followed by reverse(x)[1:]
   const long long total = (long long)B * (t1 - t0) * H * W;
   TG_DISPATCH(dtype, content_loss_kernel, dim3(grid_for(total, kClThreads, 256)), dim3(kClThreads), (hipStream_t)stream, gen, y,
-              (char*)dpre, acc, B, T, H, W, gscale, t0, t1, pp_T, pp_coef, loss_scale, bias_acc ? bias_acc : acc + 8);
+              (char*)dpre, acc, B, T, H, W, gscale, t0, t1, pp_T, pp_coef, loss_scale, bias_acc ? bias_acc : acc + 8,
+              dpre_channels);
   return tg_launch_status();
 }
 

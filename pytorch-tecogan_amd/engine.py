@@ -704,6 +704,7 @@ class GeneratorEngine:
         if self.finalizer is not None and self.trunk_group is not None and _wgrad_lists() and \
                 dtype_t in (torch.bfloat16, torch.float16):
             self.hr_list, self.trunk_group = WgradList(K.persist_wgs("G")), WgradList(K.persist_wgs("G"))
+        self._rgb_cache = {}
         self.fused_rb = dtype_t in (torch.bfloat16, torch.float16) and os.environ.get("TECOGAN_FUSED_RESBLOCK", "1") != "0"
         # the fused input-gradient launch (tg_resblock_bwd) is numerically identical and was measured EQUAL in time on the
         # batched backward (15 x 28.2 us vs 30 x 14.9 us at 40 samples: 640 workgroups each re-read 147 KB of weights), so
@@ -712,6 +713,37 @@ class GeneratorEngine:
 
     def repack(self):
         self.repacker.run()
+
+    def set_cap(self, cap):
+        """workgroups of the generator's persistent launches (register-weights convs, weight-gradient work lists); a scheduling
+        knob only - call before the first backward pass of a shape (launch plans are cached per cap)"""
+        for c in self.convs:
+            c.persist_wgs = cap
+        for lst in (self.hr_list, self.trunk_group):
+            if isinstance(lst, WgradList):
+                lst.cap = cap
+
+    def rgb_bwd_ok(self):
+        """the output layer's backward as ONE launch (tg_conv3x3_rgb_bwd, a compact [..., 4] dpre): 16-bit modes with the deferred
+        fold (TECOGAN_RGB_BWD=0: the generic input-gradient launch + the layer's place in the weight-gradient work list)"""
+        return self.dt in (torch.bfloat16, torch.float16) and self.finalizer is not None and self.out_ch == 3 and \
+            os.environ.get("TECOGAN_RGB_BWD", "1") != "0"
+
+    def _rgb_bwd(self, x, dpre4, dx):
+        c = self.cout
+        key = (x.data_ptr(), dpre4.data_ptr(), dx.data_ptr(), tuple(x.shape))
+        ent = self._rgb_cache.get(key)
+        if ent is None:
+            if self.ws.frozen:
+                raise L.TecoganHipError("new output-layer backward shape after graph capture")
+            cap = int(os.environ.get("TECOGAN_RGB_BWD_WGS", "256"))   # 160 / 256 / 512 / 1024: 4.37 4.37 4.39 4.41 ms per step
+            nwg = K.rgb_bwd_workgroups(x.shape[0], x.shape[1], x.shape[2], cap)
+            slot = int(L.load().tg_conv3x3_rgb_bwd_slot_floats())
+            slab = torch.empty(nwg * slot, dtype=torch.float32, device=x.device)
+            _, _, taps, ca, cb, s_a, s_b = c.spec.wgrad_info()
+            ent = self._rgb_cache[key] = (slab, cap, [slab.data_ptr(), c.gw.data_ptr(), s_a, s_b, nwg, len(taps), 64, 32, ca, cb, 0, slot])
+        slab, cap, c.fin_job = ent
+        K.conv3x3_rgb_bwd(dpre4, x, c.w, dx, slab, cap)
 
     def alloc(self, NS, h, w):
         """selects (creating it on first use) the activation storage for NS samples (NS = T*B when training, B for
@@ -808,10 +840,14 @@ class GeneratorEngine:
 
     def _backward_hr(self, a, g, wh, hr, RELU):
         dA = g["dA"]
-        wh(self.cout, a["u4"], g["dpre"])                           # output bias grad: see TecoGANStep
+        # (output bias gradient: the content-loss kernel's channel sums, see TecoGANStep)
+        if g["dpre"].shape[-1] == 4:    # compact dpre: input gradient + weight gradient of the output layer in one pass
+            self._rgb_bwd(a["u4"], g["dpre"], g["hr64"])
+        else:
+            wh(self.cout, a["u4"], g["dpre"])
+            self.cout.dgrad(g["dpre"], g["hr64"], mask=a["u4"], mask_mode=RELU)
         # bias gradients of plain convs come out of their own wgrad launch (bias_sum): the output gradient is that
         # launch's Y operand, so its channel sums cost a few VALU adds there instead of an atomics epilogue here
-        self.cout.dgrad(g["dpre"], g["hr64"], mask=a["u4"], mask_mode=RELU)
         wh(self.c6, a["u3"], g["hr64"], True)
         self.c6.dgrad(g["hr64"], g["hr128"], mask=a["u3"], mask_mode=RELU, bias_grad_of=self.ct4)
         wh(self.ct4, a["u2"], g["hr128"])

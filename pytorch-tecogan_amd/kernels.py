@@ -277,6 +277,17 @@ def persist_wgs(net):
     return int(os.environ.get(f"TECOGAN_PERSIST_WGS_{net}", default.get(net, PERSIST_WGS)))
 
 
+def persist_wgs_g_for(lr_pixels):
+    """the generator's cap for a training step whose recurrent pass has `lr_pixels` = B * h * w pixels per launch, or None when
+    the environment fixes it.  Up to 4096 pixels (configs[1]: 4 x 32 x 32) the chain's launches fill half the chip or less and the
+    step is bound by lane B beside the G backward: 144 (round 3, after the output layer's backward became one streaming launch and
+    lane A ~70 us shorter: G = 120/136/144/152/160 -> 4.39 4.33 4.33 4.36 4.38 ms).  The configs[3] shard (2 x 64 x 64) keeps 160:
+    10.34 vs 10.47 ms (profiles/r03_o_rgb_bwd_ab.log)."""
+    if "TECOGAN_PERSIST_WGS" in os.environ or "TECOGAN_PERSIST_WGS_G" in os.environ:
+        return None
+    return min(PERSIST_WGS, 144) if lr_pixels <= 4096 else PERSIST_WGS
+
+
 def wgrad_plan(N, YH, YW, S, ntaps, cx_p, cy_p, cap=None):
     """(nsplit, taps_per_wg).  Layers with few pixel tiles split the taps over workgroups (3 of 9 / 4 of 16 each): the fp32
     slab traffic (nsplit x taps x Cx x Cy x 4 B written, then read by the fold) is what bounds them; layers with thousands
@@ -329,6 +340,24 @@ def conv3x3_rgb(x, w_packed, bias, out_buf, out_off, n_stride, c_real, act=L.ACT
         raise L.TecoganHipError("tg_conv3x3_rgb: output window exceeds the fp32 buffer")
     L.check(L.load().tg_conv3x3_rgb(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), out_buf.data_ptr() + 4 * out_off,
                                     n_stride, c_real, N, H, W, cin, act, _stream()), "tg_conv3x3_rgb")
+
+
+def rgb_bwd_workgroups(N, H, W, cap):
+    """persistent workgroups (= slab slots, = the fold job's nsplit) of tg_conv3x3_rgb_bwd"""
+    return max(1, min(N * ((H + 15) // 16) * ((W + 15) // 16), cap))
+
+
+def conv3x3_rgb_bwd(dpre4, x, w_master, dx, slab, cap):
+    """backward of the generator's output layer in one pass (csrc/rgb_bwd.hip): dx = relu-masked input gradient, slab = one
+    partial-dW slot per workgroup; dpre4 [N,H,W,4] (content_loss(dpre_channels=4)), w_master the fp32 [3,64,3,3] weight"""
+    N, H, W, cin = x.shape
+    if dpre4.shape != (N, H, W, 4) or dx.shape != x.shape or w_master.dtype != torch.float32 or w_master.numel() != 3 * cin * 9:
+        raise L.TecoganHipError("tg_conv3x3_rgb_bwd: operand shapes")
+    lib = L.load()
+    if slab.numel() < rgb_bwd_workgroups(N, H, W, cap) * int(lib.tg_conv3x3_rgb_bwd_slot_floats()):
+        raise L.TecoganHipError("tg_conv3x3_rgb_bwd: slab too small")
+    L.check(lib.tg_conv3x3_rgb_bwd(tg_dtype(x.dtype), _ptr(dpre4), _ptr(x), _ptr(w_master), _ptr(dx), _ptr(slab), N, H, W, cin, cap,
+                                   _stream()), "tg_conv3x3_rgb_bwd")
 
 
 def conv4s2_fwd(x, w_packed, bias, out, stats=None, groups=1, stats_replicas=1):
@@ -546,10 +575,12 @@ def absdiff_sum_multi(dtype_t, jobs, njobs, blocks_per_job=128):
 
 def content_loss(gen, y, dpre, acc, B, T, H, W, gscale, t0=0, t1=None, pp_T=0, pp_coef=0.0, loss_scale=None, bias_acc=None):
     """loss_scale: device float (fp16 mode) multiplied into every backward seed - here d(loss)/d(pre-sigmoid);
-    bias_acc: 3 floats that receive the channel sums of dpre (the output layer's bias gradient); default acc[8:11]"""
+    bias_acc: 3 floats that receive the channel sums of dpre (the output layer's bias gradient); default acc[8:11];
+    dpre: [..., 32] (padded conv operand) or [..., 4] (16-bit: the compact operand of conv3x3_rgb_bwd)"""
     dt = tg_dtype(dpre.dtype) if dpre is not None else L.TG_F32
     L.check(L.load().tg_content_loss(dt, _ptr(gen), _ptr(y), _ptr(dpre), _ptr(acc), B, T, H, W, gscale, t0,
-                                     T if t1 is None else t1, pp_T, pp_coef, _ptr(loss_scale), _ptr(bias_acc), _stream()),
+                                     T if t1 is None else t1, pp_T, pp_coef, _ptr(loss_scale), _ptr(bias_acc),
+                                     int(dpre.shape[-1]) if dpre is not None else 32, _stream()),
             "tg_content_loss")
 
 

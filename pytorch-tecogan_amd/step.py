@@ -167,10 +167,16 @@ class TecoGANStep:
         self.ring_i = 0
         # the engines keep one buffer set per launch shape; this step's sets are pinned (its graphs hold their addresses)
         # and re-selected at the start of every run(), so a module forward at another shape in between is harmless
+        cap_g = K.persist_wgs_g_for(B * h * h)
+        if cap_g is not None:
+            G.set_cap(cap_g)
         G.sets.pin((T * B, h, h))
         G.alloc(T * B, h, h)
         G._alloc_grad()
-        self.dpre = torch.empty(T * B, H, H, 32, dtype=G.dt, device=device)
+        # d(loss)/d(pre-sigmoid): 3 real channels.  16-bit modes without the VGG term keep it compact ([..., 4]) and run the
+        # output layer's backward as one launch (csrc/rgb_bwd.hip); else the padded operand of the generic conv launches
+        compact = G.rgb_bwd_ok() and self.vgg_scaling <= 0.0
+        self.dpre = torch.empty(T * B, H, H, 4 if compact else 32, dtype=G.dt, device=device)
         # TECOGAN_LANES=0: the whole forward/backward as ONE forked capture (lane B's stream is then an ordinary one:
         # a CU mask is lost inside a forked graph)
         self.lanes = os.environ.get("TECOGAN_LANES", "1") != "0"

@@ -763,6 +763,72 @@ def test_gen_input_pack(dt):
     assert float(got[:, 3:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W,cap", [(2, 32, 32, 512), (3, 40, 24, 5), (1, 16, 16, 3), (2, 20, 52, 2)])
+def test_output_layer_backward_single_pass(N, H, W, cap, dt):
+    """tg_conv3x3_rgb_bwd: input gradient (under the ReLU mask of the layer input) and weight gradient of the conv 64 -> 3 output
+    layer from a compact [N,H,W,4] d(pre-sigmoid), one launch of persistent workgroups + the network's fold - against torch
+    autograd of F.conv2d on the rounded operands, and against the generic pair of launches on the padded operand; tiles cut by
+    the image edges, more tiles than workgroups and the reverse."""
+    from pytorch_tecogan_amd import engine as E
+    lib = L.load()
+    x = q(torch.relu(rnd((N, 64, H, W), 901)), dt)          # a ReLU output: zeros where the mask closes
+    d = q(rnd((N, 3, H, W), 902, -0.5, 0.5), dt)
+    w = rnd((3, 64, 3, 3), 903, -0.1, 0.1)
+    xr = x.clone().requires_grad_(True)
+    wr = q(w, dt).clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, 1, 1).backward(d)
+    ref_dx = xr.grad * (x > 0)
+    xd = K.to_nhwc(x.to(DEV), dt)
+    d4 = torch.zeros(N, H, W, 4, dtype=dt, device=DEV)
+    d4[..., :3] = d.permute(0, 2, 3, 1).to(DEV)
+    dx = torch.full_like(xd, float("nan"))
+    slot = int(lib.tg_conv3x3_rgb_bwd_slot_floats())
+    nwg = K.rgb_bwd_workgroups(N, H, W, cap)
+    assert nwg == min(cap, N * ((H + 15) // 16) * ((W + 15) // 16))
+    slab = torch.full((nwg * slot,), float("nan"), device=DEV)
+    wd = w.to(DEV).contiguous()
+    K.conv3x3_rgb_bwd(d4, xd, wd, dx, slab, cap)
+    gw = torch.zeros(3, 64, 3, 3, device=DEV)
+    rows, nitems = E.fold_items([[slab.data_ptr(), gw.data_ptr(), 9, 576, nwg, 9, 64, 32, 64, 3, 0, slot]])
+    ft = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    L.check(lib.tg_wgrad_fold_items(ft.data_ptr(), 1, nitems, 9, None), "tg_wgrad_fold_items")
+    torch.cuda.synchronize()
+    got_dx = K.to_nchw(dx, 64).cpu()
+    assert torch.isfinite(got_dx).all()
+    torch.testing.assert_close(got_dx, q(ref_dx, dt), rtol=2e-2, atol=float(ref_dx.abs().max()) * 1e-2)
+    assert float((got_dx[x == 0]).abs().max()) == 0.0
+    assert rel_err(gw.cpu(), wr.grad) < 2e-3, rel_err(gw.cpu(), wr.grad)
+    # the generic pair on the padded operand: tg_conv (input gradient, ReLU mask) gives the same values up to the summation order
+    spec = K.ConvSpec("c3", 64, 3)
+    flat = E.FlatParams({"w": spec.weight_shape}, torch.device(DEV))
+    flat.load({"w": w})
+    conv = E.Conv(flat, "w", None, spec, dt, E.Workspace(torch.device(DEV)))
+    conv.repack()
+    d32 = torch.zeros(N, H, W, 32, dtype=dt, device=DEV)
+    d32[..., :3] = d4[..., :3]
+    dx2 = torch.empty_like(xd)
+    conv.dgrad(d32, dx2, mask=xd, mask_mode=L.MASK_RELU)
+    torch.cuda.synchronize()
+    assert float((dx.float() - dx2.float()).abs().max()) <= 8e-3 * float(dx2.float().abs().max())
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_content_loss_compact_rows(dt):
+    """tg_content_loss with a [..., 4] dpre writes the same three values per pixel as the padded [..., 32] rows (and a zero pad)"""
+    B, T, H = 2, 3, 24
+    gen, y = rnd((B, T, 3, H, H), 911, 0.05, 0.95).to(DEV), rnd((B, T, 3, H, H), 912, 0, 1).to(DEV)
+    d32, d4 = torch.empty(T * B, H, H, 32, dtype=dt, device=DEV), torch.full((T * B, H, H, 4), 7.0, dtype=dt, device=DEV)
+    acc32, acc4 = torch.zeros(16, device=DEV), torch.zeros(16, device=DEV)
+    K.content_loss(gen, y, d32, acc32, B, T, H, H, 0.01)
+    K.content_loss(gen, y, d4, acc4, B, T, H, H, 0.01)
+    torch.cuda.synchronize()
+    assert torch.equal(d4[..., :3], d32[..., :3]) and float(d4[..., 3].abs().max()) == 0.0
+    torch.testing.assert_close(acc4, acc32, rtol=1e-5, atol=1e-6)
+    with pytest.raises(L.TecoganHipError):   # fp32 keeps the padded operand
+        K.content_loss(gen, y, torch.empty(T * B, H, H, 4, device=DEV), acc4, B, T, H, H, 0.01)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_d_assemble_vs_oracle(dt):
     B, T, h = 2, 10, 8
@@ -868,7 +934,7 @@ def test_content_loss_pingpong_term(dt):
     torch.testing.assert_close(got, pre.grad, rtol=1e-2 if dt != torch.float32 else 1e-4, atol=1e-6)
     # the sequence must be x ++ reverse(x)[1:]
     assert L.load().tg_content_loss(K.tg_dtype(dt), gen.to(DEV).data_ptr(), y.to(DEV).data_ptr(), dpre.data_ptr(),
-                                    acc.data_ptr(), B, T, H, H, gscale, 0, T, n + 1, 0.0, None, None, None) == -1
+                                    acc.data_ptr(), B, T, H, H, gscale, 0, T, n + 1, 0.0, None, None, 32, None) == -1
 
 
 @pytest.mark.parametrize("dt", DTYPES)

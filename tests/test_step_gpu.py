@@ -311,6 +311,30 @@ def test_step_bf16_psnr_and_losses(oracle_b1, monkeypatch):
         assert rel(p.grad.cpu(), o["gg"][name]) < 8e-2, name
 
 
+def test_output_layer_single_pass_backward_equals_generic_path(monkeypatch):
+    """bf16 step with the output layer's backward as one launch on a compact d(pre-sigmoid) (tg_conv3x3_rgb_bwd, default) and with
+    TECOGAN_RGB_BWD=0 (tg_conv + the layer's place in the weight-gradient work list on the 32-channel operand): same forward, the
+    generator's gradients agree to the rounding of one bf16 tensor"""
+    monkeypatch.setenv("TECOGAN_GRAPH", "0")
+    grads, outs = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TECOGAN_RGB_BWD", mode)
+        hip_train._STEPS.clear()
+        args, G, D, og, od, gp, dp = build(1, "bf16")
+        x, y = synth(2, 10, 32, 1)
+        out = train.FRVSR_Train(x.cuda(), y.cuda(), args, D, G, 0, 0.0, 0.0, og, od)
+        st = next(iter(hip_train._STEPS.values()))
+        assert st.dpre.shape[-1] == (4 if mode == "1" else 32)
+        grads[mode] = {n: p.grad.detach().cpu().clone() for n, p in G.named_parameters()}
+        outs[mode] = (out.gen_output.cpu(), float(out.gen_loss))
+    hip_train._STEPS.clear()
+    assert torch.equal(outs["1"][0], outs["0"][0])
+    np.testing.assert_allclose(outs["1"][1], outs["0"][1], rtol=2e-5)   # (the loss sum's float atomics arrive in any order)
+    for n in grads["1"]:
+        assert rel(grads["1"][n], grads["0"][n]) < (3e-3 if n.startswith("output.") else 2e-2), (n, rel(grads["1"][n], grads["0"][n]))
+    torch.testing.assert_close(grads["1"]["output.bias"], grads["0"]["output.bias"], rtol=1e-5, atol=1e-7)
+
+
 def test_modules_forward_match_golden(golden_dir):
     u = np.load(os.path.join(golden_dir, "units.npz"))
     args = orc.default_args()
