@@ -288,6 +288,17 @@ def persist_wgs_g_for(lr_pixels):
     return min(PERSIST_WGS, 144) if lr_pixels <= 4096 else PERSIST_WGS
 
 
+def persist_wgs_dreal_for(lr_pixels):
+    """cap of the discriminator's persistent launches in its REAL half for a step of `lr_pixels` (see persist_wgs_g_for), or None.
+    The real half runs beside the latency-bound chain and lane B then waits ~0.4 ms for the chain's last frame: with 80 instead of
+    96 workgroups it gives the chain more of the chip and still ends before the chain does - 4.36 -> 4.32 ms/step (64 / 72 / 80
+    equal, 48: 4.51: the real half becomes the long pole); the configs[3] shard is not chain-bound: no gain there
+    (profiles/r03_o_rgb_bwd_ab.log)."""
+    if any(k in os.environ for k in ("TECOGAN_PERSIST_WGS", "TECOGAN_PERSIST_WGS_D", "TECOGAN_PERSIST_WGS_DREAL")):
+        return None
+    return 80 if lr_pixels <= 4096 else None
+
+
 def wgrad_plan(N, YH, YW, S, ntaps, cx_p, cy_p, cap=None):
     """(nsplit, taps_per_wg).  Layers with few pixel tiles split the taps over workgroups (3 of 9 / 4 of 16 each): the fp32
     slab traffic (nsplit x taps x Cx x Cy x 4 B written, then read by the fold) is what bounds them; layers with thousands

@@ -167,9 +167,11 @@ class TecoGANStep:
         self.ring_i = 0
         # the engines keep one buffer set per launch shape; this step's sets are pinned (its graphs hold their addresses)
         # and re-selected at the start of every run(), so a module forward at another shape in between is harmless
-        cap_g = K.persist_wgs_g_for(B * h * h)
+        cap_g, cap_dr = K.persist_wgs_g_for(B * h * h), K.persist_wgs_dreal_for(B * h * h)
         if cap_g is not None:
             G.set_cap(cap_g)
+        if cap_dr is not None:
+            D.cap[0] = cap_dr
         G.sets.pin((T * B, h, h))
         G.alloc(T * B, h, h)
         G._alloc_grad()
