@@ -816,6 +816,9 @@ class GeneratorEngine:
         NS = self.shape[0]
         s1 = NS if s1 is None else s1
         n = s1 - s0
+        if self.finalizer is not None and (s0, s1) != (0, NS):
+            # the deferred fold takes each layer's LAST launch: a partial range would lose the slabs of the ranges before it
+            raise L.TecoganHipError("GeneratorEngine.backward: sample ranges need per-layer folds (TECOGAN_DEFER_FINALIZE=0)")
         a = {k: ([t[s0:s1] for t in v] if isinstance(v, list) else v[s0:s1]) for k, v in self.act.items()}
         g = {k: ([t[:n] for t in v] if isinstance(v, list) else v[:n]) for k, v in self.grad.items()}
         if dpre is not None:
