@@ -183,7 +183,16 @@ class TecoGANStep:
         # a CU mask is lost inside a forked graph)
         self.lanes = os.environ.get("TECOGAN_LANES", "1") != "0"
         # data-parallel mode: two gradient buckets per network, all-reduced where they become final (TecoGANStep._run_lanes)
-        self.buckets = self.lanes and process_group is not None and os.environ.get("TECOGAN_DP_BUCKETS", "1") != "0"
+        # Data-parallel collectives.  Default: ONE all-reduce per network issued as a SYNCHRONOUS call on the lane's own stream, behind
+        # the piece that completes the gradients (this torch build enqueues a synchronous RCCL collective on the current stream:
+        # no hand-over to the backend's internal stream and back).  One RCCL rank on one GPU: 4.318 ms/step vs 4.313 without a
+        # process group; the asynchronous forms pay two cross-stream event hops per collective: 4.58 ms with one per network,
+        # 4.64 with the two buckets per network of TECOGAN_DP_INLINE=0 (profiles/r03_q_dp_inline.log).  What the inline form
+        # gives up is overlap of the first bucket (~4 MB of 7 / 13 MB) with the rest of the backward pass - worth less than
+        # the hops as long as a bucket's all-reduce is shorter than ~0.3 ms.
+        self.dp_inline = process_group is not None and os.environ.get("TECOGAN_DP_INLINE", "1") != "0"
+        self.buckets = self.lanes and process_group is not None and os.environ.get("TECOGAN_DP_BUCKETS", "1") != "0" and \
+            not self.dp_inline
         # measured (tools/lane_matrix.sh, profiles/r02_b_lane_matrix.log): reserving CUs for the chain does not pay - the dense
         # lane loses more on 192 CUs than the chain gains - so the default is an unmasked lane B
         self.reserve = int(os.environ.get("TECOGAN_CU_RESERVE", "0")) if self.lanes else 0
@@ -496,7 +505,13 @@ class TecoGANStep:
 
     # ---------------------------------------------------------------------------------------------------------- schedule
     def _allreduce(self, buf):
-        if self.pg is not None and os.environ.get("TECOGAN_FORCE_COLLECTIVES", "0") == "1":
+        forced = self.pg is not None and os.environ.get("TECOGAN_FORCE_COLLECTIVES", "0") == "1"
+        if self.dp_inline and (forced or self.world > 1):
+            import torch.distributed as dist
+            if dist.get_backend(self.pg) != "gloo" or not buf.is_cuda:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)   # stream-ordered on the current (lane) stream
+                return None
+        if forced:
             import torch.distributed as dist  # test hook: exercise the collective's call path even with one rank
             return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         return parallel.allreduce_sum_async(buf, self.pg, self.world)

@@ -36,9 +36,10 @@ def _launch(script_args, port, env_extra, cwd, timeout=900):
 
 
 @pytest.mark.timeout(1200)
-def test_two_rank_step_equals_two_shards_with_local_bn_and_averaged_gradients(tmp_path):
+@pytest.mark.parametrize("mode", [{}, {"TECOGAN_DP_INLINE": "0"}], ids=["one-allreduce-per-network", "two-buckets-per-network"])
+def test_two_rank_step_equals_two_shards_with_local_bn_and_averaged_gradients(tmp_path, mode):
     out = tmp_path / "dp"
-    r = _launch([os.path.join(ROOT, "tests", "dp_worker.py"), str(out)], _free_port(), {}, ROOT)
+    r = _launch([os.path.join(ROOT, "tests", "dp_worker.py"), str(out)], _free_port(), dict(mode), ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     res = [json.load(open(f"{out}.{k}")) for k in range(2)]
     for x in res:

@@ -437,13 +437,16 @@ def test_bench_refuses_more_gpus_than_are_visible():
     assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in r.stderr, (r.returncode, r.stderr[-500:])
 
 
-def test_data_parallel_collectives_on_one_gpu(tmp_path):
-    """The 8-GPU run is the driver's; here the same code path (torch.distributed.run, RCCL process group, the two
-    asynchronous all-reduces issued between the per-lane graph replays - TecoGANStep._run_lanes) is exercised with ONE rank
-    (TECOGAN_FORCE_COLLECTIVES=1 issues them although world == 1) and must reproduce the single-process losses."""
+@pytest.mark.parametrize("mode,bound", [({}, 1.1), ({"TECOGAN_DP_INLINE": "0"}, 1.2)])
+def test_data_parallel_collectives_on_one_gpu(tmp_path, mode, bound):
+    """The 8-GPU run is the driver's; here the same code path (torch.distributed.run, RCCL process group, the all-reduces
+    issued between the per-lane graph replays - TecoGANStep._run_lanes) is exercised with ONE rank
+    (TECOGAN_FORCE_COLLECTIVES=1 issues them although world == 1) and must reproduce the single-process losses.  Default: one
+    synchronous all-reduce per network on its lane's stream (no measurable cost with one rank); TECOGAN_DP_INLINE=0: two
+    asynchronous gradient buckets per network on the backend's stream."""
     import json
     import subprocess
-    env = dict(os.environ, TECOGAN_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, TECOGAN_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **mode)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
            "--warmup", "2", "--no-cpu-baseline", "--no-roofline"]
@@ -458,7 +461,7 @@ def test_data_parallel_collectives_on_one_gpu(tmp_path):
     assert sp["pg_backend"] is None
     # the two lanes must still overlap beside RCCL's own streams (they shared one hardware queue with the runtime's default
     # of 4 queues: 7.1 vs 4.5 ms per step; pytorch-tecogan_amd/__init__.py).  4 collectives of 1 rank cost ~0.1 ms of host time
-    assert dp["ms_per_step"] < 1.2 * sp["ms_per_step"], (dp["ms_per_step"], sp["ms_per_step"])
+    assert dp["ms_per_step"] < bound * sp["ms_per_step"], (dp["ms_per_step"], sp["ms_per_step"])
     np.testing.assert_allclose(dp["final_losses"]["gen_loss"], sp["final_losses"]["gen_loss"], rtol=2e-3)
     np.testing.assert_allclose(dp["final_losses"]["d_loss"], sp["final_losses"]["d_loss"], rtol=5e-2, atol=2e-3)
 

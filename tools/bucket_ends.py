@@ -1,7 +1,7 @@
 """Data-parallel gradient buckets: WHEN is each bucket's all-reduce issued relative to the end of its backward pass?
 One rank on one GPU with the real RCCL process group (TECOGAN_FORCE_COLLECTIVES=1 issues the collectives although
 world == 1), the step replayed from its per-lane graphs with events behind every bucket piece.
-    TECOGAN_FORCE_COLLECTIVES=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 \
+    TECOGAN_DP_INLINE=0 TECOGAN_FORCE_COLLECTIVES=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 \
         --master-port 29577 tools/bucket_ends.py
 """
 import os
@@ -30,7 +30,7 @@ for s in range(3):
     TR.FRVSR_Train(x, y, args, D, G, s, 0., 0., og, od)
 torch.cuda.synchronize()
 st = next(iter(TR._STEPS.values()))
-assert st.buckets and st.graphs is not None, "needs TECOGAN_FORCE_COLLECTIVES=1 under torch.distributed.run"
+assert st.buckets and st.graphs is not None, "needs TECOGAN_DP_INLINE=0 TECOGAN_FORCE_COLLECTIVES=1 under torch.distributed.run"
 g = st.graphs
 names = ["start", "tail_end", "g_hr_end", "g_trunk_end", "d_hi_end", "d_lo_end", "g_ar1_done", "g_ar2_done", "d_ar1_done", "d_ar2_done",
          "step_end"]
