@@ -52,6 +52,26 @@ struct RwK {
 
 template <typename T> __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return Mma16<T>::run(a, b, c); }
 
+// The activation patch of the NEXT tile goes straight from global memory into the other LDS buffer (global_load_lds_dwordx4, as in
+// wgrad_group.hip): no staging registers (24 per thread at Cin = 128, where the wave's 144 weight registers already spill) and no
+// ds_write pass.  One wave-instruction fills 1 KiB = 16 rows of a chunk image; the swizzle moves to the per-lane SOURCE address,
+// patch positions outside the image (and the 6 pitch-padding rows per patch row) read a page of zeros.  -DRW_NO_DMA: the
+// register-staged path of round 2 (A/B builds).
+#ifndef RW_NO_DMA
+#define RW_DMA 1
+#else
+#define RW_DMA 0
+#endif
+__device__ __attribute__((aligned(16))) unsigned int tg_rw_zero_page[4];
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
 // LDS-only barrier: __syncthreads() would also wait for the epilogue's global stores and the next tile's patch loads
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -76,6 +96,9 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
 #define RW_EARLY (NCH == 2)
 #endif
   constexpr bool EARLY = RW_EARLY;
+  // DMA staging where the registers are short (Cin = 128: 21-59 spilled VGPRs -> 0-28, c32's input-gradient 112 -> 78 us);
+  // Cin = 64 keeps the register-staged patch (no spills there, and ~1 us per launch faster: tools/mb_rw.py)
+  constexpr bool kDma = RW_DMA && NCH == 4;
   static_assert(NCH == 2 || NCH == 4, "Cin = 64 or 128");
   constexpr int PT = NCH == 2 ? 2 : 4;          // output rows per wave in the k-loop
   constexpr int PF = 2;                         // output rows per wave in the epilogue (NCH = 4: half of PT after the exchange)
@@ -97,9 +120,22 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
 
   // ---- per-thread patch pieces: coordinates inside the patch are the same for every tile.  One packed word per piece
   // (py | px << 4 | (chunk*4 + piece) << 9 | LDS offset/16 << 13 | in-range << 25): registers are what this kernel is short of
-  unsigned pinfo[NLD];
+  constexpr int NDI = (NCH * (kChunkBytes / 1024) + 7) / 8;   // DMA wave-instructions per wave and tile (15 KiB per chunk image)
+  unsigned dinfo[kDma ? NDI : 1];  // instruction wid + 8 u: py | px << 4 | byte offset inside the pixel << 9 | valid << 25
+  if constexpr (kDma) {
 #pragma unroll
-  for (int u = 0; u < NLD; ++u) {
+    for (int u = 0; u < NDI; ++u) {
+      const int j = wid + 8 * u;                       // 1-KiB block j of the buffer: chunk j / 15, rows 16 (j % 15) + lane / 4
+      const int cc = j / (kChunkBytes / 1024), row = (j - cc * (kChunkBytes / 1024)) * 16 + (lane >> 2);
+      const int py = row / kPitch, px = row - py * kPitch;
+      const int piece = (lane & 3) ^ ((row >> 1) & 2);  // the logical piece this physical slot holds (swz is an involution)
+      const bool valid = j < NCH * (kChunkBytes / 1024) && px < kPW;
+      dinfo[u] = (unsigned)py | ((unsigned)px << 4) | ((unsigned)(cc * 64 + piece * 16) << 9) | ((valid ? 1u : 0u) << 25);
+    }
+  }
+  unsigned pinfo[kDma ? 1 : NLD];
+#pragma unroll
+  for (int u = 0; u < (kDma ? 0 : NLD); ++u) {
     const int i = tid + u * 512;
     const bool in_range = i < NCH * kPH * kPW * 4;
     const int ic = in_range ? i : NCH * kPH * kPW * 4 - 1;
@@ -110,8 +146,10 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
     pinfo[u] = (unsigned)py | ((unsigned)px << 4) | ((unsigned)(cc * 4 + s) << 9) | ((unsigned)(dst >> 4) << 13) |
                ((in_range ? 1u : 0u) << 25);
   }
-  u32x4 va[NLD];
+  u32x4 va[kDma ? 1 : NLD];
   unsigned vok = 0;  // bit u: piece u of the patch in flight lies inside the image
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int wid_u = wid;
   auto decode = [&](int t, int& n, int& ty0, int& tx0) {
     const int txb = t % p.tiles_x;
     t /= p.tiles_x;
@@ -122,13 +160,29 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
   };
   // loads are unconditional from a clamped address and zeroed at the LDS store: a load under a divergent `if` makes the
   // compiler wait for each one before it issues the next
+  // DMA form: the whole patch of tile t into buffer `buf` (asynchronous: s_waitcnt vmcnt(0) + barrier before it is read)
+  auto dma_patch = [&](int t, int buf) {
+    int n, ty0, tx0;
+    decode(t, n, ty0, tx0);
+    const char* in_n = p.in + (size_t)n * p.H * p.W * pix_bytes;
+    const char* zero = reinterpret_cast<const char*>(tg_rw_zero_page);
+#pragma unroll
+    for (int u = 0; u < NDI; ++u) {
+      if (wid_u + 8 * u < NCH * (kChunkBytes / 1024)) {  // wave-uniform
+        const int iy = ty0 - 1 + (int)(dinfo[u] & 15u), ix = tx0 - 1 + (int)((dinfo[u] >> 4) & 31u);
+        const bool ok = (dinfo[u] >> 25) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const char* src = in_n + ((long long)iy * p.W + ix) * (long long)pix_bytes + ((dinfo[u] >> 9) & 0xffffu);
+        glds16(ok ? src : zero, lds0 + buf * kBufBytes + (wid_u + 8 * u) * 1024);
+      }
+    }
+  };
   auto issue_patch = [&](int t) {
     int n, ty0, tx0;
     decode(t, n, ty0, tx0);
     const char* in_n = p.in + (size_t)n * p.H * p.W * pix_bytes;
     vok = 0;
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
+    for (int u = 0; u < (kDma ? 0 : NLD); ++u) {
       const int iy = ty0 - 1 + (int)(pinfo[u] & 15u), ix = tx0 - 1 + (int)((pinfo[u] >> 4) & 31u);
       vok |= (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? (1u << u) : 0u;
       const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
@@ -138,13 +192,17 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
   auto store_patch = [&](int buf) {
     char* dst = smem + buf * kBufBytes;
 #pragma unroll
-    for (int u = 0; u < NLD; ++u)
+    for (int u = 0; u < (kDma ? 0 : NLD); ++u)
       if (pinfo[u] >> 25)
         *reinterpret_cast<u32x4*>(dst + ((pinfo[u] >> 13) & 4095u) * 16) = ((vok >> u) & 1u) ? va[u] : u32x4{0u, 0u, 0u, 0u};
   };
 
   int tile = blockIdx.x;
-  if (tile < p.ntiles) issue_patch(tile);
+  if constexpr (kDma) {
+    if (tile < p.ntiles) dma_patch(tile, 0);
+  } else {
+    if (tile < p.ntiles) issue_patch(tile);
+  }
 
   // ---- the wave's weights: A-fragments of packed rows 32*wc + 16*a + idx for 9 taps x 2 chunks, in k-loop order.
   // Packed image [tap][chunk][Cout rows][64 B]; the input-gradient launch pairs spatial offset `so` with slot 8 - so.
@@ -231,14 +289,19 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
     }
   };
 
-  if (tile < p.ntiles) store_patch(0);
+  if constexpr (kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first patch (and the weights) have landed
+  else if (tile < p.ntiles) store_patch(0);
   lds_barrier();
 
   for (int buf = 0; tile < p.ntiles; tile += gridDim.x, buf ^= 1) {
     const int next = tile + gridDim.x;
     int n, ty0, tx0;
     decode(tile, n, ty0, tx0);
-    if (next < p.ntiles) issue_patch(next);  // in flight during this tile's MFMAs
+    if constexpr (kDma) {
+      if (next < p.ntiles) dma_patch(next, buf ^ 1);  // lands in the other buffer during this tile's MFMAs
+    } else {
+      if (next < p.ntiles) issue_patch(next);  // in flight during this tile's MFMAs
+    }
     // the epilogue's mask rows (a launch without a mask: its residual rows) of the two output rows this wave finalises
     const int frow0 = NCH == 4 ? r0 + 2 * kh : r0;
     const char* pre_src = p.mask_mode != TG_MASK_NONE ? p.mask : p.res;
@@ -274,6 +337,9 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
       }
     }
 
+    // DMA form: the next tile's pieces of this wave have landed by now (issued a whole k-loop ago); behind this point the only
+    // vector-memory operations in flight are the epilogue's own, so the barrier at the end of the tile publishes the buffer
+    if constexpr (kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- NCH = 4: the two K halves add their accumulators; each wave finalises two of the pair's four rows
     f32x4 fin[2][PF];
     if constexpr (NCH == 4) {
@@ -355,7 +421,9 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
       }
     }
 
-    if (next < p.ntiles) store_patch(buf ^ 1);
+    if constexpr (!kDma) {
+      if (next < p.ntiles) store_patch(buf ^ 1);
+    }
     lds_barrier();  // the other buffer is complete; everyone has finished reading this one (and the exchange slots)
   }
   if constexpr (STATS) {

@@ -198,8 +198,8 @@ def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False):
     npix = N * H * W
     if cin_p == 64:
         return npix >= 131072
-    if masked and npix >= 131072:  # Cin = 128 has no registers for the early mask fetch: tg_conv's epilogue (all mask vectors in
-        return False               # one round trip) wins on c32's input-gradient, 88 vs 99 us
+    if masked and npix >= 131072 and os.environ.get("TECOGAN_RW_MASKED128", "0") != "1":
+        return False  # Cin = 128 has no registers for the early mask fetch: tg_conv's epilogue (all mask vectors in one round trip)
     return cout_p == 128 and (npix >= 131072 or (H == 32 and W == 32 and npix >= 8192))
 
 
