@@ -279,24 +279,24 @@ def persist_wgs(net):
 
 def persist_wgs_g_for(lr_pixels):
     """the generator's cap for a training step whose recurrent pass has `lr_pixels` = B * h * w pixels per launch, or None when
-    the environment fixes it.  Up to 4096 pixels (configs[1]: 4 x 32 x 32) the chain's launches fill half the chip or less and the
-    step is bound by lane B beside the G backward: 144 (round 3, after the output layer's backward became one streaming launch and
-    lane A ~70 us shorter: G = 120/136/144/152/160 -> 4.39 4.33 4.33 4.36 4.38 ms).  The configs[3] shard (2 x 64 x 64) keeps 160:
-    10.34 vs 10.47 ms (profiles/r03_o_rgb_bwd_ab.log)."""
+    the environment fixes it.  History (profiles/r03_o_rgb_bwd_ab.log, r03_r_rw_dma_ab.log): with the one-pass output-layer backward
+    lane A became ~70 us shorter and 144 was best for configs[1] (G = 120/136/144/152/160 -> 4.39 4.33 4.33 4.36 4.38 ms); once the
+    register-weights kernel stopped spilling, lane B got shorter too and the optimum moved back: 136/144/152/160 -> 4.277 4.264 4.249
+    4.24 ms.  The configs[3] shard always preferred 160 (10.34 vs 10.47 ms)."""
     if "TECOGAN_PERSIST_WGS" in os.environ or "TECOGAN_PERSIST_WGS_G" in os.environ:
         return None
-    return min(PERSIST_WGS, 144) if lr_pixels <= 4096 else PERSIST_WGS
+    return PERSIST_WGS
 
 
 def persist_wgs_dreal_for(lr_pixels):
     """cap of the discriminator's persistent launches in its REAL half for a step of `lr_pixels` (see persist_wgs_g_for), or None.
-    The real half runs beside the latency-bound chain and lane B then waits ~0.4 ms for the chain's last frame: with 80 instead of
-    96 workgroups it gives the chain more of the chip and still ends before the chain does - 4.36 -> 4.32 ms/step (64 / 72 / 80
-    equal, 48: 4.51: the real half becomes the long pole); the configs[3] shard is not chain-bound: no gain there
-    (profiles/r03_o_rgb_bwd_ab.log)."""
+    The real half runs beside the latency-bound chain and lane B then waits ~0.4 ms for the chain's last frame: with fewer
+    workgroups than the fake half's 96 it loads the memory system less while the chain runs and still ends before the chain does -
+    96 -> 80: 4.36 -> 4.32 ms/step; after the register-weights change 80 / 72 / 64 = 4.238 4.226 4.218 (48: +0.18 ms, the real half
+    becomes the long pole; 72 keeps a margin).  The configs[3] shard is not chain-bound: no gain there."""
     if any(k in os.environ for k in ("TECOGAN_PERSIST_WGS", "TECOGAN_PERSIST_WGS_D", "TECOGAN_PERSIST_WGS_DREAL")):
         return None
-    return 80 if lr_pixels <= 4096 else None
+    return 72 if lr_pixels <= 4096 else None
 
 
 def wgrad_plan(N, YH, YW, S, ntaps, cx_p, cy_p, cap=None):
