@@ -26,6 +26,7 @@ def tg_dtype(dt):
 
 
 _RW = os.environ.get("TECOGAN_RW", "1")  # 0: never, 1: where it measured faster (rw_eligible), all: every shape it takes
+_RW_EXTRA = os.environ.get("TECOGAN_RW_EXTRA", "trunk,c30,m128")  # launch classes routed there for the STEP's sake (rw_eligible)
 
 
 def _stream():
@@ -190,15 +191,27 @@ def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False):
     Measured against tg_conv on the step's dense shapes (tools/mb_rw.py, profiles/r02_c_mb_rw.log):
       64 -> 64  @64x64   N=40  32.7 -> 20.0 us      64 -> 128 @128x128 N=40  154 -> 106 us     128 -> 128 @64x64 N=40 78.5 -> 74.1
       128 -> 128 @32x32  N=12  14.9 -> 11.9 us
-    and slower on the rest (128 -> 64, the 32x32 trunk at N=40, every N=4 launch of the recurrent pass, 16x16 images)."""
+    and slower ALONE on the rest.  In the step, though, a capped persistent launch is the better neighbour for the other lane than a
+    grid of thousands of short workgroups, and since the Cin = 128 instantiations stopped spilling (round 3) three more classes pay
+    there although tg_conv wins or ties alone (TECOGAN_RW_EXTRA, profiles/r03_r_rw_dma_ab.log): the trunk's input-gradients at 40 x
+    32 x 32 (4.23 -> 4.205 ms/step), 128 -> 64 input-gradients (c30: -> 4.204) and masked 128 -> 128 ones (c32, with both: 4.195);
+    the discriminator's stage 1 (64 -> 64 @64x64 N=12: 4.30) and stage 3 (16 x 16: 4.32) stay on tg_conv."""
     if _RW == "0" or dtype_t not in (torch.bfloat16, torch.float16) or cin_p not in (64, 128) or cout_p % 64:
         return False
     if _RW == "all":
         return N * H * W >= 8192
     npix = N * H * W
+    if "trunk" in _RW_EXTRA and cin_p == 64 and H == 32 and W == 32 and npix >= 32768:
+        return True
+    if "c30" in _RW_EXTRA and cin_p == 128 and cout_p == 64 and npix >= 131072:
+        return True
+    if "s1" in _RW_EXTRA and cin_p == 64 and H >= 64 and npix >= 32768:         # (A/B only: slower)
+        return True
+    if "s3" in _RW_EXTRA and cin_p == 128 and cout_p == 128 and H == 16 and npix >= 2048:   # (A/B only: slower)
+        return True
     if cin_p == 64:
         return npix >= 131072
-    if masked and npix >= 131072 and os.environ.get("TECOGAN_RW_MASKED128", "0") != "1":
+    if masked and npix >= 131072 and "m128" not in _RW_EXTRA:
         return False  # Cin = 128 has no registers for the early mask fetch: tg_conv's epilogue (all mask vectors in one round trip)
     return cout_p == 128 and (npix >= 131072 or (H == 32 and W == 32 and npix >= 8192))
 
