@@ -145,6 +145,7 @@ class Conv:
         self.persist_wgs = K.PERSIST_WGS  # workgroups of this layer's persistent launches (the engines set their network's cap)
         self.persist_rw = 0               # ... of its register-weights conv launches, when different (0: the same)
         self.rw_off = False               # route this conv's launches past the register-weights kernel (A/B knob of the D halves)
+        self.rw_extra = ""                # more launch classes of kernels.rw_eligible for this conv (set per D half)
 
     def repack(self):
         s = self.spec
@@ -180,7 +181,7 @@ class Conv:
             K.conv3x3_rgb(x, self.wf, self.bias, nchw[0], nchw[1], nchw[2], nchw[3], act)
             return
         if self.spec.kind == "c3" and nchw is None and self.tile == L.TILE_AUTO and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) \
-                and not self.rw_off and K.rw_eligible(self.dt, self.cin_p, self.cout_p, N, H, W):
+                and not self.rw_off and K.rw_eligible(self.dt, self.cin_p, self.cout_p, N, H, W, extra=self.rw_extra):
             self.last_desc, self.last_rw_nch = "rw", self.cin_p // 32  # persistent register-weights kernel (csrc/conv3_rw.hip)
             K.conv3x3_rw(x, self.wf, out, False, bias=self.bias, res=res, act=act, stats=stats, stats_mode=2, groups=groups,
                          stats_replicas=stats_r, max_workgroups=self.persist_rw or self.persist_wgs)
@@ -250,7 +251,8 @@ class Conv:
             return
         st = bias_grad_of.gbias if bias_grad_of is not None else None
         if self.spec.kind == "c3" and self.tile == L.TILE_AUTO and \
-                not self.rw_off and K.rw_eligible(self.dt, self.cout_p, self.cin_p, N, H, W, masked=mask is not None):
+                not self.rw_off and K.rw_eligible(self.dt, self.cout_p, self.cin_p, N, H, W, masked=mask is not None,
+                                                  extra=self.rw_extra):
             self.last_desc, self.last_rw_nch = "rw", self.cout_p // 32  # the input-gradient of a 3x3 conv is the same conv with mirrored taps
             K.conv3x3_rw(dout, self.wb, out, True, res=res, mask=mask, mask_mode=mask_mode, stats=st, stats_mode=1,
                          max_workgroups=self.persist_rw or self.persist_wgs)
@@ -1203,12 +1205,18 @@ class DiscriminatorEngine:
         self.cap = {None: K.persist_wgs("D"), 1: K.persist_wgs("D"),
                     0: int(os.environ.get("TECOGAN_PERSIST_WGS_DREAL", K.persist_wgs("D")))}
 
+    # launch classes of kernels.rw_eligible added for the REAL half only (TecoGANStep sets "s1" for chain-bound steps: the real
+    # half runs beside the chain with slack, and its stage-1 convs are better neighbours as capped persistent launches: 4.194 ->
+    # 4.18 ms/step; for the fake half - on the critical path - the same routing costs 0.07 ms)
+    rw_extra_real = os.environ.get("TECOGAN_RW_EXTRA_DREAL", "")
+
     def _set_cap(self, half):
         cap = self.cap[half]
         off = os.environ.get("TECOGAN_RW_DHALF_OFF", "")   # "1": the fake half's convs on tg_conv, "0": the real half's, "01": both
         for c in self.convs:
             c.persist_wgs = cap
             c.rw_off = half is not None and str(half) in off
+            c.rw_extra = self.rw_extra_real if half == 0 else ""
         if isinstance(self.res_group, WgradList):
             self.res_group.cap = cap
 

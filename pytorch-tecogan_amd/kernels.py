@@ -26,7 +26,7 @@ def tg_dtype(dt):
 
 
 _RW = os.environ.get("TECOGAN_RW", "1")  # 0: never, 1: where it measured faster (rw_eligible), all: every shape it takes
-_RW_EXTRA = os.environ.get("TECOGAN_RW_EXTRA", "trunk,c30,m128")  # launch classes routed there for the STEP's sake (rw_eligible)
+_RW_EXTRA_ENV = os.environ.get("TECOGAN_RW_EXTRA", "trunk,c30,m128")  # launch classes routed there for the STEP's sake (rw_eligible)
 
 
 def _stream():
@@ -186,7 +186,7 @@ def conv3x3_rw(x, w_packed, out, flip=False, bias=None, res=None, mask=None, mas
                                    max_workgroups or PERSIST_WGS, _stream()), "tg_conv3x3_rw")
 
 
-def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False):
+def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False, extra=""):
     """launch shapes routed to the persistent register-weights 3x3 kernel (csrc/conv3_rw.hip).  cin_p = reduction channels.
     Measured against tg_conv on the step's dense shapes (tools/mb_rw.py, profiles/r02_c_mb_rw.log):
       64 -> 64  @64x64   N=40  32.7 -> 20.0 us      64 -> 128 @128x128 N=40  154 -> 106 us     128 -> 128 @64x64 N=40 78.5 -> 74.1
@@ -201,6 +201,7 @@ def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False):
     if _RW == "all":
         return N * H * W >= 8192
     npix = N * H * W
+    _RW_EXTRA = _RW_EXTRA_ENV + "," + extra if extra else _RW_EXTRA_ENV
     if "trunk" in _RW_EXTRA and cin_p == 64 and H == 32 and W == 32 and npix >= 32768:
         return True
     if "c30" in _RW_EXTRA and cin_p == 128 and cout_p == 64 and npix >= 131072:

@@ -172,6 +172,8 @@ class TecoGANStep:
             G.set_cap(cap_g)
         if cap_dr is not None:
             D.cap[0] = cap_dr
+            if "TECOGAN_RW_EXTRA_DREAL" not in os.environ:
+                D.rw_extra_real = "s1"
         G.sets.pin((T * B, h, h))
         G.alloc(T * B, h, h)
         G._alloc_grad()
