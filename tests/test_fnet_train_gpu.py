@@ -230,6 +230,10 @@ def test_main_py_trains_the_estimator_and_resumes_from_fnet_pt(tmp_path, monkeyp
     hip_train._STEPS.clear()
     common = ["--synthetic", "8", "--max_epochs", "1", "--tg_dtype", "bf16", "--num_resblock", "2", "--discrim_resblocks", "1",
               "--tg_fnet", "true", "--tg_fnet_train", "true"]
+    # main.py draws its initial weights and synthetic frames from the global generators: seeded here, because an unlucky estimator
+    # can send every sample of the warp outside the image - zero gradient, Adam update 0 / (0 + eps), weights legitimately unchanged
+    torch.manual_seed(int(os.environ.get('TG_TEST_SEED', '1234')))
+    np.random.seed(1234)
     tg_main.main(common)
     f_ck = torch.load(tmp_path / "fnet.pt")
     assert set(f_ck) == {"model_state_dict", "optimizer_state_dict"}
@@ -237,11 +241,14 @@ def test_main_py_trains_the_estimator_and_resumes_from_fnet_pt(tmp_path, monkeyp
     assert len(f_ck["optimizer_state_dict"]["state"]) == 36 and float(f_ck["optimizer_state_dict"]["state"][0]["step"]) == 2.0
     w1 = f_ck["model_state_dict"]["up1.2.weight"].clone()
     hip_train._STEPS.clear()
+    torch.manual_seed(4321)
+    np.random.seed(4321)
     tg_main.main(["--synthetic", "4", "--max_epochs", "1", "--tg_dtype", "bf16", "--num_resblock", "2", "--discrim_resblocks", "1",
                   "--tg_fnet", "true", "--tg_fnet_train", "true", "--pre_trained_model", "true", "--g_checkpoint",
                   str(tmp_path / "generator.pt"), "--d_checkpoint", str(tmp_path / "discrim.pt"), "--f_checkpoint",
                   str(tmp_path / "fnet.pt")])
     f2 = torch.load(tmp_path / "fnet.pt")
     assert float(f2["optimizer_state_dict"]["state"][0]["step"]) == 3.0
-    assert not torch.equal(f2["model_state_dict"]["up1.2.weight"], w1)
+    changed = [k for k, v in f2["model_state_dict"].items() if not torch.equal(v, f_ck["model_state_dict"][k])]
+    assert "up1.2.weight" in changed and len(changed) == len(f2["model_state_dict"]), changed
     hip_train._STEPS.clear()
