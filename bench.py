@@ -187,6 +187,7 @@ def roofline_pass(st, dtype):
     rb_fl = lambda x, *a, **k: 2 * 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * 9 * x.shape[3] * x.shape[3]  # noqa: E731
     wrap(K, "resblock_fwd", lambda *a, **k: "resblock_kernel<false>", rb_fl, "mfma")
     wrap(K, "resblock_bwd", lambda *a, **k: "resblock_kernel<true>", rb_fl, "mfma")
+    wrap(K, "resblock2_fwd", lambda *a, **k: f"resblock2_kernel<{T16}>", lambda x, *a, **k: 2 * rb_fl(x), "mfma")  # two blocks
     def time_group(cls, label):
         orig_group = cls.launch
         saved.append((cls, "launch", orig_group))

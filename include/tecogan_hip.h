@@ -255,6 +255,15 @@ int tg_resblock_fwd(int dtype, const void* in, const void* w1_packed, const floa
                     void* out_a, int N, int H, int W, int C, int add_skip, const void* next_w1_packed,
                     const void* next_w2_packed, void* stream);
 
+/* TWO consecutive residual blocks in ONE launch (8 x 4 output tiles, halo recomputed: h1 on 14 x 10, a1 on 12 x 8, h2 on 10 x 6
+ * pixels from a 16 x 12 patch): out_h1 = relu(conv(in, w1a) + b1a), out_a1 = in + conv(out_h1, w2a), out_h2 = relu(conv(out_a1, w1b)
+ * + b1b), out_a2 = out_a1 + conv(out_h2, w2b) - bit-identical to two tg_resblock_fwd launches, one launch boundary and one
+ * patch round trip fewer on the recurrent pass's serial chain.  next_w4: host array of the NEXT launch's four packed weight
+ * images (L2 prefetch hint) or null.  Same dtype / channel limits as tg_resblock_fwd. */
+int tg_resblock2_fwd(int dtype, const void* in, const void* w1a_packed, const float* b1a, const void* w2a_packed,
+                     const void* w1b_packed, const float* b1b, const void* w2b_packed, void* out_h1, void* out_a1, void* out_h2,
+                     void* out_a2, int N, int H, int W, int C, const void* const* next_w4, void* stream);
+
 /* Input-gradient of the same block in ONE launch (aten::convolution_backward x2 + threshold_backward, code/train.py:336):
  * out_dh = (h > 0) * conv3x3^T(dout, w2), out_din = dout + conv3x3^T(out_dh, w1); w*_dgrad_packed are the role-swapped
  * ("dgrad") packings of tg_pack_conv_weights; h is the forward pass's out_h.  out_dh is the Y operand of the first conv's

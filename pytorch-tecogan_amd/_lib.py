@@ -66,6 +66,7 @@ _PROTOS = {
     "tg_nchw_to_nhwc": (_I, [_I, _P, _L, _P, _I, _I, _I, _I, _I, _P]),
     "tg_nhwc_to_nchw": (_I, [_I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "tg_resblock_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "tg_resblock2_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "tg_conv3x3_rgb": (_I, [_I, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "tg_conv3x3_rgb_bwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "tg_conv3x3_rgb_bwd_slot_floats": (_L, []),

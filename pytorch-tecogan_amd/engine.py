@@ -518,6 +518,11 @@ def _defer_finalize():
 
 
 _FOLD_ITEMS = os.environ.get("TECOGAN_FOLD_ITEMS", "1") != "0"
+# Two residual blocks per launch on the recurrent pass (csrc/resblock2.hip: halo recomputed, no cross-workgroup traffic, results
+# bit-identical): built, tested and measured SLOWER - 21 MFMA pixel tiles instead of 2 x 6 put 1.75x the matrix and LDS work on
+# the workgroup's serial path, which costs more than the launch boundary and patch round trip it saves: a generator pass 0.200 ->
+# 0.219 ms alone, the chain 1.56 -> 1.71 ms, the step 4.20 -> 4.34 ms (profiles/r03_t_resblock2_ab.log).  Off by default.
+_RB_PAIR = os.environ.get("TECOGAN_RB_PAIR", "0") == "1"
 # Batch-norm backward sums in the epilogue of the input-gradient launch that produces dy (9 of the 17 BN layers per pass):
 # built, parity-tested (tests/test_kernels_gpu.py::test_bn_backward_sums_in_the_dgrad_epilogue) and measured SLOWER in the step
 # - 18 tg_bn_bwd_reduce launches fewer, but the sums need the general conv epilogue (the plain launch takes the slim one) and
@@ -771,7 +776,21 @@ class GeneratorEngine:
         a = self.act
         sl = slice(s0, s0 + B)
         self.conv0.fwd(a["in0"][sl], a["a"][0][sl], act=L.ACT_RELU)
+        # small launches (the recurrent pass: <= 128 tiles of 8 x 8): TWO blocks per launch, halo recomputed (csrc/resblock2.hip)
+        pair = self.fused_rb and _RB_PAIR and B * ((a["in0"].shape[1] + 7) // 8) * ((a["in0"].shape[2] + 7) // 8) <= 128
+        skip_next = False
         for i, (c1, c2) in enumerate(self.rb):
+            if skip_next:
+                skip_next = False
+                continue
+            if pair and i + 1 < self.nrb:
+                c3, c4 = self.rb[i + 1]
+                nxt = (self.rb[i + 2][0].wf, self.rb[i + 2][1].wf, self.rb[i + 3][0].wf, self.rb[i + 3][1].wf) \
+                    if i + 3 < self.nrb else None
+                K.resblock2_fwd(a["a"][i][sl], c1.wf, c1.bias, c2.wf, c3.wf, c3.bias, c4.wf, a["h"][i][sl], a["a"][i + 1][sl],
+                                a["h"][i + 1][sl], a["a"][i + 2][sl], next_w=nxt)
+                skip_next = True
+                continue
             if self.fused_rb:  # conv-relu-conv-skip in one launch (csrc/resblock.hip)
                 nxt = (self.rb[i + 1][0].wf, self.rb[i + 1][1].wf) if i + 1 < self.nrb else None
                 K.resblock_fwd(a["a"][i][sl], c1.wf, c1.bias, c2.wf, a["h"][i][sl], a["a"][i + 1][sl], next_w=nxt)

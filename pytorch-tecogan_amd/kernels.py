@@ -414,6 +414,18 @@ def convt_fwd(x, w_packed, bias, out, act=L.ACT_NONE):
                                   out.shape[3], act, _stream()), "tg_convt_fwd")
 
 
+def resblock2_fwd(x, w1a, b1a, w2a, w1b, b1b, w2b, out_h1, out_a1, out_h2, out_a2, next_w=None):
+    """two consecutive residual blocks in one launch (csrc/resblock2.hip); next_w: the four packed weight images of the next
+    launch (L2 prefetch hint) or None"""
+    N, H, W, C_ = x.shape
+    nxt = None
+    if next_w is not None:
+        nxt = (C.c_void_p * 4)(*[t.data_ptr() for t in next_w])
+    L.check(L.load().tg_resblock2_fwd(tg_dtype(x.dtype), _ptr(x), _ptr(w1a), _ptr(b1a), _ptr(w2a), _ptr(w1b), _ptr(b1b), _ptr(w2b),
+                                      _ptr(out_h1), _ptr(out_a1), _ptr(out_h2), _ptr(out_a2), N, H, W, C_, nxt, _stream()),
+            "tg_resblock2_fwd")
+
+
 def resblock_bwd(dout, w2b, h, w1b, out_dh, out_din, next_w=None):
     """input-gradient of conv-relu-conv-skip in one launch; w*b = dgrad packings, h = saved forward activation"""
     N, H, W, C_ = dout.shape

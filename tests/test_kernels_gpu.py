@@ -1037,6 +1037,39 @@ def test_fused_resblock_backward(N, H, W):
     torch.testing.assert_close(K.to_nchw(da_f, 64).cpu(), da, **tol(dt))
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W", [(4, 32, 32), (1, 20, 12), (2, 8, 8), (1, 5, 37), (3, 3, 3)])
+def test_two_resblocks_per_launch_bit_identical(N, H, W, dt):
+    """tg_resblock2_fwd (two residual blocks per launch, halo recomputed on 14x10 / 12x8 / 10x6 pixel regions) writes exactly the
+    four tensors two tg_resblock_fwd launches write - images smaller than the halo, ragged tiles, both 16-bit types, with and
+    without the L2 prefetch hint."""
+    spec = K.ConvSpec("c3", 64, 64)
+    x = q(rnd((N, 64, H, W), 180), dt)
+    ws = [rnd(spec.weight_shape, 181 + i, -0.05, 0.05) for i in range(4)]
+    b1a, b1b = rnd((64,), 186, -0.1, 0.1).to(DEV), rnd((64,), 187, -0.1, 0.1).to(DEV)
+    xd = K.to_nhwc(x.to(DEV), dt)
+    rows, Kd, s_row, s_k = spec.fwd_pack()
+    slots = K.slot_table(9, DEV)
+    wp = [K.pack_weights(dt, w.to(DEV), rows, Kd, s_row, s_k, 9, slots) for w in ws]
+    mk = lambda: torch.full((N, H, W, 64), float("nan"), dtype=dt, device=DEV)  # noqa: E731
+    h1, a1, h2, a2 = mk(), mk(), mk(), mk()
+    K.resblock_fwd(xd, wp[0], b1a, wp[1], h1, a1)
+    K.resblock_fwd(a1, wp[2], b1b, wp[3], h2, a2)
+    g = [mk() for _ in range(4)]
+    K.resblock2_fwd(xd, wp[0], b1a, wp[1], wp[2], b1b, wp[3], *g)
+    torch.cuda.synchronize()
+    for name, got, ref in zip(("h1", "a1", "h2", "a2"), g, (h1, a1, h2, a2)):
+        assert not torch.isnan(got.float()).any(), name
+        assert torch.equal(got, ref), (name, float((got.float() - ref.float()).abs().max()))
+    g2 = [mk() for _ in range(4)]
+    K.resblock2_fwd(xd, wp[0], b1a, wp[1], wp[2], b1b, wp[3], *g2, next_w=(wp[2], wp[3], wp[0], wp[1]))
+    torch.cuda.synchronize()
+    assert all(torch.equal(u, v) for u, v in zip(g2, g))
+    assert L.load().tg_resblock2_fwd(L.TG_F32, xd.data_ptr(), wp[0].data_ptr(), b1a.data_ptr(), wp[1].data_ptr(), wp[2].data_ptr(),
+                                     b1b.data_ptr(), wp[3].data_ptr(), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
+                                     g[3].data_ptr(), N, H, W, 64, None, None) == -2
+
+
 def _random_conv_cases(n, seed):
     rng = np.random.default_rng(seed)
     cases = []
