@@ -644,7 +644,13 @@ class TecoGANStep:
         if self.lanes:
             fns = self._piece_fns()
             names = (self.PIECES_DP if self.buckets else self.PIECES) + (("fnet_bwd", "update_f") if self.F_train else ())
-            lane = lambda k: self.sBm if k in ("prep", "d_real", "fnet_bwd", "update_f") else (self.sB if k in self.LANE_B else None)  # noqa: E731
+            # Lane B's pieces are captured on torch's own capture stream, not on lane B's stream (only a CU-masked lane stream is
+            # captured on itself): the default data-parallel mode records RCCL work events on the lane streams, the backend's
+            # watchdog thread polls them, and hipEventQuery on an event whose stream is capturing aborts the process
+            # (hipErrorCapturedEvent - 1 run in 10 of the one-rank RCCL test before this).  Replay picks the lane's stream.
+            masked = self.sBm is not self.sB
+            lane = lambda k: (self.sBm if k in ("prep", "d_real", "fnet_bwd", "update_f") else (self.sB if k in self.LANE_B else None)) \
+                if masked else None  # noqa: E731
             self.graphs = {k: cap(fns[k], lane(k)) for k in names}
         else:
             self.graphs = (cap(self._fork_join), cap(self._update_all))

@@ -143,11 +143,13 @@ def test_step_b2_fixture_of_the_reference_on_gpu(golden_dir, monkeypatch):
         close(sdG["output.weight"], gold[p + "post_output_weight"])
         close(sdD["fc.weight"], gold[p + "post_fc_weight"])
         close(sdD["block5.0.weight"], gold[p + "post_block5_weight"])
+        # (step 1 is free-running: a running mean near zero - 4e-4 among entries of 1e-2 ... 6e-2 - moves by 1.3e-5 when the real
+        # half's weight-gradient slabs are summed in another order; the absolute floor follows the weights' `at` above)
         for bn in ("block1.1", "resids3.3.1"):
             np.testing.assert_allclose(sdD[bn + ".running_mean"].cpu().numpy(), gold[p + bn + ".running_mean"], rtol=tol,
-                                       atol=1e-5)
+                                       atol=1e-5 if s == 0 else 5e-5)
             np.testing.assert_allclose(sdD[bn + ".running_var"].cpu().numpy(), gold[p + bn + ".running_var"], rtol=tol,
-                                       atol=1e-5)
+                                       atol=1e-5 if s == 0 else 5e-5)
             assert int(sdD[bn + ".num_batches_tracked"]) == int(gold[p + bn + ".nbt"]) == 2 * (s + 1)
         if s == 0:
             np.testing.assert_allclose(dict(G.named_parameters())["output.weight"].grad.cpu().numpy(),

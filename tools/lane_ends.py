@@ -76,8 +76,14 @@ for rep in range(R + 2):
         run("update_d", sB, g["update_d"])
         st.ev["d"].record(sB)
     run("g_bwd", main, g["g_bwd"])
-    main.wait_event(st.ev["d"])
-    run("update", main, g["update"])
+    if st.scaler is None:   # as TecoGANStep._run_lanes: G's Adam + repack beside lane B's tail, then the caller's stream joins lane B
+        run("update", main, g["update"])
+        main.wait_event(st.ev["d"])
+    else:
+        main.wait_event(st.ev["d"])
+        run("update", main, g["update"])
+    ev["end"] = torch.cuda.Event(enable_timing=True)
+    ev["end"].record(main)
     evs.append(ev)
 torch.cuda.synchronize()
 iv = {}
@@ -86,7 +92,7 @@ for k in A_PIECES + B_PIECES:
     b = sum(e["start"].elapsed_time(e[k][1]) for e in evs[2:]) / R
     iv[k] = (a, b)
     print(f"{k:12s} {a:7.3f} -> {b:7.3f} ms  ({b - a:6.3f})")
-step = iv["update"][1]
+step = sum(e["start"].elapsed_time(e["end"]) for e in evs[2:]) / R   # the caller's stream has joined lane B
 
 
 def overlap(x, y):
