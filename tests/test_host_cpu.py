@@ -434,6 +434,56 @@ def test_wgrad_work_list_plan_covers_every_unit_once_and_slots_are_disjoint():
     assert units == 2 * 8 and [(f[1], f[2]) for f in fold] == [(0, 0), (0, 64)]
 
 
+def test_step_aware_caps_and_register_weights_routing(monkeypatch):
+    """host rules added in round 3: the discriminator's real half runs at 72 persistent workgroups for chain-bound steps (<= 4096 LR
+    pixels per pass) unless the environment fixes a cap; the register-weights kernel takes the trunk / c30 / masked-c32
+    input-gradients of the batched G backward (TECOGAN_RW_EXTRA), the discriminator's stage 1 only where asked per conv"""
+    import importlib
+    import torch
+    from pytorch_tecogan_amd import kernels as K
+    for k in ("TECOGAN_PERSIST_WGS", "TECOGAN_PERSIST_WGS_G", "TECOGAN_PERSIST_WGS_D", "TECOGAN_PERSIST_WGS_DREAL", "TECOGAN_RW_EXTRA",
+              "TECOGAN_RW"):
+        monkeypatch.delenv(k, raising=False)
+    K = importlib.reload(K)
+    assert K.persist_wgs_g_for(4 * 32 * 32) == 160 and K.persist_wgs_g_for(2 * 64 * 64) == 160
+    assert K.persist_wgs_dreal_for(4 * 32 * 32) == 72 and K.persist_wgs_dreal_for(2 * 64 * 64) is None
+    monkeypatch.setenv("TECOGAN_PERSIST_WGS_DREAL", "96")
+    assert K.persist_wgs_dreal_for(4096) is None
+    monkeypatch.delenv("TECOGAN_PERSIST_WGS_DREAL")
+    monkeypatch.setenv("TECOGAN_PERSIST_WGS_G", "128")
+    assert K.persist_wgs_g_for(4096) is None
+    monkeypatch.delenv("TECOGAN_PERSIST_WGS_G")
+    bf = torch.bfloat16
+    el = K.rw_eligible
+    assert el(bf, 64, 64, 40, 32, 32) and not el(bf, 64, 64, 4, 32, 32)                 # trunk input-gradients: batched only
+    assert el(bf, 128, 64, 40, 64, 64) and not el(bf, 128, 64, 4, 64, 64)               # c30's input-gradient
+    assert el(bf, 128, 128, 40, 64, 64, masked=True)                                      # c32's (masked)
+    assert not el(bf, 64, 64, 12, 64, 64) and el(bf, 64, 64, 12, 64, 64, extra="s1")     # D stage 1: per conv (real half)
+    assert not el(bf, 128, 128, 12, 16, 16) and el(bf, 128, 128, 12, 32, 32)             # D stage 3 stays, stage 2 as before
+    assert not el(torch.float32, 64, 64, 40, 32, 32) and not el(bf, 32, 64, 40, 32, 32) and not el(bf, 64, 96, 40, 64, 64)
+    monkeypatch.setenv("TECOGAN_RW_EXTRA", "none")
+    K = importlib.reload(K)
+    assert not K.rw_eligible(bf, 64, 64, 40, 32, 32) and not K.rw_eligible(bf, 128, 128, 40, 64, 64, masked=True)
+    monkeypatch.delenv("TECOGAN_RW_EXTRA")
+    importlib.reload(K)
+    assert K.rgb_bwd_workgroups(40, 128, 128, 256) == 256 and K.rgb_bwd_workgroups(1, 20, 52, 256) == 2 * 4
+
+
+def test_wgrad_work_list_plan_with_wide_channel_blocks():
+    """WgradList.plan for the 64 x 128 block variants: b_blocks = ceil(Cy / 128), fold spans step by 128 in b, slot count follows;
+    the variants are opt-in (variant_of keeps every layer in its kind's 64 x 64 list by default)"""
+    from pytorch_tecogan_amd import _lib as L
+    from pytorch_tecogan_amd import engine as E
+    slot = 9 * 64 * 128 + 128
+    tw, rows, units, wgs, fold, slots = E.WgradList.plan([(40, 64, 64, 128, 128), (40, 64, 64, 64, 256), (2, 16, 16, 128, 160)], 7, slot,
+                                                        L.WGROUP_C3_B128)
+    tiles = [40 * 2 * 16, 40 * 2 * 16, 2 * 1 * 4]
+    assert tw == 32 and units == 2 * tiles[0] + 2 * tiles[1] + 2 * 2 * tiles[2]
+    assert [(f[0], f[1], f[2]) for f in fold] == [(0, 0, 0), (0, 64, 0), (1, 0, 0), (1, 0, 128), (2, 0, 0), (2, 0, 128), (2, 64, 0), (2, 64, 128)]
+    assert E.WgradList.block_b(L.WGROUP_CT_B128) == 128 and E.WgradList.block_b(L.WGROUP_C4S2) == 64
+    assert E.WgradList.WIDE_MIN_PIXELS == 0     # measured slower: opt-in only
+
+
 def test_fold_items_prefix_table():
     """engine.fold_items (host side of tg_wgrad_fold_items): item counts per job = tiles x chunks of 8 slabs"""
     from pytorch_tecogan_amd import engine as E
