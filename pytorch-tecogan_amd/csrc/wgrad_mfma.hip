@@ -13,6 +13,7 @@
 //
 // Replaces aten::convolution_backward (weight path) behind code/train.py:336,340.
 #include "common.h"
+#include <cstdlib>
 
 #ifdef TG_STAMP
 // Diagnostic build only (build.sh -DTG_STAMP): wave 0 of workgroup 0 accumulates s_memtime differences per phase of the tile
@@ -473,15 +474,17 @@ __global__ __launch_bounds__(256) void wgrad_finalize_multi_kernel(const long lo
 // blocks_per_job x jobs, and a job of a few slabs has 4-8 items - with ~80 jobs per discriminator pass, 4500 of 5000
 // workgroups (each reserving the 66-KB transposition image) were dispatched only to exit (103-147 us for 123 MB of slabs).
 // Job rows carry a 13th entry here: the job's first item index in the launch.
-__global__ __launch_bounds__(256) void wgrad_fold_items_kernel(const long long* __restrict__ jobs, int njobs) {
+__global__ __launch_bounds__(256) void wgrad_fold_items_kernel(const long long* __restrict__ jobs, int njobs, int nitems) {
   extern __shared__ __attribute__((aligned(16))) float fold_sh[];
-  const int it = blockIdx.x;
-  int lo = 0, hi = njobs - 1;  // last job whose first item is <= it
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if ((int)jobs[13 * mid + 12] <= it) lo = mid; else hi = mid - 1;
+  // (the grid may be smaller than the item count: TECOGAN_FOLD_WGS, a workgroup then walks items blockIdx.x, + gridDim.x, ...)
+  for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+    int lo = 0, hi = njobs - 1;  // last job whose first item is <= it
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if ((int)jobs[13 * mid + 12] <= it) lo = mid; else hi = mid - 1;
+    }
+    fold2_dispatch(jobs + 13 * lo, fold_sh, it - (int)jobs[13 * lo + 12], 1 << 30);
   }
-  fold2_dispatch(jobs + 13 * lo, fold_sh, it - (int)jobs[13 * lo + 12], 1 << 30);
 }
 
 struct WgCfg {
@@ -675,7 +678,9 @@ extern "C" int tg_wgrad_fold_items(const int64_t* jobs_dev, int njobs, int nitem
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kFold2Lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(wgrad_fold_items_kernel, dim3((unsigned)nitems), dim3(256), lds, (hipStream_t)stream,
-                     (const long long*)jobs_dev, njobs);
+  static const int cap = [] { const char* e = getenv("TECOGAN_FOLD_WGS"); return e ? atoi(e) : 0; }();   // 0: one workgroup per item
+  const int grid = cap > 0 && cap < nitems ? cap : nitems;
+  hipLaunchKernelGGL(wgrad_fold_items_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream,
+                     (const long long*)jobs_dev, njobs, nitems);
   return tg_launch_status();
 }
