@@ -252,7 +252,7 @@ class Conv:
         st = bias_grad_of.gbias if bias_grad_of is not None else None
         if self.spec.kind == "c3" and self.tile == L.TILE_AUTO and \
                 not self.rw_off and K.rw_eligible(self.dt, self.cout_p, self.cin_p, N, H, W, masked=mask is not None,
-                                                  extra=self.rw_extra):
+                                                  extra=self.rw_extra, dgrad=True):
             self.last_desc, self.last_rw_nch = "rw", self.cout_p // 32  # the input-gradient of a 3x3 conv is the same conv with mirrored taps
             K.conv3x3_rw(dout, self.wb, out, True, res=res, mask=mask, mask_mode=mask_mode, stats=st, stats_mode=1,
                          max_workgroups=self.persist_rw or self.persist_wgs)

@@ -186,7 +186,7 @@ def conv3x3_rw(x, w_packed, out, flip=False, bias=None, res=None, mask=None, mas
                                    max_workgroups or PERSIST_WGS, _stream()), "tg_conv3x3_rw")
 
 
-def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False, extra=""):
+def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False, extra="", dgrad=False):
     """launch shapes routed to the persistent register-weights 3x3 kernel (csrc/conv3_rw.hip).  cin_p = reduction channels.
     Measured against tg_conv on the step's dense shapes (tools/mb_rw.py, profiles/r02_c_mb_rw.log):
       64 -> 64  @64x64   N=40  32.7 -> 20.0 us      64 -> 128 @128x128 N=40  154 -> 106 us     128 -> 128 @64x64 N=40 78.5 -> 74.1
@@ -202,9 +202,11 @@ def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False, extra=""):
         return N * H * W >= 8192
     npix = N * H * W
     _RW_EXTRA = _RW_EXTRA_ENV + "," + extra if extra else _RW_EXTRA_ENV
-    if "trunk" in _RW_EXTRA and cin_p == 64 and H == 32 and W == 32 and npix >= 32768:
+    # (input-gradient launches only: the same shapes as FORWARD launches - c6 at 512 x 512 in config-5 inference - are faster on
+    #  tg_conv and have no neighbour to be kind to: 2740 vs 2600 HR-frames/s)
+    if dgrad and "trunk" in _RW_EXTRA and cin_p == 64 and H == 32 and W == 32 and npix >= 32768:
         return True
-    if "c30" in _RW_EXTRA and cin_p == 128 and cout_p == 64 and npix >= 131072:
+    if dgrad and "c30" in _RW_EXTRA and cin_p == 128 and cout_p == 64 and npix >= 131072:
         return True
     if "s1" in _RW_EXTRA and cin_p == 64 and H >= 64 and npix >= 32768:         # (A/B only: slower)
         return True

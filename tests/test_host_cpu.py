@@ -455,15 +455,16 @@ def test_step_aware_caps_and_register_weights_routing(monkeypatch):
     monkeypatch.delenv("TECOGAN_PERSIST_WGS_G")
     bf = torch.bfloat16
     el = K.rw_eligible
-    assert el(bf, 64, 64, 40, 32, 32) and not el(bf, 64, 64, 4, 32, 32)                 # trunk input-gradients: batched only
-    assert el(bf, 128, 64, 40, 64, 64) and not el(bf, 128, 64, 4, 64, 64)               # c30's input-gradient
-    assert el(bf, 128, 128, 40, 64, 64, masked=True)                                      # c32's (masked)
+    assert el(bf, 64, 64, 40, 32, 32, dgrad=True) and not el(bf, 64, 64, 4, 32, 32, dgrad=True)      # trunk input-gradients: batched only
+    assert el(bf, 128, 64, 40, 64, 64, dgrad=True) and not el(bf, 128, 64, 4, 64, 64, dgrad=True)    # c30's input-gradient
+    assert not el(bf, 64, 64, 40, 32, 32) and not el(bf, 128, 64, 1, 512, 512)            # ... not the same shapes going forward
+    assert el(bf, 128, 128, 40, 64, 64, masked=True, dgrad=True)                          # c32's (masked)
     assert not el(bf, 64, 64, 12, 64, 64) and el(bf, 64, 64, 12, 64, 64, extra="s1")     # D stage 1: per conv (real half)
     assert not el(bf, 128, 128, 12, 16, 16) and el(bf, 128, 128, 12, 32, 32)             # D stage 3 stays, stage 2 as before
     assert not el(torch.float32, 64, 64, 40, 32, 32) and not el(bf, 32, 64, 40, 32, 32) and not el(bf, 64, 96, 40, 64, 64)
     monkeypatch.setenv("TECOGAN_RW_EXTRA", "none")
     K = importlib.reload(K)
-    assert not K.rw_eligible(bf, 64, 64, 40, 32, 32) and not K.rw_eligible(bf, 128, 128, 40, 64, 64, masked=True)
+    assert not K.rw_eligible(bf, 64, 64, 40, 32, 32, dgrad=True) and not K.rw_eligible(bf, 128, 128, 40, 64, 64, masked=True, dgrad=True)
     monkeypatch.delenv("TECOGAN_RW_EXTRA")
     importlib.reload(K)
     assert K.rgb_bwd_workgroups(40, 128, 128, 256) == 256 and K.rgb_bwd_workgroups(1, 20, 52, 256) == 2 * 4
