@@ -99,6 +99,10 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
   // DMA staging where the registers are short (Cin = 128: 21-59 spilled VGPRs -> 0-28, c32's input-gradient 112 -> 78 us);
   // Cin = 64 keeps the register-staged patch (no spills there, and ~1 us per launch faster: tools/mb_rw.py)
   constexpr bool kDma = RW_DMA && NCH == 4;
+  // Cin = 128 with statistics: the 16 per-lane accumulators would be live across the k-loop on top of 144 weight registers (28
+  // VGPRs spilled).  There the sums of each tile are reduced over the wave right behind its stores and added into an LDS
+  // accumulator; the flush reads that.
+  constexpr bool kLdsStats = STATS && NCH == 4;
   static_assert(NCH == 2 || NCH == 4, "Cin = 64 or 128");
   constexpr int PT = NCH == 2 ? 2 : 4;          // output rows per wave in the k-loop
   constexpr int PF = 2;                         // output rows per wave in the epilogue (NCH = 4: half of PT after the exchange)
@@ -251,9 +255,21 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) s2[e] = 0.f;
   }
+  if constexpr (kLdsStats) {
+    if (tid < 128) red[tid] = 0.f;   // [sum, sum of squares][64 channels]; published by the barrier behind the first patch
+  }
   // per-channel statistics of the stored values: lanes -> wave -> workgroup -> one atomic per channel (uniform control flow)
   auto flush_stats = [&](int grp) {
-    if constexpr (STATS) {
+    if constexpr (kLdsStats) {
+      lds_barrier();   // every wave's tile sums are in
+      if (tid < 64 * SM) {
+        const int which = tid >> 6, chn = tid & 63;
+        const size_t rep = (size_t)(blockIdx.x & (p.stats_replicas - 1)) * p.stats_groups * 2 * p.Cout;
+        atomicAdd(p.stats + rep + ((size_t)grp * 2 + which) * p.Cout + co_base + chn, red[which * 64 + chn]);
+        red[which * 64 + chn] = 0.f;
+      }
+      lds_barrier();
+    } else if constexpr (STATS) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
 #pragma unroll
@@ -418,6 +434,28 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
             if constexpr (SM == 2) s2[e] += v[e] * v[e];
           }
         }
+      }
+    }
+    if constexpr (kLdsStats) {   // this tile's sums: over the 16 pixels of the wave's rows, then into the LDS accumulator
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          s1[e] += __shfl_xor(s1[e], m);
+          if constexpr (SM == 2) s2[e] += __shfl_xor(s2[e], m);
+        }
+      }
+      if (idx == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          atomicAdd(&red[wc * 32 + 8 * g + e], s1[e]);
+          if constexpr (SM == 2) atomicAdd(&red[64 + wc * 32 + 8 * g + e], s2[e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1[e] = 0.f;
+        if constexpr (SM == 2) s2[e] = 0.f;
       }
     }
 
