@@ -170,10 +170,9 @@ class TecoGANStep:
         cap_g, cap_dr = K.persist_wgs_g_for(B * h * h), K.persist_wgs_dreal_for(B * h * h)
         if cap_g is not None:
             G.set_cap(cap_g)
-        if cap_dr is not None:
-            D.cap[0] = cap_dr
-            if "TECOGAN_RW_EXTRA_DREAL" not in os.environ:
-                D.rw_extra_real = "s1"
+        # (set both ways: the engine may have served a step of another size before)
+        D.cap[0] = cap_dr if cap_dr is not None else int(os.environ.get("TECOGAN_PERSIST_WGS_DREAL", K.persist_wgs("D")))
+        D.rw_extra_real = os.environ.get("TECOGAN_RW_EXTRA_DREAL", "s1" if cap_dr is not None else "")
         G.sets.pin((T * B, h, h))
         G.alloc(T * B, h, h)
         G._alloc_grad()
