@@ -493,6 +493,9 @@ def _wgrad_lists():
     return os.environ.get("TECOGAN_WGRAD_LIST", "1") != "0"
 
 
+_PACK_BLOCKS = int(os.environ.get("TECOGAN_PACK_BLOCKS", "48"))   # workgroups per (conv, packing) job of the repack launch (16 / 48 / 96: D update 52 / 42 / 38 us alone, step 4.186 / 4.177 / 4.182 ms)
+
+
 class Repacker:
     """fp32 master weights -> packed compute copies (forward + dgrad) of every conv of a network in one launch."""
 
@@ -508,7 +511,7 @@ class Repacker:
         self.n, self.tg = len(jobs), K.tg_dtype(dtype_t)
 
     def run(self):
-        L.check(L.load().tg_pack_conv_weights_multi(self.tg, self.jobs.data_ptr(), self.n, 16,
+        L.check(L.load().tg_pack_conv_weights_multi(self.tg, self.jobs.data_ptr(), self.n, _PACK_BLOCKS,
                                                     torch.cuda.current_stream().cuda_stream), "tg_pack_conv_weights_multi")
 
 
