@@ -37,7 +37,7 @@ WORKLOADS = {2: dict(batch=4, T=10, cs=32, dtype="bf16", gflop_per_seq=380.0, ex
                      name="configs[3]: same step at 64x64->256x256, seq-16, fp16 with dynamic loss scaling (tg_extend shapes)")}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -50,7 +50,13 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--dry", action="store_true", help="launch logic only: gloo rendezvous on the CPU, no GPU work")
-    return ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip psnr_delta_db and other_configs (configs[3] shard, configs[4] inference) behind the headline line")
+    ap.add_argument("--dp-mode", default="inline", choices=["inline", "buckets", "both"],
+                    help="data-parallel collectives (N > 1): one synchronous all-reduce per network on its lane's stream | two "
+                         "asynchronous buckets per network | both measured, the better one is `value`, the other under dp.alt")
+    ap.add_argument("--dp-steps", type=int, default=10, help="steps of the two extra data-parallel passes (event-timed, no collectives)")
+    return ap.parse_args(argv)
 
 
 def free_port():
@@ -94,8 +100,16 @@ def dry_run(a, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert float(t.item()) == float(n)
     if rank == 0:
-        print(json.dumps({"dry": True, "n_gpus": n, "pg_world_size": n, "pg_backend": "gloo" if n > 1 or "RANK" in os.environ else None,
-                          "config": {"parallelism": f"dp{n}", "global_batch": n * WORKLOADS[a.config]["batch"]}}), flush=True)
+        line = {"dry": True, "n_gpus": n, "pg_world_size": n, "pg_backend": "gloo" if n > 1 or "RANK" in os.environ else None,
+                "config": {"parallelism": f"dp{n}", "global_batch": n * WORKLOADS[a.config]["batch"]}}
+        if n > 1 or "RANK" in os.environ:   # the data-parallel object's shape: the modes a real run would time, fields unfilled
+            modes = ["inline", "buckets"] if a.dp_mode == "both" else [a.dp_mode]
+            blank = lambda m: {"mode": m, "requested_mode": m, "allreduce_exposed_ms_laneA": None,  # noqa: E731
+                               "allreduce_exposed_ms_laneB": None, "step_ms_no_collectives": None, "probe_steps": a.dp_steps}
+            line["dp"] = blank(modes[0])
+            if len(modes) > 1:
+                line["dp"]["alt"] = blank(modes[1])
+        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -245,7 +259,7 @@ def roofline_pass(st, dtype):
             if c.fin_job is not None:  # one fold job per conv, or one per 64 x 64 channel block (engine.WgradList)
                 jobs += c.fin_job if isinstance(c.fin_job[0], list) else [c.fin_job]
         return float(sum(j[4] * j[11] * 4 + j[5] * j[8] * j[9] * 4 for j in jobs))  # slabs read + gradient written
-    wrap(E.Finalizer, "run", lambda self, **k: "wgrad_fold_items_kernel" if E._FOLD_ITEMS else "wgrad_finalize_multi_kernel",
+    wrap(E.Finalizer, "run", lambda self, **k: "wgrad_fold_items_kernel" if self.fold_items else "wgrad_finalize_multi_kernel",
          lambda self, **k: fold_bytes(self, **k), "hbm")
     try:
         torch.cuda.synchronize()
@@ -354,8 +368,245 @@ def cpu_baseline(B, n_steps):
                        f"os.cpu_count()={os.cpu_count()}, usable (affinity/cgroup quota)={threads}")
 
 
-def main():
-    a = parse()
+def roofline_object(st, dtype):
+    """the `roofline` object of the bench line (contract: task description, part 4)"""
+    fam, hbm = roofline_pass(st, dtype)
+    dom = max(fam, key=lambda k: fam[k]["ms"])
+    d = fam[dom]
+    ach_alone = d["work"] / (d["ms"] * 1e-3) / 1e12
+    # `achieved` / `frac` are quoted from the bracket taken beside the other lane's work (what rocprofv3 reports for the
+    # kernel inside the overlapped step); the stand-alone bracket is kept as frac_standalone
+    ach = d["work"] / (d.get("ms_in_step", d["ms"]) * 1e-3) / 1e12
+    pmc, pmc_src = pmc_traffic(dom)
+
+    def busy(label):  # MFMA-pipe busy share of the kernel's SQ busy cycles, from the committed counter passes
+        e, _ = pmc_traffic(label)
+        return e.get("mfma_busy_pct") if e else None
+    return {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
+                       "peak": MFMA_PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                       "frac": round(ach / MFMA_PEAK_TFLOPS[dtype], 5),
+                       "traffic": int(pmc["hbm_bytes_per_launch"]) if pmc else None,
+                       "traffic_source": pmc_src, "mfma_busy_pct": busy(dom),
+                       "rocprof_names": pmc["rocprof_names"] if pmc else None,
+                       "frac_standalone": round(ach_alone / MFMA_PEAK_TFLOPS[dtype], 5),
+                       "achieved_standalone": round(ach_alone, 2),
+                       "frac_basis": "family bracketed with HIP events on its stream while the discriminator's real half "
+                                     "replays on the other lane (in-step conditions); *_standalone: the family alone",
+                       "launches_per_step": d["launches"],
+                       "avg_launch_us": round(d.get("ms_in_step", d["ms"]) * 1e3 / d["launches"], 2),
+                       "avg_launch_us_standalone": round(d["ms"] * 1e3 / d["launches"], 2),
+                       "avg_launch_gflop": round(d["work"] / d["launches"] / 1e9, 3),
+                       # rocprofv3 lists the 9-tap weight-gradient kernel as ONE row (single-layer and grouped launches
+                       # are the same instantiation); bracketed here as three families - their sum, for comparison
+                       "also": (lambda ws: {"kernel": "all weight gradients: wgrad_group_kernel (work-list launches) + wgrad_kernel (the layers it does not take)",
+                                            "launches_per_step": sum(v["launches"] for v in ws),
+                                            "ms": round(sum(v["ms"] for v in ws), 3),
+                                            "achieved": round(sum(v["work"] for v in ws) / (sum(v["ms"] for v in ws) * 1e-3) / 1e12, 2),
+                                            "frac": round(sum(v["work"] for v in ws) / (sum(v["ms"] for v in ws) * 1e-3) / 1e12
+                                                          / MFMA_PEAK_TFLOPS[dtype], 5)} if ws else None)(
+                           [v for k, v in fam.items() if k.startswith("wgrad_kernel<") or k.startswith("wgrad_group_kernel<")]),
+                       "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                        "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                        "mfma_busy_pct": busy(k)}
+                                    for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
+                       # the HBM-bound kernels of the step (SURVEY.md 8d: reported separately, as GB/s of algorithmic bytes)
+                       "hbm_kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                           "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
+                                           "GBps": round(v["work"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                           "frac_of_8TBps": round(v["work"] / (v["ms"] * 1e-3) / 8e12, 4),
+                                           # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE)
+                                           # beside the algorithmic bytes per launch
+                                           "algorithmic_bytes_per_launch": int(v["work"] / v["launches"]),
+                                           "pmc_hbm_bytes_per_launch": (lambda e: int(e["hbm_bytes_per_launch"]) if e and
+                                                                        "hbm_bytes_per_launch" in e else None)(pmc_traffic(k)[0])}
+                                       for k, v in sorted(hbm.items(), key=lambda kv: -kv[1]["ms"])}}
+
+
+def build_step_objects(args, dev):
+    from pytorch_tecogan_amd import models as M
+    G, D = M.generator(3, args).to(dev), M.discriminator(args).to(dev)
+    og = torch.optim.Adam(G.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
+    od = torch.optim.Adam(D.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
+    return G, D, og, od
+
+
+def timed_region(run_step, first, warmup, steps, world, dev, log=None):
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; MAX over ranks.
+    Returns (seconds, result of the last step)."""
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+    for s in range(warmup):
+        run_step(first + s)
+        torch.cuda.synchronize()
+        if log:
+            log(f"warm-up step {s} done")
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        out = run_step(first + warmup + s)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, out
+
+
+def dp_breakdown(st, run_step, first, steps, world, dev):
+    """What a data-parallel step pays for its collectives, so that a scaling curve explains itself:
+      allreduce_exposed_ms_laneA / _laneB  HIP events on each lane's stream: from the end of the lane's last backward piece to the
+                                            point where its Adam may start (the all-reduce(s) issued or still pending there) - the
+                                            part of the collectives that nothing hides; mean over `steps` steps, MAX over ranks
+      step_ms_no_collectives                the same `steps` steps with every all-reduce skipped (replicas diverge: last pass)"""
+    ev = {k: torch.cuda.Event(enable_timing=True) for k in ("A0", "A1", "B0", "B1")}
+    st.dp_events = ev
+    acc = {"A": 0.0, "B": 0.0}
+    for s in range(steps):
+        run_step(first + s)
+        torch.cuda.synchronize()
+        acc["A"] += ev["A0"].elapsed_time(ev["A1"])
+        acc["B"] += ev["B0"].elapsed_time(ev["B1"])
+    st.dp_events = None
+    t = torch.tensor([acc["A"] / steps, acc["B"] / steps], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    st.skip_collectives = True
+    dt, _ = timed_region(run_step, first + steps, 1, steps, world, dev)
+    st.skip_collectives = False
+    return {"allreduce_exposed_ms_laneA": round(float(t[0]), 4), "allreduce_exposed_ms_laneB": round(float(t[1]), 4),
+            "step_ms_no_collectives": round(dt / steps * 1e3, 4), "probe_steps": steps,
+            "grad_bytes": {"G": int(st.G.flat.g.numel() * 4), "D": int(st.D.flat.g.numel() * 4)}}
+
+
+def psnr_delta(dev):
+    """Second half of BASELINE.json's metric ("...; PSNR delta vs ref", north_star: within 0.05 dB): the bf16 HIP recurrent
+    generator against the fp32 CPU oracle at the config-1 shape (1 sequence of 10 32x32 frames), compute_psnr
+    (code/ops.py:130-139) on x255 outputs.  Working point of tests/test_bench_config_gpu.py::test_psnr_gate_bf16_vs_fp32_oracle_can_fail
+    (where the gate is proven able to fail): the target is the output of a TEACHER generator (oracle init, conv weights x1.8: a
+    structured output), the generator under test is the teacher with 10 % multiplicative weight noise - PSNR ~27 dB, the level
+    TecoGAN reaches on real video, so a compute error of 1-2 % of the output range moves it.  The oracle is the checker here."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import tecogan_oracle as orc
+    from pytorch_tecogan_amd import models as M
+    from pytorch_tecogan_amd import ops as O
+    torch.set_num_threads(usable_cores())
+    teacher = orc.init_params(orc.generator_param_shapes(16), 31)
+    teacher = {k: (v * 1.8 if k.endswith(".weight") else v) for k, v in teacher.items()}
+    x, _ = synth(1, 10, 32, 33)
+    rng = np.random.default_rng(32)
+    student = {k: v * torch.from_numpy(1.0 + 0.10 * rng.standard_normal(v.shape).astype(np.float32)) for k, v in teacher.items()}
+    with torch.no_grad():
+        y = orc.recurrent_generator(teacher, x, orc.pseudo_flow(x)).reshape(10, 3, 128, 128)
+        ref = orc.recurrent_generator(student, x, orc.pseudo_flow(x)).reshape(10, 3, 128, 128)
+    psnr_ref = float(orc.compute_psnr(ref * 255, y * 255))
+    G = M.generator(3, default_args("bf16"))
+    G.load_state_dict(student)
+    out = G.to(dev).recurrent(x.to(dev), use_graph=False).cpu().reshape(10, 3, 128, 128)
+    psnr_hip = float(O.compute_psnr(out * 255, y * 255))
+    rel = float((out - ref).norm() / ref.norm())
+    return {"psnr_delta_db": round(psnr_hip - psnr_ref, 5),
+            "psnr": {"hip_bf16_db": round(psnr_hip, 4), "ref_fp32_oracle_db": round(psnr_ref, 4), "gate_db": 0.05,
+                     "within_gate": abs(psnr_hip - psnr_ref) <= 0.05, "output_rel_err": round(rel, 6),
+                     "working_point": "configs[0] shape (1 x 10 frames 32->128); target = teacher generator (oracle init seed 31, conv "
+                                      "weights x1.8), generator under test = teacher x (1 + 0.10 N(0,1)) seed 32; compute_psnr on x255"}}
+
+
+def other_config4(dev, steps, warmup, log):
+    """BASELINE configs[3], per-GPU shard (B=2 of the global 16, T=16, 64->256, fp16 + dynamic loss scaling; args.tg_extend): the
+    training step through FRVSR_Train, then the per-family brackets of one eager step."""
+    from pytorch_tecogan_amd import train as TR
+    wl = WORKLOADS[4]
+    args = default_args(wl["dtype"], wl["T"], wl["cs"], wl["extend"])
+    torch.manual_seed(1)
+    G, D, og, od = build_step_objects(args, dev)
+    B, T, cs = wl["batch"], wl["T"], wl["cs"]
+    x, y = synth(B, T, cs, 1)
+    x, y = x.to(dev), y.to(dev)
+    run = lambda s: TR.FRVSR_Train(x, y, args, D, G, s, 0.0, 0.0, og, od)  # noqa: E731
+    dt, out = timed_region(run, 0, warmup, steps, 1, dev)
+    ms = dt / steps * 1e3
+    res = {"workload": f"{wl['name']}, B={B} sequences/GPU (per-GPU shard of global 16), T={T}, {cs}x{cs}->{4 * cs}x{4 * cs}",
+           "dtype": wl["dtype"], "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4),
+           "hr_frames_per_s": round(B * T * steps / dt, 1), "step_tflops": round(B * wl["gflop_per_seq"] / 1e3 / (dt / steps), 2),
+           "step_mfma_frac": round(B * wl["gflop_per_seq"] / 1e3 / (dt / steps) / MFMA_PEAK_TFLOPS[wl["dtype"]], 5),
+           "finite": bool(np.isfinite(float(out.gen_loss)) and np.isfinite(float(out.d_loss)))}
+    st = next(iter(TR._STEPS.values()))
+    res["loss_scale"] = st.scaler_state()
+    fam, _ = roofline_pass(st, wl["dtype"])
+    dom = max(fam, key=lambda k: fam[k]["ms"])
+    tf = lambda v, key="ms": v["work"] / (v[key] * 1e-3) / 1e12  # noqa: E731
+    res["dominant_family"] = {"kernel": dom, "launches_per_step": fam[dom]["launches"], "ms": round(fam[dom]["ms"], 3),
+                              "tflops": round(tf(fam[dom]), 1), "frac": round(tf(fam[dom]) / MFMA_PEAK_TFLOPS[wl["dtype"]], 5)}
+    if "ms_in_step" in fam[dom]:
+        res["dominant_family"]["frac_in_step"] = round(tf(fam[dom], "ms_in_step") / MFMA_PEAK_TFLOPS[wl["dtype"]], 5)
+    res["families_top"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(tf(v), 1)}
+                           for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])[:6]}
+    for s_ in list(TR._STEPS.values()):
+        s_.close()
+    TR._STEPS.clear()
+    return res
+
+
+def other_config5(dev, frames, reps, log):
+    """BASELINE configs[4]: generator-only recurrent inference, 1 sequence of `frames` 128x128 LR frames -> 512x512, per-frame
+    hipGraph replay (main.py:171-219 of the reference: the loop of the inference caller), bf16."""
+    from pytorch_tecogan_amd import models as M
+    from pytorch_tecogan_amd import engine as E
+    from pytorch_tecogan_amd import kernels as K
+    lr = 128
+    torch.manual_seed(1)
+    G = M.generator(3, default_args("bf16", cs=lr)).to(dev)
+    x = torch.from_numpy(np.random.default_rng(1).random((1, frames, 3, lr, lr), dtype=np.float32)).to(dev)
+    out = G.recurrent(x, use_graph=True)   # warm-up: eager frame, capture of both parities
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = G.recurrent(x, use_graph=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    gflop = 8.648 * (lr / 32) ** 2        # SURVEY.md 8a1: forward GFLOP per LR frame at 32x32, x16 at 128x128
+    res = {"workload": f"configs[4]: generator-only recurrent inference, {lr}x{lr}->{4 * lr}x{4 * lr}, seq-{frames}, hipGraph per frame",
+           "dtype": "bf16", "frames": frames, "reps": reps, "hr_frames_per_s": round(frames / dt, 1),
+           "ms_per_frame": round(dt / frames * 1e3, 4), "tflops": round(gflop * frames / dt / 1e3, 1),
+           "mfma_frac": round(gflop * frames / dt / 1e3 / MFMA_PEAK_TFLOPS["bf16"], 5), "finite": bool(torch.isfinite(out).all())}
+    # the fused residual block (the trunk: 16 launches + conv_trans.2 per frame) bracketed over one eager frame's launches
+    calls, fl = [], [0.0]
+    orig = K.resblock_fwd
+
+    def rec(xa, *a, **k):
+        r = orig(xa, *a, **k)
+        calls.append(lambda: orig(xa, *a, **k))
+        fl[0] += 2 * 2.0 * xa.shape[0] * xa.shape[1] * xa.shape[2] * 9 * xa.shape[3] * xa.shape[3]
+        return r
+    K.resblock_fwd = rec
+    try:
+        G._rec._frame(1)
+    finally:
+        K.resblock_fwd = orig
+    if calls:
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(0.008 * 2.0e9))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for c in calls:
+            c()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        res["trunk_family"] = {"kernel": "resblock_kernel<false>", "launches_per_frame": len(calls), "ms_per_frame": round(ms, 4),
+                               "tflops": round(fl[0] / (ms * 1e-3) / 1e12, 1),
+                               "frac": round(fl[0] / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["bf16"], 5),
+                               "share_of_frame": round(ms / (dt / frames * 1e3), 3)}
+    G._rec.close()
+    return res
+
+
+def main(argv=None):
+    a = parse(argv)
     if a.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if "RANK" not in os.environ and a.gpus > 1:
@@ -385,7 +636,6 @@ def main():
     os.environ["TECOGAN_GRAPH"] = "0" if a.no_graph else "1"
 
     import pytorch_tecogan_amd  # noqa: F401
-    from pytorch_tecogan_amd import models as M
     from pytorch_tecogan_amd import train as TR
 
     wl = WORKLOADS[a.config]
@@ -393,9 +643,7 @@ def main():
     a.batch = a.batch or wl["batch"]
     args = default_args(a.dtype, wl["T"], wl["cs"], wl["extend"])
     torch.manual_seed(1)
-    G, D = M.generator(3, args).to(dev), M.discriminator(args).to(dev)
-    og = torch.optim.Adam(G.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
-    od = torch.optim.Adam(D.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
+    G, D, og, od = build_step_objects(args, dev)
     B, T, cs = a.batch, wl["T"], wl["cs"]
     STEP_GFLOP_PER_SEQ = wl["gflop_per_seq"]
     x, y = synth(B, T, cs, 1 + rank)  # every rank owns different sequences (weak scaling)
@@ -409,23 +657,34 @@ def main():
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    log(f"models built ({a.dtype}, B={B}/gpu, world={world}); warm-up {a.warmup} steps (step 0 eager, then capture)")
-    for s in range(a.warmup):
-        TR.FRVSR_Train(x, y, args, D, G, s, 0.0, 0.0, og, od)
-        torch.cuda.synchronize()
-        log(f"warm-up step {s} done")
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(a.steps):
-        out = TR.FRVSR_Train(x, y, args, D, G, a.warmup + s, 0.0, 0.0, og, od)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    log(f"timed region done: {dt / a.steps * 1e3:.3f} ms/step")
+    run_step = lambda s: TR.FRVSR_Train(x, y, args, D, G, s, 0.0, 0.0, og, od)  # noqa: E731
+    # data-parallel collectives: the mode(s) to time.  A process group of one rank (torch.distributed.run with one process, or
+    # TECOGAN_FORCE_COLLECTIVES=1) runs the same code path, so the fields below can be rehearsed on one GPU.
+    from pytorch_tecogan_amd import parallel
+    dp_live = parallel.dist_info()[0] is not None
+    modes = (["inline", "buckets"] if a.dp_mode == "both" else [a.dp_mode]) if dp_live else [None]
+    runs, first = [], 0
+    for mode in modes:
+        if mode is not None:
+            os.environ["TECOGAN_DP_INLINE"] = "1" if mode == "inline" else "0"
+            for s_ in list(TR._STEPS.values()):   # a step is built for one mode
+                s_.close()
+            TR._STEPS.clear()
+        log(f"models built ({a.dtype}, B={B}/gpu, world={world}, dp mode {mode}); warm-up {a.warmup} steps (step 0 eager, then capture)")
+        dt, out = timed_region(run_step, first, a.warmup, a.steps, world, dev, log)
+        first += a.warmup + a.steps
+        st = next(iter(TR._STEPS.values()))
+        rec = {"mode": mode, "dt": dt, "out": out}
+        log(f"timed region done: {dt / a.steps * 1e3:.3f} ms/step")
+        if mode is not None:
+            rec["mode"] = "inline" if st.dp_inline else ("buckets" if st.buckets else "single")
+            rec["requested_mode"] = mode
+            rec["sync_allreduce_stream_ordered"] = st.dp_sync_ordered
+            rec.update(dp_breakdown(st, run_step, first, a.dp_steps, world, dev))
+            first += 2 * a.dp_steps + 1
+        runs.append(rec)
+    best = min(runs, key=lambda r: r["dt"])
+    dt, out = best["dt"], best["out"]
     gen_loss, d_loss = float(out.gen_loss), float(out.d_loss)
     if not (np.isfinite(gen_loss) and np.isfinite(d_loss)):
         raise SystemExit(f"non-finite losses after the timed steps: {gen_loss} {d_loss}")
@@ -433,7 +692,7 @@ def main():
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = world * B * T * a.steps / dt
-        res = {"metric": f"HR frames/sec per train step, 4x {cs}->{4 * cs} seq-{T}", "value": round(value, 2),
+        res = {"metric": f"HR frames/sec per train step, 4x {cs}->{4 * cs} seq-{T}; PSNR delta vs ref", "value": round(value, 2),
                "unit": "HR-frames/s", "n_gpus": world, "pg_world_size": world if pg_backend else None,
                "pg_backend": pg_backend, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -444,62 +703,32 @@ def main():
                "step_tflops": round(world * B * STEP_GFLOP_PER_SEQ / 1e3 / (dt / a.steps), 2),
                "step_mfma_frac": round(B * STEP_GFLOP_PER_SEQ / 1e3 / (dt / a.steps) / MFMA_PEAK_TFLOPS[a.dtype], 5),
                "final_losses": {"gen_loss": round(gen_loss, 5), "d_loss": round(d_loss, 5)}}
+        if best["mode"] is not None:
+            keep = lambda r: {k: v for k, v in r.items() if k not in ("dt", "out")}  # noqa: E731
+            res["dp"] = dict(keep(best), ms_per_step=round(best["dt"] / a.steps * 1e3, 4))
+            alt = [r for r in runs if r is not best]
+            if alt:
+                res["dp"]["alt"] = dict(keep(alt[0]), ms_per_step=round(alt[0]["dt"] / a.steps * 1e3, 4))
         if not a.no_roofline:
             st = next(iter(TR._STEPS.values()))
             log("roofline pass (one eager step recorded, every kernel family replayed inside one event bracket)")
-            fam, hbm = roofline_pass(st, a.dtype)
-            dom = max(fam, key=lambda k: fam[k]["ms"])
-            d = fam[dom]
-            ach_alone = d["work"] / (d["ms"] * 1e-3) / 1e12
-            # `achieved` / `frac` are quoted from the bracket taken beside the other lane's work (what rocprofv3 reports for the
-            # kernel inside the overlapped step); the stand-alone bracket is kept as frac_standalone
-            ach = d["work"] / (d.get("ms_in_step", d["ms"]) * 1e-3) / 1e12
-            pmc, pmc_src = pmc_traffic(dom)
-
-            def busy(label):  # MFMA-pipe busy share of the kernel's SQ busy cycles, from the committed counter passes
-                e, _ = pmc_traffic(label)
-                return e.get("mfma_busy_pct") if e else None
-            res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
-                               "peak": MFMA_PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
-                               "frac": round(ach / MFMA_PEAK_TFLOPS[a.dtype], 5),
-                               "traffic": int(pmc["hbm_bytes_per_launch"]) if pmc else None,
-                               "traffic_source": pmc_src, "mfma_busy_pct": busy(dom),
-                               "rocprof_names": pmc["rocprof_names"] if pmc else None,
-                               "frac_standalone": round(ach_alone / MFMA_PEAK_TFLOPS[a.dtype], 5),
-                               "achieved_standalone": round(ach_alone, 2),
-                               "frac_basis": "family bracketed with HIP events on its stream while the discriminator's real half "
-                                             "replays on the other lane (in-step conditions); *_standalone: the family alone",
-                               "launches_per_step": d["launches"],
-                               "avg_launch_us": round(d.get("ms_in_step", d["ms"]) * 1e3 / d["launches"], 2),
-                               "avg_launch_us_standalone": round(d["ms"] * 1e3 / d["launches"], 2),
-                               "avg_launch_gflop": round(d["work"] / d["launches"] / 1e9, 3),
-                               # rocprofv3 lists the 9-tap weight-gradient kernel as ONE row (single-layer and grouped launches
-                               # are the same instantiation); bracketed here as three families - their sum, for comparison
-                               "also": (lambda ws: {"kernel": "all weight gradients: wgrad_group_kernel (work-list launches) + wgrad_kernel (the layers it does not take)",
-                                                    "launches_per_step": sum(v["launches"] for v in ws),
-                                                    "ms": round(sum(v["ms"] for v in ws), 3),
-                                                    "achieved": round(sum(v["work"] for v in ws) / (sum(v["ms"] for v in ws) * 1e-3) / 1e12, 2),
-                                                    "frac": round(sum(v["work"] for v in ws) / (sum(v["ms"] for v in ws) * 1e-3) / 1e12
-                                                                  / MFMA_PEAK_TFLOPS[a.dtype], 5)} if ws else None)(
-                                   [v for k, v in fam.items() if k.startswith("wgrad_kernel<") or k.startswith("wgrad_group_kernel<")]),
-                               "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                                "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                                "mfma_busy_pct": busy(k)}
-                                            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
-                               # the HBM-bound kernels of the step (reported separately, as GB/s of algorithmic bytes)
-                               "hbm_kernels": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                                   "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
-                                                   "GBps": round(v["work"] / (v["ms"] * 1e-3) / 1e9, 1),
-                                                   "frac_of_8TBps": round(v["work"] / (v["ms"] * 1e-3) / 8e12, 4),
-                                                   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE)
-                                                   # beside the algorithmic bytes per launch
-                                                   "algorithmic_bytes_per_launch": int(v["work"] / v["launches"]),
-                                                   "pmc_hbm_bytes_per_launch": (lambda e: int(e["hbm_bytes_per_launch"]) if e and
-                                                                                "hbm_bytes_per_launch" in e else None)(pmc_traffic(k)[0])}
-                                               for k, v in sorted(hbm.items(), key=lambda kv: -kv[1]["ms"])}}
+            res["roofline"] = roofline_object(st, a.dtype)
         if not a.no_cpu_baseline and a.config == 2:
             log(f"cpu baseline: oracle, {a.cpu_steps}+1 steps on {usable_cores()} usable host cores")
             res["cpu_baseline"] = cpu_baseline(B, a.cpu_steps)
+        if world == 1 and not a.no_extras and a.config == 2:
+            # the rest of BASELINE.json's metric and the configurations the headline line does not time, in this same process
+            for s_ in list(TR._STEPS.values()):
+                s_.close()
+            TR._STEPS.clear()
+            del G, D, og, od, run_step
+            log("psnr_delta_db: bf16 HIP recurrent generator vs the fp32 oracle (checker leg, like cpu_baseline)")
+            res.update(psnr_delta(dev))
+            res["other_configs"] = {}
+            log("other_configs.config4: configs[3] shard (B=2, T=16, 64->256, fp16), 10 steps")
+            res["other_configs"]["config4"] = other_config4(dev, 10, 3, log)
+            log("other_configs.config5: configs[4] inference (128->512, 120 frames, graph replay)")
+            res["other_configs"]["config5"] = other_config5(dev, 120, 2, log)
         print(json.dumps(res), flush=True)
     barrier()
     if torch.distributed.is_available() and torch.distributed.is_initialized():

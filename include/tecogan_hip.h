@@ -38,7 +38,7 @@ enum {
 };
 
 enum { TG_ACT_NONE = 0, TG_ACT_RELU = 1, TG_ACT_LRELU = 2, TG_ACT_SIGMOID = 3, TG_ACT_TANH24 = 4 /* 24*tanh, code/models.py:50 */ };
-enum { TG_MASK_NONE = 0, TG_MASK_RELU = 1, TG_MASK_LRELU = 2, TG_MASK_BNZ = 3 /* tg_conv stats_mode 3: `mask` is z */ };
+enum { TG_MASK_NONE = 0, TG_MASK_RELU = 1, TG_MASK_LRELU = 2, TG_MASK_BNZ = 3 /* tg_conv stats_mode 3: `mask` is z (experiments build only) */ };
 enum { TG_OUT_NHWC = 0, TG_OUT_NCHW_F32 = 1 };
 
 #define TG_MAX_TAPS 16
@@ -83,6 +83,11 @@ enum { TG_TILE_AUTO = 0, TG_TILE_64x256 = 1, TG_TILE_64x64 = 2, TG_TILE_128x128 
 
 int tg_abi_version(void);
 const char* tg_error_string(int code);
+/* 1 when the library was built with -DTG_EXPERIMENTS (csrc/build.sh --experiments): it then also exports the entry points declared
+ * under `#ifdef TG_EXPERIMENTS` below and accepts the arguments marked "experiments build" - variants that were built, measured
+ * slower and rejected, kept buildable so that the A/B logs under profiles/ can be reproduced.  The default library is
+ * what the default step can reach. */
+int tg_has_experiments(void);
 
 /* Bytes needed for the packed weights of a conv with `nslots` weight slots (taps). */
 int64_t tg_packed_weight_bytes(int dtype, int nslots, int cout_p, int cin_p);
@@ -197,22 +202,20 @@ int tg_wgrad_fold_items(const int64_t* jobs_dev, int njobs, int nitems, int max_
  * tiles_y = ceil(H / (128 / tile_w)), y_sum (0/1), ordinal of the job's first channel block among all blocks of the list};
  * x [N,H,W,Cx], y [N,H,W,Cy] NHWC, Cx % 32 == Cy % 32 == 0; channel blocks are 64 x 64, a_blocks = ceil(Cx / 64),
  * b_blocks = ceil(Cy / 64) (a 32-channel remainder is a block whose upper half holds don't-care values: fold real channels only).
- * slab: slots of tg_wgrad_group_slot_floats() floats = [9 taps][64 a][64 b] partial dW + [64] channel sums of Y (the conv's
+ * slab: slots of tg_wgrad_group_slot_floats_v(TG_WGROUP_C3) floats = [9 taps][64 a][64 b] partial dW + [64] channel sums of Y (the conv's
  * bias gradient; zeros unless y_sum and a_block == 0; entries of padded channels are don't-care).  The segment of workgroup w inside channel block g (global ordinal)
  * goes to slot w + g: block g owns slots [w_first(g) + g, w_last(g) + g], at most W' + (number of blocks) slots in all,
  * and tg_wgrad_finalize_multi folds them with one job per block (ca_p = cb_p = 64, stride = the slot size).
- * tile_w: 32 (tiles of 32 x 4 pixels) or 16 (16 x 8).  TG_E_UNSUPPORTED for fp32: use tg_wgrad. */
-int64_t tg_wgrad_group_slot_floats(void);
-int tg_wgrad_group(int dtype, int tile_w, const int64_t* jobs_dev, int njobs, int units_total, int workgroups, float* slab,
-                   void* stream);
-/* The same work-list launch for the two stride-2 layer kinds (tile_w = 16: tiles of 16 x 4 pixels of y; H, W of a job row
+ * tile_w: 32 (tiles of 32 x 4 pixels) or 16 (16 x 8).  TG_E_UNSUPPORTED for fp32: use tg_wgrad.
+ * Entry point: tg_wgrad_group_v(dtype, TG_WGROUP_C3, ...) below.
+ * The same work-list launch for the two stride-2 layer kinds (tile_w = 16: tiles of 16 x 4 pixels of y; H, W of a job row
  * are y's, x lives on the 2H x 2W grid; 64-pixel tiles, so tiles_x = ceil(W / 16), tiles_y = ceil(H / 4)):
  *   TG_WGROUP_CT    conv-transpose k3 s2 p1 op1 (code/ops.py:45-54): x = the output gradient [N,2H,2W,Cx], y = the layer input
  *                   [N,H,W,Cy]; dW[t][a][b] = sum x[n, 2y + dy[t], 2x + dx[t]][a] * y[n, y, x][b], 9 taps (dy, dx) in -1..1;
  *   TG_WGROUP_C4S2  conv k4 s2 p1 (code/models.py:90-94): x = the layer input [N,2H,2W,Cx], y = the output gradient [N,H,W,Cy];
  *                   16 taps (dy, dx) in -1..2.
- * TG_WGROUP_C3 is tg_wgrad_group.  Slot size: tg_wgrad_group_slot_floats_v(variant) = [taps][64][64] + [64].
- *   TG_WGROUP_C3_B128 / TG_WGROUP_CT_B128: the same two kinds with 64 x 128 channel blocks (b_blocks = ceil(Cy / 128), slot =
+ * TG_WGROUP_C3 is the 3x3 stride-1 kind described above.  Slot size: tg_wgrad_group_slot_floats_v(variant) = [taps][64][64] + [64].
+ *   TG_WGROUP_C3_B128 / TG_WGROUP_CT_B128 (experiments build only, else TG_E_UNSUPPORTED: 1.1-2.5x slower, spills): the same two kinds with 64 x 128 channel blocks (b_blocks = ceil(Cy / 128), slot =
  *                   [9][64][128] + [128]; fold jobs with cb_p = 128): for layers with >= 128 y channels - x is fetched once per
  *                   128 of them and a 32-pixel k-step is 26 transposed LDS reads per 36 MFMAs instead of 22 per 18. */
 #define TG_WGROUP_C3 0
@@ -255,6 +258,7 @@ int tg_resblock_fwd(int dtype, const void* in, const void* w1_packed, const floa
                     void* out_a, int N, int H, int W, int C, int add_skip, const void* next_w1_packed,
                     const void* next_w2_packed, void* stream);
 
+#ifdef TG_EXPERIMENTS
 /* TWO consecutive residual blocks in ONE launch (8 x 4 output tiles, halo recomputed: h1 on 14 x 10, a1 on 12 x 8, h2 on 10 x 6
  * pixels from a 16 x 12 patch): out_h1 = relu(conv(in, w1a) + b1a), out_a1 = in + conv(out_h1, w2a), out_h2 = relu(conv(out_a1, w1b)
  * + b1b), out_a2 = out_a1 + conv(out_h2, w2b) - bit-identical to two tg_resblock_fwd launches, one launch boundary and one
@@ -263,6 +267,7 @@ int tg_resblock_fwd(int dtype, const void* in, const void* w1_packed, const floa
 int tg_resblock2_fwd(int dtype, const void* in, const void* w1a_packed, const float* b1a, const void* w2a_packed,
                      const void* w1b_packed, const float* b1b, const void* w2b_packed, void* out_h1, void* out_a1, void* out_h2,
                      void* out_a2, int N, int H, int W, int C, const void* const* next_w4, void* stream);
+#endif
 
 /* Input-gradient of the same block in ONE launch (aten::convolution_backward x2 + threshold_backward, code/train.py:336):
  * out_dh = (h > 0) * conv3x3^T(dout, w2), out_din = dout + conv3x3^T(out_dh, w1); w*_dgrad_packed are the role-swapped
@@ -331,6 +336,7 @@ int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, const void* z, 
                     int red_replicas, const float* gamma, void* dz, float* dgamma, float* dbeta, int N, int HW, int C,
                     int groups, int act, int red_raw, void* stream);
 
+#ifdef TG_EXPERIMENTS
 /* The same backward pass (reduce + apply) as ONE launch for a tensor of at most tg_bn_bwd_fused_max_pixels() pixels per group
  * (the discriminator's 16x16 ... 4x4 layers): one workgroup per 16-byte channel piece keeps its share of the tensors in registers
  * between the sums and dz and is the only writer of its channels' dgamma / dbeta (+=).  act: TG_ACT_NONE or TG_ACT_LRELU.
@@ -338,6 +344,7 @@ int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, const void* z, 
 int tg_bn_bwd_fused(int dtype, const void* dy, const void* yact, const void* z, const float* save, const float* gamma,
                     void* dz, float* dgamma, float* dbeta, int N, int HW, int C, int groups, int act, void* stream);
 int tg_bn_bwd_fused_max_pixels(void);
+#endif
 
 /* ---- heads and losses (code/models.py:143-145; code/train.py:205-333) ----------------------------------- */
 int tg_fc_head_fwd(int dtype, const void* feat, const float* w, const float* b, float* prob, int N, int HW, int C,
@@ -349,9 +356,6 @@ int tg_absdiff_sum(int dtype, const void* a, const void* b, float* acc, int64_t 
 /* The same for njobs tensor pairs in one launch (the four D layer losses of code/train.py:205-226): jobs_dev = njobs x 6 int64
  * {a ptr, b ptr, acc ptr, npix, C, Cp}; blocks_per_job workgroups walk each pair. */
 int tg_absdiff_sum_multi(int dtype, const int64_t* jobs_dev, int njobs, int blocks_per_job, void* stream);
-/* acc[0] += sum |a[a_off[k]+e] - b[b_off[k]+e]| (ping-pong loss, code/train.py:275-279). */
-int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const float* b, const int64_t* b_off_dev, float* acc,
-                    int nblocks, int64_t len, void* stream);
 /* content loss partial sum and d(pre-sigmoid) for the generator output (code/train.py:239-241):
  * acc (>= 16 floats): acc[0] += sum (gen-y)^2 ; dpre[nhwc] = gscale * 2*(gen-y) * gen*(1-gen) ; bias_acc[c] += sum dpre[c], c < 3
  * (the output layer's bias gradient; bias_acc null: acc + 8).  gen/y are NCHW fp32 (B,T,3,H,W);

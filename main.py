@@ -91,7 +91,8 @@ def main(argv=None):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     # one GPU per rank.  Only the gloo test backend can share a device (ranks beyond the visible devices wrap around there);
     # RCCL fails obscurely with two ranks on one GPU, so that is refused here
-    backend = os.environ.get("TECOGAN_DIST_BACKEND", "nccl")  # "nccl" is RCCL here; gloo: ranks sharing one GPU (tests)
+    from pytorch_tecogan_amd import tuning
+    backend = tuning.current().dist_backend  # TECOGAN_DIST_BACKEND: "nccl" is RCCL here; gloo: ranks sharing one GPU (tests)
     local, ndev = int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.device_count()
     if local >= max(1, ndev):
         if world > 1 and backend == "nccl":
@@ -213,7 +214,7 @@ def main(argv=None):
             sch_f.step()
         if world > 1:
             from pytorch_tecogan_amd import parallel
-            if not parallel.replicas_equal((G, D)):
+            if not parallel.replicas_equal((G, D) + ((Fn,) if Fn is not None else ())):   # (the estimator too when it trains)
                 raise RuntimeError(f"data-parallel replicas diverged (rank {rank}, epoch {e + 1})")
             if rank == 0:
                 print(f"replica check ok ({world} ranks)")

@@ -47,6 +47,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _PROTOS = {
     "tg_abi_version": (C.c_int, []),
     "tg_error_string": (C.c_char_p, [_I]),
+    "tg_has_experiments": (C.c_int, []),
     "tg_packed_weight_bytes": (_L, [_I, _I, _I, _I]),
     "tg_pack_conv_weights": (_I, [_I, _P, _P, _I, _I, _I, _I, _L, _L, _I, _P, _P]),
     "tg_pack_conv_weights_multi": (_I, [_I, _P, _I, _I, _P]),
@@ -56,8 +57,6 @@ _PROTOS = {
     "tg_wgrad_slab_floats": (_L, [C.POINTER(WgradDesc)]),
     "tg_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P]),
     "tg_wgrad_multi": (_I, [C.POINTER(WgradDesc), _P, _I, _P]),
-    "tg_wgrad_group_slot_floats": (_L, []),
-    "tg_wgrad_group": (_I, [_I, _I, _P, _I, _I, _I, _P, _P]),
     "tg_wgrad_group_slot_floats_v": (_L, [_I]),
     "tg_wgrad_group_v": (_I, [_I, _I, _I, _P, _I, _I, _I, _P, _P]),
     "tg_wgrad_finalize": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _L, _L, _P, _I, _P, _L, _P]),
@@ -66,7 +65,6 @@ _PROTOS = {
     "tg_nchw_to_nhwc": (_I, [_I, _P, _L, _P, _I, _I, _I, _I, _I, _P]),
     "tg_nhwc_to_nchw": (_I, [_I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "tg_resblock_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "tg_resblock2_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "tg_conv3x3_rgb": (_I, [_I, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "tg_conv3x3_rgb_bwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "tg_conv3x3_rgb_bwd_slot_floats": (_L, []),
@@ -88,13 +86,10 @@ _PROTOS = {
     "tg_bn_apply": (_I, [_I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P, _P]),
     "tg_bn_bwd_reduce": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "tg_bn_bwd_apply": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "tg_bn_bwd_fused": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "tg_bn_bwd_fused_max_pixels": (_I, []),
     "tg_fc_head_fwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tg_fc_head_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tg_absdiff_sum": (_I, [_I, _P, _P, _P, _L, _I, _I, _P]),
     "tg_absdiff_sum_multi": (_I, [_I, _P, _I, _I, _P]),
-    "tg_absdiff_nchw": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
     "tg_content_loss": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _I, _F, _P, _P, _I, _P]),
     "tg_loss_finalize": (_I, [_P, _P, _P, _P, _I, _P, _P, _P]),
     "tg_dlogit_real": (_I, [_P, _P, _I, _P, _P, _P]),
@@ -110,6 +105,13 @@ _PROTOS = {
     "tg_resample_u8": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "tg_stream_create_cumask": (_I, [_I, C.POINTER(C.c_void_p)]),
     "tg_stream_destroy": (_I, [_P]),
+}
+
+# entry points of the experiments build only (include/tecogan_hip.h, `#ifdef TG_EXPERIMENTS`; csrc/build.sh --experiments)
+_PROTOS_EXPERIMENTS = {
+    "tg_resblock2_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "tg_bn_bwd_fused": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "tg_bn_bwd_fused_max_pixels": (_I, []),
 }
 
 EXPORTED = tuple(_PROTOS.keys())
@@ -136,8 +138,18 @@ def load():
         fn.argtypes = args
     if lib.tg_abi_version() != 1:
         raise TecoganHipError("libtecogan_hip.so ABI version mismatch")
+    if lib.tg_has_experiments():
+        for name, (res, args) in _PROTOS_EXPERIMENTS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
+
+
+def has_experiments():
+    """True when the loaded library is the experiments build (TECOGAN_LIB=.../libtecogan_hip_experiments.so)"""
+    return bool(load().tg_has_experiments())
 
 
 def check(code, what=""):

@@ -1,17 +1,36 @@
 #!/bin/bash
-# Builds libtecogan_hip.so for gfx950 in-tree (next to this script).  Usage: build.sh [extra hipcc flags]
+# Builds libtecogan_hip.so for gfx950 in-tree (next to this script).  Usage: build.sh [--experiments] [extra hipcc flags]
+#   --experiments   also compile the variants that were built, measured slower and rejected (-DTG_EXPERIMENTS: resblock2.hip,
+#                   the 64 x 128 work-list blocks, tg_bn_bwd_fused, tg_conv's stats_mode 3, the item-walking fold, the forced
+#                   trunk tile) into libtecogan_hip_experiments.so - objects under exp/, the default library is untouched.
+#                   Load it with TECOGAN_LIB=.../libtecogan_hip_experiments.so; tests: pytest -m experiments.
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+SRCS="conv_mfma wgrad_mfma wgrad_group warp elementwise fnet resblock convt_mfma conv4s2_mfma runtime conv3_rw vgg conv_rgb rgb_bwd"
+OUT=libtecogan_hip.so
+OBJ=.
+EXTRA=""
+if [ "${1:-}" = "--experiments" ]; then
+  shift
+  SRCS="$SRCS resblock2"
+  OUT=libtecogan_hip_experiments.so
+  OBJ=exp
+  EXTRA="-DTG_EXPERIMENTS"
+  mkdir -p exp
+fi
 pids=""
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-for f in conv_mfma wgrad_mfma wgrad_group warp elementwise fnet resblock convt_mfma conv4s2_mfma runtime conv3_rw vgg conv_rgb rgb_bwd resblock2; do
-  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ ../../include/tecogan_hip.h -nt $f.o ]; then
-    rm -f $f.o   # a failed compile must not leave the previous object behind for the link below
-    $HIPCC $FLAGS "$@" -c $f.hip -o $f.o &
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $EXTRA"
+objs=""
+for f in $SRCS; do
+  o=$OBJ/$f.o
+  objs="$objs $o"
+  if [ ! -f $o ] || [ $f.hip -nt $o ] || [ common.h -nt $o ] || [ ../../include/tecogan_hip.h -nt $o ]; then
+    rm -f $o   # a failed compile must not leave the previous object behind for the link below
+    $HIPCC $FLAGS "$@" -c $f.hip -o $o &
     pids="$pids $!"
   fi
 done
 for p in $pids; do wait $p; done   # (a bare `wait` returns 0 whatever the jobs did)
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libtecogan_hip.so conv_mfma.o wgrad_mfma.o wgrad_group.o warp.o elementwise.o fnet.o resblock.o convt_mfma.o conv4s2_mfma.o runtime.o conv3_rw.o vgg.o conv_rgb.o rgb_bwd.o resblock2.o
-echo "built $(pwd)/libtecogan_hip.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $objs
+echo "built $(pwd)/$OUT"

@@ -12,6 +12,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+// Variants that were built, measured slower and rejected (DESIGN.md "rejected") are compiled only into the experiments
+// library (build.sh --experiments => -DTG_EXPERIMENTS): the default libtecogan_hip.so exports what the default step can reach.
+#ifdef TG_EXPERIMENTS
+constexpr bool kTgExperiments = true;
+#else
+constexpr bool kTgExperiments = false;
+#endif
+
 struct BF16 {};  // tag types: element type is a template tag, never a runtime branch inside kernels
 struct F32 {};
 struct F16 {};   // IEEE half (BASELINE configs[3]: the reference's fp16 autocast path); same layouts as BF16

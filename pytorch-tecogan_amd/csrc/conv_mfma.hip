@@ -497,7 +497,7 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gather_kernel(const ConvK p
           float* o = reinterpret_cast<float*>(p.out) + (size_t)n * p.out_n_stride + (size_t)oy * p.OW + ox;
           for (int e = 0; e < p.c_real; ++e) o[(size_t)e * p.OH * p.OW] = v[e];
         }
-        if (!SLIM && p.stats_mode == 3) {
+        if (kTgExperiments && !SLIM && p.stats_mode == 3) {
           // batch-norm backward sums for the layer this output is the gradient of (TG_MASK_BNZ: `mask` is that layer's
           // pre-normalisation tensor z): sum dy and sum dy * z per channel, of the values as STORED (what tg_bn_bwd_reduce,
           // which this replaces, would read back)
@@ -717,6 +717,7 @@ static int prepare_conv(const tg_conv_desc* d, const void* in, const void* w_pac
     if (d->stats_mode && !stats) return TG_E_BADARG;
   }
   if (d->stats_mode < 0 || d->stats_mode > 3) return TG_E_BADARG;
+  if (!kTgExperiments && (d->stats_mode == 3 || d->mask_mode == TG_MASK_BNZ)) return TG_E_UNSUPPORTED;  // experiments build only
   if ((d->stats_mode == 3) != (d->mask_mode == TG_MASK_BNZ)) return TG_E_BADARG;  // the BN sums need z in the mask slot
   if (d->mask_mode == TG_MASK_BNZ && !mask && check_ptrs) return TG_E_BADARG;
   if (d->stats_mode && (d->stats_groups <= 0 || d->N % d->stats_groups)) return TG_E_BADARG;

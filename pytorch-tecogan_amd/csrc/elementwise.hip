@@ -318,6 +318,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
   }
 }
 
+#ifdef TG_EXPERIMENTS   // measured slower than the two coalesced launches (profiles/r03_l_bn_bwd_fused_ab.log)
 // Batch-norm backward of a SMALL tensor (<= kBfThreads * kBfTrips pixels per group) in ONE launch: workgroup v owns the E
 // channels of 16-byte piece v of every pixel, keeps its share of dy / z (/ yact) in registers between the reduction and the
 // apply, and is the only writer of those channels' dgamma / dbeta.  The two-launch path (tg_bn_bwd_reduce + tg_bn_bwd_apply)
@@ -402,6 +403,8 @@ __global__ __launch_bounds__(kBfThreads) void bn_bwd_fused_kernel(const char* __
     }
   }
 }
+
+#endif  // TG_EXPERIMENTS
 
 template <typename T>
 __global__ void fc_head_fwd_kernel(const char* __restrict__ feat, const float* __restrict__ w,
@@ -568,23 +571,6 @@ __global__ __launch_bounds__(kClThreads) void content_loss_kernel(const float* _
     else if (threadIdx.x == 3) { if (pp_T > 0) atomicAdd(acc + 6, t); }
     else atomicAdd(bias_acc + threadIdx.x, t);  // output-layer bias gradient
   }
-}
-
-__global__ void absdiff_nchw_kernel(const float* __restrict__ a, const long long* __restrict__ a_off,
-                                    const float* __restrict__ b, const long long* __restrict__ b_off,
-                                    float* __restrict__ acc, int nblocks, long long len) {
-  __shared__ float sh[4];
-  const long long total = (long long)nblocks * len;
-  float s = 0.f;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += 256LL * gridDim.x) {
-    const int k = (int)(i / len);
-    const long long e = i - (long long)k * len;
-    s += fabsf(a[a_off[k] + e] - b[b_off[k] + e]);
-  }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(acc, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
 // cfg layout (floats): 0 content_div, 1 warp_div, 2..5 layer_div, 6 EPS, 7 ratio, 8 dt_ratio, 9 use_layerloss,
@@ -757,6 +743,7 @@ extern "C" int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, cons
   return tg_launch_status();
 }
 
+#ifdef TG_EXPERIMENTS
 extern "C" int tg_bn_bwd_fused_max_pixels(void) { return kBfThreads * kBfTrips; }
 
 extern "C" int tg_bn_bwd_fused(int dtype, const void* dy, const void* yact, const void* z, const float* save,
@@ -773,6 +760,8 @@ extern "C" int tg_bn_bwd_fused(int dtype, const void* dy, const void* yact, cons
               (const char*)z, save, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act);
   return tg_launch_status();
 }
+
+#endif  // TG_EXPERIMENTS
 
 extern "C" int tg_fc_head_fwd(int dtype, const void* feat, const float* w, const float* b, float* prob, int N, int HW,
                               int C, int Cp, void* stream) {
@@ -803,15 +792,6 @@ extern "C" int tg_absdiff_sum_multi(int dtype, const int64_t* jobs_dev, int njob
   if (!jobs_dev || njobs <= 0 || blocks_per_job <= 0) return TG_E_BADARG;
   TG_DISPATCH(dtype, absdiff_sum_multi_kernel, dim3((unsigned)blocks_per_job, (unsigned)njobs), dim3(256), (hipStream_t)stream,
               (const long long*)jobs_dev);
-  return tg_launch_status();
-}
-
-extern "C" int tg_absdiff_nchw(const float* a, const int64_t* a_off_dev, const float* b, const int64_t* b_off_dev,
-                               float* acc, int nblocks, int64_t len, void* stream) {
-  if (!a || !b || !a_off_dev || !b_off_dev || !acc || nblocks <= 0 || len <= 0) return TG_E_BADARG;
-  hipLaunchKernelGGL(absdiff_nchw_kernel, dim3(grid_for((long long)nblocks * len, 1024, 512)), dim3(256), 0,
-                     (hipStream_t)stream, a, (const long long*)a_off_dev, b, (const long long*)b_off_dev, acc, nblocks,
-                     (long long)len);
   return tg_launch_status();
 }
 
@@ -953,6 +933,7 @@ extern "C" int tg_reduce_replicas(const float* src, int replicas, int stride, in
 }
 
 extern "C" int tg_abi_version(void) { return TG_ABI_VERSION; }
+extern "C" int tg_has_experiments(void) { return kTgExperiments ? 1 : 0; }
 
 extern "C" const char* tg_error_string(int code) {
   switch (code) {

@@ -379,7 +379,7 @@ int resblock_launch(bool bwd, const void* in, const void* wa, const float* b1, c
   k.N = N; k.H = H; k.W = W; k.skip = add_skip ? 1 : 0;
   k.tiles_x = (W + 7) / 8;
   // 8x4 tiles while 8x8 tiles would leave half of the chip's CUs without a workgroup (TECOGAN_RB_TILE=8/4 forces one)
-  static const int forced = [] { const char* e = getenv("TECOGAN_RB_TILE"); return e ? atoi(e) : 0; }();
+  static const int forced = [] { const char* e = kTgExperiments ? getenv("TECOGAN_RB_TILE") : nullptr; return e ? atoi(e) : 0; }();
   const long long blocks8 = (long long)k.tiles_x * ((H + 7) / 8) * N;
   const int th = forced == 4 || forced == 8 ? forced : (blocks8 <= 128 ? 4 : 8);
   k.tiles_y = (H + th - 1) / th;
@@ -397,7 +397,7 @@ int resblock_launch(bool bwd, const void* in, const void* wa, const float* b1, c
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::kLdsTotal));
     attr_done = true;
   }
-  static const int xcd = [] { const char* e = getenv("TECOGAN_RB_XCD"); return e ? atoi(e) : 0; }();
+  static const int xcd = [] { const char* e = kTgExperiments ? getenv("TECOGAN_RB_XCD") : nullptr; return e ? atoi(e) : 0; }();
   k.xcd_blocks = (xcd && blocks % 8 == 0) ? (int)(blocks / 8) : 0;
   const dim3 grid((unsigned)blocks), blk(512);
   hipStream_t st = (hipStream_t)stream;

@@ -354,20 +354,20 @@ int launch_group(const WgGroupK& k, int nwg, hipStream_t st) {
 template <typename T>
 int dispatch_group(int variant, int tile_w, const WgGroupK& k, int nwg, hipStream_t st) {
   if (variant == TG_WGROUP_C3) return tile_w == 32 ? launch_group<T, 32, 1, 3>(k, nwg, st) : launch_group<T, 16, 1, 3>(k, nwg, st);
+#ifdef TG_EXPERIMENTS   // 64 x 128 channel blocks: 1.1-2.5x slower (spills), profiles/r03_m_wgrad_b128.log
   if (variant == TG_WGROUP_C3_B128)
     return tile_w == 32 ? launch_group<T, 32, 1, 3, 2>(k, nwg, st) : launch_group<T, 16, 1, 3, 2>(k, nwg, st);
-  if (variant == TG_WGROUP_CT) return launch_group<T, 16, 2, 3>(k, nwg, st);
   if (variant == TG_WGROUP_CT_B128) return launch_group<T, 16, 2, 3, 2>(k, nwg, st);
+#endif
+  if (variant == TG_WGROUP_CT) return launch_group<T, 16, 2, 3>(k, nwg, st);
   return launch_group<T, 16, 2, 4>(k, nwg, st);
 }
 
 }  // namespace
 
-extern "C" int64_t tg_wgrad_group_slot_floats(void) { return 9 * 64 * 64 + 64; }
-
 extern "C" int64_t tg_wgrad_group_slot_floats_v(int variant) {
   if (variant == TG_WGROUP_C3 || variant == TG_WGROUP_CT) return 9 * 64 * 64 + 64;
-  if (variant == TG_WGROUP_C3_B128 || variant == TG_WGROUP_CT_B128) return 9 * 64 * 128 + 128;
+  if (kTgExperiments && (variant == TG_WGROUP_C3_B128 || variant == TG_WGROUP_CT_B128)) return 9 * 64 * 128 + 128;
   if (variant == TG_WGROUP_C4S2) return 16 * 64 * 64 + 64;
   return TG_E_BADARG;
 }
@@ -378,6 +378,7 @@ int group_launch(int dtype, int variant, int tile_w, const int64_t* jobs_dev, in
   if (!jobs_dev || !slab || njobs <= 0 || units_total <= 0 || workgroups <= 0) return TG_E_BADARG;
   if (!tg_aligned16(slab)) return TG_E_ALIGN;
   if (dtype != TG_BF16 && dtype != TG_F16) return TG_E_UNSUPPORTED;
+  if (!kTgExperiments && (variant == TG_WGROUP_C3_B128 || variant == TG_WGROUP_CT_B128)) return TG_E_UNSUPPORTED;
   if (variant == TG_WGROUP_C3 || variant == TG_WGROUP_C3_B128) {
     if (tile_w != 32 && tile_w != 16) return TG_E_UNSUPPORTED;
   } else if (variant == TG_WGROUP_CT || variant == TG_WGROUP_C4S2 || variant == TG_WGROUP_CT_B128) {
@@ -396,11 +397,6 @@ int group_launch(int dtype, int variant, int tile_w, const int64_t* jobs_dev, in
   return dtype == TG_BF16 ? dispatch_group<BF16>(variant, tile_w, k, nwg, st) : dispatch_group<F16>(variant, tile_w, k, nwg, st);
 }
 }  // namespace
-
-extern "C" int tg_wgrad_group(int dtype, int tile_w, const int64_t* jobs_dev, int njobs, int units_total, int workgroups,
-                              float* slab, void* stream) {
-  return group_launch(dtype, TG_WGROUP_C3, tile_w, jobs_dev, njobs, units_total, workgroups, slab, stream);
-}
 
 extern "C" int tg_wgrad_group_v(int dtype, int variant, int tile_w, const int64_t* jobs_dev, int njobs, int units_total,
                                 int workgroups, float* slab, void* stream) {

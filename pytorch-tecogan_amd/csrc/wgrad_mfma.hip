@@ -678,7 +678,8 @@ extern "C" int tg_wgrad_fold_items(const int64_t* jobs_dev, int njobs, int nitem
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kFold2Lds));
     attr_done = true;
   }
-  static const int cap = [] { const char* e = getenv("TECOGAN_FOLD_WGS"); return e ? atoi(e) : 0; }();   // 0: one workgroup per item
+  // (experiments build: TECOGAN_FOLD_WGS makes a smaller grid walk the items - nothing to gain, profiles/r03_r_rw_dma_ab.log)
+  static const int cap = [] { const char* e = kTgExperiments ? getenv("TECOGAN_FOLD_WGS") : nullptr; return e ? atoi(e) : 0; }();   // 0: one workgroup per item
   const int grid = cap > 0 && cap < nitems ? cap : nitems;
   hipLaunchKernelGGL(wgrad_fold_items_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream,
                      (const long long*)jobs_dev, njobs, nitems);

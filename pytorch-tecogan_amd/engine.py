@@ -10,13 +10,13 @@ Reference behaviour reproduced (file:line into the reference):
   detach structure         code/train.py:90,108,199  (no gradient through warp / recurrence / from D into G), hence the
                            T generator passes are independent in backward and are run as ONE batch of T*B samples.
 """
-import os
 from collections import OrderedDict
 
 import torch
 
 from . import _lib as L
 from . import kernels as K
+from . import tuning
 from .kernels import ConvSpec, pad32
 
 
@@ -112,13 +112,29 @@ class ShapeSets:
             self.sets.pop(shape, None)
 
 
-_SUBPIX_CT = os.environ.get("TECOGAN_SUBPIX_CT", "1") != "0"
-_FAST_C4S2 = os.environ.get("TECOGAN_FAST_C4S2", "1") != "0"
-_RGB_OUT = os.environ.get("TECOGAN_RGB_OUT", "1") != "0"
-# replica blocks of the batch-norm accumulators (include/tecogan_hip.h, tg_bn_apply): a power of two; 1 = one shared block
-STATS_R = int(os.environ.get("TECOGAN_STATS_REPLICAS", "4"))
-if STATS_R < 1 or STATS_R & (STATS_R - 1):
-    raise ValueError("TECOGAN_STATS_REPLICAS must be a power of two")
+def release_plans(engine):
+    """Forgets every launch plan of `engine` that is tied to buffer ADDRESSES of a buffer set (weight-gradient work lists and
+    their slabs, the output layer's backward plan, fold tables) and lifts the post-capture freeze.  TecoGANStep.close() calls it:
+    the step's buffer sets are dropped there, a replacement step allocates new addresses, and plans keyed by the old ones would
+    miss under `ws.frozen` ("new wgrad shape after graph capture") - and their slabs (~25 MB per launch) would never be freed."""
+    engine.ws.frozen = False
+    for name in ("hr_list", "trunk_group", "res_group", "wlist"):
+        lst = getattr(engine, name, None)
+        if lst is not None:
+            lst.cache.clear()
+            lst.items = []
+    if getattr(engine, "_rgb_cache", None) is not None:
+        engine._rgb_cache.clear()
+    fin = getattr(engine, "finalizer", None)
+    if fin is not None:
+        fin.tables.clear()
+    convs = engine.convs.values() if isinstance(engine.convs, dict) else engine.convs
+    for c in convs:
+        c._desc = {k: v for k, v in c._desc.items() if k[0] != "w"}   # (shape-keyed conv descriptors hold no addresses)
+        c.fin_job = None
+
+
+TU = tuning.current   # every scheduling / routing knob comes from this object (tuning.KNOBS: defaults + evidence)
 
 
 class Conv:
@@ -126,6 +142,7 @@ class Conv:
 
     def __init__(self, flat, wname, bname, spec, dtype_t, ws, need_dgrad=True, tile=L.TILE_AUTO):
         self.flat, self.spec, self.dt, self.ws = flat, spec, dtype_t, ws
+        self.tu = TU()
         self.tg = K.tg_dtype(dtype_t)
         self.w = flat.view(flat.p, wname)
         self.gw = flat.view(flat.g, wname) if flat.g is not None else None
@@ -161,7 +178,7 @@ class Conv:
         N, H, W, _ = x.shape
         OH, OW = self.spec.out_hw(H, W)
         if self.spec.kind == "ct" and self.cout_p % 64 == 0 and res is None and stats is None and nchw is None and \
-                act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and self.tile == L.TILE_AUTO and _SUBPIX_CT and \
+                act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and self.tile == L.TILE_AUTO and self.tu.subpix_ct and \
                 N * ((H + 7) // 8) * ((W + 15) // 16) * (self.cout_p // 64) >= 128:
             # one sub-pixel launch for all four classes (csrc/convt_mfma.hip).  Measured (tools/mb_convt.py): 128->128 on
             # 4x64x64 14.4 vs 24.5 us; with only 32 workgroups (64->64 on 4x32x32) the four-class launch wins, 6.9 vs 9.8 us
@@ -169,13 +186,13 @@ class Conv:
             K.convt_fwd(x, self.wf, self.bias, out, act)
             return
         if self.spec.kind == "c4s2" and self.cout_p % 64 == 0 and res is None and nchw is None and act == L.ACT_NONE and \
-                self.tile == L.TILE_AUTO and _FAST_C4S2 and H % 2 == 0 and W % 2 == 0 and \
+                self.tile == L.TILE_AUTO and self.tu.fast_c4s2 and H % 2 == 0 and W % 2 == 0 and \
                 (stats is None or K.stats_replicas_for(N * OH * OW) == 1):
             self.last_desc = "c4s2"  # compile-time-tap stride-2 kernel (csrc/conv4s2_mfma.hip)
             K.conv4s2_fwd(x, self.wf, self.bias, out, stats, groups, stats_replicas=stats_r)
             return
         if self.spec.kind == "c3" and nchw is not None and self.cin_p == 64 and self.spec.cout <= 4 and res is None and \
-                stats is None and act in (L.ACT_NONE, L.ACT_SIGMOID) and self.tile == L.TILE_AUTO and _RGB_OUT and \
+                stats is None and act in (L.ACT_NONE, L.ACT_SIGMOID) and self.tile == L.TILE_AUTO and self.tu.rgb_out and \
                 self.dt in (torch.bfloat16, torch.float16):
             self.last_desc = "rgb"  # one 16-row MFMA tile + fp32 NCHW store (csrc/conv_rgb.hip)
             K.conv3x3_rgb(x, self.wf, self.bias, nchw[0], nchw[1], nchw[2], nchw[3], act)
@@ -237,12 +254,12 @@ class Conv:
             K.conv(d, dout, self.wb, out, res=res, mask=z, stats=red)
             return
         if self.spec.kind == "ct" and self.cin_p % 64 == 0 and mask is None and res is None and bias_grad_of is None and \
-                _FAST_C4S2 and OH == 2 * H and OW == 2 * W:
+                self.tu.fast_c4s2 and OH == 2 * H and OW == 2 * W:
             self.last_desc = "ctd"  # 3x3-window stride-2 gather (csrc/conv4s2_mfma.hip, KS = 3)
             K.convt_dgrad(dout, self.wb, out)
             return
         if self.spec.kind == "c4s2" and self.cin_p % 64 == 0 and res is None and bias_grad_of is None and \
-                _FAST_C4S2 and H == 2 * OH and W == 2 * OW and N * ((OH + 7) // 8) * ((OW + 15) // 16) * (self.cin_p // 64) >= 64:
+                self.tu.fast_c4s2 and H == 2 * OH and W == 2 * OW and N * ((OH + 7) // 8) * ((OW + 15) // 16) * (self.cin_p // 64) >= 64:
             # four-class sub-pixel launch (csrc/convt_mfma.hip, PAT 1).  Measured (tools/mb_c4s2_dgrad.py, 24 samples):
             # 64->128 @64x64 15.3 vs 29.0 us, 128->128 @32x32 14.6 vs 19.1, masked 64->64 @128x128 38.1 vs 45.3; launches of
             # fewer than 64 workgroups (9.8 vs 7.0) stay on tg_conv
@@ -287,7 +304,7 @@ class Conv:
         X, Y = (x_in, dout) if x_is_in else (dout, x_in)
         N, XH, XW, cx = X.shape
         _, YH, YW, cy = Y.shape
-        key = ("w", N, XH, XW, YH, YW, bias_sum)
+        key = ("w", N, XH, XW, YH, YW, bias_sum, self.persist_wgs)
         ent = self._desc.get(key)
         if ent is None:
             nsplit, tpw = K.wgrad_plan(N, YH, YW, S, len(taps), cx, cy, cap=self.persist_wgs)
@@ -324,7 +341,8 @@ class WgradGroup:
         items, self.items = self.items, []
         if not items:
             return
-        key = tuple((id(c), x.data_ptr(), y.data_ptr(), tuple(x.shape), tuple(y.shape), b) for c, x, y, b in items)
+        key = (items[0][0].persist_wgs,) + tuple((id(c), x.data_ptr(), y.data_ptr(), tuple(x.shape), tuple(y.shape), b)
+                                                 for c, x, y, b in items)
         ent = self.cache.get(key)
         if ent is None:
             c0 = items[0][0]
@@ -376,7 +394,13 @@ class WgradList:
     # of a two-waves-per-SIMD workgroup (139-157 VGPRs spilled for the 3x3 kind, 67 for the conv-transpose kind): c32 + c30 of the
     # generator 89 -> 230 us at 160 workgroups, ct4 79 -> 87 us, the discriminator's stage 2 62 -> 126 us
     # (profiles/r03_m_wgrad_b128.log; the 64 x 64 lists run these layers at 700-1050 TFLOP/s alone).
-    WIDE_MIN_PIXELS = int(os.environ.get("TECOGAN_WGRAD_B128_PIXELS", "0"))
+
+    @staticmethod
+    def wide_min_pixels():
+        n = TU().wgrad_b128_pixels
+        if n > 0:
+            tuning.need_experiments("wgrad_b128_pixels")
+        return n
 
     def __init__(self, cap):
         self.items, self.cache, self.cap = [], {}, cap
@@ -385,9 +409,9 @@ class WgradList:
     def variant_of(cls, conv, x_in, dout):
         """the work list (L.WGROUP_*) a layer's weight gradient runs in"""
         v = cls.VARIANT[conv.spec.kind]
-        if v in cls.WIDE and cls.WIDE_MIN_PIXELS > 0:
+        if v in cls.WIDE and cls.wide_min_pixels() > 0:
             y = dout if conv.spec.wgrad_info()[0] else x_in
-            if y.shape[3] % 128 == 0 and y.shape[0] * y.shape[1] * y.shape[2] >= cls.WIDE_MIN_PIXELS:
+            if y.shape[3] % 128 == 0 and y.shape[0] * y.shape[1] * y.shape[2] >= cls.wide_min_pixels():
                 return cls.WIDE[v]
         return v
 
@@ -449,7 +473,8 @@ class WgradList:
             self._launch([it for it, v in zip(now, var) if v == variant], variant)
 
     def _launch(self, items, variant):
-        key = tuple((id(c), x.data_ptr(), y.data_ptr(), tuple(x.shape), tuple(y.shape), b) for c, x, y, b in items)
+        key = (self.cap, variant) + tuple((id(c), x.data_ptr(), y.data_ptr(), tuple(x.shape), tuple(y.shape), b)
+                                          for c, x, y, b in items)
         ent = self.cache.get(key)
         if ent is None:
             if items[0][0].ws.frozen:
@@ -490,10 +515,11 @@ class WgradList:
 
 def _wgrad_lists():
     """TECOGAN_WGRAD_LIST=0: the per-layer / same-shape launches (tg_wgrad, tg_wgrad_multi) instead of tg_wgrad_group"""
-    return os.environ.get("TECOGAN_WGRAD_LIST", "1") != "0"
+    return TU().wgrad_list
 
 
-_PACK_BLOCKS = int(os.environ.get("TECOGAN_PACK_BLOCKS", "48"))   # workgroups per (conv, packing) job of the repack launch (16 / 48 / 96: D update 52 / 42 / 38 us alone, step 4.186 / 4.177 / 4.182 ms)
+# (workgroups per (conv, packing) job of the repack launch, TECOGAN_PACK_BLOCKS: 16 / 48 / 96: D update 52 / 42 / 38 us alone, step
+# 4.186 / 4.177 / 4.182 ms)
 
 
 class Repacker:
@@ -509,36 +535,36 @@ class Repacker:
                              c.spec.nslots])
         self.jobs = torch.tensor(jobs, dtype=torch.int64, device=device)
         self.n, self.tg = len(jobs), K.tg_dtype(dtype_t)
+        self.blocks = TU().pack_blocks
 
     def run(self):
-        L.check(L.load().tg_pack_conv_weights_multi(self.tg, self.jobs.data_ptr(), self.n, _PACK_BLOCKS,
+        L.check(L.load().tg_pack_conv_weights_multi(self.tg, self.jobs.data_ptr(), self.n, self.blocks,
                                                     torch.cuda.current_stream().cuda_stream), "tg_pack_conv_weights_multi")
 
 
 def _defer_finalize():
     """one fold launch per network (every slab survives until the end of the backward pass) instead of one per conv"""
-    return os.environ.get("TECOGAN_DEFER_FINALIZE", "1") != "0"
+    return TU().defer_finalize
 
 
-_FOLD_ITEMS = os.environ.get("TECOGAN_FOLD_ITEMS", "1") != "0"
 # Two residual blocks per launch on the recurrent pass (csrc/resblock2.hip: halo recomputed, no cross-workgroup traffic, results
 # bit-identical): built, tested and measured SLOWER - 21 MFMA pixel tiles instead of 2 x 6 put 1.75x the matrix and LDS work on
 # the workgroup's serial path, which costs more than the launch boundary and patch round trip it saves: a generator pass 0.200 ->
 # 0.219 ms alone, the chain 1.56 -> 1.71 ms, the step 4.20 -> 4.34 ms (profiles/r03_t_resblock2_ab.log).  Off by default.
-_RB_PAIR = os.environ.get("TECOGAN_RB_PAIR", "0") == "1"
+# (TECOGAN_RB_PAIR: experiments build only)
 # Batch-norm backward sums in the epilogue of the input-gradient launch that produces dy (9 of the 17 BN layers per pass):
 # built, parity-tested (tests/test_kernels_gpu.py::test_bn_backward_sums_in_the_dgrad_epilogue) and measured SLOWER in the step
 # - 18 tg_bn_bwd_reduce launches fewer, but the sums need the general conv epilogue (the plain launch takes the slim one) and
 # stage 2 leaves the register-weights kernel: D real 1.589 -> 1.574 ms alone, step 4.43 -> 4.46 ms on one box
 # (profiles/r03_g_bn_fuse_ab.log).  Off by default.
-_BN_FUSE = os.environ.get("TECOGAN_BN_FUSE", "0") == "1"
+# (TECOGAN_BN_FUSE: experiments build only)
 
 
 # Backward pass of a batch norm on a small tensor (the discriminator's 16x16 ... 4x4 layers: 7 of 17 per pass) as one launch
 # (tg_bn_bwd_fused) instead of tg_bn_bwd_reduce + tg_bn_bwd_apply: built, parity-tested and measured SLOWER - a workgroup per
 # 16-byte channel piece reads 16 B of every 256-byte pixel row (64 cache lines per wave-load; 16 workgroups instead of ~50):
 # d_fake_bwd alone 0.936 -> 0.963 ms, D real 1.596 -> 1.608, step 4.405 -> 4.42 ms (profiles/r03_l_bn_bwd_fused_ab.log).  Off.
-_BN_BWD_FUSED = os.environ.get("TECOGAN_BN_BWD_FUSED", "0") == "1"
+# (TECOGAN_BN_BWD_FUSED: experiments build only)
 
 
 def fold_items(jobs):
@@ -559,6 +585,7 @@ class Finalizer:
 
     def __init__(self, convs, device):
         self.convs, self.dev, self.tables = convs, device, {}
+        self.fold_items = TU().fold_items
         for c in convs:
             c.defer_finalize = True
 
@@ -583,7 +610,7 @@ class Finalizer:
             rows, n = fold_items(jobs)
             ent = self.tables[key] = (torch.tensor(rows, dtype=torch.int64, device=self.dev), n, max(j[5] for j in jobs))
         table, nitems, max_taps = ent
-        if _FOLD_ITEMS:  # one workgroup per (tile, 8-slab chunk) item of any job
+        if self.fold_items:  # one workgroup per (tile, 8-slab chunk) item of any job
             L.check(L.load().tg_wgrad_fold_items(table.data_ptr(), len(jobs), nitems, max_taps,
                                                  torch.cuda.current_stream().cuda_stream), "tg_wgrad_fold_items")
         else:
@@ -603,7 +630,10 @@ class BatchNorm:
             prefix + ".num_batches_tracked"]
         # accumulators in R replica blocks: [half][R][2][Cp] when the halves run as separate launches, [R][2 groups][2][Cp]
         # for a whole-batch launch (zeroed once per step with the rest of the arena)
-        self.R = STATS_R
+        self.R = TU().stats_replicas
+        self.bwd_fused = TU().bn_bwd_fused
+        if self.bwd_fused:
+            tuning.need_experiments("bn_bwd_fused")
         self.stats = arena.take(2 * self.R * 2 * self.Cp)
         self.red = arena.take(2 * self.R * 2 * self.Cp)
         self.save = torch.empty(2, 2, self.Cp, device=flat.device)
@@ -636,7 +666,7 @@ class BatchNorm:
         N, H, W, C_ = z.shape
         save, red = (self.save if half is None else self.save[half]), self._slot(self.red, half)
         g = groups if half is None else 1
-        if not reduced and _BN_BWD_FUSED and (N // g) * H * W <= K.bn_bwd_fused_max_pixels():
+        if not reduced and self.bwd_fused and (N // g) * H * W <= K.bn_bwd_fused_max_pixels():
             K.bn_bwd_fused(dy, yact, z, save, self.gamma, dz, self.dgamma, self.dbeta, N, H * W, C_, g, act)
             return
         if not reduced:
@@ -706,21 +736,24 @@ class GeneratorEngine:
         self.shape = None
         self.sets = ShapeSets()
         for c in self.convs:
-            c.persist_wgs, c.persist_rw = K.persist_wgs("G"), int(os.environ.get("TECOGAN_PERSIST_RW_G", "0"))
+            c.persist_wgs, c.persist_rw = K.persist_wgs("G"), TU().persist_rw_g
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
-        self.trunk_group = WgradGroup() if os.environ.get("TECOGAN_WGRAD_GROUPS", "1") != "0" else None
+        self.trunk_group = WgradGroup() if TU().wgrad_groups else None
         # 16-bit modes: ONE work-list launch for the plain 3x3 layers of the up-sampling stage and one for the trunk
         self.hr_list = None
         if self.finalizer is not None and self.trunk_group is not None and _wgrad_lists() and \
                 dtype_t in (torch.bfloat16, torch.float16):
             self.hr_list, self.trunk_group = WgradList(K.persist_wgs("G")), WgradList(K.persist_wgs("G"))
         self._rgb_cache = {}
-        self.fused_rb = dtype_t in (torch.bfloat16, torch.float16) and os.environ.get("TECOGAN_FUSED_RESBLOCK", "1") != "0"
+        self.fused_rb = dtype_t in (torch.bfloat16, torch.float16) and TU().fused_resblock
         # the fused input-gradient launch (tg_resblock_bwd) is numerically identical and was measured EQUAL in time on the
         # batched backward (15 x 28.2 us vs 30 x 14.9 us at 40 samples: 640 workgroups each re-read 147 KB of weights), so
         # it stays an option
-        self.fused_rb_bwd = self.fused_rb and os.environ.get("TECOGAN_FUSED_RESBLOCK_BWD", "0") == "1"
+        self.fused_rb_bwd = self.fused_rb and TU().fused_resblock_bwd
+        self.rb_pair = self.fused_rb and TU().rb_pair
+        if self.rb_pair:
+            tuning.need_experiments("rb_pair")
 
     def repack(self):
         self.repacker.run()
@@ -738,7 +771,7 @@ class GeneratorEngine:
         """the output layer's backward as ONE launch (tg_conv3x3_rgb_bwd, a compact [..., 4] dpre): 16-bit modes with the deferred
         fold (TECOGAN_RGB_BWD=0: the generic input-gradient launch + the layer's place in the weight-gradient work list)"""
         return self.dt in (torch.bfloat16, torch.float16) and self.finalizer is not None and self.out_ch == 3 and \
-            os.environ.get("TECOGAN_RGB_BWD", "1") != "0"
+            TU().rgb_bwd
 
     def _rgb_bwd(self, x, dpre4, dx):
         c = self.cout
@@ -747,7 +780,7 @@ class GeneratorEngine:
         if ent is None:
             if self.ws.frozen:
                 raise L.TecoganHipError("new output-layer backward shape after graph capture")
-            cap = int(os.environ.get("TECOGAN_RGB_BWD_WGS", "256"))   # 160 / 256 / 512 / 1024: 4.37 4.37 4.39 4.41 ms per step
+            cap = TU().rgb_bwd_wgs   # 160 / 256 / 512 / 1024: 4.37 4.37 4.39 4.41 ms per step
             nwg = K.rgb_bwd_workgroups(x.shape[0], x.shape[1], x.shape[2], cap)
             slot = int(L.load().tg_conv3x3_rgb_bwd_slot_floats())
             slab = torch.empty(nwg * slot, dtype=torch.float32, device=x.device)
@@ -780,7 +813,7 @@ class GeneratorEngine:
         sl = slice(s0, s0 + B)
         self.conv0.fwd(a["in0"][sl], a["a"][0][sl], act=L.ACT_RELU)
         # small launches (the recurrent pass: <= 128 tiles of 8 x 8): TWO blocks per launch, halo recomputed (csrc/resblock2.hip)
-        pair = self.fused_rb and _RB_PAIR and B * ((a["in0"].shape[1] + 7) // 8) * ((a["in0"].shape[2] + 7) // 8) <= 128
+        pair = self.rb_pair and B * ((a["in0"].shape[1] + 7) // 8) * ((a["in0"].shape[2] + 7) // 8) <= 128
         skip_next = False
         for i, (c1, c2) in enumerate(self.rb):
             if skip_next:
@@ -1196,7 +1229,7 @@ class DiscriminatorEngine:
     def __init__(self, flat, bufs, dtype_t, resblocks=4, ch=128):
         self.flat, self.dt, self.nrb, self.ch = flat, dtype_t, resblocks, ch
         self.ws = Workspace(flat.device)
-        self.arena = Arena(32 * 1024 * STATS_R, flat.device)
+        self.arena = Arena(32 * 1024 * TU().stats_replicas, flat.device)
         mk = lambda w, b, kind, ci, co, dg=True: Conv(flat, w, b, ConvSpec(kind, ci, co), dtype_t, self.ws, need_dgrad=dg)
         bn = lambda p, c: BatchNorm(flat, p, c, bufs, dtype_t, self.arena)
         self.conv0 = mk("conv.0.weight", "conv.0.bias", "c3", 27, 64, dg=False)
@@ -1215,26 +1248,30 @@ class DiscriminatorEngine:
                                                                              self.res[st] for c in (c1, c2)]
         self.shape = None
         for c in self.convs:
-            c.persist_wgs, c.persist_rw = K.persist_wgs("D"), int(os.environ.get("TECOGAN_PERSIST_RW_D", "0"))
+            c.persist_wgs, c.persist_rw = K.persist_wgs("D"), TU().persist_rw_d
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
-        self.res_group = WgradGroup() if os.environ.get("TECOGAN_WGRAD_GROUPS", "1") != "0" else None
+        self.res_group = WgradGroup() if TU().wgrad_groups else None
         if self.finalizer is not None and self.res_group is not None and _wgrad_lists() and \
                 dtype_t in (torch.bfloat16, torch.float16):
             self.res_group = WgradList(K.persist_wgs("D"))
         # workgroups of the persistent launches per half: the REAL half runs beside the latency-bound generator chain and
         # lane B has slack there (it waits for the chain's last frame), the fake half is on the step's critical path
         self.cap = {None: K.persist_wgs("D"), 1: K.persist_wgs("D"),
-                    0: int(os.environ.get("TECOGAN_PERSIST_WGS_DREAL", K.persist_wgs("D")))}
+                    0: TU().cap_dreal_default()}
+        self.rw_extra_real = TU().rw_extra_dreal or ""
+        self.rw_dhalf_off = TU().rw_dhalf_off
+        self.bn_fuse = TU().bn_fuse
+        if self.bn_fuse:
+            tuning.need_experiments("bn_fuse")
 
     # launch classes of kernels.rw_eligible added for the REAL half only (TecoGANStep sets "s1" for chain-bound steps: the real
     # half runs beside the chain with slack, and its stage-1 convs are better neighbours as capped persistent launches: 4.194 ->
     # 4.18 ms/step; for the fake half - on the critical path - the same routing costs 0.07 ms)
-    rw_extra_real = os.environ.get("TECOGAN_RW_EXTRA_DREAL", "")
 
     def _set_cap(self, half):
         cap = self.cap[half]
-        off = os.environ.get("TECOGAN_RW_DHALF_OFF", "")   # "1": the fake half's convs on tg_conv, "0": the real half's, "01": both
+        off = self.rw_dhalf_off   # "1": the fake half's convs on tg_conv, "0": the real half's, "01": both
         for c in self.convs:
             c.persist_wgs = cap
             c.rw_off = half is not None and str(half) in off
@@ -1365,7 +1402,7 @@ class DiscriminatorEngine:
                     wg(c1, net_in, d_h, True)
                     # d_in is the output gradient of the previous block's BatchNorm (no activation): its backward sums ride
                     # in this launch's epilogue instead of a tg_bn_bwd_reduce launch
-                    fused = _BN_FUSE and j > 0
+                    fused = self.bn_fuse and j > 0
                     if fused:
                         bnp = self.res[k][j - 1][2]
                         c1.dgrad(d_h, d_in, res=d_net, bn_sums=(bnp.red_slot(half), a["r"][k][j - 1],

@@ -4,8 +4,6 @@ import ctypes as C
 from dataclasses import dataclass, field
 from typing import List, Tuple
 
-import os
-
 import torch
 
 from . import _lib as L
@@ -25,8 +23,7 @@ def tg_dtype(dt):
     raise L.TecoganHipError(f"unsupported element type {dt}")
 
 
-_RW = os.environ.get("TECOGAN_RW", "1")  # 0: never, 1: where it measured faster (rw_eligible), all: every shape it takes
-_RW_EXTRA_ENV = os.environ.get("TECOGAN_RW_EXTRA", "trunk,c30,m128")  # launch classes routed there for the STEP's sake (rw_eligible)
+from . import tuning
 
 
 def _stream():
@@ -183,7 +180,7 @@ def conv3x3_rw(x, w_packed, out, flip=False, bias=None, res=None, mask=None, mas
     L.check(L.load().tg_conv3x3_rw(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(res), _ptr(mask), _ptr(out),
                                    _ptr(stats), N, H, W, cin, out.shape[3], int(flip), act,
                                    mask_mode if mask is not None else L.MASK_NONE, stats_mode, groups, stats_replicas,
-                                   max_workgroups or PERSIST_WGS, _stream()), "tg_conv3x3_rw")
+                                   max_workgroups or persist_wgs(None), _stream()), "tg_conv3x3_rw")
 
 
 def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False, extra="", dgrad=False):
@@ -196,6 +193,8 @@ def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False, extra="", dgrad=F
     there although tg_conv wins or ties alone (TECOGAN_RW_EXTRA, profiles/r03_r_rw_dma_ab.log): the trunk's input-gradients at 40 x
     32 x 32 (4.23 -> 4.205 ms/step), 128 -> 64 input-gradients (c30: -> 4.204) and masked 128 -> 128 ones (c32, with both: 4.195);
     the discriminator's stage 1 (64 -> 64 @64x64 N=12: 4.30) and stage 3 (16 x 16: 4.32) stay on tg_conv."""
+    TU = tuning.current()
+    _RW, _RW_EXTRA_ENV = TU.rw, TU.rw_extra   # 0: never, 1: where it measured faster, all | classes routed there for the STEP's sake
     if _RW == "0" or dtype_t not in (torch.bfloat16, torch.float16) or cin_p not in (64, 128) or cout_p % 64:
         return False
     if _RW == "all":
@@ -279,7 +278,7 @@ def wgrad_nsplit(N, YH, YW, S, blocks=1):
 # 0.6 ms at the end of every step waiting for it (tools/lane_ends.py).  160 leaves 96 CUs to the neighbour: the persistent
 # launches lose ~10 %, the step 5.06 -> 4.71 ms (sweep 256/240/224/208/192/176/160/144/128/96: 5.06 5.05 4.91 4.88 4.75 4.79 4.71
 # 4.84 4.89 5.27, profiles/r02_q_persist_wgs_sweep.log).  Per network: TECOGAN_PERSIST_WGS_G / _D (else TECOGAN_PERSIST_WGS).
-PERSIST_WGS = int(os.environ.get("TECOGAN_PERSIST_WGS", "160"))
+PERSIST_WGS = 160   # the documented default (tuning.KNOBS); the live value is tuning.current().cap(None)
 
 
 def persist_wgs(net):
@@ -287,10 +286,7 @@ def persist_wgs(net):
     160/192/256 -> 4.98 4.62 4.64 4.63 4.65 4.72 4.88 4.95 ms; with D = 128: G = 128/144/160/168/176/192 -> 4.89 4.78 4.65 4.73 4.75
     4.76 (the discriminator's persistent launches - weight gradients, stage-2 convs - run beside the latency-bound chain and G
     backward tail and should hold even fewer CUs)"""
-    if not net:
-        return PERSIST_WGS
-    default = {"G": PERSIST_WGS, "D": min(PERSIST_WGS, 96) if "TECOGAN_PERSIST_WGS" not in os.environ else PERSIST_WGS}
-    return int(os.environ.get(f"TECOGAN_PERSIST_WGS_{net}", default.get(net, PERSIST_WGS)))
+    return tuning.current().cap(net or None)
 
 
 def persist_wgs_g_for(lr_pixels):
@@ -299,9 +295,7 @@ def persist_wgs_g_for(lr_pixels):
     lane A became ~70 us shorter and 144 was best for configs[1] (G = 120/136/144/152/160 -> 4.39 4.33 4.33 4.36 4.38 ms); once the
     register-weights kernel stopped spilling, lane B got shorter too and the optimum moved back: 136/144/152/160 -> 4.277 4.264 4.249
     4.24 ms.  The configs[3] shard always preferred 160 (10.34 vs 10.47 ms)."""
-    if "TECOGAN_PERSIST_WGS" in os.environ or "TECOGAN_PERSIST_WGS_G" in os.environ:
-        return None
-    return PERSIST_WGS
+    return tuning.current().cap_g_for(lr_pixels)
 
 
 def persist_wgs_dreal_for(lr_pixels):
@@ -310,9 +304,7 @@ def persist_wgs_dreal_for(lr_pixels):
     workgroups than the fake half's 96 it loads the memory system less while the chain runs and still ends before the chain does -
     96 -> 80: 4.36 -> 4.32 ms/step; after the register-weights change 80 / 72 / 64 = 4.238 4.226 4.218 (48: +0.18 ms, the real half
     becomes the long pole; 72 keeps a margin).  The configs[3] shard is not chain-bound: no gain there."""
-    if any(k in os.environ for k in ("TECOGAN_PERSIST_WGS", "TECOGAN_PERSIST_WGS_D", "TECOGAN_PERSIST_WGS_DREAL")):
-        return None
-    return 72 if lr_pixels <= 4096 else None
+    return tuning.current().cap_dreal_for(lr_pixels)
 
 
 def wgrad_plan(N, YH, YW, S, ntaps, cx_p, cy_p, cap=None):
@@ -323,8 +315,8 @@ def wgrad_plan(N, YH, YW, S, ntaps, cx_p, cy_p, cap=None):
     tiles = N * ((YW + tw - 1) // tw) * ((YH + th - 1) // th)
     blocks = wgrad_blocks(ntaps, cx_p, cy_p)
     if ntaps == 9 and tiles <= 512 and blocks == 1:  # measured: 21 vs 25 us on the 64-channel 32x32 trunk layers (N=40);
-        return max(1, min(tiles, (cap or PERSIST_WGS) // 3)), 3       # slower on every larger layer (tools/microbench.py wgrad)
-    return max(1, min(tiles, (cap or PERSIST_WGS) // max(1, blocks))), 0
+        return max(1, min(tiles, (cap or persist_wgs(None)) // 3)), 3       # slower on every larger layer (tools/microbench.py wgrad)
+    return max(1, min(tiles, (cap or persist_wgs(None)) // max(1, blocks))), 0
 
 
 def wgrad_blocks(ntaps, cx_p, cy_p):

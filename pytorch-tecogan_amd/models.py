@@ -6,7 +6,6 @@ the HIP library the modules raise.  The first forward / training step after a de
 views of one flat fp32 buffer per network (this is what lets one Adam launch and one RCCL all-reduce cover a network).
 """
 import math
-import os
 from collections import OrderedDict
 
 import torch
@@ -15,6 +14,7 @@ import torch.nn as nn
 from . import _lib as L
 from . import engine as E
 from . import kernels as K
+from . import tuning
 from .step import RecurrentGenerator
 
 
@@ -22,7 +22,7 @@ def compute_dtype(args=None):
     """bf16 by default (BASELINE config 2); TECOGAN_DTYPE / args.tg_dtype = 'fp32' selects the fp32 parity mode, 'fp16' the
     reference's own autocast element type (BASELINE configs[3]) - the training step then runs with dynamic loss scaling
     (step.TecoGANStep, torch.cuda.amp.GradScaler semantics of code/train.py:9,335-342)."""
-    name = getattr(args, "tg_dtype", None) or os.environ.get("TECOGAN_DTYPE", "bf16")
+    name = getattr(args, "tg_dtype", None) or tuning.current().dtype
     name = str(name).lower()
     if name in ("fp32", "f32", "float32"):
         return torch.float32

@@ -9,18 +9,81 @@ after construction and after a checkpoint load).
 
 BatchNorm statistics stay per rank (standard DDP; the reference's D is called on per-rank batches anyway), so an N-rank run
 equals "N shards evaluated with local BN, gradients averaged" - that is what tests/test_parallel_cpu.py checks on gloo."""
-import os
-
 import torch
 import torch.distributed as dist
+
+from . import tuning
 
 
 def dist_info():
     """(process_group or None, world_size)."""
     if dist.is_available() and dist.is_initialized():
-        if dist.get_world_size() > 1 or os.environ.get("TECOGAN_FORCE_COLLECTIVES", "0") == "1":
+        if dist.get_world_size() > 1 or tuning.current().force_collectives:
             return dist.group.WORLD, dist.get_world_size()
     return None, 1
+
+
+_SYNC_ORDERED = {}
+
+
+def sync_allreduce_stream_ordered(group, device):
+    """True when `dist.all_reduce(t, group=group)` (async_op=False) issued under a side stream is ORDERED on that stream: it
+    reads what the stream wrote before it and the stream's next operation sees its result - with the producer deliberately
+    late (a ~8 ms device-side sleep in front of the write), so an implementation that ran the collective elsewhere without
+    waiting would reduce stale zeros.  The data-parallel default (step.TecoGANStep, TECOGAN_DP_INLINE) issues ONE such call
+    per network on its lane's stream and relies on exactly this; DESIGN.md (e) observed it for torch 2.10's RCCL backend, this
+    checks it where it is used.  None: not applicable (no group, gloo - those take the staged asynchronous path).  One check per
+    process group; every rank must call it at the same point (it is a collective)."""
+    if group is None or not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_backend(group) == "gloo":
+        return None
+    key = id(group)
+    if key in _SYNC_ORDERED:
+        return _SYNC_ORDERED[key]
+    import time
+    world = dist.get_world_size(group)
+    t = torch.zeros(2, dtype=torch.float32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)      # communicator warm-up (lazy initialisation is host work)
+    torch.cuda.synchronize(device)
+    s = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(s):
+        torch.cuda._sleep(int(0.008 * 2.0e9))
+        t.fill_(1.0)                                           # the producer, late
+        t0 = time.perf_counter()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)  # the call under test
+        host_ms = (time.perf_counter() - t0) * 1e3
+        out = t * 2.0                                          # the consumer, on the same stream
+    s.synchronize()
+    ok = bool((out == 2.0 * world).all().item())
+    _SYNC_ORDERED[key] = ok
+    _SYNC_ORDERED[(key, "host_ms")] = host_ms                  # (diagnostic: a stream-ordered call returns long before the sleep ends)
+    return ok
+
+
+def streams_overlap(device, s1, s2):
+    """True when work on the two streams really runs concurrently.  The step's two lanes need their own hardware queues: with an
+    RCCL process group in the process and the HIP runtime's default GPU_MAX_HW_QUEUES (4) both lane streams land on ONE queue
+    and the step runs 1.6x slower (profiles/r03_c_dp_hw_queues.log).  The package sets GPU_MAX_HW_QUEUES=8 at
+    import - which only works if that happens before the process's FIRST HIP call (torch.cuda.is_available() / device_count()
+    may already be one), so the effect is measured here instead of assumed: a device-side sleep on each stream, alone and
+    together (~1.5 ms of GPU time, once per step construction under a process group)."""
+    def span(streams):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cur = torch.cuda.current_stream(device)
+        torch.cuda.synchronize(device)
+        e0.record(cur)
+        for st in streams:
+            st.wait_event(e0)
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(int(0.0004 * 2.0e9))
+            cur.wait_stream(st)
+        e1.record(cur)
+        torch.cuda.synchronize(device)
+        return e0.elapsed_time(e1)
+    one = span([s1])
+    both = span([s1, s2])
+    return both < 1.6 * one
 
 
 def shard_bounds(n, world, rank):
@@ -38,7 +101,7 @@ class _StagedWork:
     the copy's event and reduces the pinned host buffer; wait() joins that job and enqueues the copy back on the
     caller's current stream.  The step's launches issued between all-reduce and wait() run meanwhile, which is the
     interleave the RCCL path has."""
-    _queue, _thread, _pinned = None, None, {}
+    _queue, _thread, _pinned, _groups = None, None, {}, {}
 
     def __init__(self, buf, group):
         import queue
@@ -48,11 +111,17 @@ class _StagedWork:
             cls._queue = queue.Queue()
             cls._thread = threading.Thread(target=cls._serve, args=(cls._queue,), daemon=True)
             cls._thread.start()
-        key = (buf.data_ptr(), buf.numel())
+        key = (buf.data_ptr(), buf.numel(), buf.dtype)
         host = cls._pinned.get(key)
         if host is None:
             host = cls._pinned[key] = torch.empty(buf.numel(), dtype=buf.dtype).pin_memory()
-        self.buf, self.host, self.group = buf, host, group
+        # the worker thread reduces on a gloo group of its OWN: the main thread may issue collectives on `group` at the same time
+        # (replicas_equal, barrier, broadcast_state), and two threads on one group have no common issue order across ranks.
+        # (created at the first staged all-reduce, which every rank reaches at the same point of the step)
+        own = cls._groups.get(id(group))
+        if own is None:
+            own = cls._groups[id(group)] = dist.new_group(ranks=dist.get_process_group_ranks(group), backend="gloo")
+        self.buf, self.host, self.group = buf, host, own
         self.done, self.error = threading.Event(), None
         host.copy_(buf.view(-1), non_blocking=True)
         self.copied = torch.cuda.Event()

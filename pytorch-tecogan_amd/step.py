@@ -10,13 +10,12 @@ buffers - which is what makes it hipGraph-capturable - plus the generator-only r
 Data parallel: sequences are sharded over ranks; the flat G and D gradient buffers are all-reduced over RCCL, each
 issued where its inputs become final - the D all-reduce behind lane B's last backward launch, the G all-reduce behind
 lane A's (TecoGANStep._run_lanes)."""
-import os
-
 import torch
 
 from . import _lib as L
 from . import kernels as K
 from . import parallel
+from . import tuning
 from .kernels import pad32
 
 LAYER_NORM = (12.0, 14.0, 24.0, 100.0)  # code/train.py:214
@@ -167,12 +166,13 @@ class TecoGANStep:
         self.ring_i = 0
         # the engines keep one buffer set per launch shape; this step's sets are pinned (its graphs hold their addresses)
         # and re-selected at the start of every run(), so a module forward at another shape in between is harmless
+        tu = self.tu = tuning.current()
         cap_g, cap_dr = K.persist_wgs_g_for(B * h * h), K.persist_wgs_dreal_for(B * h * h)
         if cap_g is not None:
             G.set_cap(cap_g)
         # (set both ways: the engine may have served a step of another size before)
-        D.cap[0] = cap_dr if cap_dr is not None else int(os.environ.get("TECOGAN_PERSIST_WGS_DREAL", K.persist_wgs("D")))
-        D.rw_extra_real = os.environ.get("TECOGAN_RW_EXTRA_DREAL", "s1" if cap_dr is not None else "")
+        D.cap[0] = cap_dr if cap_dr is not None else tu.cap_dreal_default()
+        D.rw_extra_real = tu.rw_extra_dreal if tu.rw_extra_dreal is not None else ("s1" if cap_dr is not None else "")
         G.sets.pin((T * B, h, h))
         G.alloc(T * B, h, h)
         G._alloc_grad()
@@ -182,7 +182,7 @@ class TecoGANStep:
         self.dpre = torch.empty(T * B, H, H, 4 if compact else 32, dtype=G.dt, device=device)
         # TECOGAN_LANES=0: the whole forward/backward as ONE forked capture (lane B's stream is then an ordinary one:
         # a CU mask is lost inside a forked graph)
-        self.lanes = os.environ.get("TECOGAN_LANES", "1") != "0"
+        self.lanes = tu.lanes
         # data-parallel mode: two gradient buckets per network, all-reduced where they become final (TecoGANStep._run_lanes)
         # Data-parallel collectives.  Default: ONE all-reduce per network issued as a SYNCHRONOUS call on the lane's own stream, behind
         # the piece that completes the gradients (this torch build enqueues a synchronous RCCL collective on the current stream:
@@ -191,12 +191,24 @@ class TecoGANStep:
         # 4.64 with the two buckets per network of TECOGAN_DP_INLINE=0 (profiles/r03_q_dp_inline.log).  What the inline form
         # gives up is overlap of the first bucket (~4 MB of 7 / 13 MB) with the rest of the backward pass - worth less than
         # the hops as long as a bucket's all-reduce is shorter than ~0.3 ms.
-        self.dp_inline = process_group is not None and os.environ.get("TECOGAN_DP_INLINE", "1") != "0"
-        self.buckets = self.lanes and process_group is not None and os.environ.get("TECOGAN_DP_BUCKETS", "1") != "0" and \
+        self.dp_inline = process_group is not None and tu.dp_inline
+        # The inline form relies on a synchronous all-reduce being ordered on the issuing stream (true of this torch build's RCCL
+        # backend); checked once per process group on a 2-element tensor, with the asynchronous form as fallback.
+        self.dp_sync_ordered = None
+        if self.dp_inline:
+            self.dp_sync_ordered = parallel.sync_allreduce_stream_ordered(process_group, device)
+            if self.dp_sync_ordered is False:
+                import warnings
+                warnings.warn("pytorch-tecogan_amd: a synchronous all_reduce is NOT ordered on the issuing stream with this torch / "
+                              "backend - falling back to asynchronous collectives (TECOGAN_DP_INLINE=0 behaviour)")
+                self.dp_inline = False
+        # bench.py: HIP events around each lane's exposed collective time / a pass with every all-reduce skipped (dp_breakdown)
+        self.dp_events, self.skip_collectives = None, False
+        self.buckets = self.lanes and process_group is not None and tu.dp_buckets and \
             not self.dp_inline
         # measured (tools/lane_matrix.sh, profiles/r02_b_lane_matrix.log): reserving CUs for the chain does not pay - the dense
         # lane loses more on 192 CUs than the chain gains - so the default is an unmasked lane B
-        self.reserve = int(os.environ.get("TECOGAN_CU_RESERVE", "0")) if self.lanes else 0
+        self.reserve = tu.cu_reserve if self.lanes else 0
         # hipExtStreamCreateWithCUMask makes a BLOCKING stream: it serialises against the legacy default stream.  Lane A
         # therefore runs on a stream of its own as well (the caller's stream only brackets the step)
         # lane A is the caller's stream (no hand-over: two cross-stream waits cost ~15 us of idle chip each, every step) -
@@ -206,7 +218,12 @@ class TecoGANStep:
         # the real half runs BESIDE the chain (phase 1): only there can a CU reservation pay - its stream may be masked off
         # the first TECOGAN_CU_RESERVE CUs; the fake half (phase 2, beside the dense G backward) always has the whole chip
         self.sBm = lane_stream(device, self.reserve) if self.reserve > 0 else self.sB
-        self.dreal_bwd_early = os.environ.get("TECOGAN_DREAL_BWD", "1") != "0"
+        self.dreal_bwd_early = tu.dreal_bwd
+        if self.lanes and process_group is not None and not parallel.streams_overlap(device, torch.cuda.current_stream(device), self.sB):
+            import warnings
+            warnings.warn("pytorch-tecogan_amd: the step's two lane streams do NOT overlap (they share a hardware queue): expect "
+                          "~1.6x the step time.  Set GPU_MAX_HW_QUEUES=8 (or import pytorch_tecogan_amd) BEFORE the process's first "
+                          "HIP call - torch.cuda.is_available() / device_count() may already be one (DESIGN.md (e))")
         self.ev = {k: torch.cuda.Event() for k in ("start", "prep", "chain", "tail", "d", "dreal")}
         D.sets.pin((2 * self.tb, H))
         D.alloc(2 * self.tb, H)
@@ -258,11 +275,14 @@ class TecoGANStep:
         """releases the pins on the engines' buffer sets (train.get_step calls it when another configuration replaces
         this one); the graphs of a closed step must not be replayed"""
         self.graphs = None
+        self._merge_skipped_updates()
+        from .engine import release_plans
         for eng, shape in ((self.G, (self.T * self.B, self.h, self.h)), (self.D, (2 * self.tb, self.H)),
                            (self.F, (self.B * self.T, self.h, self.h)), (self.V, (self.T * self.B, self.H, self.H))):
             if eng is not None:
                 eng.sets.unpin(shape)
                 eng.sets.drop(shape)      # the step's activation / gradient buffers go with it
+                release_plans(eng)        # ... and every launch plan keyed by their addresses; the capture freeze is lifted
                 if eng.shape == shape:    # the engine re-selects (re-creates) a set at its next alloc()
                     eng.shape = None
                     for attr in ("cur", "act", "grad", "gbuf", "g_c0", "prob", "dlogit"):
@@ -273,6 +293,19 @@ class TecoGANStep:
             torch.cuda.synchronize(self.dev)
             L.check(L.load().tg_stream_destroy(ctypes.c_void_p(self.sBm.cuda_stream)), "tg_stream_destroy")
             self.sBm = self.sB
+
+    def _merge_skipped_updates(self):
+        """fp16: Adam's true step count is the host's count minus the updates this step's scaler skipped (scaler[5:7], device).
+        Moves that count into the bound optimisers' step tensors (train.sync_optimizer_steps does the same before a checkpoint)
+        so that it survives this step being closed or its scaler state being overwritten.  Synchronises; no-op otherwise."""
+        opts = getattr(self, "_opts", None)
+        if self.scaler is None or not opts:
+            return
+        skipped = self.scaler[5:7].cpu()
+        for opt, k in zip(opts, (0, 1)):
+            if getattr(opt, "_tg_step", None) is not None and float(skipped[k]) != 0.0:
+                opt._tg_step -= float(skipped[k])
+        self.scaler[5:7].zero_()
 
     # ----------------------------------------------------------------------------------------------------------
     def _host_params(self, global_step, lr_g, lr_d, betas_g, betas_d, eps_g, eps_d, f_hyper=None):
@@ -506,7 +539,9 @@ class TecoGANStep:
 
     # ---------------------------------------------------------------------------------------------------------- schedule
     def _allreduce(self, buf):
-        forced = self.pg is not None and os.environ.get("TECOGAN_FORCE_COLLECTIVES", "0") == "1"
+        if self.skip_collectives:
+            return None
+        forced = self.pg is not None and self.tu.force_collectives
         if self.dp_inline and (forced or self.world > 1):
             import torch.distributed as dist
             if dist.get_backend(self.pg) != "gloo" or not buf.is_cuda:
@@ -522,6 +557,7 @@ class TecoGANStep:
         recorded between the pieces; the collectives of data-parallel mode are issued where their inputs become final (see
         below: two buckets per network).  Work.wait() of the RCCL backend makes the current STREAM wait (no host block)."""
         main, sB, sBm, ev = torch.cuda.current_stream(), self.sB, self.sBm, self.ev
+        tm = self.dp_events   # {"A0", "A1", "B0", "B1"}: timing events around what each lane waits for its collectives (bench.py)
         # the step's prologue (zeroing, pseudo-flow, T_vel: 8 small launches, ~60 us) runs at the head of lane B while lane A
         # is already in the first generator pass - frame 0 has no previous frame, so it needs neither the flow nor any of
         # the zeroed accumulators; lane A picks the prologue up before pass 1 (kernel trace: 125 us from the previous
@@ -557,8 +593,12 @@ class TecoGANStep:
             # issued first - lane B ends before lane A
             with torch.cuda.stream(sB):
                 fn["d_fake_bwd"]()
+                if tm:
+                    tm["B0"].record(sB)
                 works_d = (self._allreduce(self.D.flat.g),)
             fn["g_bwd"]()
+            if tm:
+                tm["A0"].record(main)
             works_g = (self._allreduce(self.G.flat.g),)
         else:
             # Data parallel.  RCCL runs a process group's collectives on ONE internal stream in issue order (the same on every
@@ -575,19 +615,27 @@ class TecoGANStep:
             with torch.cuda.stream(sB):
                 w_d1 = self._allreduce(D.flat.g[ds:])
                 fn["d_fake_bwd_lo"]()
+                if tm:
+                    tm["B0"].record(sB)
                 w_d2 = self._allreduce(D.flat.g[:ds])
             fn["g_bwd_trunk"]()
+            if tm:
+                tm["A0"].record(main)
             w_g2 = self._allreduce(G.flat.g[:gs])
             works_d, works_g = (w_d1, w_d2), (w_g1, w_g2)
         with torch.cuda.stream(sB):
             for w in works_d:
                 if w is not None:
                     w.wait()       # (RCCL: makes lane B's stream wait, no host block)
+            if tm:
+                tm["B1"].record(sB)
             fn["update_d"]()
             ev["d"].record(sB)
         for w in works_g:
             if w is not None:
                 w.wait()
+        if tm:
+            tm["A1"].record(main)
         if self.scaler is None:
             # the generator's Adam + repack need nothing of lane B: they run beside lane B's tail (the fake half's last weight
             # gradients, fold, D update); the caller's stream then picks lane B up (its results are read next)

@@ -2,12 +2,12 @@
 modules' parameters / BN buffers and both optimisers updated in place) and the same `Network` result tuple
 (code/train.py:354-377).  The arithmetic runs in step.TecoGANStep on HIP kernels."""
 import collections
-import os
 
 import torch
 
 from . import _lib as L
 from . import parallel
+from . import tuning
 from .models import compute_dtype
 from .step import TecoGANStep
 
@@ -71,6 +71,7 @@ def load_loss_scaler_state(state):
 def _apply_scaler(st):
     global _PENDING_SCALER
     if _PENDING_SCALER is not None and st.scaler is not None:
+        st._merge_skipped_updates()     # the skip counters in scaler[5:7] are overwritten below
         s = float(_PENDING_SCALER["scale"])
         st.scaler.copy_(torch.tensor([s, float(_PENDING_SCALER.get("growth_tracker", 0)), 0.0, 0.0, 1.0 / s, 0.0, 0.0, 0.0]))
         _PENDING_SCALER = None
@@ -79,7 +80,7 @@ def _apply_scaler(st):
 def get_step(generator_F, discriminator_F, B, T, h, args, device, dtype_t=None, use_graph=None):
     dtype_t = dtype_t or compute_dtype(args)
     if use_graph is None:
-        use_graph = os.environ.get("TECOGAN_GRAPH", "1") != "0"
+        use_graph = tuning.current().graph
     Ge, De = generator_F.engine(dtype_t), discriminator_F.engine(dtype_t)
     if float(getattr(args, "vgg_scaling", -1.0)) > 0.0 and getattr(args, "tg_vgg", None) is None:
         from .models import VGG19          # the frozen feature extractor is built ONCE and kept on args
@@ -105,13 +106,8 @@ def sync_optimizer_steps(optimizer_g, optimizer_d):
     optimizer.step() then (code/train.py:337,341).  Before optimizer.state_dict() is written the two are merged: the skip
     counts move from the device into the optimisers' step tensors.  Synchronises; no-op outside fp16 mode."""
     for st in _STEPS.values():
-        if st.scaler is None:
-            continue
-        skipped = st.scaler[5:7].cpu()
-        for opt, k in ((optimizer_g, 0), (optimizer_d, 1)):
-            if getattr(opt, "_tg_step", None) is not None and float(skipped[k]) != 0.0:
-                opt._tg_step -= float(skipped[k])
-        st.scaler[5:7].zero_()
+        st._opts = (optimizer_g, optimizer_d)
+        st._merge_skipped_updates()
 
 
 def TecoGAN(r_inputs, r_targets, discriminator_F, generator_F, args, Global_step, counter1, counter2, optimizer_g,
@@ -131,6 +127,7 @@ def TecoGAN(r_inputs, r_targets, discriminator_F, generator_F, args, Global_step
     st = get_step(generator_F, discriminator_F, B, T, h, args, r_inputs.device)
     _bind_optimizer(optimizer_g, generator_F)
     _bind_optimizer(optimizer_d, discriminator_F)
+    st._opts = (optimizer_g, optimizer_d)   # (close() / a scaler reload merge the device-side skip counts into their step tensors)
     gg, gd = optimizer_g.param_groups[0], optimizer_d.param_groups[0]
     st.adam_t = [int(optimizer_g._tg_step), int(optimizer_d._tg_step), 0]
     f_hyper, opt_f = None, None

@@ -1,0 +1,184 @@
+"""Every scheduling / routing knob of the product path in ONE place.
+
+The knobs are read from `TECOGAN_*` environment variables, parsed ONCE into a `Tuning` object (`current()`); the engines and
+the step take their settings from that object when they are built - nothing else in the package reads the environment (the
+library path `TECOGAN_LIB` of `_lib.py`, needed before anything else can load, is the one exception and is listed here too).
+`current()` re-parses only when one of the listed variables changed since the last parse (tests and the A/B tools set them
+between two constructions); objects already built keep what they were built with.
+
+Each knob carries its default and the file under `profiles/` (or the test) that measured it: INTEGRATION.md's table is
+generated from `KNOBS` (`python -m pytorch_tecogan_amd.tuning`), and tests/test_host_cpu.py holds the defaults to the
+documented optimum.  Variants that were built, measured slower and rejected live behind `-DTG_EXPERIMENTS`
+(`csrc/build.sh --experiments`): their knobs are marked `experiment=True` and raise unless that library is loaded."""
+import os
+from collections import OrderedDict, namedtuple
+
+Knob = namedtuple("Knob", "env attr kind default evidence doc experiment")
+
+
+def _k(env, attr, kind, default, evidence, doc, experiment=False):
+    return Knob("TECOGAN_" + env, attr, kind, default, evidence, doc, experiment)
+
+
+# kind: "on" (anything but "0" is on), "flag" (only "1" is on), "int", "str", "oint" / "ostr" (None when unset: "the package decides")
+KNOBS = OrderedDict((k.attr, k) for k in (
+    # ---- step schedule (step.TecoGANStep)
+    _k("GRAPH", "graph", "on", True, "profiles/r01_h_bench_6p1ms.json",
+       "replay the step as per-lane hipGraphs (0: eager launches)"),
+    _k("LANES", "lanes", "on", True, "profiles/r02_a_overlap_probe_priority_cumask.log, r02_d_schedule_matrix.log",
+       "two lanes of per-stream graphs (0: one forked capture on one stream)"),
+    _k("CU_RESERVE", "cu_reserve", "int", 0, "profiles/r02_b_lane_matrix.log, r02_m_cu_reserve_rerun.log",
+       "CUs masked off the real half's stream for the chain (0: none; every value measured slower)"),
+    _k("DREAL_BWD", "dreal_bwd", "on", True, "profiles/r02_d_schedule_matrix.log",
+       "the real half's backward beside the chain (0: batched with the fake half's)"),
+    _k("DP_INLINE", "dp_inline", "on", True, "profiles/r03_q_dp_inline.log",
+       "data parallel: one synchronous all-reduce per network on its lane's stream (0: asynchronous, see DP_BUCKETS)"),
+    _k("DP_BUCKETS", "dp_buckets", "on", True, "profiles/r03_j_bucket_ends_rccl_1rank.log",
+       "with DP_INLINE=0: two buckets per network issued where they become final (0: one asynchronous all-reduce per network)"),
+    _k("FORCE_COLLECTIVES", "force_collectives", "flag", False, "tests/test_step_gpu.py (one-rank RCCL group)",
+       "issue the collectives even with one rank (test hook)"),
+    # ---- persistent launches: workgroup caps (kernels.persist_wgs*)
+    _k("PERSIST_WGS", "persist_wgs", "oint", None, "profiles/r02_q_persist_wgs_sweep.log",
+       "cap of every persistent launch (unset: G 160, D 96, D real half 72 for steps of <= 4096 LR pixels)"),
+    _k("PERSIST_WGS_G", "persist_wgs_g", "oint", None, "profiles/r03_r_rw_dma_ab.log", "generator's cap (unset: 160)"),
+    _k("PERSIST_WGS_D", "persist_wgs_d", "oint", None, "profiles/r02_q_persist_wgs_sweep.log", "discriminator's cap (unset: 96)"),
+    _k("PERSIST_WGS_DREAL", "persist_wgs_dreal", "oint", None, "profiles/r03_r_rw_dma_ab.log",
+       "cap of the discriminator's REAL half, which runs beside the chain (unset: 72 for chain-bound steps, else the D cap)"),
+    _k("PERSIST_RW_G", "persist_rw_g", "int", 0, "profiles/r02_q_persist_wgs_sweep.log",
+       "separate cap for the generator's register-weights conv launches (0: the same cap)"),
+    _k("PERSIST_RW_D", "persist_rw_d", "int", 0, "profiles/r02_q_persist_wgs_sweep.log", "... the discriminator's"),
+    # ---- kernel routing (engine.Conv, kernels.rw_eligible)
+    _k("RW", "rw", "str", "1", "profiles/r02_c_mb_rw.log", "register-weights 3x3 kernel: 0 never, 1 where measured faster, all"),
+    _k("RW_EXTRA", "rw_extra", "str", "trunk,c30,m128", "profiles/r03_r_rw_dma_ab.log",
+       "launch classes routed to it for the STEP's sake (capped persistent launches are better neighbours)"),
+    _k("RW_EXTRA_DREAL", "rw_extra_dreal", "ostr", None, "profiles/r03_r_rw_dma_ab.log",
+       "more classes for the discriminator's real half only (unset: s1 for chain-bound steps)"),
+    _k("RW_DHALF_OFF", "rw_dhalf_off", "str", "", "profiles/r03_r_rw_dma_ab.log",
+       "A/B: discriminator halves ('0', '1', '01') whose convs bypass the register-weights kernel"),
+    _k("SUBPIX_CT", "subpix_ct", "on", True, "profiles/r01_h_bench_6p1ms.json (tools/mb_convt.py)",
+       "conv-transpose forward as one four-class sub-pixel launch"),
+    _k("FAST_C4S2", "fast_c4s2", "on", True, "profiles/r01_h_bench_6p1ms.json (tools/mb_c4s2.py)",
+       "dedicated stride-2 kernels (4x4 s2 forward / input-gradient, conv-transpose input-gradient)"),
+    _k("RGB_OUT", "rgb_out", "on", True, "profiles/r02_i_bench_5p25ms.json", "output layer forward on conv_rgb.hip"),
+    _k("RGB_BWD", "rgb_bwd", "on", True, "profiles/r03_o_rgb_bwd_ab.log", "output layer backward as one launch (rgb_bwd.hip)"),
+    _k("RGB_BWD_WGS", "rgb_bwd_wgs", "int", 256, "profiles/r03_o_rgb_bwd_ab.log", "its workgroups (160 / 256 / 512 / 1024 measured)"),
+    _k("FUSED_RESBLOCK", "fused_resblock", "on", True, "profiles/r01_h_bench_6p1ms.json",
+       "conv-relu-conv(+skip) of the trunk in one launch (resblock.hip)"),
+    _k("FUSED_RESBLOCK_BWD", "fused_resblock_bwd", "flag", False, "DESIGN.md 'resblock' (15 x 28.2 vs 30 x 14.9 us: equal)",
+       "both input-gradients of a trunk block in one launch"),
+    # ---- weight gradients
+    _k("WGRAD_LIST", "wgrad_list", "on", True, "profiles/r03_a_mb_wgrad_group.log, r03_a_wgrad_group_step_ab.log",
+       "work-list weight-gradient launches (wgrad_group.hip)"),
+    _k("WGRAD_GROUPS", "wgrad_groups", "on", True, "profiles/r01_f_bench_8p45ms.json", "same-shape layers in one grid (fp32 mode)"),
+    _k("DEFER_FINALIZE", "defer_finalize", "on", True, "profiles/r01_f_bench_8p45ms.json", "one slab fold per network and backward part"),
+    _k("FOLD_ITEMS", "fold_items", "on", True, "profiles/r03_d_fold_items_ab.log", "item-indexed fold (0: blocks_per_job x jobs grid)"),
+    _k("PACK_BLOCKS", "pack_blocks", "int", 48, "commit 0a9ce4b (16 / 48 / 96: 4.186 / 4.177 / 4.182 ms)",
+       "workgroups per job of the weight repack launch"),
+    # ---- batch norm
+    _k("STATS_REPLICAS", "stats_replicas", "int", 4, "profiles/r02_k_mb_stats_replicas.log, r02_k_stats_replicas_ab.log",
+       "replica blocks of the batch-norm accumulators (a power of two)"),
+    # ---- element type / library / launcher
+    _k("DTYPE", "dtype", "str", "bf16", "BASELINE.json configs[1]", "compute element type when args.tg_dtype is unset (bf16 | fp16 | fp32)"),
+    _k("LIB", "lib", "ostr", None, "tools/ab_libs.sh", "path of an alternative libtecogan_hip.so (A/B builds); read by _lib.py at import"),
+    _k("DIST_BACKEND", "dist_backend", "str", "nccl", "tests/test_dp_gpu.py", "main.py's process-group backend (gloo: ranks sharing one GPU, tests)"),
+    # ---- rejected experiments: need the -DTG_EXPERIMENTS library (csrc/build.sh --experiments)
+    _k("RB_PAIR", "rb_pair", "flag", False, "profiles/r03_t_resblock2_ab.log (chain 1.56 -> 1.71 ms)",
+       "two trunk blocks per launch, halo recomputed (resblock2.hip)", True),
+    _k("BN_FUSE", "bn_fuse", "flag", False, "profiles/r03_g_bn_fuse_ab.log (step 4.43 -> 4.46 ms)",
+       "batch-norm backward sums in the producing input-gradient's epilogue (stats_mode 3)", True),
+    _k("BN_BWD_FUSED", "bn_bwd_fused", "flag", False, "profiles/r03_l_bn_bwd_fused_ab.log (step 4.405 -> 4.42 ms)",
+       "single-launch batch-norm backward for small tensors (tg_bn_bwd_fused)", True),
+    _k("WGRAD_B128_PIXELS", "wgrad_b128_pixels", "int", 0, "profiles/r03_m_wgrad_b128.log (1.1-2.5x slower: spills)",
+       "64 x 128 channel blocks in the work lists for layers with at least this many pixels (0: never)", True),
+))
+
+_SIG = None
+_CUR = None
+
+
+class Tuning:
+    """parsed knob values as attributes (see KNOBS); `explicit` = the set of attrs whose variable was set"""
+
+    def __init__(self, env=None):
+        env = os.environ if env is None else env
+        self.explicit = set()
+        for k in KNOBS.values():
+            raw = env.get(k.env)
+            if raw is not None:
+                self.explicit.add(k.attr)
+            if k.kind == "on":
+                v = k.default if raw is None else raw != "0"
+            elif k.kind == "flag":
+                v = k.default if raw is None else raw == "1"
+            elif k.kind == "int":
+                v = k.default if raw is None else int(raw)
+            elif k.kind == "oint":
+                v = None if raw is None else int(raw)
+            else:  # "str" / "ostr"
+                v = k.default if raw is None else raw
+            setattr(self, k.attr, v)
+        r = self.stats_replicas
+        if r < 1 or r & (r - 1):
+            raise ValueError("TECOGAN_STATS_REPLICAS must be a power of two")
+
+    # ---- derived values (the defaults' history is in kernels.py next to the functions that use them)
+    def cap(self, net):
+        """workgroups of network `net`'s persistent launches ('G', 'D' or None = the global cap)"""
+        base = self.persist_wgs if self.persist_wgs is not None else 160
+        if net == "G":
+            return self.persist_wgs_g if self.persist_wgs_g is not None else base
+        if net == "D":
+            if self.persist_wgs_d is not None:
+                return self.persist_wgs_d
+            return base if self.persist_wgs is not None else min(base, 96)
+        return base
+
+    def cap_g_for(self, lr_pixels):
+        """the generator's cap for a training step of `lr_pixels` = B * h * w, or None when the environment fixes it"""
+        if self.persist_wgs is not None or self.persist_wgs_g is not None:
+            return None
+        return self.cap(None)
+
+    def cap_dreal_for(self, lr_pixels):
+        """cap of the discriminator's REAL half for such a step, or None (environment fixes it / step is not chain-bound)"""
+        if self.persist_wgs is not None or self.persist_wgs_d is not None or self.persist_wgs_dreal is not None:
+            return None
+        return 72 if lr_pixels <= 4096 else None
+
+    def cap_dreal_default(self):
+        return self.persist_wgs_dreal if self.persist_wgs_dreal is not None else self.cap("D")
+
+
+def _signature():
+    g = os.environ.get
+    return tuple(g(k.env) for k in KNOBS.values())
+
+
+def current():
+    """the Tuning object for the environment as it is now (cached; one parse per distinct setting)"""
+    global _SIG, _CUR
+    sig = _signature()
+    if _CUR is None or sig != _SIG:
+        _CUR, _SIG = Tuning(), sig
+    return _CUR
+
+
+def need_experiments(attr):
+    """called where a knob marked `experiment` is switched on: the rejected variants are not in the default library"""
+    from . import _lib as L
+    if not L.has_experiments():
+        raise L.TecoganHipError(f"{KNOBS[attr].env} needs the experiments build of libtecogan_hip.so "
+                                "(pytorch-tecogan_amd/csrc/build.sh --experiments; default builds leave the rejected variants out)")
+
+
+def markdown_table():
+    rows = ["| Variable | Default | What it does | Evidence |", "|---|---|---|---|"]
+    for k in KNOBS.values():
+        d = {True: "1", False: "0", None: "(unset)"}.get(k.default, k.default) if not isinstance(k.default, int) or isinstance(k.default, bool) \
+            else k.default
+        rows.append(f"| `{k.env}`{' (experiments build)' if k.experiment else ''} | `{d}` | {k.doc} | {k.evidence} |")
+    return "\n".join(rows)
+
+
+if __name__ == "__main__":
+    print(markdown_table())

@@ -13,6 +13,21 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experiments: a rejected variant; needs the experiments build of the library "
+                                       "(csrc/build.sh --experiments, TECOGAN_LIB=.../libtecogan_hip_experiments.so) - skipped otherwise")
+
+
+def pytest_collection_modifyitems(config, items):
+    """tests of the rejected variants run only against the experiments library (never loaded by default)"""
+    exp = [it for it in items if it.get_closest_marker("experiments")]
+    if not exp:
+        return
+    lib = os.environ.get("TECOGAN_LIB", "")
+    if "experiments" in os.path.basename(lib) and os.path.exists(lib):
+        return
+    skip = pytest.mark.skip(reason="needs the experiments build: csrc/build.sh --experiments and TECOGAN_LIB=<that library>")
+    for it in exp:
+        it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

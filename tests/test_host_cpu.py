@@ -26,12 +26,22 @@ import tecogan_oracle as orc  # noqa: E402
 def test_capi_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "tecogan_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(tg_[a-z0-9_]+)\s*\(", hdr))
+    # the rejected variants are declared under `#ifdef TG_EXPERIMENTS` and exported by the experiments build only
+    exp_blocks = re.findall(r"#ifdef TG_EXPERIMENTS(.*?)#endif", hdr, flags=re.S)
+    experimental = set(re.findall(r"\b(tg_[a-z0-9_]+)\s*\(", "".join(exp_blocks)))
+    declared = set(re.findall(r"\b(tg_[a-z0-9_]+)\s*\(", re.sub(r"#ifdef TG_EXPERIMENTS.*?#endif", "", hdr, flags=re.S)))
     assert len(declared) >= 25
+    assert experimental == set(L._PROTOS_EXPERIMENTS), experimental ^ set(L._PROTOS_EXPERIMENTS)
     lib = L.load()  # raises if the .so is missing: there is no fallback
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/tecogan_hip.h but not exported"
     assert declared == set(L.EXPORTED), declared ^ set(L.EXPORTED)
+    # the default library exports exactly the declared set: nothing of the experiments, nothing undeclared
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True)
+    if nm.returncode == 0 and not lib.tg_has_experiments():
+        exported = {ln.split()[-1] for ln in nm.stdout.splitlines() if " T tg_" in ln}
+        assert exported == declared, exported ^ declared
     assert lib.tg_abi_version() == 1
     assert lib.tg_error_string(-2) == b"unsupported shape"
 
@@ -360,12 +370,12 @@ def test_persistent_workgroup_caps_defaults_and_overrides(monkeypatch):
     from pytorch_tecogan_amd import kernels as K
     for k in ("TECOGAN_PERSIST_WGS", "TECOGAN_PERSIST_WGS_G", "TECOGAN_PERSIST_WGS_D"):
         monkeypatch.delenv(k, raising=False)
-    K = importlib.reload(K)
+    for k in ("TECOGAN_PERSIST_WGS_DREAL",):
+        monkeypatch.delenv(k, raising=False)
     assert (K.PERSIST_WGS, K.persist_wgs("G"), K.persist_wgs("D"), K.persist_wgs(None)) == (160, 160, 96, 160)
     monkeypatch.setenv("TECOGAN_PERSIST_WGS_D", "128")
     assert K.persist_wgs("D") == 128 and K.persist_wgs("G") == 160
     monkeypatch.setenv("TECOGAN_PERSIST_WGS", "256")
-    K = importlib.reload(K)
     monkeypatch.delenv("TECOGAN_PERSIST_WGS_D")
     assert (K.persist_wgs("G"), K.persist_wgs("D")) == (256, 256)
     # 9-tap 128 -> 64 layer on 40 x 128x128 pixels: 2 channel blocks; all taps in one workgroup
@@ -482,7 +492,7 @@ def test_wgrad_work_list_plan_with_wide_channel_blocks():
     assert tw == 32 and units == 2 * tiles[0] + 2 * tiles[1] + 2 * 2 * tiles[2]
     assert [(f[0], f[1], f[2]) for f in fold] == [(0, 0, 0), (0, 64, 0), (1, 0, 0), (1, 0, 128), (2, 0, 0), (2, 0, 128), (2, 64, 0), (2, 64, 128)]
     assert E.WgradList.block_b(L.WGROUP_CT_B128) == 128 and E.WgradList.block_b(L.WGROUP_C4S2) == 64
-    assert E.WgradList.WIDE_MIN_PIXELS == 0     # measured slower: opt-in only
+    assert E.WgradList.wide_min_pixels() == 0     # measured slower: opt-in only (experiments build)
 
 
 def test_fold_items_prefix_table():
@@ -494,3 +504,98 @@ def test_fold_items_prefix_table():
             [0, 0, 9, 576, 96, 9, 64, 32, 64, 3, 0, 18432]]       # BB = 32: AB = 32 -> 2 tiles x 12
     rows, n = E.fold_items(jobs)
     assert [r[12] for r in rows] == [0, 4, 20, 52] and n == 76 and all(r[:12] == j for r, j in zip(rows, jobs))
+
+
+# ------------------------------------------------------------------------------------------------ tuning object
+def test_tuning_defaults_equal_the_documented_optimum(monkeypatch):
+    """ONE object holds every TECOGAN_* knob (pytorch-tecogan_amd/tuning.py).  With a clean environment its values are the
+    measured optimum the documentation quotes (INTEGRATION.md's table is generated from the same KNOBS; DESIGN.md: caps 160 / 96 /
+    72, four replica blocks, work lists, inline collectives, every rejected experiment off), and each knob names its evidence."""
+    from pytorch_tecogan_amd import tuning
+    for k in tuning.KNOBS.values():
+        monkeypatch.delenv(k.env, raising=False)
+    t = tuning.current()
+    assert not t.explicit
+    assert (t.cap("G"), t.cap("D"), t.cap(None), t.cap_g_for(4096), t.cap_dreal_for(4096), t.cap_dreal_for(8192)) == \
+        (160, 96, 160, 160, 72, None)
+    assert (t.graph, t.lanes, t.dreal_bwd, t.dp_inline, t.dp_buckets, t.cu_reserve, t.force_collectives) == \
+        (True, True, True, True, True, 0, False)
+    assert (t.rw, t.rw_extra, t.rw_extra_dreal, t.rw_dhalf_off) == ("1", "trunk,c30,m128", None, "")
+    assert (t.wgrad_list, t.wgrad_groups, t.defer_finalize, t.fold_items, t.pack_blocks, t.stats_replicas) == \
+        (True, True, True, True, 48, 4)
+    assert (t.fused_resblock, t.fused_resblock_bwd, t.subpix_ct, t.fast_c4s2, t.rgb_out, t.rgb_bwd, t.rgb_bwd_wgs) == \
+        (True, False, True, True, True, True, 256)
+    assert t.dtype == "bf16"
+    # every rejected experiment is off, and is marked as needing the experiments build
+    exp = [k for k in tuning.KNOBS.values() if k.experiment]
+    assert {k.attr for k in exp} == {"rb_pair", "bn_fuse", "bn_bwd_fused", "wgrad_b128_pixels"}
+    assert all(not getattr(t, k.attr) for k in exp)
+    for k in tuning.KNOBS.values():
+        assert k.evidence and k.doc, k.env
+        for f in re.findall(r"profiles/[A-Za-z0-9_./]+", k.evidence):
+            if "*" not in f and f.endswith((".log", ".json", ".csv")):
+                assert os.path.exists(os.path.join(ROOT, f)), (k.env, f)
+    # the INTEGRATION.md table is this object's
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for k in tuning.KNOBS.values():
+        assert f"`{k.env}`" in doc, f"{k.env} missing from INTEGRATION.md's knob table"
+    # nothing else in the package reads a TECOGAN_ variable (one parse site)
+    pkg = os.path.join(ROOT, "pytorch-tecogan_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py") and fn not in ("tuning.py", "_lib.py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"environ[^\n]*TECOGAN_", src), fn
+    # overrides are seen by the NEXT current() (tests / A-B tools set them between constructions)
+    monkeypatch.setenv("TECOGAN_PERSIST_WGS", "256")
+    monkeypatch.setenv("TECOGAN_DP_INLINE", "0")
+    t2 = tuning.current()
+    assert t2 is not t and (t2.cap("G"), t2.cap("D"), t2.cap_g_for(4096), t2.cap_dreal_for(4096), t2.dp_inline) == \
+        (256, 256, None, None, False)
+    assert tuning.current() is t2
+    monkeypatch.setenv("TECOGAN_STATS_REPLICAS", "3")
+    with pytest.raises(ValueError):
+        tuning.current()
+
+
+def test_rejected_experiments_need_the_experiments_library(monkeypatch):
+    """the default library does not contain the rejected variants: switching one on fails loudly instead of silently running
+    something else; the default .so reports itself as a non-experiments build"""
+    from pytorch_tecogan_amd import tuning
+    if L.has_experiments():
+        pytest.skip("TECOGAN_LIB points at the experiments build")
+    for attr in ("rb_pair", "bn_fuse", "bn_bwd_fused", "wgrad_b128_pixels"):
+        with pytest.raises(L.TecoganHipError, match="experiments build"):
+            tuning.need_experiments(attr)
+    lib = L.load()
+    for name in L._PROTOS_EXPERIMENTS:
+        assert not hasattr(lib, name)
+    # argument forms of the experiments are refused by the default library (validated before any launch)
+    assert lib.tg_wgrad_group_slot_floats_v(L.WGROUP_C3_B128) == -1
+    import ctypes
+    d = K.make_conv_desc(K.ConvSpec("c3", 64, 64).dgrad_geom(), L.TG_BF16, 1, 8, 8, 64, 8, 8, 64, mask_mode=L.MASK_BNZ, stats_mode=3)
+    assert lib.tg_conv(ctypes.byref(d), 16, 16, None, None, 16, 16, 16, None) == -2  # TG_E_UNSUPPORTED
+
+
+def test_bench_flags_and_dry_dp_fields():
+    """bench.py's data-parallel flags (--dp-mode inline|buckets|both, --dp-steps, --no-extras) and the shape of the `dp` object a
+    multi-rank line carries (rehearsed by the --dry launch: gloo rendezvous on the CPU, two ranks started by bench.py itself)"""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    a = bench.parse([])
+    assert (a.dp_mode, a.dp_steps, a.no_extras, a.gpus) == ("inline", 10, False, 1)
+    a = bench.parse(["--gpus", "8", "--dp-mode", "both", "--dp-steps", "4", "--no-extras"])
+    assert (a.dp_mode, a.dp_steps, a.no_extras, a.gpus) == ("both", 4, True, 8)
+    with pytest.raises(SystemExit):
+        bench.parse(["--dp-mode", "ring"])
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--dp-mode", "both", "--dp-steps", "3"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["dp"]["mode"] == "inline" and line["dp"]["alt"]["mode"] == "buckets"
+    for k in ("allreduce_exposed_ms_laneA", "allreduce_exposed_ms_laneB", "step_ms_no_collectives", "probe_steps"):
+        assert k in line["dp"] and k in line["dp"]["alt"]
+    assert line["dp"]["probe_steps"] == 3

@@ -348,7 +348,7 @@ def test_wgrad_group_work_list_vs_torch(cap, shapes, dt):
     cut tiles, real channel counts below the padded ones, bias sums on some layers only."""
     from pytorch_tecogan_amd import engine as E
     lib = L.load()
-    slot = int(lib.tg_wgrad_group_slot_floats())
+    slot = int(lib.tg_wgrad_group_slot_floats_v(L.WGROUP_C3))
     specs = [K.ConvSpec("c3", cin, cout) for (_, _, _, cin, cout, _) in shapes]
     xs = [q(rnd((N, cin, H, W), 300 + i), dt) for i, (N, H, W, cin, cout, _) in enumerate(shapes)]
     ds = [q(rnd((N, cout, H, W), 400 + i), dt) for i, (N, H, W, cin, cout, _) in enumerate(shapes)]
@@ -361,7 +361,8 @@ def test_wgrad_group_work_list_vs_torch(cap, shapes, dt):
         r[8] = 1 if sh[5] else 0
         jobs.append([X.data_ptr(), Y.data_ptr()] + r)
     jt = torch.tensor(jobs, dtype=torch.int64, device=DEV)
-    L.check(lib.tg_wgrad_group(K.tg_dtype(dt), tw, jt.data_ptr(), len(jobs), units, nwg, slab.data_ptr(), None), "tg_wgrad_group")
+    L.check(lib.tg_wgrad_group_v(K.tg_dtype(dt), L.WGROUP_C3, tw, jt.data_ptr(), len(jobs), units, nwg, slab.data_ptr(), None),
+            "tg_wgrad_group_v")
     grads = [torch.zeros(sp.weight_shape, device=DEV) for sp in specs]
     gbs = [torch.zeros(K.pad32(sp.cout), device=DEV) for sp in specs]
     fin = []
@@ -444,6 +445,7 @@ def test_wgrad_group_stride2_kinds_vs_torch(kind, cap, layers, dt):
     ("ct", 5, [(2, 16, 16, 128, 64, False), (1, 32, 32, 128, 128, False), (2, 8, 20, 256, 64, False)]),
     ("ct", 160, [(3, 64, 64, 128, 128, False)]),
 ])
+@pytest.mark.experiments
 def test_wgrad_group_wide_channel_blocks_vs_torch(kind, cap, layers, dt):
     """TG_WGROUP_C3_B128 / TG_WGROUP_CT_B128: the work-list launch with 64 x 128 channel blocks (256-byte Y rows in LDS, four B
     fragments per wave), folded with cb_p = 128 jobs - against torch autograd; Y channel counts that are not multiples of 128 run
@@ -554,6 +556,7 @@ def test_batchnorm_train_fwd_bwd(C_, act, skip, dt):
         torch.testing.assert_close(dbet.cpu(), bet.grad, rtol=1e-2, atol=1e-2 if dt != torch.float32 else 1e-4)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("C_,N,H,G", [(64, 4, 16, 1), (128, 4, 8, 2), (64, 2, 24, 1)])
 def test_bn_backward_sums_in_the_dgrad_epilogue(C_, N, H, G, dt):
@@ -614,6 +617,7 @@ def test_bn_backward_sums_in_the_dgrad_epilogue(C_, N, H, G, dt):
         torch.testing.assert_close(db.cpu(), bt.grad, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("C_,N,H,G,act", [(128, 12, 16, 1, "none"), (128, 12, 16, 1, "lrelu"), (64, 12, 8, 1, "lrelu"),
                                           (32, 12, 4, 1, "lrelu"), (64, 6, 16, 2, "none"), (128, 16, 16, 1, "none"), (64, 3, 5, 1, "lrelu")])
@@ -1037,6 +1041,7 @@ def test_fused_resblock_backward(N, H, W):
     torch.testing.assert_close(K.to_nchw(da_f, 64).cpu(), da, **tol(dt))
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,W", [(4, 32, 32), (1, 20, 12), (2, 8, 8), (1, 5, 37), (3, 3, 3)])
 def test_two_resblocks_per_launch_bit_identical(N, H, W, dt):

@@ -132,3 +132,42 @@ def test_optimizer_load_state_dict_after_the_first_step_is_applied(monkeypatch):
     (g_a, d_a), (g_b, d_b) = run(False), run(True)
     # (D: chaotic at this size, see above; ignoring the restored moments / step count would cost ~3e-3 on G as well)
     assert rel(g_b, g_a) < 2e-4 and rel(d_b, d_a) < 2e-3
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_step_rebuild_on_the_same_engines_after_graph_capture(monkeypatch, dtype):
+    """get_step replaces a captured step by one of another batch size ON THE SAME G / D engines (a last,
+    smaller batch of an epoch; a changed B after a resume).  close() drops the old step's buffer sets, so the new step's
+    weight-gradient work lists / output-layer backward plan / fold tables - all keyed by buffer addresses - must be rebuilt, which the
+    post-capture freeze used to refuse ("new wgrad shape after graph capture").  B = 1 (eager + capture + replays) -> B = 2 ->
+    B = 1 again, all under graphs: every step runs, results of the last B = 1 phase continue the trajectory of a run that never
+    switched (the weights moved by two B = 2 steps in between, so only finiteness and the step counters are compared), the
+    plan caches hold one configuration, and in fp16 the Adam step count stays torch's."""
+    monkeypatch.setenv("TECOGAN_GRAPH", "1")
+    train._STEPS.clear()
+    args, G, D, og, od, _, _ = build(7, dtype, num_resblock=2, discrim_resblocks=1)
+    x1, y1 = (t.cuda() for t in synth(1, 10, 32, 5))
+    x2, y2 = (t.cuda() for t in synth(2, 10, 32, 6))
+    step = 0
+    seen, sizes = [], []
+    for (x, y), n in (((x1, y1), 3), ((x2, y2), 3), ((x1, y1), 3)):
+        for _ in range(n):
+            out = train.FRVSR_Train(x, y, args, D, G, step, 0.0, 0.0, og, od)
+            step += 1
+            assert bool(torch.isfinite(out.gen_output).all()) and np.isfinite(float(out.gen_loss)) and np.isfinite(float(out.d_loss))
+        st = next(iter(train._STEPS.values()))
+        assert st.use_graph and st.graphs is not None and st.B == x.shape[0]     # the phase ended in graph replays
+        seen.append(st)
+        Ge, De = G.engine(), D.engine()
+        # one configuration's plans only: nothing of the closed step survives (its slabs were ~25 MB per launch)
+        sizes.append((len(Ge.hr_list.cache), len(Ge.trunk_group.cache), len(De.res_group.cache), len(Ge._rgb_cache),
+                      len(Ge.finalizer.tables), len(De.finalizer.tables)))
+    assert sizes[0] == sizes[1] == sizes[2] and sizes[0][3] == (1 if Ge.rgb_bwd_ok() else 0), sizes
+    assert seen[0] is not seen[1] and seen[1] is not seen[2] and seen[0].graphs is None and seen[1].graphs is None
+    torch.cuda.synchronize()
+    train.sync_optimizer_steps(og, od)
+    n_g = float(og.state[next(iter(G.parameters()))]["step"])
+    # (fp16: an update skipped on overflow is not an optimizer step - the skip counts of the CLOSED steps were merged by close())
+    assert n_g == 9.0 if dtype == "bf16" else 0.0 < n_g <= 9.0
+    assert int(D.state_dict()["block1.1.num_batches_tracked"]) == 18
+    train._STEPS.clear()

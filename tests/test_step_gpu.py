@@ -449,16 +449,24 @@ def test_data_parallel_collectives_on_one_gpu(tmp_path, mode, bound):
     env = dict(os.environ, TECOGAN_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **mode)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "12",
-           "--warmup", "3", "--no-cpu-baseline", "--no-roofline"]
+           "--warmup", "3", "--no-cpu-baseline", "--no-roofline", "--no-extras", "--dp-steps", "4"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     dp = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3",
-                         "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                         "--no-cpu-baseline", "--no-roofline", "--no-extras"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r2.returncode == 0, r2.stderr[-2000:]
     sp = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
     assert dp["n_gpus"] == 1 and dp["config"]["parallelism"] == "dp1" and dp["pg_world_size"] == 1 and dp["pg_backend"] == "nccl"
-    assert sp["pg_backend"] is None
+    assert sp["pg_backend"] is None and "dp" not in sp
+    # the line explains its collectives: mode as run, exposed all-reduce time per lane (HIP events on the lane streams), the
+    # step without collectives, and the start-up check that a synchronous all-reduce is ordered on the issuing stream
+    d = dp["dp"]
+    assert d["mode"] == ("buckets" if mode else "inline") and d["requested_mode"] == d["mode"]
+    assert d["sync_allreduce_stream_ordered"] is (None if mode else True)
+    assert 0.0 <= d["allreduce_exposed_ms_laneA"] < 1.0 and 0.0 <= d["allreduce_exposed_ms_laneB"] < 1.0
+    assert 0.5 * dp["ms_per_step"] < d["step_ms_no_collectives"] < 1.2 * dp["ms_per_step"]
+    assert d["grad_bytes"]["G"] > 7e6 and d["grad_bytes"]["D"] > 13e6 and d["probe_steps"] == 4
     # the two lanes must still overlap beside RCCL's own streams (they shared one hardware queue with the runtime's default
     # of 4 queues: 7.1 vs 4.5 ms per step; pytorch-tecogan_amd/__init__.py).  4 collectives of 1 rank cost ~0.1 ms of host time
     assert dp["ms_per_step"] < bound * sp["ms_per_step"], (dp["ms_per_step"], sp["ms_per_step"])
@@ -477,8 +485,17 @@ def test_bench_contract_line_with_roofline_pass():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "psnr_delta_db", "psnr", "other_configs"):
         assert k in line, k
+    # the second half of BASELINE.json's metric and the configurations the headline line does not time
+    assert line["metric"].endswith("PSNR delta vs ref") and abs(line["psnr_delta_db"]) <= 0.05 and line["psnr"]["within_gate"]
+    assert 22.0 < line["psnr"]["ref_fp32_oracle_db"] < 35.0 and line["psnr"]["output_rel_err"] < 2e-2
+    c4, c5 = line["other_configs"]["config4"], line["other_configs"]["config5"]
+    assert c4["dtype"] == "fp16" and c4["finite"] and c4["steps"] == 10 and 1.0 < c4["ms_per_step"] < 40.0
+    assert abs(c4["hr_frames_per_s"] - 2 * 16 / (c4["ms_per_step"] * 1e-3)) < 0.01 * c4["hr_frames_per_s"]
+    assert 0.0 < c4["dominant_family"]["frac"] < 1.0 and c4["loss_scale"]["scale"] > 0
+    assert c5["frames"] == 120 and c5["finite"] and 500.0 < c5["hr_frames_per_s"] < 20000.0
+    assert c5["trunk_family"]["launches_per_frame"] == 17 and 0.0 < c5["trunk_family"]["frac"] < 1.0
     assert line["steps"] == 3 and line["n_gpus"] == 1 and line["dtype"] == "bf16" and "workload" in line["config"]
     rf = line["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0.0 < rf["frac"] < 1.0
@@ -490,8 +507,9 @@ def test_bench_contract_line_with_roofline_pass():
     # of this same command, and the in-step launch time agrees with that summary's average
     import csv
     import glob
-    stats = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*kernel_stats*.csv")))
-    assert stats, "profiles/r03_*kernel_stats*.csv (rocprofv3 --kernel-trace --stats of bench.py) is missing"
+    stats = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_*kernel_stats*.csv"))) or \
+        sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*kernel_stats*.csv")))
+    assert stats, "profiles/r0[34]_*kernel_stats*.csv (rocprofv3 --kernel-trace --stats of bench.py) is missing"
     rows = list(csv.DictReader(open(stats[-1])))
     top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
     assert "resblock_kernel<false" in top["Name"] and rf["kernel"].startswith("resblock_kernel<false"), (top["Name"], rf["kernel"])
@@ -519,7 +537,7 @@ def test_persistent_workgroup_cap_is_a_scheduling_knob_only():
         if cap:
             env["TECOGAN_PERSIST_WGS"] = cap
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
-                            "--no-roofline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+                            "--no-roofline", "--no-extras"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["final_losses"])
     np.testing.assert_allclose(res[0]["gen_loss"], res[1]["gen_loss"], rtol=2e-3)

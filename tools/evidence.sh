@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 timeout -k 10 1100 python -m pytest tests -m gpu -q > gpurun_out/${tag}_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/${tag}_pytest.log
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/${tag}_smoke.log
 timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc=$?"; cut -c1-200 gpurun_out/${tag}_bench.json
-timeout -k 10 300 bash tools/prof_top.sh $tag --steps 13 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/${tag}_prof_top.log 2>&1; echo "prof rc=$?"
+timeout -k 10 300 bash tools/prof_top.sh $tag --steps 13 --warmup 3 --no-cpu-baseline --no-roofline --no-extras > gpurun_out/${tag}_prof_top.log 2>&1; echo "prof rc=$?"
 cp gpurun_out/prof_$tag/${tag}_kernel_stats.csv gpurun_out/${tag}_kernel_stats.csv
 python tools/overlap_from_trace.py gpurun_out/prof_$tag/${tag}_kernel_trace.csv 3 > gpurun_out/${tag}_overlap_trace.json
 timeout -k 10 500 bash tools/pmc_collect.sh $tag gpurun_out/prof_$tag/${tag}_kernel_stats.csv > gpurun_out/${tag}_pmc.log 2>&1; echo "pmc rc=$?"

@@ -39,7 +39,7 @@ def flops(shapes):
 
 def run_set(name, shapes, cap):
     lib = L.load()
-    slot = int(lib.tg_wgrad_group_slot_floats())
+    slot = int(lib.tg_wgrad_group_slot_floats_v(L.WGROUP_C3))
     Xs = [torch.randn(N, H, W, cx, device=DEV).to(bf) for N, H, W, cx, cy in shapes]
     Ys = [torch.randn(N, H, W, cy, device=DEV).to(bf) for N, H, W, cx, cy in shapes]
     fl = flops(shapes)
@@ -52,8 +52,8 @@ def run_set(name, shapes, cap):
                          count, 9, 64, 64, 64, 64, 0, slot] for j, a0, b0, first, count in fold], dtype=torch.int64, device=DEV)
 
     def new_k():
-        L.check(lib.tg_wgrad_group(L.TG_BF16, tw, jt.data_ptr(), len(shapes), units, nwg, slab.data_ptr(),
-                                   torch.cuda.current_stream().cuda_stream), "tg_wgrad_group")
+        L.check(lib.tg_wgrad_group_v(L.TG_BF16, L.WGROUP_C3, tw, jt.data_ptr(), len(shapes), units, nwg, slab.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream), "tg_wgrad_group_v")
 
     def new_kf():
         new_k()

@@ -8,7 +8,7 @@ tag=${1:-pmc}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT unset)}"
 pass() {  # dir, counters...
   local d=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $d -o pmc -- python3 bench.py --steps 2 --warmup 2 --no-roofline --no-cpu-baseline > $d.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $d -o pmc -- python3 bench.py --steps 2 --warmup 2 --no-roofline --no-cpu-baseline --no-extras > $d.log 2>&1
 }
 pass gpurun_out/pmc_fetch FETCH_SIZE
 pass gpurun_out/pmc_write WRITE_SIZE
