@@ -52,9 +52,10 @@ def parse(argv=None):
     ap.add_argument("--dry", action="store_true", help="launch logic only: gloo rendezvous on the CPU, no GPU work")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip psnr_delta_db and other_configs (configs[3] shard, configs[4] inference) behind the headline line")
-    ap.add_argument("--dp-mode", default="inline", choices=["inline", "buckets", "both"],
+    ap.add_argument("--dp-mode", default=None, choices=["inline", "buckets", "both"],
                     help="data-parallel collectives (N > 1): one synchronous all-reduce per network on its lane's stream | two "
-                         "asynchronous buckets per network | both measured, the better one is `value`, the other under dp.alt")
+                         "asynchronous buckets per network | both measured, the better one is `value`, the other under dp.alt "
+                         "(default: the package's, i.e. inline unless TECOGAN_DP_INLINE=0)")
     ap.add_argument("--dp-steps", type=int, default=10, help="steps of the two extra data-parallel passes (event-timed, no collectives)")
     return ap.parse_args(argv)
 
@@ -103,7 +104,7 @@ def dry_run(a, rank, world):
         line = {"dry": True, "n_gpus": n, "pg_world_size": n, "pg_backend": "gloo" if n > 1 or "RANK" in os.environ else None,
                 "config": {"parallelism": f"dp{n}", "global_batch": n * WORKLOADS[a.config]["batch"]}}
         if n > 1 or "RANK" in os.environ:   # the data-parallel object's shape: the modes a real run would time, fields unfilled
-            modes = ["inline", "buckets"] if a.dp_mode == "both" else [a.dp_mode]
+            modes = ["inline", "buckets"] if a.dp_mode == "both" else [a.dp_mode or "inline"]
             blank = lambda m: {"mode": m, "requested_mode": m, "allreduce_exposed_ms_laneA": None,  # noqa: E731
                                "allreduce_exposed_ms_laneB": None, "step_ms_no_collectives": None, "probe_steps": a.dp_steps}
             line["dp"] = blank(modes[0])
@@ -216,11 +217,17 @@ def roofline_pass(st, dtype):
             if not items:
                 return
             fl = sum(conv_flops(c.spec, x.shape[0], x.shape[1], x.shape[2]) for c, x, _, _ in items)
+            cap = getattr(self, "cap", None)   # (the discriminator's halves run their lists under different caps: plans are per cap)
 
             def again():
                 rest, self.items = self.items, list(items)
+                keep = getattr(self, "cap", None)
+                if cap is not None:
+                    self.cap = cap
                 orig_group(self)
                 self.items = rest
+                if cap is not None:
+                    self.cap = keep
             record(label(items), fl, again, "mfma")
         cls.launch = group_timed
     time_group(E.WgradGroup, lambda items: f"wgrad_kernel<{T16}, 9, 9, ..> (tg_wgrad_multi, {len(items)} layers)")
@@ -662,10 +669,10 @@ def main(argv=None):
     # TECOGAN_FORCE_COLLECTIVES=1) runs the same code path, so the fields below can be rehearsed on one GPU.
     from pytorch_tecogan_amd import parallel
     dp_live = parallel.dist_info()[0] is not None
-    modes = (["inline", "buckets"] if a.dp_mode == "both" else [a.dp_mode]) if dp_live else [None]
+    modes = (["inline", "buckets"] if a.dp_mode == "both" else [a.dp_mode or "env"]) if dp_live else [None]
     runs, first = [], 0
     for mode in modes:
-        if mode is not None:
+        if mode in ("inline", "buckets"):
             os.environ["TECOGAN_DP_INLINE"] = "1" if mode == "inline" else "0"
             for s_ in list(TR._STEPS.values()):   # a step is built for one mode
                 s_.close()

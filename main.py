@@ -73,6 +73,19 @@ def build_parser():
     return p
 
 
+def make_train_loader(args, dataset, sampler=None):
+    """The training DataLoader.  Batch size 4 is hard-coded in the reference (main.py:227); per rank here.  drop_last: the step is a
+    static launch sequence for ONE batch shape (the reference would run a short last batch through eager PyTorch).  Real data: the
+    PNG decode (+ resize, unless --tg_gpu_resize) of code/dataloader.py runs in --queue_thread worker processes (the flag the
+    reference defines and never uses, main.py:64) with pinned, prefetched batches, so ingest overlaps the GPU step
+    (tools/ingest_bench.py measures what this loader delivers against what the step consumes)."""
+    import torch
+    workers = 0 if args.synthetic else max(0, min(int(args.queue_thread), len(os.sched_getaffinity(0))))
+    return torch.utils.data.DataLoader(dataset, batch_size=4, shuffle=sampler is None, sampler=sampler, drop_last=True,
+                                       num_workers=workers, pin_memory=True, persistent_workers=workers > 0,
+                                       prefetch_factor=4 if workers > 0 else None)
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     args.RNN_N = int(args.RNN_N)  # the reference leaves a CLI value as str (main.py:78-79)
@@ -142,14 +155,7 @@ def main(argv=None):
     if world > 1:
         sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True,
                                                                   seed=args.rand_seed, drop_last=True)
-    # batch size 4 is hard-coded in the reference (main.py:227); per rank here.  drop_last: the step is a static launch
-    # sequence for ONE batch shape (the reference would run a short last batch through eager PyTorch)
-    # real data: the PNG decode + resize pipeline of code/dataloader.py runs in --queue_thread worker processes (the flag the
-    # reference defines and never uses, main.py:64) with pinned, prefetched batches, so ingest overlaps the GPU step
-    workers = 0 if args.synthetic else max(0, min(int(args.queue_thread), len(os.sched_getaffinity(0))))
-    loader = torch.utils.data.DataLoader(dataset, batch_size=4, shuffle=sampler is None, sampler=sampler, drop_last=True,
-                                         num_workers=workers, pin_memory=True, persistent_workers=workers > 0,
-                                         prefetch_factor=4 if workers > 0 else None)
+    loader = make_train_loader(args, dataset, sampler)
     if len(loader) == 0:
         raise ValueError(f"{len(dataset)} training sequences give rank {rank} of {world} no full batch of 4: nothing would "
                          "be trained")

@@ -81,6 +81,20 @@ def build_tables(B, T, h, K, pingpang=False, fnet_flow=False):
     return out
 
 
+_LANE_STREAMS = {}
+
+
+def lane_b_stream(device):
+    """lane B's stream: ONE per device for the life of the process.  A step that replaces another (train.get_step: another batch
+    size, another data-parallel mode) reuses it - hardware queues are few (GPU_MAX_HW_QUEUES) and the runtime deals streams onto
+    them round-robin, so every further stream raises the odds that the two lanes of the live step share a queue and serialise."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    s = _LANE_STREAMS.get(key)
+    if s is None:
+        s = _LANE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return s
+
+
 def lane_stream(device, reserve_cus):
     """stream of the dense lane: confined to every CU except the first `reserve_cus` mask bits (tg_stream_create_cumask),
     or an ordinary stream when reserve_cus == 0"""
@@ -214,7 +228,7 @@ class TecoGANStep:
         # lane A is the caller's stream (no hand-over: two cross-stream waits cost ~15 us of idle chip each, every step) -
         # except beside a CU-masked lane B, whose BLOCKING stream would serialise against the legacy default stream
         self.sA = torch.cuda.Stream(device=device) if self.reserve > 0 else None
-        self.sB = torch.cuda.Stream(device=device)
+        self.sB = lane_b_stream(torch.device(device))
         # the real half runs BESIDE the chain (phase 1): only there can a CU reservation pay - its stream may be masked off
         # the first TECOGAN_CU_RESERVE CUs; the fake half (phase 2, beside the dense G backward) always has the whole chip
         self.sBm = lane_stream(device, self.reserve) if self.reserve > 0 else self.sB

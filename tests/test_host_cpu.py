@@ -583,7 +583,7 @@ def test_bench_flags_and_dry_dp_fields():
     import importlib
     bench = importlib.import_module("bench")
     a = bench.parse([])
-    assert (a.dp_mode, a.dp_steps, a.no_extras, a.gpus) == ("inline", 10, False, 1)
+    assert (a.dp_mode, a.dp_steps, a.no_extras, a.gpus) == (None, 10, False, 1)
     a = bench.parse(["--gpus", "8", "--dp-mode", "both", "--dp-steps", "4", "--no-extras"])
     assert (a.dp_mode, a.dp_steps, a.no_extras, a.gpus) == ("both", 4, True, 8)
     with pytest.raises(SystemExit):

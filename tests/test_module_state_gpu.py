@@ -17,6 +17,7 @@ sys.path.insert(1, os.path.join(ROOT, "code"))
 import models  # noqa: E402
 import train  # noqa: E402
 import tecogan_oracle as orc  # noqa: E402
+from pytorch_tecogan_amd import train as hip_train  # noqa: E402
 
 
 def synth(B, T, cs, seed):
@@ -144,7 +145,7 @@ def test_step_rebuild_on_the_same_engines_after_graph_capture(monkeypatch, dtype
     switched (the weights moved by two B = 2 steps in between, so only finiteness and the step counters are compared), the
     plan caches hold one configuration, and in fp16 the Adam step count stays torch's."""
     monkeypatch.setenv("TECOGAN_GRAPH", "1")
-    train._STEPS.clear()
+    hip_train._STEPS.clear()
     args, G, D, og, od, _, _ = build(7, dtype, num_resblock=2, discrim_resblocks=1)
     x1, y1 = (t.cuda() for t in synth(1, 10, 32, 5))
     x2, y2 = (t.cuda() for t in synth(2, 10, 32, 6))
@@ -155,7 +156,7 @@ def test_step_rebuild_on_the_same_engines_after_graph_capture(monkeypatch, dtype
             out = train.FRVSR_Train(x, y, args, D, G, step, 0.0, 0.0, og, od)
             step += 1
             assert bool(torch.isfinite(out.gen_output).all()) and np.isfinite(float(out.gen_loss)) and np.isfinite(float(out.d_loss))
-        st = next(iter(train._STEPS.values()))
+        st = next(iter(hip_train._STEPS.values()))
         assert st.use_graph and st.graphs is not None and st.B == x.shape[0]     # the phase ended in graph replays
         seen.append(st)
         Ge, De = G.engine(), D.engine()
@@ -165,9 +166,9 @@ def test_step_rebuild_on_the_same_engines_after_graph_capture(monkeypatch, dtype
     assert sizes[0] == sizes[1] == sizes[2] and sizes[0][3] == (1 if Ge.rgb_bwd_ok() else 0), sizes
     assert seen[0] is not seen[1] and seen[1] is not seen[2] and seen[0].graphs is None and seen[1].graphs is None
     torch.cuda.synchronize()
-    train.sync_optimizer_steps(og, od)
+    hip_train.sync_optimizer_steps(og, od)
     n_g = float(og.state[next(iter(G.parameters()))]["step"])
     # (fp16: an update skipped on overflow is not an optimizer step - the skip counts of the CLOSED steps were merged by close())
     assert n_g == 9.0 if dtype == "bf16" else 0.0 < n_g <= 9.0
     assert int(D.state_dict()["block1.1.num_batches_tracked"]) == 18
-    train._STEPS.clear()
+    hip_train._STEPS.clear()

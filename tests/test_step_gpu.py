@@ -462,7 +462,7 @@ def test_data_parallel_collectives_on_one_gpu(tmp_path, mode, bound):
     # the line explains its collectives: mode as run, exposed all-reduce time per lane (HIP events on the lane streams), the
     # step without collectives, and the start-up check that a synchronous all-reduce is ordered on the issuing stream
     d = dp["dp"]
-    assert d["mode"] == ("buckets" if mode else "inline") and d["requested_mode"] == d["mode"]
+    assert d["mode"] == ("buckets" if mode else "inline") and d["requested_mode"] == "env"   # (no --dp-mode: the environment's)
     assert d["sync_allreduce_stream_ordered"] is (None if mode else True)
     assert 0.0 <= d["allreduce_exposed_ms_laneA"] < 1.0 and 0.0 <= d["allreduce_exposed_ms_laneB"] < 1.0
     assert 0.5 * dp["ms_per_step"] < d["step_ms_no_collectives"] < 1.2 * dp["ms_per_step"]

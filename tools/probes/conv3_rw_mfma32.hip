@@ -1,3 +1,6 @@
+// ARCHIVED EXPERIMENT (round 4; not part of the library): the wave-specialised register-weights kernel with v_mfma_f32_32x32x16 consumers.
+// Measured against the 16x16x32 form that ships (profiles/r04_f_stamp_rw_v2d_mfma32.log, r04_f_mb_rw_v2d_mfma32.log vs r04_e_*): same k-loop time,
+// producers no faster, launches 3-10 % slower.  Parity-tested (tests/test_conv3_rw_gpu.py, 21 passed) when it was built in place of csrc/conv3_rw.hip.
 // 3x3 stride-1 convolution (forward, or input-gradient = taps mirrored) for the DENSE launches of the step - the batched
 // generator backward (40 samples), the discriminator's residual stages (12 samples) - with the weights held in REGISTERS
 // for the lifetime of a persistent workgroup:
@@ -11,8 +14,8 @@
 // 600-2100, epilogue 2600-3000, LDS-DMA issue 4000-5000 (each of the 8 DMA instructions re-loaded the zero page's address from
 // the GOT: a scalar-memory round trip).  Now the eight waves of a workgroup have two roles (waves w and w + 4 share a SIMD):
 //   * CONSUMERS (waves 0-3, one per SIMD) hold the weights - 32 output channels x 9 taps x 64 input channels = 36 A-fragments,
-//     144 VGPRs - and do nothing but the k-loop: B-fragments from the LDS patch image, 144 MFMAs per tile back to back (2304
-//     cycles), then the 32 accumulator registers go to an LDS accumulator image ([pixel][64 channels] fp32, 272-byte pixel pitch: conflict-free
+//     144 VGPRs - and do nothing but the k-loop: B-fragments from the LDS patch image, 72 v_mfma_f32_32x32x16 per tile back to
+//     back (2304 cycles), then the 32 accumulator registers go to an LDS accumulator image ([pixel][64 channels] fp32, 272-byte pixel pitch: conflict-free
 //     for the 16-byte stores).  Cin = 64: wave (wc, rg) = channel half x 4 of the tile's 8 rows.  Cin = 128: wave (wc, kh) =
 //     channel half x K half over a 4-row tile; the two K halves land in two accumulator images and the epilogue adds them (the
 //     split-K exchange, its barrier and its 32 KB of LDS are gone).
@@ -21,13 +24,29 @@
 //     +bias, +res, act, *act'(mask), 16-byte NHWC stores (8 lanes = one pixel's 64 channels: 1 KiB contiguous per wave-store),
 //     per-channel statistics in registers.  The epilogue's mask / residual rows are fetched one tile ahead.
 //   * ONE barrier per tile; patch and accumulator images are double-buffered, so consumers of tile i, the DMA of tile i + 1 and
-//     the epilogue of tile i - 1 overlap.  A tile costs what its 144 MFMAs per SIMD cost (2304 cycles) plus the accumulator store.
+//     the epilogue of tile i - 1 overlap.  A tile costs what its 72 MFMAs per SIMD cost (2304 cycles) plus the accumulator store.
 // LDS: 2 x 30 KB patches + 2 x 34 KB accumulator images (Cin = 64); 2 x 36 KB + 2 x 34 KB (Cin = 128).
 // LDS image and packed-weight layout are those of conv_mfma.hip's pipelined path (swizzled 64-byte rows, patch pitch 24).
 //
 // Replaces aten::conv2d / convolution_backward(input) of the 3x3 layers (code/models.py:54-58,68,73-76,102 via
 // code/ops.py:57-63; autograd of code/train.py:336,340) where tg_conv is the general entry point.
-#include "common.h"
+#include "../../pytorch-tecogan_amd/csrc/common.h"
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+// 32x32x16 MFMA on 16-bit operands: lane l (r = l & 31, h = l >> 5) holds A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7;
+// D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 h.  32 cycles per instruction of which 8 hold the SIMD's vector issue (the
+// 16x16x32 form: 8 of 16) - the form to use where another wave's vector work shares the SIMD (csrc/conv3_rw.hip)
+template <typename T> struct Mma32;
+template <> struct Mma32<BF16> {
+  __device__ __forceinline__ static f32x16 run(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma32<F16> {
+  __device__ __forceinline__ static f32x16 run(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
 #include <type_traits>
 
 #ifdef TG_STAMP
@@ -56,7 +75,6 @@ __device__ __attribute__((aligned(16))) unsigned int tg_rw_zero_page[4];
 namespace {
 
 constexpr int kRow = 64, kPitch = 24, kPW = 18;
-constexpr int kRedBytes = 1024;   // statistics: [2][64] fp32 sums of the four producer waves + a ticket
 constexpr int kAccPitch = 272;  // bytes per pixel of an accumulator image (64 fp32 + 16: 8 lanes' 16-byte stores hit 32 distinct banks)
 
 template <int NCH> struct Geo {
@@ -72,7 +90,7 @@ template <int NCH> struct Geo {
   static constexpr int kAccHalf = kPix * kAccPitch;
   static constexpr int kAccBytes = kHalves * kAccHalf;           // 34 816 either way
   static constexpr int KS = kPix / 32;                           // 8-pixel store instructions per producer wave and tile
-  static constexpr int kLds = 2 * kBufBytes + 2 * kAccBytes;       // (+ kRedBytes of statistics scratch behind it)
+  static constexpr int kLds = 2 * kBufBytes + 2 * kAccBytes;
   static_assert(kChunkBytes % 1024 == 0, "a DMA block must not straddle two chunk images");
 };
 
@@ -109,19 +127,6 @@ template <typename T> __device__ __forceinline__ void unpack8(const u32x4 r, flo
   }
 }
 
-// two floats -> one register of two 16-bit values, round to nearest even (ONE v_cvt_pk_* instruction; element-wise conversion +
-// shift + or costs three)
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
-template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi);
-template <> __device__ __forceinline__ unsigned pack2<BF16>(float lo, float hi) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
-}
-template <> __device__ __forceinline__ unsigned pack2<F16>(float lo, float hi) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));
-}
-
 // SM: statistics of the stored values - 0 none, 1 per-channel sums (a bias gradient), 2 sums and sums of squares (batch norm).
 template <int NCH, int SM, typename T = BF16>
 __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
@@ -148,83 +153,87 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
 
   if (wid < 4) {
     // ============================================================ CONSUMER: weights in registers, k-loop, accumulators -> LDS
-    // (v_mfma_f32_16x16x32.  The 32x32x16 form was built too - profiles/r04_f_*_mfma32.log: same k-loop time, the producers no
-    // faster, the launches 3-10 % slower - so the producers' pace is not set by the matrix instructions' hold on the vector issue.)
-    const int idx = lane & 15, g = lane >> 4;
+    // v_mfma_f32_32x32x16: A = the wave's 32 output channels (packed rows 32 wc + r), B = 32 pixels (two tile rows), K = 16 input
+    // channels.  The same FLOP per cycle as the 16x16x32 form, but an instruction holds the SIMD's vector issue for 8 of 32 cycles
+    // instead of 8 of 16: the producer wave on this SIMD issues its epilogue / DMA instructions twice as fast
+    // (profiles/r04_e_stamp_rw_v2c_noslp.log: with 16x16x32 the producers needed ~6000 ticks per tile, the consumers 3400).
+    const int r = lane & 31, h = lane >> 5;
     const int wc = wid & 1;                                   // channel half: packed rows 32*wc .. 32*wc + 31
     const int kh = NCH == 4 ? wid >> 1 : 0;                   // input-channel half (Cin = 128)
     const int r0 = NCH == 4 ? 0 : (wid >> 1) * 4;             // first of the wave's 4 tile rows
-    // A-fragments of packed rows 32*wc + 16*a + idx for 9 taps x 2 chunks, in k-loop order.  Packed image
-    // [tap][chunk][Cout rows][64 B]; the input-gradient launch pairs spatial offset `so` with slot 8 - so.
-    bf16x8 wfr[2][9][2];
+    // pixel of MFMA column r inside a 2-row x 16-column block: ds_read_b128 serves lanes {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}
+    // (and the same + 32) as one LDS cycle each if they hit 16 distinct 16-byte slots mod 256 B - true of 16 CONSECUTIVE patch
+    // positions of one row (swz), so each of those lane sets gets one image row: 4-lane block b = r / 4 -> row parity(b), columns
+    // 4 (b / 2) .. + 3
+    const int blk = r >> 2;
+    const int rsel = __popc(blk) & 1, col = (blk >> 1) * 4 + (r & 3);
+    // A-fragments: 2 chunks x 9 taps x 2 K steps, in k-loop order.  Packed image [tap][chunk][Cout rows][64 B = 32 channels];
+    // the input-gradient launch pairs spatial offset `so` with slot 8 - so.
+    bf16x8 wfr[36];
     {
-      const char* wl = p.w + ((size_t)co_base + wc * 32 + idx) * 64 + g * 16;
+      const char* wl = p.w + ((size_t)co_base + wc * 32 + r) * 64 + h * 16;
 #pragma unroll
-      for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-        for (int so = 0; so < 9; ++so)
-#pragma unroll
-          for (int a = 0; a < 2; ++a) {
-            const int slot = p.flip ? 8 - so : so;
-            const int chunk = kh * 2 + ci;
-            wfr[ci][so][a] = *reinterpret_cast<const bf16x8*>(wl + ((size_t)(slot * NCH + chunk) * p.Cout + a * 16) * 64);
-          }
+      for (int s_ = 0; s_ < 36; ++s_) {
+        const int ci = s_ / 18, so = (s_ % 18) / 2, ks = s_ & 1;
+        const int slot = p.flip ? 8 - so : so;
+        const int chunk = kh * 2 + ci;
+        wfr[s_] = *reinterpret_cast<const bf16x8*>(wl + (size_t)(slot * NCH + chunk) * p.Cout * 64 + ks * 32);
+      }
     }
     RW_STAMP(1);
-    // fragment addresses of the wave's rows inside one chunk image (column taps 0..2); row taps add multiples of the pitch
-    // (two 16-bit offsets per register)
-    unsigned xbase[6];
+    // B-fragment addresses inside one chunk image for the wave's first pixel block: column tap c, K step ks (16-byte piece 2 ks + h;
+    // the swizzle makes ks = 1 an XOR, not an offset).  Row taps and the second pixel block add multiples of the pitch, which leave
+    // the swizzle alone.  Two 16-bit offsets per register.
+    unsigned xbase[3];
 #pragma unroll
-    for (int q = 0; q < 12; q += 2)
-      xbase[q / 2] = (unsigned)swz((r0 + q / 3) * kPitch + idx + q % 3, g) |
-                     ((unsigned)swz((r0 + (q + 1) / 3) * kPitch + idx + (q + 1) % 3, g) << 16);
-    auto xoff = [&](int b, int c) {  // compile-time (b, c) after unrolling
-      const int q = b * 3 + c;
-      return (int)((q & 1) ? xbase[q / 2] >> 16 : xbase[q / 2] & 0xffffu);
-    };
-    // lane (idx, g) ends with channels 32*wc + 8g .. + 7 (two row-interleaved MFMA tiles, common.h) of pixel (r0 + b, idx)
-    const int acc_off = kh * G::kAccHalf + (r0 * 16 + idx) * kAccPitch + (wc * 32 + 8 * g) * 4;
+    for (int c = 0; c < 3; ++c)
+      xbase[c] = (unsigned)swz((r0 + rsel) * kPitch + col + c, h) | ((unsigned)swz((r0 + rsel) * kPitch + col + c, 2 + h) << 16);
+    auto xoff = [&](int c, int ks) { return (int)(ks ? xbase[c] >> 16 : xbase[c] & 0xffffu); };   // compile-time (c, ks)
+    // D: lane (r, h), register 4 v + j = packed row 8 v + 4 h + j = channel 32 wc + 16 (v & 1) + 8 h + 4 (v >> 1) + j (common.h,
+    // row_to_channel) of pixel (r0 + 2 pt + rsel, col): four consecutive channels per register quad
+    const int acc_off = kh * G::kAccHalf + ((r0 + rsel) * 16 + col) * kAccPitch + (wc * 32 + 8 * h) * 4;
     RW_STAMP(2);
     lds_barrier();   // patch 0 is in LDS
     RW_STAMP(3);
     for (int i = 0; i <= ntl; ++i) {
       RW_STAMP(4 + 6 * i + 0);
       if (i < ntl) {
-        f32x4 acc[2][4];
+        f32x16 acc[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int e = 0; e < 16; ++e) acc[pt][e] = 0.f;
         const char* img = smem + (i & 1) * G::kBufBytes + kh * 2 * G::kChunkBytes;
-        // k-loop: 18 steps (2 chunks x 9 taps) of 4 B-fragment reads + 8 MFMAs.  The wave is alone on its SIMD's matrix pipe, so
-        // the fragments of steps s + 1 and s + 2 are in flight while step s multiplies (left to itself the compiler reads one
-        // fragment, waits lgkmcnt(0), issues two MFMAs: the whole LDS latency per 32 cycles of matrix work)
-        bf16x8 xf[3][4];
+        // k-loop: 36 steps (2 chunks x 9 taps x 2 K steps) of 2 B-fragment reads + 2 MFMAs.  The wave is alone on its SIMD's matrix
+        // pipe, so the fragments of steps s + 1 .. s + 3 are in flight while step s multiplies (left to itself the compiler reads a
+        // fragment, waits lgkmcnt(0), multiplies: the whole LDS latency per step)
+        constexpr int kAhead = 3;
+        bf16x8 xf[kAhead + 1][2];
         auto frags = [&](int s_, int buf) {   // compile-time arguments after unrolling
-          const int ci = s_ / 9, so = s_ % 9;
+          const int ci = s_ / 18, so = (s_ % 18) / 2, ks = s_ & 1;
 #pragma unroll
-          for (int b = 0; b < 4; ++b)
-            xf[buf][b] = *reinterpret_cast<const bf16x8*>(img + ci * G::kChunkBytes + xoff(b, so % 3) + (so / 3) * kPitch * kRow);
+          for (int pt = 0; pt < 2; ++pt)
+            xf[buf][pt] = *reinterpret_cast<const bf16x8*>(img + ci * G::kChunkBytes + xoff(so % 3, ks) +
+                                                           (so / 3 + 2 * pt) * kPitch * kRow);
         };
-        frags(0, 0);
-        frags(1, 1);
 #pragma unroll
-        for (int s_ = 0; s_ < 18; ++s_) {
-          if (s_ + 2 < 18) frags(s_ + 2, (s_ + 2) % 3);
+        for (int s_ = 0; s_ < kAhead; ++s_) frags(s_, s_);
+#pragma unroll
+        for (int s_ = 0; s_ < 36; ++s_) {
+          if (s_ + kAhead < 36) frags(s_ + kAhead, (s_ + kAhead) % (kAhead + 1));
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int a = 0; a < 2; ++a) acc[a][b] = mma<T>(wfr[s_ / 9][s_ % 9][a], xf[s_ % 3][b], acc[a][b]);
+          for (int pt = 0; pt < 2; ++pt) acc[pt] = Mma32<T>::run(wfr[s_], xf[s_ % (kAhead + 1)][pt], acc[pt]);
           __builtin_amdgcn_sched_barrier(0);
         }
         RW_STAMP(4 + 6 * i + 1);
         char* dst = accb + (i & 1) * G::kAccBytes + acc_off;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          *reinterpret_cast<f32x4*>(dst + b * 16 * kAccPitch) = acc[0][b];
-          *reinterpret_cast<f32x4*>(dst + b * 16 * kAccPitch + 16) = acc[1][b];
-        }
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            *reinterpret_cast<f32x4*>(dst + pt * 32 * kAccPitch + 64 * (v & 1) + 16 * (v >> 1)) =
+                f32x4{acc[pt][4 * v], acc[pt][4 * v + 1], acc[pt][4 * v + 2], acc[pt][4 * v + 3]};
       }
       RW_STAMP(4 + 6 * i + 2);
       lds_barrier();
@@ -315,16 +324,8 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) s2[e] = 0.f;
   }
-  // per-channel statistics of the stored values: lanes -> wave (over the 8 pixels of a store instruction) -> the four producer
-  // waves through an LDS accumulator -> ONE global atomic per channel and workgroup, issued by whichever wave arrives last (a ticket
-  // in LDS; a wave's LDS operations are served in order, so every wave's sums are in before its ticket is).  A persistent workgroup
-  // flushes once per statistics group it touches; flushes of consecutive groups are an iteration's barrier apart.
-  // (Per-wave global atomics - 8 instructions of 8 lanes each - took 147 us instead of 34 on c20's input-gradient: 5120 atomic
-  // instructions on the same four cache lines serialise at ~25 ns each; profiles/r04_i_g_bwd_anatomy_v2e.log.)
-  float* const red = reinterpret_cast<float*>(smem + G::kLds);   // [2][64] sums, [128] the ticket
-  if constexpr (STATS) {
-    if (tid - 256 < 132) red[tid - 256] = 0.f;   // published by the first barrier
-  }
+  // per-channel statistics of the stored values: lanes -> wave (over the 8 pixels of a store instruction), one atomic per channel
+  // and wave; a persistent workgroup flushes once per statistics group it touches
   auto flush_stats = [&](int grp) {
     if constexpr (STATS) {
 #pragma unroll
@@ -336,23 +337,12 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
         }
       }
       if (lane < 8) {
+        const size_t rep = (size_t)(blockIdx.x & (p.stats_replicas - 1)) * p.stats_groups * 2 * p.Cout;
+        float* dst = p.stats + rep + (size_t)grp * 2 * p.Cout + ch0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          atomicAdd(&red[8 * q8 + e], s1[e]);
-          if constexpr (SM == 2) atomicAdd(&red[64 + 8 * q8 + e], s2[e]);
-        }
-      }
-      unsigned ticket = 0;
-      if (lane == 0) ticket = atomicAdd(reinterpret_cast<unsigned*>(red + 128), 1u);
-      ticket = __builtin_amdgcn_readfirstlane(ticket);
-      if ((ticket & 3u) == 3u) {   // the last of the four producer waves
-        const size_t rep = (size_t)(blockIdx.x & (p.stats_replicas - 1)) * p.stats_groups * 2 * p.Cout;
-        float* dst = p.stats + rep + (size_t)grp * 2 * p.Cout + co_base + lane;
-        atomicAdd(dst, red[lane]);
-        red[lane] = 0.f;
-        if constexpr (SM == 2) {
-          atomicAdd(dst + p.Cout, red[64 + lane]);
-          red[64 + lane] = 0.f;
+          atomicAdd(dst + e, s1[e]);
+          if constexpr (SM == 2) atomicAdd(dst + p.Cout + e, s2[e]);
         }
       }
 #pragma unroll
@@ -362,17 +352,10 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
       }
     }
   };
-  // The epilogue of a tile is split over two iterations: COMPUTE (accumulator image -> 16-bit results in registers) while the
-  // consumers multiply the next tile, and the STORES of those registers at the top of the following iteration.  That way the only
-  // vector-memory operations an iteration issues behind its DMA are loads whose data is needed an iteration later, so the wait in
-  // front of the barrier never waits for a store and the DMA - issued first - has the whole iteration to land.  (One fused loop made
-  // the compiler wait vmcnt(0) for the mask rows in each of its KS bodies, which also waited for the store the previous body had just
-  // issued: 5400 ticks per tile; with the stores behind the bodies and the DMA last, the DMA's landing was exposed instead: 1000-3300
-  // ticks; tools/stamp_rw.py, profiles/r04_c_*, r04_e_*.)
-  u32x4 ov[G::KS];
-  unsigned okm = 0;
-  Tile st_tile = {0, 0, 0};
-  auto compute = [&](const Tile& tl, int buf, const u32x4* mk) {
+  // Two passes: every accumulator read and every use of the prefetched mask / residual rows comes BEFORE the first global store.
+  // (One fused loop made the compiler wait vmcnt(0) for pre[k] in each of its KS bodies - which also waits for the store the
+  // previous body had just issued: a full write round trip per 8 pixels, 5400 ticks per tile; tools/stamp_rw.py.)
+  auto epilogue = [&](const Tile& tl, int buf) {
     const int n = tl.n, ty0 = tl.ty0, tx0 = tl.tx0;
     if constexpr (STATS) {
       const int grp = n / (p.N / p.stats_groups);
@@ -393,9 +376,11 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
         a1[k] += *reinterpret_cast<const f32x4*>(ab + G::kAccHalf + pl * kAccPitch + 16);
       }
     }
+    // the tile's first output pixel (uniform) + the lane's 32-bit offset: 64-bit arithmetic stays on the scalar unit
+    char* const out_t = p.out + ((((size_t)n * p.H + ty0) * p.W + tx0) * p.Cout) * 2;
     const char* const res_t = p.res ? p.res + ((((size_t)n * p.H + ty0) * p.W + tx0) * p.Cout) * 2 : nullptr;
-    okm = 0;
-    st_tile = tl;
+    u32x4 ov[G::KS];
+    unsigned okm = 0;
 #pragma unroll
     for (int k = 0; k < G::KS; ++k) {
       const int pl = pl0 + 8 * k;
@@ -414,7 +399,7 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
       }
       if (p.res) {
         float r[8];
-        if (p.mask_mode == TG_MASK_NONE) unpack8<T>(mk[k], r);
+        if (p.mask_mode == TG_MASK_NONE) unpack8<T>(pre[k], r);
         else if (ok) Vec<T>::load(res_t + (unsigned)((ry * p.W + rx) * p.Cout + ch0) * 2u, r);   // (res AND mask: the trunk's first block only)
         else {
 #pragma unroll
@@ -430,25 +415,14 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
       }
-      if (p.mask_mode == TG_MASK_RELU) {
-        // mask value > 0 on its 16-bit pattern (sign clear, not zero): the low half as the sign of word << 16, the high half as
-        // word > 0xffff - no unpacking to float
+      if (p.mask_mode != TG_MASK_NONE) {
+        float m[8];
+        unpack8<T>(pre[k], m);
+        const float neg = p.mask_mode == TG_MASK_LRELU ? 0.2f : 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int w_ = (int)mk[k][e];
-          v[2 * e] = (int)((unsigned)w_ << 16) > 0 ? v[2 * e] : 0.f;
-          v[2 * e + 1] = w_ > 0xffff ? v[2 * e + 1] : 0.f;
-        }
-      } else if (p.mask_mode == TG_MASK_LRELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int w_ = (int)mk[k][e];
-          v[2 * e] = (int)((unsigned)w_ << 16) > 0 ? v[2 * e] : 0.2f * v[2 * e];
-          v[2 * e + 1] = w_ > 0xffff ? v[2 * e + 1] : 0.2f * v[2 * e + 1];
-        }
+        for (int e = 0; e < 8; ++e) v[e] *= (m[e] > 0.f ? 1.f : neg);
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ov[k][e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+      Vec<T>::store(&ov[k], v);
       if constexpr (STATS) {
         if (ok) {
 #pragma unroll
@@ -459,9 +433,6 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
         }
       }
     }
-  };
-  auto store_results = [&]() {   // of the tile `compute` ran on last: the tile's first output pixel (uniform) + a 32-bit lane offset
-    char* const out_t = p.out + ((((size_t)st_tile.n * p.H + st_tile.ty0) * p.W + st_tile.tx0) * p.Cout) * 2;
 #pragma unroll
     for (int k = 0; k < G::KS; ++k) {
       const int pl = pl0 + 8 * k;
@@ -470,8 +441,9 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
     }
   };
 
-  Tile cur = tile_of((int)blockIdx.x), prev = cur, st_prev = cur;   // the consumers' tile of iteration i, of i - 1; st_prev: see below
+  Tile cur = tile_of((int)blockIdx.x), prev = cur;   // the tile the consumers work on in iteration i, and the one before
   dma_patch(cur, 0);
+  issue_pre(cur);
   RW_STAMP(1);
   RW_STAMP(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // patch 0 has landed
@@ -480,33 +452,23 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
   int tile = (int)blockIdx.x;
   for (int i = 0; i <= ntl; ++i, tile += (int)gridDim.x) {
     RW_STAMP(4 + 6 * i + 0);
-    if (i >= 2) store_results();   // tile i - 2, computed during iteration i - 1
-    // the previous tile's mask / residual rows arrived during iteration i - 1 (its vmcnt(0)); taken over into registers the compiler
-    // does not connect with a load any more, so that nothing below waits on the vector-memory counter
-    u32x4 mk[G::KS];
-#pragma unroll
-    for (int k = 0; k < G::KS; ++k) {
-      mk[k] = pre[k];
-      asm volatile("" : "+v"(mk[k]));
-    }
-    // the next tile's patch (its buffer was last read in iteration i - 1) and this tile's mask / residual rows
+    // epilogue of the previous tile (its accumulators were published by the barrier that ended iteration i - 1; its mask / residual
+    // rows were fetched during iteration i - 1), then this tile's rows for the next iteration
+    if (i >= 1) epilogue(prev, (i - 1) & 1);
+    RW_STAMP(4 + 6 * i + 1);
+    if (i < ntl) issue_pre(cur);
     prev = cur;
+    // the next tile's patch: the buffer was last read in iteration i - 1
     if (i + 1 < ntl) {
       cur = tile_of(tile + (int)gridDim.x);
       dma_patch(cur, (i + 1) & 1);
     }
-    if (i < ntl) issue_pre(prev);
-    RW_STAMP(4 + 6 * i + 1);
-    // the previous tile's accumulators were published by the barrier that ended iteration i - 1
-    if (i >= 1) compute(st_prev, (i - 1) & 1, mk);
-    st_prev = prev;
     RW_STAMP(4 + 6 * i + 2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA (and the rows) have landed before the barrier publishes the patch
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... has landed before the barrier publishes it
     RW_STAMP(4 + 6 * i + 3);
     lds_barrier();
     RW_STAMP(4 + 6 * i + 4);
   }
-  if (ntl >= 1) store_results();   // the last tile
   if constexpr (STATS) {
     if (cur_grp >= 0) flush_stats(cur_grp);
   }
@@ -515,7 +477,7 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
 
 template <int NCH, int SM, typename T>
 int launch_rw(const RwK& k, dim3 grid, hipStream_t st) {
-  constexpr int lds = Geo<NCH>::kLds + kRedBytes;
+  constexpr int lds = Geo<NCH>::kLds;
   auto fn = conv3_rw_kernel<NCH, SM, T>;
   static std::atomic<bool> attr_done{false};  // one-time function attribute (benign race: idempotent)
   if (!attr_done) {
