@@ -4,7 +4,11 @@
     len(scenes) windows; frames are resized to 4*crop (HR) and crop (LR) with bilinear filtering; frame 0 only gets an
     independent RandomResizedCrop for LR and HR (:91-93).
   * inference_dataset: one item per sub-folder, all frames resized to crop x crop.
-Not on the timed path; kept so that main.py is a drop-in."""
+Not on the timed path; kept so that main.py is a drop-in.  Measured against the step's demand by
+tools/ingest_bench.py (profiles/r04_*_ingest.log): the reference's pipeline - 10 PNG decodes + 20 PIL resizes per sequence in the
+workers - delivers a fraction of the ~1000 sequences/s one MI355X consumes, so the defaults are: decoded frames cached per
+worker (the 110 windows of a scene overlap in 9 of 10 frames, and an epoch only visits the first len(scenes) windows), workers
+that only decode, uint8 batches pinned by the loader, and the PIL-exact resize on the GPU."""
 import math
 import os
 import random
@@ -13,6 +17,38 @@ import numpy as np
 import torch
 from PIL import Image
 from torch.utils.data import Dataset
+
+
+class FrameCache:
+    """Decoded RGB frames (PIL images or uint8 arrays) of one worker process, least recently used out first, bounded in bytes.
+    The training windows are sliding windows of 10 over a scene's 120 frames: every frame is part of 10 windows, and the
+    reference's __len__ quirk makes an epoch visit the first len(scenes) windows only - a handful of scenes.  Decoding each PNG
+    once per worker instead of once per visit removes most of the ingest's CPU time; a dataset larger than the budget simply
+    thrashes the cache and costs what it did before."""
+
+    def __init__(self, budget_mb):
+        import collections
+        self.budget, self.used, self.items = int(budget_mb) << 20, 0, collections.OrderedDict()
+        self.hits = self.misses = 0
+
+    def get(self, path, as_array):
+        key = (path, as_array)
+        ent = self.items.get(key)
+        if ent is not None:
+            self.items.move_to_end(key)
+            self.hits += 1
+            return ent[0]
+        self.misses += 1
+        img = Image.open(path).convert("RGB")
+        val = np.asarray(img) if as_array else img
+        size = img.size[0] * img.size[1] * 3
+        if self.budget > 0:
+            self.items[key] = (val, size)
+            self.used += size
+            while self.used > self.budget and len(self.items) > 1:
+                _, (_, sz) = self.items.popitem(last=False)
+                self.used -= sz
+        return val
 
 
 def _to_tensor(img):
@@ -78,11 +114,51 @@ def frames_to_batches(frames_u8, crop_size, first_frame_crop=True):
     return lr, hr
 
 
+def device_batches(loader, device, crop_size):
+    """(inputs, targets) on `device`, one batch AHEAD of the consumer: the host-to-device copy of batch i + 1 and (decode-only
+    workers) its resize run on a side stream while the training step of batch i runs on the caller's stream.  Taken inline on the
+    caller's stream - which is lane A of the step - the 8-MB copy and the resize kernels cost 0.5 ms of every 4-ms step
+    (tools/ingest_bench.py, profiles/r04_m_ingest.log: 878 of the 993 sequences/s the step takes).  `loader` may yield either
+    batch form (uint8 frames, or the reference pipeline's [LR, HR] pair)."""
+    side = torch.cuda.Stream(device=device)
+
+    def stage(batch):
+        with torch.cuda.stream(side):
+            if torch.is_tensor(batch):
+                x, y = frames_to_batches(batch.to(device, non_blocking=True), crop_size)
+            else:
+                x, y = batch[0].to(device, non_blocking=True), batch[1].to(device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return x, y, ev
+
+    it = iter(loader)
+    try:
+        nxt = stage(next(it))
+    except StopIteration:
+        return
+    while nxt is not None:
+        x, y, ev = nxt
+        try:
+            nxt = stage(next(it))
+        except StopIteration:
+            nxt = None
+        cur = torch.cuda.current_stream(device)
+        cur.wait_event(ev)
+        x.record_stream(cur)   # (allocated on the side stream: the allocator must not hand the memory out while the step reads it)
+        y.record_stream(cur)
+        yield x, y
+
+
 class train_dataset(Dataset):
     def __init__(self, args, decode_only=False):
         """decode_only: __getitem__ returns the window's DECODED frames as one uint8 tensor (10,H,W,3); the resize to the LR
-        and HR sizes then happens on the GPU (frames_to_batches) - the PNG decode is all the workers do."""
+        and HR sizes then happens on the GPU (frames_to_batches) - the PNG decode is all the workers do.  "auto": decode-only when
+        the dataset's frames share one size (probed on the first and last scene), else the reference pipeline.
+        args.tg_frame_cache_mb (default 512): per-worker budget of the decoded-frame cache, 0 = off."""
         self.decode_only = decode_only
+        self.cache = None   # per process: created on first use, i.e. inside each DataLoader worker
+        self.cache_mb = int(getattr(args, "tg_frame_cache_mb", 512))
         if args.input_video_dir == "":
             raise ValueError("Video input directory input_video_dir is not provided")
         if not os.path.exists(args.input_video_dir):
@@ -100,6 +176,19 @@ class train_dataset(Dataset):
             frames = [os.path.join(d, "col_high_%04d.png" % k) for k in range(args.max_frm + 1)]
             self.scenes += 1
             self.windows += [frames[i:i + 10] for i in range(110)]
+        if self.decode_only == "auto":
+            sizes = set()
+            for w in (self.windows[:1] + self.windows[-1:]):
+                with Image.open(w[0]) as im:
+                    sizes.add(im.size)
+                with Image.open(w[-1]) as im:
+                    sizes.add(im.size)
+            self.decode_only = len(sizes) == 1
+
+    def _frame(self, path, as_array):
+        if self.cache is None:
+            self.cache = FrameCache(self.cache_mb)
+        return self.cache.get(path, as_array)
 
     def __len__(self):
         return self.scenes  # reference quirk: scene count, not window count
@@ -107,10 +196,10 @@ class train_dataset(Dataset):
     def __getitem__(self, idx):
         cs = self.args.crop_size
         if self.decode_only:
-            return torch.from_numpy(np.stack([np.asarray(Image.open(p).convert("RGB")) for p in self.windows[idx]]))
+            return torch.from_numpy(np.stack([self._frame(p, True) for p in self.windows[idx]]))
         lr, hr = [], []
         for i, path in enumerate(self.windows[idx]):
-            img = Image.open(path)
+            img = self._frame(path, False)
             h_t, l_t = _to_tensor(_resize(img, 4 * cs)), _to_tensor(_resize(img, cs))
             if i == 0:
                 h_t, l_t = _random_resized_crop(h_t, 4 * cs), _random_resized_crop(l_t, cs)

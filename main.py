@@ -57,9 +57,12 @@ def build_parser():
     a("--D_LAYERLOSS", default=True, type=str2bool)
     a("--synthetic", default=0, type=int, help="train on this many random sequences (no dataset)")
     a("--tg_dtype", default=None, choices=[None, "bf16", "fp16", "fp32"])
-    a("--tg_gpu_resize", default=False, type=str2bool,
+    a("--tg_gpu_resize", default="auto", type=lambda v: "auto" if str(v).lower() == "auto" else str2bool(v),
       help="data ingest: the workers only decode the PNGs; the PIL-bilinear resize to the LR / HR sizes runs on the GPU "
-           "(bit-exact restatement of PIL's resize; frames of one dataset must share a size)")
+           "(bit-exact restatement of PIL's resize).  auto (default): when the dataset's frames share one size, else the "
+           "reference's pipeline (decode + two PIL resizes per frame in the workers); tools/ingest_bench.py measures both")
+    a("--tg_frame_cache_mb", default=512, type=int,
+      help="data ingest: per-worker budget of the decoded-frame cache (a scene's 110 windows overlap in 9 of 10 frames); 0 = off")
     a("--tg_fnet", default=False, type=str2bool,
       help="opt-in (not reference behaviour): the flow comes from the f_net estimator the reference defines and never calls "
            "(main.py:231): gen_flow = up4(4 * f_net(previous LR frame)) instead of the raw-frame pseudo-flow")
@@ -150,7 +153,7 @@ def main(argv=None):
         dataset = data
     else:
         from dataloader import train_dataset
-        dataset = train_dataset(args, decode_only=bool(args.tg_gpu_resize))
+        dataset = train_dataset(args, decode_only=args.tg_gpu_resize)
     sampler = None
     if world > 1:
         sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True,
@@ -202,18 +205,16 @@ def main(argv=None):
     for e in range(epoch0, args.max_epochs):
         g_loss = d_loss = 0.0
         output = inputs = targets = None
+        t_epoch, n_batches = time.time(), 0
         if sampler is not None:
             sampler.set_epoch(e)
-        for batch_idx, batch in enumerate(loader):
-            if torch.is_tensor(batch):  # --tg_gpu_resize: decoded uint8 frames (B,T,H,W,3); resize on the device
-                from dataloader import frames_to_batches
-                inputs, targets = frames_to_batches(batch.to(dev, non_blocking=True), args.crop_size)
-            else:
-                inputs, targets = batch
-                inputs, targets = inputs.to(dev, non_blocking=True), targets.to(dev, non_blocking=True)
+        # batches arrive on the device one step ahead (copy + GPU-side resize on a side stream: dataloader.device_batches)
+        from dataloader import device_batches
+        for batch_idx, (inputs, targets) in enumerate(device_batches(loader, dev, args.crop_size)):
             output = FRVSR_Train(inputs, targets, args, D, G, batch_idx, 0.0, 0.0, opt_g, opt_d)
             g_loss = g_loss + (output.gen_loss.data - g_loss) / (batch_idx + 1)   # running means stay on the device
             d_loss = d_loss + (output.d_loss.data - d_loss) / (batch_idx + 1)
+            n_batches += 1
         sch_d.step()
         sch_g.step()
         if sch_f is not None:
@@ -225,6 +226,10 @@ def main(argv=None):
             if rank == 0:
                 print(f"replica check ok ({world} ranks)")
         if rank == 0 and output is not None:
+            torch.cuda.synchronize()
+            dt_e = max(time.time() - t_epoch, 1e-9)   # ingest + steps of this epoch (before the per-epoch samples / checkpoints below)
+            print(f"epoch {e + 1}: {n_batches} steps in {dt_e:.3f} s = {n_batches / dt_e:.1f} steps/s = "
+                  f"{4 * n_batches / dt_e:.1f} sequences/s per rank")
             print("Epoch: {}".format(e + 1))
             print("\nGenerator loss is: {} \nDiscriminator loss is: {}".format(float(g_loss), float(d_loss)))
             print(f"\nGenerator lr is: {opt_g.param_groups[0]['lr']}, Discriminator lr is: {opt_d.param_groups[0]['lr']}")

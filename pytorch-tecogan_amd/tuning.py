@@ -49,7 +49,7 @@ KNOBS = OrderedDict((k.attr, k) for k in (
     _k("PERSIST_RW_D", "persist_rw_d", "int", 0, "profiles/r02_q_persist_wgs_sweep.log", "... the discriminator's"),
     # ---- kernel routing (engine.Conv, kernels.rw_eligible)
     _k("RW", "rw", "str", "1", "profiles/r02_c_mb_rw.log", "register-weights 3x3 kernel: 0 never, 1 where measured faster, all"),
-    _k("RW_EXTRA", "rw_extra", "str", "trunk,c30,m128", "profiles/r03_r_rw_dma_ab.log",
+    _k("RW_EXTRA", "rw_extra", "str", "trunk,c30,m128,s3", "profiles/r03_r_rw_dma_ab.log, r04_l_rw_extra_s3.log",
        "launch classes routed to it for the STEP's sake (capped persistent launches are better neighbours)"),
     _k("RW_EXTRA_DREAL", "rw_extra_dreal", "ostr", None, "profiles/r03_r_rw_dma_ab.log",
        "more classes for the discriminator's real half only (unset: s1 for chain-bound steps)"),
