@@ -251,7 +251,8 @@ int tg_conv3x3_rgb_bwd(int dtype, const void* dpre4, const void* x, const float*
  * out_h = relu(conv3x3(in, w1) + b1), out_a = (add_skip ? in : 0) + conv3x3(out_h, w2) in ONE launch (add_skip = 0: the
  * conv-relu-conv pair of conv_trans.2, code/models.py:73); tensors NHWC [N][H][W][64]; w1 / w2 are
  * the forward packings of tg_pack_conv_weights (9 slots).  out_h is rounded to bf16 before the second conv, exactly like
- * the two-launch sequence.  TG_E_UNSUPPORTED for any other dtype / channel count (run two tg_conv launches then).
+ * the two-launch sequence.  out_h may be null: the intermediate activation is then not stored (inference: only the backward pass reads
+ * it).  TG_E_UNSUPPORTED for any other dtype / channel count (run two tg_conv launches then).
  * next_w1_packed / next_w2_packed (both or neither; may be null): packed weights of the residual block that will be
  * launched next; the kernel touches them so that they sit in L2 when that launch streams them (values are not used). */
 int tg_resblock_fwd(int dtype, const void* in, const void* w1_packed, const float* b1, const void* w2_packed, void* out_h,

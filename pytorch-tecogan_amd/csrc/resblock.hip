@@ -276,7 +276,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
           }
           const uint2 pk = pack4<T>(v);
           *reinterpret_cast<uint2*>(lds_h + chunk * kHRows * kRow + lds_off(hy * kHP + hx, g) + half * 8) = pk;
-          if (inside && hy >= 1 && hy <= TH && hx >= 1 && hx <= 8)
+          if (p.out_h && inside && hy >= 1 && hy <= TH && hx >= 1 && hx <= 8)   // (out_h null: inference, nobody reads h)
             *reinterpret_cast<uint2*>(p.out_h + (((size_t)n * p.H + y) * p.W + x) * 128 + ch0 * 2) = pk;
         }
       }
@@ -415,9 +415,9 @@ int resblock_launch(bool bwd, const void* in, const void* wa, const float* b1, c
 extern "C" int tg_resblock_fwd(int dtype, const void* in, const void* w1_packed, const float* b1, const void* w2_packed,
                                void* out_h, void* out_a, int N, int H, int W, int C, int add_skip,
                                const void* next_w1_packed, const void* next_w2_packed, void* stream) {
-  if (!in || !w1_packed || !b1 || !w2_packed || !out_h || !out_a || N <= 0 || H <= 0 || W <= 0) return TG_E_BADARG;
+  if (!in || !w1_packed || !b1 || !w2_packed || !out_a || N <= 0 || H <= 0 || W <= 0) return TG_E_BADARG;   // (out_h may be null)
   if ((dtype != TG_BF16 && dtype != TG_F16) || C != 64) return TG_E_UNSUPPORTED;  // the trunk shape, 16-bit; else two tg_conv launches
-  if (!tg_aligned16(in) || !tg_aligned16(w1_packed) || !tg_aligned16(w2_packed) || !tg_aligned16(out_h) ||
+  if (!tg_aligned16(in) || !tg_aligned16(w1_packed) || !tg_aligned16(w2_packed) || (out_h && !tg_aligned16(out_h)) ||
       !tg_aligned16(out_a) || !tg_aligned16(b1))
     return TG_E_ALIGN;
   if (dtype == TG_F16)

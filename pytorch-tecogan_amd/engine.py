@@ -750,6 +750,10 @@ class GeneratorEngine:
         # the fused input-gradient launch (tg_resblock_bwd) is numerically identical and was measured EQUAL in time on the
         # batched backward (15 x 28.2 us vs 30 x 14.9 us at 40 samples: 640 workgroups each re-read 147 KB of weights), so
         # it stays an option
+        # L2 prefetch of the next block's weights by the fused launches: round 2 measured a gain (the weights came back from the
+        # Infinity Cache every pass); since the 16 blocks' 2.4 MB stay in the XCDs' L2s between passes it only costs issue slots and
+        # traffic - chain 1.970 -> 1.862 ms alone, step 4.008 -> 3.898 ms without it (profiles/r04_p_resblock_prefetch_ab.log)
+        self.rb_prefetch = TU().rb_prefetch
         self.fused_rb_bwd = self.fused_rb and TU().fused_resblock_bwd
         self.rb_pair = self.fused_rb and TU().rb_pair
         if self.rb_pair:
@@ -807,10 +811,13 @@ class GeneratorEngine:
         self.cur = self.sets.get((NS, h, w), make)
         self.act, self.shape, self.grad = self.cur["act"], (NS, h, w), self.cur["grad"]
 
-    def forward(self, s0, B, out_buf, out_off, out_n_stride):
-        """runs samples [s0, s0+B) of act['in0'] through the net; sigmoid output goes to out_buf (fp32 NCHW)."""
+    def forward(self, s0, B, out_buf, out_off, out_n_stride, keep_h=True):
+        """runs samples [s0, s0+B) of act['in0'] through the net; sigmoid output goes to out_buf (fp32 NCHW).
+        keep_h=False (inference): the fused residual blocks do not store their intermediate activation - only the backward pass
+        reads it (2 MB of writes per block at 128 x 128)."""
         a = self.act
         sl = slice(s0, s0 + B)
+        hbuf = (lambda t: t[sl]) if keep_h else (lambda t: None)
         self.conv0.fwd(a["in0"][sl], a["a"][0][sl], act=L.ACT_RELU)
         # small launches (the recurrent pass: <= 128 tiles of 8 x 8): TWO blocks per launch, halo recomputed (csrc/resblock2.hip)
         pair = self.rb_pair and B * ((a["in0"].shape[1] + 7) // 8) * ((a["in0"].shape[2] + 7) // 8) <= 128
@@ -828,14 +835,14 @@ class GeneratorEngine:
                 skip_next = True
                 continue
             if self.fused_rb:  # conv-relu-conv-skip in one launch (csrc/resblock.hip)
-                nxt = (self.rb[i + 1][0].wf, self.rb[i + 1][1].wf) if i + 1 < self.nrb else None
-                K.resblock_fwd(a["a"][i][sl], c1.wf, c1.bias, c2.wf, a["h"][i][sl], a["a"][i + 1][sl], next_w=nxt)
+                nxt = (self.rb[i + 1][0].wf, self.rb[i + 1][1].wf) if (self.rb_prefetch and i + 1 < self.nrb) else None
+                K.resblock_fwd(a["a"][i][sl], c1.wf, c1.bias, c2.wf, hbuf(a["h"][i]), a["a"][i + 1][sl], next_w=nxt)
                 continue
             c1.fwd(a["a"][i][sl], a["h"][i][sl], act=L.ACT_RELU)
             c2.fwd(a["h"][i][sl], a["a"][i + 1][sl], res=a["a"][i][sl])
         self.ct0.fwd(a["a"][self.nrb][sl], a["u0"][sl], act=L.ACT_RELU)
         if self.fused_rb:  # conv_trans.2 is conv-relu-conv without a skip: the same fused launch
-            K.resblock_fwd(a["u0"][sl], self.c20.wf, self.c20.bias, self.c22.wf, a["hh"][sl], a["u1"][sl], skip=False)
+            K.resblock_fwd(a["u0"][sl], self.c20.wf, self.c20.bias, self.c22.wf, hbuf(a["hh"]), a["u1"][sl], skip=False)
         else:
             self.c20.fwd(a["u0"][sl], a["hh"][sl], act=L.ACT_RELU)
             self.c22.fwd(a["hh"][sl], a["u1"][sl])

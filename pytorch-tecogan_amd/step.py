@@ -795,7 +795,7 @@ class RecurrentGenerator:
         H, W = 4 * h, 4 * w
         K.up4_planes(self.lr[1 - k], self.fsrc, self.flow, self.fdst, 2 * B, h, w, pre=4.0)
         K.gen_input(self.lr[k], 0, 3 * h * w, self.hr[1 - k], 0, 3 * H * W, self.flow, 0, 2 * H * W, G.act["in0"], B, h, w)
-        G.forward(0, B, self.hr[k], 0, 3 * H * W)
+        G.forward(0, B, self.hr[k], 0, 3 * H * W, keep_h=False)
 
     def run(self, frames):
         """frames (B,T,3,h,w) fp32 device -> (B,T,3,4h,4w)."""
@@ -805,7 +805,7 @@ class RecurrentGenerator:
         outs = torch.empty(B, T, 3, 4 * h, 4 * w, dtype=torch.float32, device=self.dev)
         self.lr[0].copy_(frames[:, 0])
         K.gen_input(self.lr[0], 0, 3 * h * w, None, 0, 0, None, 0, 0, self.G.act["in0"], B, h, w)
-        self.G.forward(0, B, self.hr[0], 0, 3 * 16 * h * w)
+        self.G.forward(0, B, self.hr[0], 0, 3 * 16 * h * w, keep_h=False)
         outs[:, 0].copy_(self.hr[0])
         for t in range(1, T):
             k = t & 1
