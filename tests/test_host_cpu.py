@@ -470,7 +470,7 @@ def test_step_aware_caps_and_register_weights_routing(monkeypatch):
     assert not el(bf, 64, 64, 40, 32, 32) and not el(bf, 128, 64, 1, 512, 512)            # ... not the same shapes going forward
     assert el(bf, 128, 128, 40, 64, 64, masked=True, dgrad=True)                          # c32's (masked)
     assert not el(bf, 64, 64, 12, 64, 64) and el(bf, 64, 64, 12, 64, 64, extra="s1")     # D stage 1: per conv (real half)
-    assert not el(bf, 128, 128, 12, 16, 16) and el(bf, 128, 128, 12, 32, 32)             # D stage 3 stays, stage 2 as before
+    assert el(bf, 128, 128, 12, 16, 16) and el(bf, 128, 128, 12, 32, 32)                 # D stage 3 (round 4: the wave-specialised kernel wins there) and stage 2
     assert not el(torch.float32, 64, 64, 40, 32, 32) and not el(bf, 32, 64, 40, 32, 32) and not el(bf, 64, 96, 40, 64, 64)
     monkeypatch.setenv("TECOGAN_RW_EXTRA", "none")
     K = importlib.reload(K)
