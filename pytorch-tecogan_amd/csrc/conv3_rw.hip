@@ -215,7 +215,13 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
 #pragma unroll
           for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int a = 0; a < 2; ++a) acc[a][b] = mma<T>(wfr[s_ / 9][s_ % 9][a], xf[s_ % 3][b], acc[a][b]);
+            for (int a = 0; a < 2; ++a) {
+#ifdef RW_DIAG_NOMFMA   // diagnostic: the consumer without its matrix instructions (what do the producers cost then?)
+              acc[a][b][0] += __builtin_bit_cast(f32x4, xf[s_ % 3][b])[a] + __builtin_bit_cast(f32x4, wfr[s_ / 9][s_ % 9][a])[0];
+#else
+              acc[a][b] = mma<T>(wfr[s_ / 9][s_ % 9][a], xf[s_ % 3][b], acc[a][b]);
+#endif
+            }
           __builtin_amdgcn_sched_barrier(0);
         }
         RW_STAMP(4 + 6 * i + 1);
@@ -371,8 +377,20 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
   // ticks; tools/stamp_rw.py, profiles/r04_c_*, r04_e_*.)
   u32x4 ov[G::KS];
   unsigned okm = 0;
+  [[maybe_unused]] int st_it = 0;
   Tile st_tile = {0, 0, 0};
-  auto compute = [&](const Tile& tl, int buf, const u32x4* mk) {
+  // The epilogue's options are launch-uniform.  Tested inside the unrolled body they became 72 scalar branches and ~270 register
+  // moves at their joins per tile (2500 ticks for ~150 useful vector instructions: tools/stamp_rw.py, profiles/r04_s_*); so the
+  // body is instantiated for the three combinations the step's launches use, chosen once per tile, plus the general form:
+  //   0 forward: + bias, activation, no mask / residual      1 input-gradient under a ReLU mask (no bias / activation / residual)
+  //   2 input-gradient + residual (no bias / activation / mask)      3 anything else (every option tested at run time)
+  const int emode = (p.mask_mode == TG_MASK_NONE && !p.res) ? 0
+                    : (p.mask_mode == TG_MASK_RELU && !p.res && !p.bias && p.act == TG_ACT_NONE) ? 1
+                    : (p.mask_mode == TG_MASK_NONE && p.res && !p.bias && p.act == TG_ACT_NONE) ? 2 : 3;
+  // activation as max(v, slope * v): slope 1 = none, 0 = ReLU, 0.2 = LeakyReLU (mode 0: no branch on p.act)
+  const float act_slope = p.act == TG_ACT_RELU ? 0.f : p.act == TG_ACT_LRELU ? 0.2f : 1.f;
+  auto compute = [&](const Tile& tl, int buf, const u32x4* mk, auto MODE) {
+    constexpr int M = decltype(MODE)::value;
     const int n = tl.n, ty0 = tl.ty0, tx0 = tl.tx0;
     if constexpr (STATS) {
       const int grp = n / (p.N / p.stats_groups);
@@ -393,7 +411,11 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
         a1[k] += *reinterpret_cast<const f32x4*>(ab + G::kAccHalf + pl * kAccPitch + 16);
       }
     }
-    const char* const res_t = p.res ? p.res + ((((size_t)n * p.H + ty0) * p.W + tx0) * p.Cout) * 2 : nullptr;
+#ifdef TG_STAMP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (diagnostic: stamp 5 of the iteration = the accumulator reads have landed)
+    RW_STAMP(4 + 6 * st_it + 5);
+#endif
+    const char* const res_t = (M == 3 && p.res) ? p.res + ((((size_t)n * p.H + ty0) * p.W + tx0) * p.Cout) * 2 : nullptr;
     okm = 0;
     st_tile = tl;
 #pragma unroll
@@ -408,29 +430,13 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
         v[e] = a0[k][e];
         v[4 + e] = a1[k][e];
       }
-      if (p.bias) {
+      if constexpr (M == 0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bias_r[e];
-      }
-      if (p.res) {
-        float r[8];
-        if (p.mask_mode == TG_MASK_NONE) unpack8<T>(mk[k], r);
-        else if (ok) Vec<T>::load(res_t + (unsigned)((ry * p.W + rx) * p.Cout + ch0) * 2u, r);   // (res AND mask: the trunk's first block only)
-        else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) r[e] = 0.f;
+        for (int e = 0; e < 8; ++e) {
+          v[e] += bias_r[e];                         // (zeros without a bias)
+          v[e] = fmaxf(v[e], act_slope * v[e]);
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += r[e];
-      }
-      if (p.act == TG_ACT_RELU) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-      } else if (p.act == TG_ACT_LRELU) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
-      }
-      if (p.mask_mode == TG_MASK_RELU) {
+      } else if constexpr (M == 1) {
         // mask value > 0 on its 16-bit pattern (sign clear, not zero): the low half as the sign of word << 16, the high half as
         // word > 0xffff - no unpacking to float
 #pragma unroll
@@ -439,12 +445,37 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
           v[2 * e] = (int)((unsigned)w_ << 16) > 0 ? v[2 * e] : 0.f;
           v[2 * e + 1] = w_ > 0xffff ? v[2 * e + 1] : 0.f;
         }
-      } else if (p.mask_mode == TG_MASK_LRELU) {
+      } else if constexpr (M == 2) {
+        float r[8];
+        unpack8<T>(mk[k], r);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int w_ = (int)mk[k][e];
-          v[2 * e] = (int)((unsigned)w_ << 16) > 0 ? v[2 * e] : 0.2f * v[2 * e];
-          v[2 * e + 1] = w_ > 0xffff ? v[2 * e + 1] : 0.2f * v[2 * e + 1];
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+      } else {
+        if (p.bias) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bias_r[e];
+        }
+        if (p.res) {
+          float r[8];
+          if (p.mask_mode == TG_MASK_NONE) unpack8<T>(mk[k], r);
+          else if (ok) Vec<T>::load(res_t + (unsigned)((ry * p.W + rx) * p.Cout + ch0) * 2u, r);   // (res AND mask: the trunk's first block only)
+          else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], act_slope * v[e]);
+        if (p.mask_mode != TG_MASK_NONE) {
+          const float neg = p.mask_mode == TG_MASK_LRELU ? 0.2f : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int w_ = (int)mk[k][e];
+            v[2 * e] = (int)((unsigned)w_ << 16) > 0 ? v[2 * e] : neg * v[2 * e];
+            v[2 * e + 1] = w_ > 0xffff ? v[2 * e + 1] : neg * v[2 * e + 1];
+          }
         }
       }
 #pragma unroll
@@ -479,6 +510,7 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
   RW_STAMP(3);
   int tile = (int)blockIdx.x;
   for (int i = 0; i <= ntl; ++i, tile += (int)gridDim.x) {
+    st_it = i;
     RW_STAMP(4 + 6 * i + 0);
     if (i >= 2) store_results();   // tile i - 2, computed during iteration i - 1
     // the previous tile's mask / residual rows arrived during iteration i - 1 (its vmcnt(0)); taken over into registers the compiler
@@ -498,7 +530,12 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
     if (i < ntl) issue_pre(prev);
     RW_STAMP(4 + 6 * i + 1);
     // the previous tile's accumulators were published by the barrier that ended iteration i - 1
-    if (i >= 1) compute(st_prev, (i - 1) & 1, mk);
+    if (i >= 1) {
+      if (emode == 0) compute(st_prev, (i - 1) & 1, mk, std::integral_constant<int, 0>{});
+      else if (emode == 1) compute(st_prev, (i - 1) & 1, mk, std::integral_constant<int, 1>{});
+      else if (emode == 2) compute(st_prev, (i - 1) & 1, mk, std::integral_constant<int, 2>{});
+      else compute(st_prev, (i - 1) & 1, mk, std::integral_constant<int, 3>{});
+    }
     st_prev = prev;
     RW_STAMP(4 + 6 * i + 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA (and the rows) have landed before the barrier publishes the patch

@@ -53,5 +53,6 @@ for name, cin, cout, N, H, W, flip, masked, cap in CASES:
             n = len(names)
             if t[b + n] <= t[b]:
                 break
-            line += f" it{i}: " + " ".join(f"{nm} {t[b+j+1]-t[b+j]}" for j, nm in enumerate(names)) + f" = {t[b+n]-t[b]} |"
+            line += f" it{i}: " + " ".join(f"{nm} {t[b+j+1]-t[b+j]}" for j, nm in enumerate(names)) + f" = {t[b+n]-t[b]}" + \
+                (f" (of compute: acc reads landed after {t[b+5]-t[b+1]})" if role == 1 and t[b + 5] > t[b + 1] else "") + " |"
         print(line + f" total {t[28]-t[0]}")
