@@ -595,7 +595,7 @@ def test_bench_flags_and_dry_dp_fields():
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["dp"]["mode"] == "inline" and line["dp"]["alt"]["mode"] == "buckets"
+    assert line["n_gpus"] == 2 and {line["dp"]["mode"], line["dp"]["alt"]["mode"]} == {"inline", "buckets"}
     for k in ("allreduce_exposed_ms_laneA", "allreduce_exposed_ms_laneB", "step_ms_no_collectives", "probe_steps"):
         assert k in line["dp"] and k in line["dp"]["alt"]
     assert line["dp"]["probe_steps"] == 3

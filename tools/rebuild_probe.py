@@ -38,3 +38,35 @@ for m in modes:
     st = next(iter(TR._STEPS.values()))
     print(f"mode {m}: {(time.perf_counter() - t0) / 30 * 1e3:.3f} ms/step  (dp_inline={st.dp_inline} buckets={st.buckets} graphs={'yes' if st.graphs else 'no'} "
           f"sB={st.sB.cuda_stream:#x})", flush=True)
+    # anatomy: every captured piece alone (serial replays on the caller's stream), then the step with its collectives skipped
+    if st.graphs and isinstance(st.graphs, dict):
+        parts = []
+        for k, rp in st.graphs.items():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                rp()
+            torch.cuda.synchronize()
+            parts.append(f"{k}={(time.perf_counter() - t0) / 10 * 1e3:.3f}")
+        print("   pieces alone (ms): " + " ".join(parts), flush=True)
+        st.skip_collectives = True
+        for _ in range(2):
+            TR.FRVSR_Train(x, y, args, D, G, step, 0.0, 0.0, og, od); step += 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            TR.FRVSR_Train(x, y, args, D, G, step, 0.0, 0.0, og, od); step += 1
+        torch.cuda.synchronize()
+        print(f"   collectives skipped: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms/step", flush=True)
+        st.skip_collectives = False
+    if os.environ.get("PROBE_PROFILE") == m:   # where does the host spend a slow mode's step?
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(10):
+            TR.FRVSR_Train(x, y, args, D, G, step, 0.0, 0.0, og, od); step += 1
+        t_issue = time.perf_counter()
+        torch.cuda.synchronize()
+        pr.disable()
+        print(f"   host: 10 steps issued, then {1e3 * (time.perf_counter() - t_issue):.2f} ms until the GPU drained", flush=True)
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
