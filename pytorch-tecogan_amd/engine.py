@@ -841,7 +841,10 @@ class GeneratorEngine:
             c1.fwd(a["a"][i][sl], a["h"][i][sl], act=L.ACT_RELU)
             c2.fwd(a["h"][i][sl], a["a"][i + 1][sl], res=a["a"][i][sl])
         self.ct0.fwd(a["a"][self.nrb][sl], a["u0"][sl], act=L.ACT_RELU)
-        if self.fused_rb:  # conv_trans.2 is conv-relu-conv without a skip: the same fused launch
+        # conv_trans.2 is conv-relu-conv without a skip: the same fused launch - up to TECOGAN_PAIR_RW_MIN pixels; beyond that two
+        # launches of the register-weights kernel are faster (config 5: 256 x 256, profiles/r04_x_rw_fwd_routing.log)
+        npix2 = B * a["u0"].shape[1] * a["u0"].shape[2]
+        if self.fused_rb and not (0 < TU().pair_rw_min <= npix2 and K.rw_eligible(self.dt, 64, 64, B, a["u0"].shape[1], a["u0"].shape[2])):
             K.resblock_fwd(a["u0"][sl], self.c20.wf, self.c20.bias, self.c22.wf, hbuf(a["hh"]), a["u1"][sl], skip=False)
         else:
             self.c20.fwd(a["u0"][sl], a["hh"][sl], act=L.ACT_RELU)

@@ -192,7 +192,11 @@ def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False, extra="", dgrad=F
     grid of thousands of short workgroups, and since the Cin = 128 instantiations stopped spilling (round 3) three more classes pay
     there although tg_conv wins or ties alone (TECOGAN_RW_EXTRA, profiles/r03_r_rw_dma_ab.log): the trunk's input-gradients at 40 x
     32 x 32 (4.23 -> 4.205 ms/step), 128 -> 64 input-gradients (c30: -> 4.204) and masked 128 -> 128 ones (c32, with both: 4.195);
-    the discriminator's stage 1 (64 -> 64 @64x64 N=12: 4.30) and stage 3 (16 x 16: 4.32) stay on tg_conv."""
+    the discriminator's stage 1 (64 -> 64 @64x64 N=12: 4.30) and stage 3 (16 x 16: 4.32) stayed on tg_conv.
+    Round 4 (the kernel is wave-specialised; profiles/r04_l_rw_extra_s3.log, r04_x_rw_fwd_routing.log): stage 3 moved (s3), then every
+    FORWARD launch of >= TECOGAN_RW_FWD_MIN = 4096 pixels (the chain's conv0 / c30 / c32 / c6, the discriminator's stage 1, config 5's
+    HR stage: config 2 3.92 -> 3.80 ms, config 5 2840 -> 2946 frames/s at 160 workgroups, 3130 at 256) and stage 1's input-gradients
+    in both halves (s1); with conv_trans.2's pair as two launches and the generator at 144 workgroups config 2 runs at 3.75 ms."""
     TU = tuning.current()
     _RW, _RW_EXTRA_ENV = TU.rw, TU.rw_extra   # 0: never, 1: where it measured faster, all | classes routed there for the STEP's sake
     if _RW == "0" or dtype_t not in (torch.bfloat16, torch.float16) or cin_p not in (64, 128) or cout_p % 64:
@@ -201,8 +205,9 @@ def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False, extra="", dgrad=F
         return N * H * W >= 8192
     npix = N * H * W
     _RW_EXTRA = _RW_EXTRA_ENV + "," + extra if extra else _RW_EXTRA_ENV
-    # (input-gradient launches only: the same shapes as FORWARD launches - c6 at 512 x 512 in config-5 inference - are faster on
-    #  tg_conv and have no neighbour to be kind to: 2740 vs 2600 HR-frames/s)
+    # (round 3 kept these to input-gradient launches: the forward ones were faster on tg_conv; no longer - see RW_FWD_MIN above)
+    if not dgrad and TU.rw_fwd_min > 0 and npix >= TU.rw_fwd_min:
+        return True
     if dgrad and "trunk" in _RW_EXTRA and cin_p == 64 and H == 32 and W == 32 and npix >= 32768:
         return True
     if dgrad and "c30" in _RW_EXTRA and cin_p == 128 and cout_p == 64 and npix >= 131072:

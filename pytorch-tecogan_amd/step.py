@@ -802,6 +802,15 @@ class RecurrentGenerator:
         B, T = frames.shape[:2]
         h, w = self.h, self.w
         self.G.alloc(B, h, w)   # re-select this loop's buffer set (a training step may have selected its own since)
+        # no other lane here: the persistent launches may take more of the chip than inside a training step (restored below)
+        cap0 = self.G.convs[0].persist_wgs
+        self.G.set_cap(tuning.current().infer_wgs)
+        try:
+            return self._run(frames, B, T, h, w)
+        finally:
+            self.G.set_cap(cap0)
+
+    def _run(self, frames, B, T, h, w):
         outs = torch.empty(B, T, 3, 4 * h, 4 * w, dtype=torch.float32, device=self.dev)
         self.lr[0].copy_(frames[:, 0])
         K.gen_input(self.lr[0], 0, 3 * h * w, None, 0, 0, None, 0, 0, self.G.act["in0"], B, h, w)

@@ -40,7 +40,7 @@ KNOBS = OrderedDict((k.attr, k) for k in (
     # ---- persistent launches: workgroup caps (kernels.persist_wgs*)
     _k("PERSIST_WGS", "persist_wgs", "oint", None, "profiles/r02_q_persist_wgs_sweep.log",
        "cap of every persistent launch (unset: G 160, D 96, D real half 72 for steps of <= 4096 LR pixels)"),
-    _k("PERSIST_WGS_G", "persist_wgs_g", "oint", None, "profiles/r03_r_rw_dma_ab.log", "generator's cap (unset: 160)"),
+    _k("PERSIST_WGS_G", "persist_wgs_g", "oint", None, "profiles/r03_r_rw_dma_ab.log", "generator's cap (unset: 144 for steps of <= 4096 LR pixels per pass, else 160)"),
     _k("PERSIST_WGS_D", "persist_wgs_d", "oint", None, "profiles/r02_q_persist_wgs_sweep.log", "discriminator's cap (unset: 96)"),
     _k("PERSIST_WGS_DREAL", "persist_wgs_dreal", "oint", None, "profiles/r03_r_rw_dma_ab.log",
        "cap of the discriminator's REAL half, which runs beside the chain (unset: 72 for chain-bound steps, else the D cap)"),
@@ -49,10 +49,17 @@ KNOBS = OrderedDict((k.attr, k) for k in (
     _k("PERSIST_RW_D", "persist_rw_d", "int", 0, "profiles/r02_q_persist_wgs_sweep.log", "... the discriminator's"),
     # ---- kernel routing (engine.Conv, kernels.rw_eligible)
     _k("RW", "rw", "str", "1", "profiles/r02_c_mb_rw.log", "register-weights 3x3 kernel: 0 never, 1 where measured faster, all"),
-    _k("RW_EXTRA", "rw_extra", "str", "trunk,c30,m128,s3", "profiles/r03_r_rw_dma_ab.log, r04_l_rw_extra_s3.log",
+    _k("RW_EXTRA", "rw_extra", "str", "trunk,c30,m128,s3,s1", "profiles/r03_r_rw_dma_ab.log, r04_l_rw_extra_s3.log, r04_x_rw_fwd_routing.log",
        "launch classes routed to it for the STEP's sake (capped persistent launches are better neighbours)"),
     _k("RW_EXTRA_DREAL", "rw_extra_dreal", "ostr", None, "profiles/r03_r_rw_dma_ab.log",
        "more classes for the discriminator's real half only (unset: s1 for chain-bound steps)"),
+    _k("RW_FWD_MIN", "rw_fwd_min", "int", 4096, "profiles/r04_x_rw_fwd_routing.log",
+       "FORWARD 3x3 launches (Cin 64 / 128, any Cout multiple of 64) of at least this many pixels go to it too (0: off): "
+       "config 2 3.92 -> 3.80 ms (16384) -> 3.79 (4096), config 4 9.7 -> 9.4-9.5 ms, config 5 2840 -> 2946 frames/s"),
+    _k("PAIR_RW_MIN", "pair_rw_min", "int", 16384, "profiles/r04_x_rw_fwd_routing.log",
+       "conv_trans.2's conv pair as two register-weights launches instead of the fused block launch from this many pixels (0: never): config 5 3126 -> 3208 frames/s, config 2 -0.02 ms"),
+    _k("INFER_WGS", "infer_wgs", "int", 256, "profiles/r04_x_rw_fwd_routing.log",
+       "workgroup cap of the generator's persistent launches inside RecurrentGenerator (no other lane to leave CUs to)"),
     _k("RW_DHALF_OFF", "rw_dhalf_off", "str", "", "profiles/r03_r_rw_dma_ab.log",
        "A/B: discriminator halves ('0', '1', '01') whose convs bypass the register-weights kernel"),
     _k("SUBPIX_CT", "subpix_ct", "on", True, "profiles/r01_h_bench_6p1ms.json (tools/mb_convt.py)",
@@ -139,7 +146,9 @@ class Tuning:
         """the generator's cap for a training step of `lr_pixels` = B * h * w, or None when the environment fixes it"""
         if self.persist_wgs is not None or self.persist_wgs_g is not None:
             return None
-        return self.cap(None)
+        # chain-bound steps (<= 4096 LR pixels per pass): 144 since the chain's forward convolutions are persistent launches too
+        # (3.79 -> 3.75 ms with the rest of r04_x's routing; 128: 3.80); larger steps keep 160 (config 4: 9.72 vs 9.5-9.6 ms)
+        return 144 if lr_pixels <= 4096 else self.cap(None)
 
     def cap_dreal_for(self, lr_pixels):
         """cap of the discriminator's REAL half for such a step, or None (environment fixes it / step is not chain-bound)"""

@@ -455,7 +455,7 @@ def test_step_aware_caps_and_register_weights_routing(monkeypatch):
               "TECOGAN_RW"):
         monkeypatch.delenv(k, raising=False)
     K = importlib.reload(K)
-    assert K.persist_wgs_g_for(4 * 32 * 32) == 160 and K.persist_wgs_g_for(2 * 64 * 64) == 160
+    assert K.persist_wgs_g_for(4 * 32 * 32) == 144 and K.persist_wgs_g_for(2 * 64 * 64) == 160   # (round 4: r04_x)
     assert K.persist_wgs_dreal_for(4 * 32 * 32) == 72 and K.persist_wgs_dreal_for(2 * 64 * 64) is None
     monkeypatch.setenv("TECOGAN_PERSIST_WGS_DREAL", "96")
     assert K.persist_wgs_dreal_for(4096) is None
@@ -467,9 +467,15 @@ def test_step_aware_caps_and_register_weights_routing(monkeypatch):
     el = K.rw_eligible
     assert el(bf, 64, 64, 40, 32, 32, dgrad=True) and not el(bf, 64, 64, 4, 32, 32, dgrad=True)      # trunk input-gradients: batched only
     assert el(bf, 128, 64, 40, 64, 64, dgrad=True) and not el(bf, 128, 64, 4, 64, 64, dgrad=True)    # c30's input-gradient
-    assert not el(bf, 64, 64, 40, 32, 32) and not el(bf, 128, 64, 1, 512, 512)            # ... not the same shapes going forward
+    # FORWARD launches: from 16384 pixels since the kernel is wave-specialised (round 4, TECOGAN_RW_FWD_MIN; r04_x): the chain's
+    # c30 / c32 / c6, config 5's HR stage, the discriminator's stage 1 - not conv0 of a 4 x 32 x 32 pass
+    assert el(bf, 128, 64, 1, 512, 512) and el(bf, 128, 64, 4, 128, 128) and el(bf, 64, 128, 4, 64, 64) and el(bf, 64, 64, 4, 32, 32)
+    assert not el(bf, 64, 64, 2, 32, 32)
+    monkeypatch.setenv("TECOGAN_RW_FWD_MIN", "0")
+    assert not el(bf, 64, 64, 40, 32, 32) and not el(bf, 128, 64, 1, 512, 512)
+    monkeypatch.delenv("TECOGAN_RW_FWD_MIN")
     assert el(bf, 128, 128, 40, 64, 64, masked=True, dgrad=True)                          # c32's (masked)
-    assert not el(bf, 64, 64, 12, 64, 64) and el(bf, 64, 64, 12, 64, 64, extra="s1")     # D stage 1: per conv (real half)
+    assert el(bf, 64, 64, 12, 64, 64) and el(bf, 64, 64, 12, 64, 64, dgrad=True)         # D stage 1: both directions, both halves (r04_x)
     assert el(bf, 128, 128, 12, 16, 16) and el(bf, 128, 128, 12, 32, 32)                 # D stage 3 (round 4: the wave-specialised kernel wins there) and stage 2
     assert not el(torch.float32, 64, 64, 40, 32, 32) and not el(bf, 32, 64, 40, 32, 32) and not el(bf, 64, 96, 40, 64, 64)
     monkeypatch.setenv("TECOGAN_RW_EXTRA", "none")
@@ -517,10 +523,11 @@ def test_tuning_defaults_equal_the_documented_optimum(monkeypatch):
     t = tuning.current()
     assert not t.explicit
     assert (t.cap("G"), t.cap("D"), t.cap(None), t.cap_g_for(4096), t.cap_dreal_for(4096), t.cap_dreal_for(8192)) == \
-        (160, 96, 160, 160, 72, None)
+        (160, 96, 160, 144, 72, None)
+    assert (t.cap_g_for(8192), t.rw_fwd_min, t.pair_rw_min, t.infer_wgs) == (160, 4096, 16384, 256)
     assert (t.graph, t.lanes, t.dreal_bwd, t.dp_inline, t.dp_buckets, t.cu_reserve, t.force_collectives) == \
         (True, True, True, True, True, 0, False)
-    assert (t.rw, t.rw_extra, t.rw_extra_dreal, t.rw_dhalf_off) == ("1", "trunk,c30,m128,s3", None, "")
+    assert (t.rw, t.rw_extra, t.rw_extra_dreal, t.rw_dhalf_off) == ("1", "trunk,c30,m128,s3,s1", None, "")
     assert (t.wgrad_list, t.wgrad_groups, t.defer_finalize, t.fold_items, t.pack_blocks, t.stats_replicas) == \
         (True, True, True, True, 48, 4)
     assert (t.fused_resblock, t.fused_resblock_bwd, t.subpix_ct, t.fast_c4s2, t.rgb_out, t.rgb_bwd, t.rgb_bwd_wgs, t.rb_prefetch) == \
