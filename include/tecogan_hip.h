@@ -336,8 +336,19 @@ int tg_bn_bwd_reduce(int dtype, const void* dy, const void* yact, const void* z,
 int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, const void* z, const float* save, const float* red,
                     int red_replicas, const float* gamma, void* dz, float* dgamma, float* dbeta, int N, int HW, int C,
                     int groups, int act, int red_raw, void* stream);
-
 #ifdef TG_EXPERIMENTS
+/* tg_bn_bwd_reduce + tg_bn_bwd_apply as ONE cooperative launch (torch.nn.BatchNorm2d backward behind code/models.py:96-113 of the
+ * reference): a thread keeps its pixels' dy / z / yact vectors in registers across a grid-wide wait on the sums, so the tensors are
+ * read once.  barrier: one zeroed 32-bit word per call (counts arrived workgroups).  All workgroups must be co-resident, so the
+ * call returns TG_E_UNSUPPORTED when the tensor needs more than tg_bn_bwd_coop_max_workgroups() of them (4 or 8 pixels rows of
+ * 256 / (C / vector) pixels per workgroup) - callers then take the two launches.  red must be zeroed like for tg_bn_bwd_reduce;
+ * it holds the same sums afterwards.  A wait longer than 50 ms writes NaNs instead of hanging.
+ * Measured SLOWER than the two launches, alone (+6.7 us per layer) and in the step (3.77 -> 4.52 ms: the launch's workgroups wait
+ * for CUs behind the other lane's persistent kernels), profiles/r04_y_bn_bwd_coop_ab.log. */
+int tg_bn_bwd_coop_max_workgroups(void);
+int tg_bn_bwd_coop(int dtype, const void* dy, const void* yact, const void* z, const float* save, float* red, int red_replicas,
+                   const float* gamma, void* dz, float* dgamma, float* dbeta, int N, int HW, int C, int groups, int act,
+                   unsigned* barrier, void* stream);
 /* The same backward pass (reduce + apply) as ONE launch for a tensor of at most tg_bn_bwd_fused_max_pixels() pixels per group
  * (the discriminator's 16x16 ... 4x4 layers): one workgroup per 16-byte channel piece keeps its share of the tensors in registers
  * between the sums and dz and is the only writer of its channels' dgamma / dbeta (+=).  act: TG_ACT_NONE or TG_ACT_LRELU.

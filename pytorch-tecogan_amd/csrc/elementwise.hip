@@ -318,6 +318,149 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
   }
 }
 
+#ifdef TG_EXPERIMENTS   // measured slower, alone and in the step (profiles/r04_y_bn_bwd_coop_ab.log)
+// Batch-norm backward in ONE launch (round 4): the reduction, a grid-wide wait, the apply.  Same pixel / channel mapping as the
+// two launches above; a thread keeps its U pixels' raw dy / z (/ yact) vectors in registers across the wait, so the tensors are
+// read once.  The wait is a counter in the step's zeroed accumulator arena: every workgroup of the launch must be co-resident,
+// which the host guarantees by size (tg_bn_bwd_coop refuses more than kBcMaxWgs = 192 workgroups: a CU holds 3-4 of them, so 64
+// free CUs are enough, and two processes on one GPU fit twice over) - the other lane's persistent launches only delay the wait, nothing they run depends
+// on this kernel.  A wait of more than 50 ms (it never should take 50 us) poisons the result with NaNs instead of hanging.
+constexpr int kBcMaxWgs = 192;
+template <typename T, int U>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void bn_bwd_coop_kernel(const char* __restrict__ dy, const char* __restrict__ yact,
+                                                         const char* __restrict__ z, const float* __restrict__ save,
+                                                         float* __restrict__ red, int R, const float* __restrict__ gamma,
+                                                         char* __restrict__ dz, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, int N, int HW, int C, int groups, int act,
+                                                         unsigned* __restrict__ bar) {
+  using TR = ElemTraits<T>;
+  constexpr int E = TR::kVec;
+  __shared__ float sh[256 * 2 * E];
+  __shared__ float tot[2 * 256];
+  const int vpp = C / E;
+  const int vec = threadIdx.x % vpp, prow = threadIdx.x / vpp, rows = 256 / vpp;
+  const int grp = blockIdx.y;
+  const long long npix = (long long)(N / groups) * HW;
+  const float inv_cnt = 1.f / (float)npix;
+  const size_t rblock = (size_t)groups * 2 * C;
+  const long long base = (long long)grp * npix;
+  const long long step = (long long)gridDim.x * rows;
+  const long long p = (long long)blockIdx.x * rows + prow;
+  u32x4 rd[U], rz[U], ra[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {   // every load of the launch goes out before anything is used (raw, from clamped addresses)
+    const long long pix = p + u * step < npix ? p + u * step : npix - 1;
+    const long long off = ((base + pix) * C + vec * E) * TR::kBytes;
+    rd[u] = *reinterpret_cast<const u32x4*>(dy + off);
+    rz[u] = *reinterpret_cast<const u32x4*>(z + off);
+    if (act == TG_ACT_LRELU) ra[u] = *reinterpret_cast<const u32x4*>(yact + off);
+  }
+  float mean[E], invstd[E], k0[E], s1[E], s2[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int c = vec * E + e;
+    mean[e] = save[(grp * 2 + 0) * C + c];
+    invstd[e] = save[(grp * 2 + 1) * C + c];
+    k0[e] = gamma[c] * invstd[e];
+    s1[e] = s2[e] = 0.f;
+  }
+  unsigned pos[U];   // LeakyReLU: bit e = activation e was positive (the raw yact vectors do not survive the wait: registers)
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    pos[u] = 0xffffffffu;
+    if (act == TG_ACT_LRELU) {
+      float a[E];
+      Vec<T>::load(&ra[u], a);
+      pos[u] = 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e) pos[u] |= (a[e] > 0.f ? 1u : 0u) << e;
+    }
+    if (p + u * step < npix) {
+      float d[E], zz[E];
+      Vec<T>::load(&rd[u], d);
+      Vec<T>::load(&rz[u], zz);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float dd = d[e] * ((pos[u] >> e) & 1u ? 1.f : 0.2f);
+        s1[e] += dd;
+        s2[e] += dd * (zz[e] - mean[e]) * invstd[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    sh[(threadIdx.x * 2 + 0) * E + e] = s1[e];
+    sh[(threadIdx.x * 2 + 1) * E + e] = s2[e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, c = i % C;
+    const int v = c / E, e = c % E;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += sh[((r * vpp + v) * 2 + which) * E + e];
+    atomicAdd(red + (size_t)(blockIdx.x & (R - 1)) * rblock + (grp * 2 + which) * C + c, s);
+  }
+  // ---- grid-wide wait: this workgroup's sums are out (fence), one arrival per workgroup, thread 0 polls
+  __threadfence();
+  __syncthreads();
+  bool late = false;
+  if (threadIdx.x == 0) {
+    const unsigned nwg = gridDim.x * gridDim.y;
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+    while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nwg) {
+      __builtin_amdgcn_s_sleep(2);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) { late = true; break; }
+    }
+    tot[0] = late ? 1.f : 0.f;
+  }
+  __syncthreads();
+  late = tot[0] != 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {   // fold the replica blocks (agent-scope loads: other XCDs' atomics)
+    float s = 0.f;
+    for (int r = 0; r < R; ++r)
+      s += __hip_atomic_load(red + (size_t)r * rblock + (size_t)grp * 2 * C + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tot[i] = late ? __builtin_nanf("") : s;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < C) {   // single writer of the parameter gradients (all groups)
+    const int c = threadIdx.x;
+    float dg = 0.f, db = 0.f;
+    for (int g2 = 0; g2 < groups; ++g2)
+      for (int r = 0; r < R; ++r) {
+        db += __hip_atomic_load(red + (size_t)r * rblock + (g2 * 2 + 0) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dg += __hip_atomic_load(red + (size_t)r * rblock + (g2 * 2 + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    dgamma[c] += dg;
+    dbeta[c] += db;
+  }
+  float m1[E], m2[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    m1[e] = tot[vec * E + e] * inv_cnt;
+    m2[e] = tot[C + vec * E + e] * inv_cnt;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (p + u * step < npix) {
+      float d[E], zz[E];
+      Vec<T>::load(&rd[u], d);
+      Vec<T>::load(&rz[u], zz);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float dd = d[e] * ((pos[u] >> e) & 1u ? 1.f : 0.2f);
+        const float xh = (zz[e] - mean[e]) * invstd[e];
+        d[e] = k0[e] * (dd - m1[e] - xh * m2[e]);
+      }
+      Vec<T>::store(dz + ((base + p + u * step) * C + vec * E) * TR::kBytes, d);
+    }
+  }
+}
+
+
+#endif  // TG_EXPERIMENTS
+
 #ifdef TG_EXPERIMENTS   // measured slower than the two coalesced launches (profiles/r03_l_bn_bwd_fused_ab.log)
 // Batch-norm backward of a SMALL tensor (<= kBfThreads * kBfTrips pixels per group) in ONE launch: workgroup v owns the E
 // channels of 16-byte piece v of every pixel, keeps its share of dy / z (/ yact) in registers between the reduction and the
@@ -742,6 +885,42 @@ extern "C" int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, cons
               (const char*)z, save, red, red_replicas, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act, red_raw);
   return tg_launch_status();
 }
+
+#ifdef TG_EXPERIMENTS
+// reduce + wait + apply in one launch; TG_E_UNSUPPORTED when the tensor needs more than kBcMaxWgs workgroups (the caller then
+// takes tg_bn_bwd_reduce + tg_bn_bwd_apply).  `barrier` is one zeroed 32-bit word per call (the step's accumulator arena).
+extern "C" int tg_bn_bwd_coop_max_workgroups(void) { return kBcMaxWgs; }
+
+extern "C" int tg_bn_bwd_coop(int dtype, const void* dy, const void* yact, const void* z, const float* save, float* red,
+                              int red_replicas, const float* gamma, void* dz, float* dgamma, float* dbeta, int N, int HW, int C,
+                              int groups, int act, unsigned* barrier, void* stream) {
+  if (!dy || !z || !save || !red || !gamma || !dz || !dgamma || !dbeta || !barrier || N <= 0 || HW <= 0 || groups <= 0 || N % groups)
+    return TG_E_BADARG;
+  if (act == TG_ACT_LRELU && !yact) return TG_E_BADARG;
+  if (red_replicas < 1 || (red_replicas & (red_replicas - 1))) return TG_E_BADARG;
+  if (!bn_shape_ok(dtype, C)) return TG_E_UNSUPPORTED;
+  const int rows = 256 / (C / (dtype == TG_F32 ? 4 : 8));
+  const long long npix = (long long)(N / groups) * HW;
+  const long long g4 = (npix + rows * 4 - 1) / (rows * 4), g8 = (npix + rows * 8 - 1) / (rows * 8);
+  if (g4 * groups <= kBcMaxWgs) {
+    dim3 grid((unsigned)g4, groups);
+    if (dtype == TG_BF16) hipLaunchKernelGGL((bn_bwd_coop_kernel<BF16, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)dy, (const char*)yact, (const char*)z, save, red, red_replicas, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act, barrier);
+    else if (dtype == TG_F16) hipLaunchKernelGGL((bn_bwd_coop_kernel<F16, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)dy, (const char*)yact, (const char*)z, save, red, red_replicas, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act, barrier);
+    else if (dtype == TG_F32) hipLaunchKernelGGL((bn_bwd_coop_kernel<F32, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)dy, (const char*)yact, (const char*)z, save, red, red_replicas, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act, barrier);
+    else return TG_E_BADARG;
+  } else if (g8 * groups <= kBcMaxWgs) {
+    dim3 grid((unsigned)g8, groups);
+    if (dtype == TG_BF16) hipLaunchKernelGGL((bn_bwd_coop_kernel<BF16, 8>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)dy, (const char*)yact, (const char*)z, save, red, red_replicas, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act, barrier);
+    else if (dtype == TG_F16) hipLaunchKernelGGL((bn_bwd_coop_kernel<F16, 8>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)dy, (const char*)yact, (const char*)z, save, red, red_replicas, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act, barrier);
+    else if (dtype == TG_F32) hipLaunchKernelGGL((bn_bwd_coop_kernel<F32, 8>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)dy, (const char*)yact, (const char*)z, save, red, red_replicas, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act, barrier);
+    else return TG_E_BADARG;
+  } else {
+    return TG_E_UNSUPPORTED;
+  }
+  return tg_launch_status();
+}
+
+#endif  // TG_EXPERIMENTS
 
 #ifdef TG_EXPERIMENTS
 extern "C" int tg_bn_bwd_fused_max_pixels(void) { return kBfThreads * kBfTrips; }

@@ -636,6 +636,10 @@ class BatchNorm:
             tuning.need_experiments("bn_bwd_fused")
         self.stats = arena.take(2 * self.R * 2 * self.Cp)
         self.red = arena.take(2 * self.R * 2 * self.Cp)
+        self.bar = arena.take(32)     # arrival counters of the one-launch backward (tg_bn_bwd_coop): [half or 0] * 8, zeroed with the arena
+        self.coop = TU().bn_bwd_coop
+        if self.coop:
+            tuning.need_experiments("bn_bwd_coop")
         self.save = torch.empty(2, 2, self.Cp, device=flat.device)
 
     def _slot(self, buf, half):
@@ -668,6 +672,10 @@ class BatchNorm:
         g = groups if half is None else 1
         if not reduced and self.bwd_fused and (N // g) * H * W <= K.bn_bwd_fused_max_pixels():
             K.bn_bwd_fused(dy, yact, z, save, self.gamma, dz, self.dgamma, self.dbeta, N, H * W, C_, g, act)
+            return
+        if not reduced and self.coop and K.bn_bwd_coop_ok(N, H * W, C_, g, z.dtype):
+            bar = self.bar[(half or 0) * 8:(half or 0) * 8 + 1]
+            K.bn_bwd_coop(dy, yact, z, save, red, self.gamma, dz, self.dgamma, self.dbeta, N, H * W, C_, g, act, bar, replicas=self.R)
             return
         if not reduced:
             K.bn_bwd_reduce(dy, yact, z, save, red, N, H * W, C_, g, act, replicas=self.R)

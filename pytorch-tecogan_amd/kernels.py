@@ -572,6 +572,26 @@ def bn_bwd_apply(dy, yact, z, save, red, gamma, dz, dgamma, dbeta, N, HW, C_, gr
                                      _stream()), "tg_bn_bwd_apply")
 
 
+_BN_COOP_MAX = None
+
+
+def bn_bwd_coop_ok(N, HW, C_, groups, dtype_t):
+    """does tg_bn_bwd_coop take this tensor (all its workgroups co-resident: csrc/elementwise.hip, bn_bwd_coop_kernel)"""
+    global _BN_COOP_MAX
+    if _BN_COOP_MAX is None:
+        _BN_COOP_MAX = int(L.load().tg_bn_bwd_coop_max_workgroups())
+    rows = 256 // (C_ // (4 if dtype_t == torch.float32 else 8))
+    npix = (N // groups) * HW
+    return -(-npix // (rows * 8)) * groups <= _BN_COOP_MAX
+
+
+def bn_bwd_coop(dy, yact, z, save, red, gamma, dz, dgamma, dbeta, N, HW, C_, groups, act, bar, replicas=1):
+    """batch-norm backward (sums, grid-wide wait, apply) in one launch; `bar`: one zeroed word of the accumulator arena"""
+    L.check(L.load().tg_bn_bwd_coop(tg_dtype(z.dtype), _ptr(dy), _ptr(yact), _ptr(z), _ptr(save), _ptr(red), replicas,
+                                    _ptr(gamma), _ptr(dz), _ptr(dgamma), _ptr(dbeta), N, HW, C_, groups, act, _ptr(bar),
+                                    _stream()), "tg_bn_bwd_coop")
+
+
 _BN_FUSED_MAX = None
 
 

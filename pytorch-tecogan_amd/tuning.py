@@ -97,6 +97,8 @@ KNOBS = OrderedDict((k.attr, k) for k in (
        "batch-norm backward sums in the producing input-gradient's epilogue (stats_mode 3)", True),
     _k("BN_BWD_FUSED", "bn_bwd_fused", "flag", False, "profiles/r03_l_bn_bwd_fused_ab.log (step 4.405 -> 4.42 ms)",
        "single-launch batch-norm backward for small tensors (tg_bn_bwd_fused)", True),
+    _k("BN_BWD_COOP", "bn_bwd_coop", "flag", False, "profiles/r04_y_bn_bwd_coop_ab.log (step 3.77 -> 4.52 ms)",
+       "batch-norm backward as ONE cooperative launch (sums, grid-wide wait, apply; tg_bn_bwd_coop)", True),
     _k("WGRAD_B128_PIXELS", "wgrad_b128_pixels", "int", 0, "profiles/r03_m_wgrad_b128.log (1.1-2.5x slower: spills)",
        "64 x 128 channel blocks in the work lists for layers with at least this many pixels (0: never)", True),
 ))

@@ -660,6 +660,58 @@ def test_bn_backward_small_tensor_single_launch(C_, N, H, G, act, dt):
         K.bn_bwd_fused(big, big, big, save, gam, torch.empty_like(big), dg, db, 2 * G, 64 * 64, C_, G, act_i)
 
 
+@pytest.mark.experiments
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C_,N,H,G,act", [(64, 12, 64, 1, "none"), (128, 12, 32, 1, "lrelu"), (128, 12, 16, 1, "none"), (64, 12, 8, 1, "lrelu"),
+                                          (32, 12, 4, 1, "lrelu"), (64, 6, 16, 2, "none"), (64, 3, 5, 1, "lrelu")])
+def test_bn_backward_cooperative_single_launch(C_, N, H, G, act, dt):
+    """tg_bn_bwd_coop (sums, grid-wide wait on an arrival counter, apply - one launch, the tensors read once) against the two-launch
+    pair on the same tensors and torch autograd of training-mode batch_norm (+ LeakyReLU); dgamma / dbeta accumulate on top of what
+    is there, `red` ends with the same sums, the counter with the launch's workgroup count; a tensor that needs more workgroups than
+    can be co-resident is refused (the caller's cue for the two launches)."""
+    R, act_i = 4, (L.ACT_LRELU if act == "lrelu" else L.ACT_NONE)
+    if dt == torch.float32 and C_ > 128:
+        pytest.skip("fp32 batch norm: C <= 128")
+    z, dy = q(rnd((N, C_, H, H), 51), dt), q(rnd((N, C_, H, H), 52), dt)
+    gam, bet = rnd((C_,), 53, 0.5, 1.5).to(DEV), rnd((C_,), 54).to(DEV)
+    zd, dyd = K.to_nhwc(z.to(DEV), dt), K.to_nhwc(dy.to(DEV), dt)
+    stats = torch.zeros(R, G, 2, C_, device=DEV)
+    for g in range(G):
+        zz = zd[g * N // G:(g + 1) * N // G].float()
+        stats[0, g, 0], stats[0, g, 1] = zz.sum(dim=(0, 1, 2)), (zz * zz).sum(dim=(0, 1, 2))
+    y, save = torch.empty_like(zd), torch.empty(G, 2, C_, device=DEV)
+    K.bn_apply(zd, stats, gam, bet, y, save, N, H * H, C_, G, act_i, replicas=R)
+    if not K.bn_bwd_coop_ok(N, H * H, C_, G, dt):
+        pytest.skip("more workgroups than the cooperative launch takes at this element size")
+    red, bar = torch.zeros(R, G, 2, C_, device=DEV), torch.zeros(8, dtype=torch.int32, device=DEV)
+    dz, dg, db = torch.empty_like(zd), torch.full((C_,), 0.5, device=DEV), torch.full((C_,), -0.25, device=DEV)
+    K.bn_bwd_coop(dyd, y, zd, save, red, gam, dz, dg, db, N, H * H, C_, G, act_i, bar[:1], replicas=R)
+    red2 = torch.zeros(R, G, 2, C_, device=DEV)
+    dz2, dg2, db2 = torch.empty_like(zd), torch.full((C_,), 0.5, device=DEV), torch.full((C_,), -0.25, device=DEV)
+    K.bn_bwd_reduce(dyd, y, zd, save, red2, N, H * H, C_, G, act_i, replicas=R)
+    K.bn_bwd_apply(dyd, y, zd, save, red2, gam, dz2, dg2, db2, N, H * H, C_, G, act_i, replicas=R)
+    torch.cuda.synchronize()
+    assert int(bar[0]) > 0 and int(bar[1:].abs().sum()) == 0
+    assert bool(torch.isfinite(dz.float()).all())
+    torch.testing.assert_close(red.sum(0), red2.sum(0), rtol=1e-4, atol=2e-3)
+    torch.testing.assert_close(db, db2, rtol=1e-4, atol=2e-3)
+    torch.testing.assert_close(dg, dg2, rtol=1e-4, atol=2e-3)
+    assert float((dz.float() - dz2.float()).abs().max()) <= (1e-5 if dt == torch.float32 else 8e-3) * float(dz2.float().abs().max())
+    if dt == torch.float32:
+        zt, gt, bt = z.clone().requires_grad_(True), gam.cpu().clone().requires_grad_(True), bet.cpu().clone().requires_grad_(True)
+        for g in range(G):
+            sl = slice(g * N // G, (g + 1) * N // G)
+            o = F.batch_norm(zt[sl], None, None, gt, bt, True, 0.1, 1e-3)
+            (F.leaky_relu(o, 0.2) if act == "lrelu" else o).backward(dy[sl])
+        torch.testing.assert_close(K.to_nchw(dz, C_).cpu(), zt.grad, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(dg.cpu() - 0.5, gt.grad, rtol=1e-3, atol=2e-3)
+        torch.testing.assert_close(db.cpu() + 0.25, bt.grad, rtol=1e-3, atol=2e-3)
+    big = K.to_nhwc(torch.zeros(8 * G, C_, 128, 128, device=DEV), dt)   # 131072 pixels per group: the two launches' job
+    assert not K.bn_bwd_coop_ok(8 * G, 128 * 128, C_, G, dt)
+    with pytest.raises(L.TecoganHipError):
+        K.bn_bwd_coop(big, big, big, save, red, gam, torch.empty_like(big), dg, db, 8 * G, 128 * 128, C_, G, act_i, bar[1:2], replicas=R)
+
+
 def test_up4_matches_golden_and_torch(golden_dir):
     u = np.load(os.path.join(golden_dir, "units.npz"))
     src = torch.from_numpy(u["up4_in"]).to(DEV)

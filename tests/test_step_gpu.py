@@ -511,10 +511,18 @@ def test_bench_contract_line_with_roofline_pass():
         sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*kernel_stats*.csv")))
     assert stats, "profiles/r0[34]_*kernel_stats*.csv (rocprofv3 --kernel-trace --stats of bench.py) is missing"
     rows = list(csv.DictReader(open(stats[-1])))
-    top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
-    assert "resblock_kernel<false" in top["Name"] and rf["kernel"].startswith("resblock_kernel<false"), (top["Name"], rf["kernel"])
-    prof_us = sum(float(r["TotalDurationNs"]) for r in rows if "resblock_kernel<false" in r["Name"]) / \
-        sum(float(r["Calls"]) for r in rows if "resblock_kernel<false" in r["Name"]) / 1e3
+    import re
+    short = lambda n: re.sub(r"^void |\(anonymous namespace\)::", "", n).split(">(")[0] + ">"  # noqa: E731
+
+    def fam_rows(label):   # bench labels leave trailing template arguments open (bench.pmc_traffic's rule)
+        st = label.split(" (")[0].rstrip(">").rstrip(".").rstrip(", ")
+        return [r for r in rows if short(r["Name"]).startswith(st + ",") or short(r["Name"]).startswith(st + ">")]
+    tot = {k: sum(float(r["TotalDurationNs"]) for r in fam_rows(k)) for k in rf["families"] if "wgrad" not in k}
+    top = max(tot, key=tot.get)
+    # round 4: since the chain's forward convolutions moved to it the register-weights family (Cin = 64) is the largest, in the
+    # bench's brackets and in the profiler's rows alike (the fused trunk block was, through round 3)
+    assert top == rf["kernel"], (top, rf["kernel"], sorted(tot.items(), key=lambda kv: -kv[1])[:4])
+    prof_us = tot[top] / sum(float(r["Calls"]) for r in fam_rows(top)) / 1e3
     # (rocprofv3's kernel trace dispatches the two lanes' kernels almost serially - profiles/r03_overlap.json: 12 % of the
     # profiled step has both lanes busy, 84 % of the unprofiled one - so its per-kernel average is the STAND-ALONE launch time)
     assert abs(rf["avg_launch_us_standalone"] / prof_us - 1.0) < 0.15, (rf["avg_launch_us_standalone"], prof_us)
