@@ -57,6 +57,19 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
       : "memory");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// ... all but the n most recent vector-memory instructions of this wave have completed (n is wave-uniform, <= 7)
+__device__ __forceinline__ void dma_wait_le(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+  }
+}
 
 // Tile geometry.  S = 1 (3x3 stride-1 convs): tile TW x 128/TW output pixels, X patch (TW + 2) x (TH + 2) of pitch TW + 2.
 // S = 2 (NTS = 3: conv-transpose k3 s2, X = the output gradient on the 2h grid; NTS = 4: conv k4 s2, X = the input): tile
@@ -127,7 +140,16 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
   constexpr int kSlot = NT * 64 * CB + CB;  // floats per slab slot: [NT][64][CB] + channel sums of Y
   auto ykey = [](int k) { return NB == 1 ? (k >> 1) & 3 : k & 7; };
 
-  extern __shared__ __attribute__((aligned(1024))) char smem[];  // two buffers of BUF bytes
+  // NBUF buffers of BUF bytes: two.  -DWG_NBUF3 (tools/build_variant.sh) builds the stride-1 geometries with three (3 x 39-42 KB),
+  // the DMA of tile i + 2 issued at the head of tile i: measured 2-5 % SLOWER on every layer set (c6 91.6 -> 95.9 us at 256
+  // workgroups, step 3.76 -> 3.77 ms; profiles/r04_z_wgrad_diag.log) - the kernel does run at the sum of its MFMA time (38 us for
+  // c6) and its memory time (62 us without the matrix instructions = 400 MB of DMA at 6.4 TB/s), but DMA latency is not why.
+#ifdef WG_NBUF3
+  constexpr int NBUF = 3 * BUF <= 160 * 1024 ? 3 : 2;
+#else
+  constexpr int NBUF = 2;
+#endif
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wa = wid & 3, wb = wid >> 2;
@@ -173,6 +195,11 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
   const char* zero = reinterpret_cast<const char*>(tg_wg_zero_page);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+  int dma_per_tile = 0;   // DMA instructions this wave issues per tile (wave-uniform): what may stay in flight behind a tile
+#pragma unroll
+  for (int c = 0; c < XCW; ++c) dma_per_tile += wid_u + 8 * c < XCH ? 1 : 0;
+#pragma unroll
+  for (int c = 0; c < YCW; ++c) dma_per_tile += wid_u + 8 * c < YCH ? 1 : 0;
 
   f32x4 acc[NT][NF];
   constexpr int E = 8;
@@ -257,13 +284,21 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
     };
 
     int buf = 0;
+    if (NBUF == 3) dma_wait();   // (the previous segment's slab stores: vmcnt counts DMA pieces only from here on)
     issue(0);
+    if (NBUF == 3 && seg_n > 1) issue(BUF);
     for (int i = 0; i < seg_n; ++i, ++tile) {
-      // my DMA pieces of this tile have landed (vmcnt) and every wave is past the previous tile's reads (barrier)
-      dma_wait();
+      // my DMA pieces of this tile have landed (vmcnt: the next tile's may still be in flight) and every wave is past the
+      // previous tile's reads (barrier) - whose buffer the DMA issued below overwrites
+      if (NBUF == 3) dma_wait_le(i + 1 < seg_n ? dma_per_tile : 0);
+      else dma_wait();
       __syncthreads();
       const int bo = buf * BUF;
-      if (i + 1 < seg_n) issue(BUF - bo);
+      if (NBUF == 3) {
+        if (i + 2 < seg_n) issue((buf == 0 ? 2 : buf - 1) * BUF);
+      } else if (i + 1 < seg_n) {
+        issue(BUF - bo);
+      }
       if (ysum) {
         // bias gradient = sum over pixels of Y: thread (row tid / YPR [+ 512 / YPR ...], logical piece tid % YPR) adds its 8 channels
 #pragma unroll
@@ -293,17 +328,26 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int dy = t / NTS, dx = t % NTS;
+#ifdef WG_DIAG_NOAREAD   // diagnostic: every tap reads tap 0's fragment address (the loads collapse to one: wrong results)
+          const char* xp = base + xa[0] + Gm::tap_row(s, 0);
+#else
           const char* xp = base + xa[dx] + Gm::tap_row(s, dy);
+#endif
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xp));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(xp + HI));
           typedef __attribute__((ext_vector_type(8))) short s16x8;
           const s16x8 cat = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           const bf16x8 af = __builtin_bit_cast(bf16x8, cat);
+#ifdef WG_DIAG_NOMFMA   // diagnostic builds (tools/build_variant.sh): LDS reads without the matrix instructions (wrong results)
+#pragma unroll
+          for (int b = 0; b < NF; ++b) acc[t][b][0] += __builtin_bit_cast(f32x4, af)[b & 3];
+#else
 #pragma unroll
           for (int b = 0; b < NF; ++b) acc[t][b] = Mma16<T>::run(af, bfr[b], acc[t][b]);
+#endif
         }
       }
-      buf ^= 1;
+      buf = NBUF == 3 ? (buf == 2 ? 0 : buf + 1) : buf ^ 1;
     }
 
     // ---- the segment's partial dW -> slab slot (workgroup + global ordinal of the channel block)
@@ -340,8 +384,13 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
 template <typename T, int TW, int S, int NTS, int NB = 1>
 int launch_group(const WgGroupK& k, int nwg, hipStream_t st) {
   auto fn = wgrad_group_kernel<T, TW, S, NTS, NB>;
-  constexpr int lds = 2 * (WgGeom<TW, S, NTS>::XBYTES + WgGeom<TW, S, NTS>::TPIX * NB * 128);
-  static_assert(lds <= 160 * 1024, "two LDS buffers must fit");
+  constexpr int one = WgGeom<TW, S, NTS>::XBYTES + WgGeom<TW, S, NTS>::TPIX * NB * 128;
+#ifdef WG_NBUF3
+  constexpr int lds = (3 * one <= 160 * 1024 ? 3 : 2) * one;   // (NBUF of the kernel)
+#else
+  constexpr int lds = 2 * one;
+#endif
+  static_assert(lds <= 160 * 1024, "the LDS buffers must fit");
   static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
