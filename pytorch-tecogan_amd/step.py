@@ -757,45 +757,51 @@ class TecoGANStep:
 
 
 class RecurrentGenerator:
-    """Generator-only recurrent inference (main.py:171-219) without the per-frame CPU<->GPU bounces; the per-frame
-    step (flow -> warp + pack -> G) is captured as a hipGraph and replayed for every frame.  The HR output and the LR
-    input live in two ping-pong slots each - frame t reads slot 1 - t%2 as "previous" and writes slot t%2 - so a frame costs
-    one 200 KB LR copy in, one graph replay and one copy of the result out (the first version moved the previous output
-    and both LR frames every frame: four copies around a 0.4 ms frame)."""
+    """Generator-only recurrent inference (main.py:171-219) without the per-frame CPU<->GPU bounces.  The sequence is processed
+    in CHUNKS of up to FR frames: the chunk's LR frames are staged with one copy into slots 1..n of a ring buffer (slot 0 holds the
+    frame before the chunk), the chunk's n frame steps (flow -> warp + pack -> G, each reading slot s - 1 as "previous" and
+    writing the HR frame into slot s of the output ring) are ONE hipGraph, one strided copy takes the n results out, two small
+    copies carry slot n to slot 0.  Per frame that leaves 1/FR of a graph launch and of four copies (the first version moved
+    four tensors around every frame; round 2 one LR copy in, one graph replay and one HR copy out per frame: 19 us of a 310-us
+    frame at 128 x 128, profiles/r04_x_rw_fwd_routing.log)."""
 
     def __init__(self, G, B, h, w, device, use_graph=False):
         self.G, self.B, self.h, self.w, self.dev, self.use_graph = G, B, h, w, device, use_graph
+        self.FR = max(1, tuning.current().infer_chunk)
         H, W = 4 * h, 4 * w
         f32 = dict(dtype=torch.float32, device=device)
-        self.lr = [torch.empty(B, 3, h, w, **f32) for _ in range(2)]
-        self.hr = [torch.zeros(B, 3, H, W, **f32) for _ in range(2)]
+        n = self.n = self.FR + 1
+        self.sin = torch.empty(B, n, 3, h, w, **f32)
+        self.sout = torch.zeros(B, n, 3, H, W, **f32)
         self.flow = torch.empty(B, 2, H, W, **f32)
         hh, HH = h * w, H * W
-        src, dst = [], []
-        for b in range(B):
-            for c in range(2):
-                src.append((b * 3 + c) * hh)
-                dst.append((b * 2 + c) * HH)
-        self.fsrc, self.fdst = _i64(src, device), _i64(dst, device)
-        G.sets.pin((B, h, w))   # the per-frame graphs hold addresses of this buffer set (engine.ShapeSets)
+        # planes (x, y displacement = channels 0, 1 of the PREVIOUS LR frame, the pseudo-flow of code/train.py:77-80) of slot s
+        self.fsrc = _i64([((b * n + s) * 3 + c) * hh for s in range(n) for b in range(B) for c in range(2)], device).view(n, 2 * B)
+        self.fdst = _i64([(b * 2 + c) * HH for b in range(B) for c in range(2)], device)
+        G.sets.pin((B, h, w))   # the chunk graphs hold addresses of this buffer set (engine.ShapeSets)
         G.alloc(B, h, w)
-        self.graphs = [None, None]
+        self.graphs = {}        # frames in the chunk -> graph
 
     @property
     def out(self):
-        return self.hr[0]
+        return self.sout[:, 0]
 
     def close(self):
-        self.graphs = [None, None]
+        self.graphs = {}
         self.G.sets.unpin((self.B, self.h, self.w))
 
-    def _frame(self, k):
-        """frame with parity k: previous LR / HR frames in slot 1-k, current LR frame in slot k, result into slot k"""
-        G, B, h, w = self.G, self.B, self.h, self.w
-        H, W = 4 * h, 4 * w
-        K.up4_planes(self.lr[1 - k], self.fsrc, self.flow, self.fdst, 2 * B, h, w, pre=4.0)
-        K.gen_input(self.lr[k], 0, 3 * h * w, self.hr[1 - k], 0, 3 * H * W, self.flow, 0, 2 * H * W, G.act["in0"], B, h, w)
-        G.forward(0, B, self.hr[k], 0, 3 * H * W, keep_h=False)
+    def _frame(self, s):
+        """the frame in slot s >= 1: previous LR / HR frames in slot s - 1, result into slot s of the output ring"""
+        G, B, h, w, n = self.G, self.B, self.h, self.w, self.n
+        hh, HH = h * w, 16 * h * w
+        K.up4_planes(self.sin, self.fsrc[s - 1], self.flow, self.fdst, 2 * B, h, w, pre=4.0)
+        K.gen_input(self.sin, s * 3 * hh, n * 3 * hh, self.sout, (s - 1) * 3 * HH, n * 3 * HH, self.flow, 0, 2 * HH,
+                    G.act["in0"], B, h, w)
+        G.forward(0, B, self.sout, s * 3 * HH, n * 3 * HH, keep_h=False)
+
+    def _chunk(self, nf):
+        for s in range(1, nf + 1):
+            self._frame(s)
 
     def run(self, frames):
         """frames (B,T,3,h,w) fp32 device -> (B,T,3,4h,4w)."""
@@ -811,24 +817,32 @@ class RecurrentGenerator:
             self.G.set_cap(cap0)
 
     def _run(self, frames, B, T, h, w):
+        n, hh, HH = self.n, h * w, 16 * h * w
         outs = torch.empty(B, T, 3, 4 * h, 4 * w, dtype=torch.float32, device=self.dev)
-        self.lr[0].copy_(frames[:, 0])
-        K.gen_input(self.lr[0], 0, 3 * h * w, None, 0, 0, None, 0, 0, self.G.act["in0"], B, h, w)
-        self.G.forward(0, B, self.hr[0], 0, 3 * 16 * h * w, keep_h=False)
-        outs[:, 0].copy_(self.hr[0])
-        for t in range(1, T):
-            k = t & 1
-            self.lr[k].copy_(frames[:, t])
+        # frame 0 has no previous frame (main.py:189-196: zeros): it goes through slot 0, the first chunk's "previous" slot
+        self.sin[:, 0].copy_(frames[:, 0])
+        K.gen_input(self.sin, 0, n * 3 * hh, None, 0, 0, None, 0, 0, self.G.act["in0"], B, h, w)
+        self.G.forward(0, B, self.sout, 0, n * 3 * HH, keep_h=False)
+        outs[:, 0].copy_(self.sout[:, 0])
+        t = 1
+        while t < T:
+            nf = min(self.FR, T - t)
+            self.sin[:, 1:nf + 1].copy_(frames[:, t:t + nf])
             if self.use_graph:
-                if self.graphs[k] is None:
-                    self._frame(k)
+                g = self.graphs.get(nf)
+                if g is None:
+                    self._chunk(nf)           # warm-up: workspace growth, launch plans
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        self._frame(k)
-                    self.graphs[k] = g
-                self.graphs[k].replay()
+                        self._chunk(nf)
+                    self.graphs[nf] = g
+                g.replay()
             else:
-                self._frame(k)
-            outs[:, t].copy_(self.hr[k])
+                self._chunk(nf)
+            outs[:, t:t + nf].copy_(self.sout[:, 1:nf + 1])
+            t += nf
+            if t < T:   # the chunk's last frame becomes the next chunk's "previous"
+                self.sin[:, 0].copy_(self.sin[:, nf])
+                self.sout[:, 0].copy_(self.sout[:, nf])
         return outs

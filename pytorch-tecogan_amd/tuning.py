@@ -58,6 +58,8 @@ KNOBS = OrderedDict((k.attr, k) for k in (
        "config 2 3.92 -> 3.80 ms (16384) -> 3.79 (4096), config 4 9.7 -> 9.4-9.5 ms, config 5 2840 -> 2946 frames/s"),
     _k("PAIR_RW_MIN", "pair_rw_min", "int", 16384, "profiles/r04_x_rw_fwd_routing.log",
        "conv_trans.2's conv pair as two register-weights launches instead of the fused block launch from this many pixels (0: never): config 5 3126 -> 3208 frames/s, config 2 -0.02 ms"),
+    _k("INFER_CHUNK", "infer_chunk", "int", 16, "profiles/r04_z_inference_chunks.log",
+       "frames per hipGraph (and per staging copy) in RecurrentGenerator"),
     _k("INFER_WGS", "infer_wgs", "int", 256, "profiles/r04_x_rw_fwd_routing.log",
        "workgroup cap of the generator's persistent launches inside RecurrentGenerator (no other lane to leave CUs to)"),
     _k("RW_DHALF_OFF", "rw_dhalf_off", "str", "", "profiles/r03_r_rw_dma_ab.log",

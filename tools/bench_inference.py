@@ -13,7 +13,9 @@ torch.manual_seed(1)
 G = M.generator(3, args).cuda()
 x = torch.from_numpy(np.random.default_rng(1).random((1, a.frames, 3, a.lr, a.lr), dtype=np.float32)).cuda()
 out = G.recurrent(x, use_graph=not a.no_graph); torch.cuda.synchronize()
-t0 = time.perf_counter(); n = 3
+for _ in range(2): out = G.recurrent(x, use_graph=not a.no_graph)
+torch.cuda.synchronize()
+t0 = time.perf_counter(); n = 10
 for _ in range(n): out = G.recurrent(x, use_graph=not a.no_graph)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 gflop = 8.648 * (a.lr / 32) ** 2
