@@ -161,6 +161,7 @@ class Conv:
         self.fin_job = None
         self.persist_wgs = K.PERSIST_WGS  # workgroups of this layer's persistent launches (the engines set their network's cap)
         self.persist_rw = 0               # ... of its register-weights conv launches, when different (0: the same)
+        self.persist_fwd = 0              # ... of its FORWARD register-weights launches, when different again (0: the same)
         self.rw_off = False               # route this conv's launches past the register-weights kernel (A/B knob of the D halves)
         self.rw_extra = ""                # more launch classes of kernels.rw_eligible for this conv (set per D half)
 
@@ -201,7 +202,7 @@ class Conv:
                 and not self.rw_off and K.rw_eligible(self.dt, self.cin_p, self.cout_p, N, H, W, extra=self.rw_extra):
             self.last_desc, self.last_rw_nch = "rw", self.cin_p // 32  # persistent register-weights kernel (csrc/conv3_rw.hip)
             K.conv3x3_rw(x, self.wf, out, False, bias=self.bias, res=res, act=act, stats=stats, stats_mode=2, groups=groups,
-                         stats_replicas=stats_r, max_workgroups=self.persist_rw or self.persist_wgs)
+                         stats_replicas=stats_r, max_workgroups=self.persist_fwd or self.persist_rw or self.persist_wgs)
             return
         key = ("f", N, H, W, act, res is not None, stats is not None, groups, nchw is not None and nchw[2:], stats_r)
         ent = self._desc.get(key)
@@ -744,7 +745,7 @@ class GeneratorEngine:
         self.shape = None
         self.sets = ShapeSets()
         for c in self.convs:
-            c.persist_wgs, c.persist_rw = K.persist_wgs("G"), TU().persist_rw_g
+            c.persist_wgs, c.persist_rw, c.persist_fwd = K.persist_wgs("G"), TU().persist_rw_g, TU().persist_fwd_g
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
         self.trunk_group = WgradGroup() if TU().wgrad_groups else None
@@ -770,11 +771,13 @@ class GeneratorEngine:
     def repack(self):
         self.repacker.run()
 
-    def set_cap(self, cap):
+    def set_cap(self, cap, fwd=0):
         """workgroups of the generator's persistent launches (register-weights convs, weight-gradient work lists); a scheduling
-        knob only - call before the first backward pass of a shape (launch plans are cached per cap)"""
+        knob only - call before the first backward pass of a shape (launch plans are cached per cap).  fwd: the FORWARD
+        register-weights launches' own cap (0: the same) - the chain runs beside the real half's 72 workgroups, the backward pass
+        beside the fake half's 96"""
         for c in self.convs:
-            c.persist_wgs = cap
+            c.persist_wgs, c.persist_fwd = cap, fwd
         for lst in (self.hr_list, self.trunk_group):
             if isinstance(lst, WgradList):
                 lst.cap = cap

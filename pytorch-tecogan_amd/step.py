@@ -183,7 +183,7 @@ class TecoGANStep:
         tu = self.tu = tuning.current()
         cap_g, cap_dr = K.persist_wgs_g_for(B * h * h), K.persist_wgs_dreal_for(B * h * h)
         if cap_g is not None:
-            G.set_cap(cap_g)
+            G.set_cap(cap_g, tu.cap_fwd_g_for(B * h * h))
         # (set both ways: the engine may have served a step of another size before)
         D.cap[0] = cap_dr if cap_dr is not None else tu.cap_dreal_default()
         D.rw_extra_real = tu.rw_extra_dreal if tu.rw_extra_dreal is not None else ("s1" if cap_dr is not None else "")
@@ -809,12 +809,12 @@ class RecurrentGenerator:
         h, w = self.h, self.w
         self.G.alloc(B, h, w)   # re-select this loop's buffer set (a training step may have selected its own since)
         # no other lane here: the persistent launches may take more of the chip than inside a training step (restored below)
-        cap0 = self.G.convs[0].persist_wgs
+        cap0, fwd0 = self.G.convs[0].persist_wgs, self.G.convs[0].persist_fwd
         self.G.set_cap(tuning.current().infer_wgs)
         try:
             return self._run(frames, B, T, h, w)
         finally:
-            self.G.set_cap(cap0)
+            self.G.set_cap(cap0, fwd0)
 
     def _run(self, frames, B, T, h, w):
         n, hh, HH = self.n, h * w, 16 * h * w

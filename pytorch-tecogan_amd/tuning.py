@@ -46,6 +46,8 @@ KNOBS = OrderedDict((k.attr, k) for k in (
        "cap of the discriminator's REAL half, which runs beside the chain (unset: 72 for chain-bound steps, else the D cap)"),
     _k("PERSIST_RW_G", "persist_rw_g", "int", 0, "profiles/r02_q_persist_wgs_sweep.log",
        "separate cap for the generator's register-weights conv launches (0: the same cap)"),
+    _k("PERSIST_FWD_G", "persist_fwd_g", "int", 0, "profiles/r04_z_fwd_cap.log",
+       "cap of the generator's FORWARD register-weights launches (the chain, beside the real half); 0: 192 for steps of <= 4096 LR pixels per pass, else the generator's"),
     _k("PERSIST_RW_D", "persist_rw_d", "int", 0, "profiles/r02_q_persist_wgs_sweep.log", "... the discriminator's"),
     # ---- kernel routing (engine.Conv, kernels.rw_eligible)
     _k("RW", "rw", "str", "1", "profiles/r02_c_mb_rw.log", "register-weights 3x3 kernel: 0 never, 1 where measured faster, all"),
@@ -153,6 +155,14 @@ class Tuning:
         # chain-bound steps (<= 4096 LR pixels per pass): 144 since the chain's forward convolutions are persistent launches too
         # (3.79 -> 3.75 ms with the rest of r04_x's routing; 128: 3.80); larger steps keep 160 (config 4: 9.72 vs 9.5-9.6 ms)
         return 144 if lr_pixels <= 4096 else self.cap(None)
+
+    def cap_fwd_g_for(self, lr_pixels):
+        """cap of the generator's FORWARD register-weights launches for such a step (0: the generator's cap): the chain's launches
+        run beside the real half (72 workgroups) and may take more of the chip than the backward pass beside the fake half's 96 -
+        176 / 192 / 208 / 256: 3.727 / 3.735 / 3.763 / 3.751 vs 3.762-3.780 ms at the generator's 144 (profiles/r04_z_fwd_cap.log)"""
+        if self.persist_fwd_g:
+            return self.persist_fwd_g
+        return 192 if lr_pixels <= 4096 else 0
 
     def cap_dreal_for(self, lr_pixels):
         """cap of the discriminator's REAL half for such a step, or None (environment fixes it / step is not chain-bound)"""
