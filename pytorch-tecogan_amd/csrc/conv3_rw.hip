@@ -30,6 +30,9 @@
 #include "common.h"
 #include <type_traits>
 
+#ifndef RW_EARLY_STEPS
+#define RW_EARLY_STEPS 8   // k-steps whose weight fragments the consumers fetch before the first barrier (18: all, the round-4 start)
+#endif
 #ifdef TG_STAMP
 // Diagnostic build only (-DTG_STAMP, tools/stamp_rw.py): consumer wave 0 and producer wave 4 of workgroup 0 record s_memtime at
 // the phase boundaries of the prologue and of their first four iterations: [role][0..3 prologue | 4 + 6 * iteration + phase]
@@ -156,20 +159,23 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
     const int r0 = NCH == 4 ? 0 : (wid >> 1) * 4;             // first of the wave's 4 tile rows
     // A-fragments of packed rows 32*wc + 16*a + idx for 9 taps x 2 chunks, in k-loop order.  Packed image
     // [tap][chunk][Cout rows][64 B]; the input-gradient launch pairs spatial offset `so` with slot 8 - so.
+    // Only the fragments of k-steps 0 .. kEarly - 1 are fetched here; the rest go out INSIDE the first tile's k-loop, two per
+    // step.  A wave pays ~130 ticks to issue one of these 1-KiB loads, 36 of them were 4300-5500 ticks of prologue during
+    // which the matrix pipe idled and the producers (patch 0 in LDS after ~3100 ticks) waited at the first barrier; most of the
+    // step's 190 launches of this kernel walk 2-6 tiles, so that was a quarter of their time (profiles/r04_t_stamp_*).
     bf16x8 wfr[2][9][2];
-    {
-      const char* wl = p.w + ((size_t)co_base + wc * 32 + idx) * 64 + g * 16;
+    const char* const wl = p.w + ((size_t)co_base + wc * 32 + idx) * 64 + g * 16;
+    auto wload = [&](int s_) {   // both fragments of k-step s_ (compile-time after unrolling)
+      const int ci = s_ / 9, so = s_ % 9;
+      const int slot = p.flip ? 8 - so : so;
+      const int chunk = kh * 2 + ci;
 #pragma unroll
-      for (int ci = 0; ci < 2; ++ci)
+      for (int a = 0; a < 2; ++a)
+        wfr[ci][so][a] = *reinterpret_cast<const bf16x8*>(wl + ((size_t)(slot * NCH + chunk) * p.Cout + a * 16) * 64);
+    };
+    constexpr int kEarly = RW_EARLY_STEPS;
 #pragma unroll
-        for (int so = 0; so < 9; ++so)
-#pragma unroll
-          for (int a = 0; a < 2; ++a) {
-            const int slot = p.flip ? 8 - so : so;
-            const int chunk = kh * 2 + ci;
-            wfr[ci][so][a] = *reinterpret_cast<const bf16x8*>(wl + ((size_t)(slot * NCH + chunk) * p.Cout + a * 16) * 64);
-          }
-    }
+    for (int s_ = 0; s_ < kEarly; ++s_) wload(s_);
     RW_STAMP(1);
     // fragment addresses of the wave's rows inside one chunk image (column taps 0..2); row taps add multiples of the pitch
     // (two 16-bit offsets per register)
@@ -208,22 +214,29 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
         };
         frags(0, 0);
         frags(1, 1);
+        auto kloop = [&](auto first) {   // first tile: the late weight fragments are fetched on the way (see kEarly)
 #pragma unroll
-        for (int s_ = 0; s_ < 18; ++s_) {
-          if (s_ + 2 < 18) frags(s_ + 2, (s_ + 2) % 3);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-#ifdef RW_DIAG_NOMFMA   // diagnostic: the consumer without its matrix instructions (what do the producers cost then?)
-              acc[a][b][0] += __builtin_bit_cast(f32x4, xf[s_ % 3][b])[a] + __builtin_bit_cast(f32x4, wfr[s_ / 9][s_ % 9][a])[0];
-#else
-              acc[a][b] = mma<T>(wfr[s_ / 9][s_ % 9][a], xf[s_ % 3][b], acc[a][b]);
-#endif
+          for (int s_ = 0; s_ < 18; ++s_) {
+            if (s_ + 2 < 18) frags(s_ + 2, (s_ + 2) % 3);
+            if constexpr (decltype(first)::value) {
+              if (kEarly + s_ < 18) wload(kEarly + s_);
             }
-          __builtin_amdgcn_sched_barrier(0);
-        }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+              for (int a = 0; a < 2; ++a) {
+#ifdef RW_DIAG_NOMFMA   // diagnostic: the consumer without its matrix instructions (what do the producers cost then?)
+                acc[a][b][0] += __builtin_bit_cast(f32x4, xf[s_ % 3][b])[a] + __builtin_bit_cast(f32x4, wfr[s_ / 9][s_ % 9][a])[0];
+#else
+                acc[a][b] = mma<T>(wfr[s_ / 9][s_ % 9][a], xf[s_ % 3][b], acc[a][b]);
+#endif
+              }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        if (i == 0) kloop(std::true_type{});
+        else kloop(std::false_type{});
         RW_STAMP(4 + 6 * i + 1);
         char* dst = accb + (i & 1) * G::kAccBytes + acc_off;
 #pragma unroll
