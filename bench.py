@@ -570,11 +570,14 @@ def other_config5(dev, frames, reps, log):
     x = torch.from_numpy(np.random.default_rng(1).random((1, frames, 3, lr, lr), dtype=np.float32)).to(dev)
     out = G.recurrent(x, use_graph=True)   # warm-up: eager chunk, capture of the chunk graphs
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    per_rep = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         out = G.recurrent(x, use_graph=True)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+        torch.cuda.synchronize()
+        per_rep.append(time.perf_counter() - t0)
+    log("config5 sequences (ms): " + " ".join(f"{1e3 * t:.1f}" for t in per_rep))
+    dt = sorted(per_rep)[len(per_rep) // 2]   # median sequence (each one is synchronised; the first may still pay allocator growth)
     gflop = 8.648 * (lr / 32) ** 2        # forward GFLOP per LR frame at 32x32, x16 at 128x128
     res = {"workload": f"configs[4]: generator-only recurrent inference, {lr}x{lr}->{4 * lr}x{4 * lr}, seq-{frames}, one hipGraph per chunk of {G._rec.FR} frames",
            "dtype": "bf16", "frames": frames, "reps": reps, "hr_frames_per_s": round(frames / dt, 1),
