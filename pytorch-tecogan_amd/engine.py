@@ -771,6 +771,13 @@ class GeneratorEngine:
     def repack(self):
         self.repacker.run()
 
+    def set_trunk_cap(self, cap):
+        """workgroups of the trunk's register-weights launches (the 32 input-gradients of the batched backward) when different
+        from the generator's (0: the same)"""
+        for pair in self.rb:
+            for c in pair:
+                c.persist_rw = cap
+
     def set_cap(self, cap, fwd=0):
         """workgroups of the generator's persistent launches (register-weights convs, weight-gradient work lists); a scheduling
         knob only - call before the first backward pass of a shape (launch plans are cached per cap).  fwd: the FORWARD

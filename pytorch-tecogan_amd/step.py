@@ -184,6 +184,7 @@ class TecoGANStep:
         cap_g, cap_dr = K.persist_wgs_g_for(B * h * h), K.persist_wgs_dreal_for(B * h * h)
         if cap_g is not None:
             G.set_cap(cap_g, tu.cap_fwd_g_for(B * h * h))
+        G.set_trunk_cap(tu.persist_trunk_g)
         # (set both ways: the engine may have served a step of another size before)
         D.cap[0] = cap_dr if cap_dr is not None else tu.cap_dreal_default()
         D.rw_extra_real = tu.rw_extra_dreal if tu.rw_extra_dreal is not None else ("s1" if cap_dr is not None else "")

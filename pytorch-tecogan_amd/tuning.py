@@ -48,6 +48,8 @@ KNOBS = OrderedDict((k.attr, k) for k in (
        "separate cap for the generator's register-weights conv launches (0: the same cap)"),
     _k("PERSIST_FWD_G", "persist_fwd_g", "int", 0, "profiles/r04_z_fwd_cap.log",
        "cap of the generator's FORWARD register-weights launches (the chain, beside the real half); 0: 192 for steps of <= 4096 LR pixels per pass, else the generator's"),
+    _k("PERSIST_TRUNK_G", "persist_trunk_g", "int", 0, "profiles/r04_z_trunk_cap.log",
+       "cap of the trunk's 32 input-gradient launches in the batched G backward (0: the generator's)"),
     _k("PERSIST_RW_D", "persist_rw_d", "int", 0, "profiles/r02_q_persist_wgs_sweep.log", "... the discriminator's"),
     # ---- kernel routing (engine.Conv, kernels.rw_eligible)
     _k("RW", "rw", "str", "1", "profiles/r02_c_mb_rw.log", "register-weights 3x3 kernel: 0 never, 1 where measured faster, all"),
