@@ -1287,6 +1287,8 @@ class DiscriminatorEngine:
         # lane B has slack there (it waits for the chain's last frame), the fake half is on the step's critical path
         self.cap = {None: K.persist_wgs("D"), 1: K.persist_wgs("D"),
                     0: TU().cap_dreal_default()}
+        # ... and of the FORWARD register-weights launches of a half when different (0: the same)
+        self.fwd_cap = {0: TU().persist_fwd_dreal, 1: TU().persist_fwd_dfake}
         self.rw_extra_real = TU().rw_extra_dreal or ""
         self.rw_dhalf_off = TU().rw_dhalf_off
         self.bn_fuse = TU().bn_fuse
@@ -1300,8 +1302,9 @@ class DiscriminatorEngine:
     def _set_cap(self, half):
         cap = self.cap[half]
         off = self.rw_dhalf_off   # "1": the fake half's convs on tg_conv, "0": the real half's, "01": both
+        fwd = self.fwd_cap.get(half, 0)
         for c in self.convs:
-            c.persist_wgs = cap
+            c.persist_wgs, c.persist_fwd = cap, fwd
             c.rw_off = half is not None and str(half) in off
             c.rw_extra = self.rw_extra_real if half == 0 else ""
         if isinstance(self.res_group, WgradList):

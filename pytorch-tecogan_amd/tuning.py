@@ -50,6 +50,9 @@ KNOBS = OrderedDict((k.attr, k) for k in (
        "cap of the generator's FORWARD register-weights launches (the chain, beside the real half); 0: 192 for steps of <= 4096 LR pixels per pass, else the generator's"),
     _k("PERSIST_TRUNK_G", "persist_trunk_g", "int", 0, "profiles/r04_z_trunk_cap.log",
        "cap of the trunk's 32 input-gradient launches in the batched G backward (0: the generator's)"),
+    _k("PERSIST_FWD_DREAL", "persist_fwd_dreal", "int", 0, "profiles/r04_z_d_fwd_caps.log",
+       "cap of the real half's FORWARD register-weights launches when different (0: the half's cap)"),
+    _k("PERSIST_FWD_DFAKE", "persist_fwd_dfake", "int", 0, "profiles/r04_z_d_fwd_caps.log", "... of the fake half's"),
     _k("PERSIST_RW_D", "persist_rw_d", "int", 0, "profiles/r02_q_persist_wgs_sweep.log", "... the discriminator's"),
     # ---- kernel routing (engine.Conv, kernels.rw_eligible)
     _k("RW", "rw", "str", "1", "profiles/r02_c_mb_rw.log", "register-weights 3x3 kernel: 0 never, 1 where measured faster, all"),
