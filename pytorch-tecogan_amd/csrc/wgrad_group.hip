@@ -35,6 +35,24 @@ namespace {
 
 constexpr int GJ = 12;  // int64 per job row (include/tecogan_hip.h, tg_wgrad_group)
 
+#ifdef TG_STAMP
+// Diagnostic build only (-DTG_STAMP, tools/stamp_wgroup.py): waves 0 and 7 of workgroup 0 record s_memtime around the phases of
+// their first 8 tiles: [wave][tile][0 loop head | 1 DMA landed | 2 barrier passed | 3 next DMA issued | 4 k-loop done]
+}  // namespace
+__device__ long long tg_wg_stamps[2 * 8 * 5];
+extern "C" int tg_debug_read_wg_stamps(long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_wg_stamps), sizeof(long long) * n);
+}
+namespace {
+#define WG_STAMP(t, ph)                                                                                        \
+  do {                                                                                                         \
+    if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 448) && (t) < 8)                                \
+      tg_wg_stamps[((threadIdx.x ? 1 : 0) * 8 + (t)) * 5 + (ph)] = (long long)__builtin_amdgcn_s_memtime();    \
+  } while (0)
+#else
+#define WG_STAMP(t, ph) do {} while (0)
+#endif
+
 struct WgGroupK {
   const long long* jobs;
   float* slab;
@@ -144,6 +162,11 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
   // the DMA of tile i + 2 issued at the head of tile i: measured 2-5 % SLOWER on every layer set (c6 91.6 -> 95.9 us at 256
   // workgroups, step 3.76 -> 3.77 ms; profiles/r04_z_wgrad_diag.log) - the kernel does run at the sum of its MFMA time (38 us for
   // c6) and its memory time (62 us without the matrix instructions = 400 MB of DMA at 6.4 TB/s), but DMA latency is not why.
+  // Stamps (tools/stamp_wgroup.py, profiles/r04_z_stamp_wgroup_before.log): a tile is ~4800 ticks = wait 450 + barrier skew up to
+  // 1200 + 1300-1700 in which all eight waves issue the next tile's 5 DMA instructions each and no MFMA runs + k-loop 1800-2600.
+  // Spreading that issue over the k-loop (three buffers, waves 0-3 in front of k-steps 0 / 1, their SIMD partners in front of 2 / 3)
+  // was built: the issue phase shrinks to 470 ticks and the k-loop GROWS by 1700 (5600 per tile, c6 94.8 -> 109.8 us, step 3.74 ->
+  // 3.80 ms; profiles/r04_z_wgrad_inloop.log) - a DMA instruction between the transposed LDS reads costs more than one at the head.
 #ifdef WG_NBUF3
   constexpr int NBUF = 3 * BUF <= 160 * 1024 ? 3 : 2;
 #else
@@ -290,15 +313,19 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
     for (int i = 0; i < seg_n; ++i, ++tile) {
       // my DMA pieces of this tile have landed (vmcnt: the next tile's may still be in flight) and every wave is past the
       // previous tile's reads (barrier) - whose buffer the DMA issued below overwrites
+      WG_STAMP(i, 0);
       if (NBUF == 3) dma_wait_le(i + 1 < seg_n ? dma_per_tile : 0);
       else dma_wait();
+      WG_STAMP(i, 1);
       __syncthreads();
+      WG_STAMP(i, 2);
       const int bo = buf * BUF;
       if (NBUF == 3) {
         if (i + 2 < seg_n) issue((buf == 0 ? 2 : buf - 1) * BUF);
       } else if (i + 1 < seg_n) {
         issue(BUF - bo);
       }
+      WG_STAMP(i, 3);
       if (ysum) {
         // bias gradient = sum over pixels of Y: thread (row tid / YPR [+ 512 / YPR ...], logical piece tid % YPR) adds its 8 channels
 #pragma unroll
@@ -347,6 +374,7 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
 #endif
         }
       }
+      WG_STAMP(i, 4);
       buf = NBUF == 3 ? (buf == 2 ? 0 : buf + 1) : buf ^ 1;
     }
 
