@@ -409,6 +409,300 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Wave-specialised form for the plain 3x3 layers (round 4; S = 1, 64 x 64 channel blocks - same units, slabs and fold as above).
+// Stamps of the kernel above (tools/stamp_wgroup.py, profiles/r04_z_stamp_wgroup_before.log): a 128-pixel tile takes ~4800 ticks
+// for 2304 of MFMA - in 1300-1700 of them all eight waves issue the next tile's DMA (5-6 instructions each through the CU's one
+// address path) and the matrix pipes idle; spreading those instructions over the k-loop is worse (r04_z_wgrad_inloop.log).  Here
+// the roles are split as in conv3_rw.hip:
+//   * waves 0-3, CONSUMERS (one per SIMD): wave w owns rows 16w .. 16w + 15 of the block and ALL 64 Y channels - 9 taps x 4 = 36
+//     accumulator tiles (144 registers, which the unified wave could not afford beside its DMA addresses: r03_m) - so a k-step is
+//     8 Y + 18 X transposed reads for 36 MFMAs instead of 4 + 18 for 18, and the matrix pipe of a SIMD is fed by one wave that
+//     never issues a vector-memory instruction;
+//   * waves 4-7, PRODUCERS: wait for their DMA pieces of tile i, pass the barrier, issue tile i + 1 into the other buffer
+//     (11 instructions per wave, nobody to compete with) and add up the bias gradient from the Y image.
+template <typename T, int TW>
+__global__ __launch_bounds__(512) void wgrad_group_ws_kernel(const WgGroupK p) {
+  using Gm = WgGeom<TW, 1, 3>;
+  constexpr int S = 1, NTS = 3, TH = Gm::TH, NT = 9, XCH = Gm::XCH, XBYTES = Gm::XBYTES, HI = Gm::HI, TPIX = Gm::TPIX;
+  constexpr int CB = 64, YROW = 128, NF = 4;
+  constexpr int YCH = TPIX / 8, BUF = XBYTES + YCH * 1024;
+  constexpr int XCW = (XCH + 3) / 4, YCW = (YCH + 3) / 4;   // DMA instructions per PRODUCER wave and tile
+  constexpr int YPR = 8, YRC = 8, PROWS = 256 / YPR;         // bias sums: 256 producer threads = 32 rows x 8 pieces
+  constexpr int kSlot = NT * 64 * CB + CB;
+  constexpr int E = 8;
+  auto ykey = [](int k) { return (k >> 1) & 3; };
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // two buffers of BUF bytes
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool consumer = wid < 4;
+  const int idx = lane & 15, g = lane >> 4, q = idx >> 2, pp = idx & 3;
+
+  int u = blockIdx.x * p.per_wg;
+  const int u_end = min(u + p.per_wg, p.units_total);
+  if (u >= u_end) return;
+  const char* zero = reinterpret_cast<const char*>(tg_wg_zero_page);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  int job = 0;
+  while (job + 1 < p.njobs && (int)p.jobs[GJ * (job + 1) + 2] <= u) ++job;
+
+  while (u < u_end) {
+    const long long* jr = p.jobs + GJ * job;
+    const char* xbase = reinterpret_cast<const char*>(jr[0]);
+    const char* ybase = reinterpret_cast<const char*>(jr[1]);
+    const int ubeg = (int)jr[2], N = (int)jr[3], H = (int)jr[4], W = (int)jr[5], Cx = (int)jr[6], Cy = (int)jr[7];
+    const int tiles_x = (int)jr[8], tiles_y = (int)jr[9], want_ysum = (int)jr[10], gb0 = (int)jr[11];
+    (void)N;
+    const int XH = H, XW = W;
+    const int tiles = tiles_x * tiles_y * N;
+    const int b_blocks = (Cy + CB - 1) / CB, blocks = ((Cx + 63) >> 6) * b_blocks;
+    const int local = u - ubeg;
+    const int blk = local / tiles;
+    int tile = local - blk * tiles;
+    const int seg_n = min(u_end - u, tiles - tile);
+    const int a0 = (blk / b_blocks) * 64, b0 = (blk % b_blocks) * CB;
+    const bool ysum = want_ysum && a0 == 0;
+    float* slab = p.slab + (size_t)(blockIdx.x + gb0 + blk) * kSlot;
+    float bsum[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) bsum[e] = 0.f;
+
+    if (consumer) {
+      // ======================================================================================================= CONSUMER
+      const int wa = wid;
+      int xa[NTS], ya[NF];
+#pragma unroll
+      for (int d = 0; d < NTS; ++d) {
+        int rb, key;
+        Gm::lane_col(4 * g + q, d, rb, key);
+        xa[d] = rb + ((wa ^ key) * 32) + 8 * pp;
+      }
+#pragma unroll
+      for (int b = 0; b < NF; ++b) {
+        const int k = 4 * g + q;
+        ya[b] = XBYTES + k * YROW + ((b ^ ykey(k)) * 32) + 8 * pp;
+      }
+      f32x4 acc[NT][NF];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int b = 0; b < NF; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      int buf = 0;
+      for (int i = 0; i < seg_n; ++i) {
+        WG_STAMP(i, 0);
+        WG_STAMP(i, 1);
+        __syncthreads();   // tile i is in LDS (the producers waited for it), everybody is past tile i - 1
+        WG_STAMP(i, 2);
+        WG_STAMP(i, 3);
+        const char* base = smem + buf * BUF;
+        // k-loop, software-pipelined by hand (left to itself the compiler hoists every fragment read of the tile above the first
+        // MFMA: 316 spilled registers).  A k-step is 32 pixels; its X fragments are pairs of HALF fragments ("slots"): TW = 16:
+        // slot j = patch row 2s + j (4 per k-step, tap row dy uses slots dy, dy + 1); TW = 32: slot 2r + h = half h of row s + r (6 per
+        // k-step, tap row dy uses slots 2dy, 2dy + 1).  Order per k-step: [reads for dy 1 | 12 MFMAs of dy 0] [reads for dy 2 | MFMAs
+        // of dy 1] [Y fragments and dy-0 slots of the NEXT k-step | MFMAs of dy 2] - every read has 12 MFMAs (~200 cycles) to land.
+        constexpr int NS = TW == 16 ? 4 : 6;
+        auto slot_off = [](int s_, int j) {   // byte offset of slot j of k-step s_ (compile-time after unrolling)
+          return TW == 16 ? (2 * s_ + j) * Gm::PITCH * 128 : (s_ + j / 2) * Gm::PITCH * 128 + (j % 2) * 16 * 128;
+        };
+        auto lo_slot = [](int dy) { return TW == 16 ? dy : 2 * dy; };
+        s16x4 xs[2][NS][NTS];
+        s16x4 ys[2][NF][2];
+        auto read_y = [&](int s_) {
+#pragma unroll
+          for (int b = 0; b < NF; ++b) {
+            const char* yp = base + ya[b] + s_ * 32 * YROW;
+            ys[s_ & 1][b][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(yp));
+            ys[s_ & 1][b][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(yp + 16 * YROW));
+          }
+        };
+        auto read_slot = [&](int s_, int j) {
+#pragma unroll
+          for (int d = 0; d < NTS; ++d)
+            xs[s_ & 1][j][d] =
+                __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + xa[d] + slot_off(s_, j)));
+        };
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        auto cat8 = [](s16x4 lo, s16x4 hi) {
+          const s16x8 c = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          return __builtin_bit_cast(bf16x8, c);
+        };
+        read_y(0);
+        read_slot(0, 0);
+        read_slot(0, 1);
+#pragma unroll
+        for (int s_ = 0; s_ < Gm::KSTEPS; ++s_) {
+#pragma unroll
+          for (int dy = 0; dy < NTS; ++dy) {
+            // reads that the NEXT group of MFMAs needs
+            if (dy + 1 < NTS) {
+              if (TW == 16) {
+                read_slot(s_, dy + 2);
+              } else {
+                read_slot(s_, 2 * dy + 2);
+                read_slot(s_, 2 * dy + 3);
+              }
+            } else if (s_ + 1 < Gm::KSTEPS) {
+              read_y(s_ + 1);
+              read_slot(s_ + 1, 0);
+              read_slot(s_ + 1, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dx = 0; dx < NTS; ++dx) {
+              const bf16x8 af = cat8(xs[s_ & 1][lo_slot(dy)][dx], xs[s_ & 1][lo_slot(dy) + 1][dx]);
+#pragma unroll
+              for (int b = 0; b < NF; ++b)
+                acc[dy * NTS + dx][b] = Mma16<T>::run(af, cat8(ys[s_ & 1][b][0], ys[s_ & 1][b][1]), acc[dy * NTS + dx][b]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        WG_STAMP(i, 4);
+        buf ^= 1;
+      }
+      // the segment's partial dW -> slab slot (workgroup + global ordinal of the channel block).  (The lane's offset goes through
+      // an empty asm: otherwise the 144 store addresses are computed - and spilled - in front of the tile loop.  Transposing the
+      // tiles through LDS for 1-KB coalesced stores was built too and measured equal: profiles/r04_z_wgrad_ws.log.)
+      int lane_off = (wa * 16 + 4 * g) * CB + idx;
+      asm volatile("" : "+v"(lane_off));
+      float* const sl = slab + lane_off;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int b = 0; b < NF; ++b) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sl[(t * 64 + j) * CB + b * 16] = acc[t][b][j];
+        }
+    } else {
+      // ======================================================================================================= PRODUCER
+      const int pw = wid - 4, ptid = tid - 256;
+      const int xpixb = Cx * 2, ypixb = Cy * 2;
+      const int jp = lane & 7, r8 = lane >> 3;
+      // A 32-channel remainder runs as a half-empty block: the pieces of its missing channels are CLAMPED onto the pixel's last
+      // real 16 bytes (what they produce is never read by the fold, see the kernel above)
+      const int xlast = xpixb - a0 * 2 - 16, ylast = ypixb - b0 * 2 - 16;
+      int xpy[XCW], xpx[XCW], xrel[XCW];
+#pragma unroll
+      for (int c = 0; c < XCW; ++c) {
+        int py, px, key;
+        bool valid;
+        Gm::decode((pw + 4 * c) * 8 + r8, py, px, key, valid);
+        xpy[c] = valid ? py : -100000;
+        xpx[c] = px;
+        const int xch = ((((jp >> 1) ^ key) * 2) + (jp & 1)) * 16;
+        xrel[c] = (max(xpy[c], 0) * XW + xpx[c]) * xpixb + min(xch, xlast);
+      }
+      int yty[YCW], ytx[YCW], yrel[YCW];
+#pragma unroll
+      for (int c = 0; c < YCW; ++c) {
+        const int k = (pw + 4 * c) * YRC + lane / YPR, yp = lane % YPR;
+        yty[c] = k / TW;
+        ytx[c] = k - yty[c] * TW;
+        const int ych = ((((yp >> 1) ^ ykey(k)) * 2) + (yp & 1)) * 16;
+        yrel[c] = (yty[c] * W + ytx[c]) * ypixb + min(ych, ylast);
+      }
+      int i_txb, i_tyb, i_n;
+      {
+        int r = tile;
+        i_txb = r % tiles_x;
+        r /= tiles_x;
+        i_tyb = r % tiles_y;
+        i_n = r / tiles_y;
+      }
+      auto issue = [&](int bufoff) {
+        const int ty0 = i_tyb * TH, tx0 = i_txb * TW;
+        const char* xo = xbase + ((long long)i_n * XH * XW + (long long)(S * ty0 - 1) * XW + (S * tx0 - 1)) * xpixb + a0 * 2;
+        const unsigned lx = lds0 + bufoff;
+#pragma unroll
+        for (int c = 0; c < XCW; ++c) {
+          if (pw + 4 * c < XCH) {  // wave-uniform
+            const int iy = ty0 - 1 + xpy[c], ix = tx0 - 1 + xpx[c];
+            const bool ok = (unsigned)iy < (unsigned)XH && (unsigned)ix < (unsigned)XW;
+            glds16(ok ? xo + xrel[c] : zero, lx + (pw + 4 * c) * 1024);
+          }
+        }
+        const char* yo = ybase + ((long long)i_n * H * W + (long long)ty0 * W + tx0) * ypixb + b0 * 2;
+#pragma unroll
+        for (int c = 0; c < YCW; ++c) {
+          if (pw + 4 * c < YCH) {  // wave-uniform
+            const bool ok = ty0 + yty[c] < H && tx0 + ytx[c] < W;
+            glds16(ok ? yo + yrel[c] : zero, lx + XBYTES + (pw + 4 * c) * 1024);
+          }
+        }
+        if (++i_txb == tiles_x) {
+          i_txb = 0;
+          if (++i_tyb == tiles_y) {
+            i_tyb = 0;
+            ++i_n;
+          }
+        }
+      };
+      int buf = 0;
+      issue(0);
+      for (int i = 0; i < seg_n; ++i) {
+        WG_STAMP(i, 0);
+        dma_wait();        // my pieces of tile i have landed
+        WG_STAMP(i, 1);
+        __syncthreads();   // ... everybody's have; the consumers are past tile i - 1, whose buffer the next DMA overwrites
+        WG_STAMP(i, 2);
+        const int bo = buf * BUF;
+        if (i + 1 < seg_n) issue(BUF - bo);
+        WG_STAMP(i, 3);
+        if (ysum) {
+          // bias gradient = sum over pixels of Y: thread (row ptid / 8 [+ 32 ...], logical piece ptid % 8) adds its 8 channels
+#pragma unroll
+          for (int h = 0; h < TPIX / PROWS; ++h) {
+            const int k = ptid / YPR + PROWS * h, lp = ptid % YPR;
+            const int phys = ((((lp >> 1) ^ ykey(k)) * 2) + (lp & 1)) * 16;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + bo + XBYTES + k * YROW + phys);
+            float f[8];
+            Vec<T>::load(&v, f);
+#pragma unroll
+            for (int e = 0; e < E; ++e) bsum[e] += f[e];
+          }
+        }
+        WG_STAMP(i, 4);
+        buf ^= 1;
+      }
+    }
+    __syncthreads();  // every wave is done with the LDS images (the next segment's DMA, or the sums below, overwrite them)
+    if (want_ysum) {
+      float* red = reinterpret_cast<float*>(smem);  // [PROWS rows][CB channels]
+      if (ysum && !consumer) {
+        const int ptid = tid - 256;
+#pragma unroll
+        for (int e = 0; e < E; ++e) red[(ptid / YPR) * CB + (ptid % YPR) * 8 + e] = bsum[e];
+      }
+      __syncthreads();
+      if (tid < CB) {
+        float sum = 0.f;
+        if (ysum)
+          for (int r = 0; r < PROWS; ++r) sum += red[r * CB + tid];
+        slab[NT * 64 * CB + tid] = sum;  // blocks with a0 != 0 write zeros: the fold reads the sums of block row 0 only
+      }
+      __syncthreads();
+    }
+    u += seg_n;
+    if (u < u_end && u >= ubeg + blocks * tiles) ++job;  // (a segment never crosses a job; ranges may)
+  }
+}
+
+template <typename T, int TW>
+int launch_group_ws(const WgGroupK& k, int nwg, hipStream_t st) {
+  auto fn = wgrad_group_ws_kernel<T, TW>;
+  constexpr int lds = 2 * (WgGeom<TW, 1, 3>::XBYTES + WgGeom<TW, 1, 3>::TPIX * 128);
+  static_assert(lds <= 160 * 1024, "two LDS buffers must fit");
+  static std::atomic<bool> attr_done{false};
+  if (!attr_done) {
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(512), lds, st, k);
+  return tg_launch_status();
+}
+
 template <typename T, int TW, int S, int NTS, int NB = 1>
 int launch_group(const WgGroupK& k, int nwg, hipStream_t st) {
   auto fn = wgrad_group_kernel<T, TW, S, NTS, NB>;
@@ -430,7 +724,15 @@ int launch_group(const WgGroupK& k, int nwg, hipStream_t st) {
 
 template <typename T>
 int dispatch_group(int variant, int tile_w, const WgGroupK& k, int nwg, hipStream_t st) {
+#ifdef WG_NO_WS   // A/B build (tools/build_variant.sh): the unified-wave kernel for the plain 3x3 layers too
   if (variant == TG_WGROUP_C3) return tile_w == 32 ? launch_group<T, 32, 1, 3>(k, nwg, st) : launch_group<T, 16, 1, 3>(k, nwg, st);
+#else
+  // the wave-specialised kernel from 12 tiles per workgroup (below that its four consumer waves' serial slab write and first-tile
+  // wait cost more than the tile loop gains: the discriminator's 16 x 16 lists, 8 tiles each, 17.8 -> 19.9 us)
+  if (variant == TG_WGROUP_C3 && k.per_wg >= 12)
+    return tile_w == 32 ? launch_group_ws<T, 32>(k, nwg, st) : launch_group_ws<T, 16>(k, nwg, st);
+  if (variant == TG_WGROUP_C3) return tile_w == 32 ? launch_group<T, 32, 1, 3>(k, nwg, st) : launch_group<T, 16, 1, 3>(k, nwg, st);
+#endif
 #ifdef TG_EXPERIMENTS   // 64 x 128 channel blocks: 1.1-2.5x slower (spills), profiles/r03_m_wgrad_b128.log
   if (variant == TG_WGROUP_C3_B128)
     return tile_w == 32 ? launch_group<T, 32, 1, 3, 2>(k, nwg, st) : launch_group<T, 16, 1, 3, 2>(k, nwg, st);

@@ -37,5 +37,6 @@ for cap in (256, 144):
                 a = t[i * 5:i * 5 + 5]
                 if i and a[0] <= t[(i - 1) * 5]:
                     break
-                line += f" t{i}: dma-wait {a[1]-a[0]} barrier {a[2]-a[1]} issue {a[3]-a[2]} k-loop {a[4]-a[3]} = {a[4]-a[0]} |"
+                nm = ("issue", "k-loop") if w == 0 else ("DMA issue", "bias sums")   # wave-specialised build: wave 0 consumes, wave 7 produces
+                line += f" t{i}: dma-wait {a[1]-a[0]} barrier {a[2]-a[1]} {nm[0]} {a[3]-a[2]} {nm[1]} {a[4]-a[3]} = {a[4]-a[0]} |"
             print(line)
