@@ -421,10 +421,11 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
 //     never issues a vector-memory instruction;
 //   * waves 4-7, PRODUCERS: wait for their DMA pieces of tile i, pass the barrier, issue tile i + 1 into the other buffer
 //     (11 instructions per wave, nobody to compete with) and add up the bias gradient from the Y image.
-template <typename T, int TW>
+template <typename T, int TW, int S>
 __global__ __launch_bounds__(512) void wgrad_group_ws_kernel(const WgGroupK p) {
-  using Gm = WgGeom<TW, 1, 3>;
-  constexpr int S = 1, NTS = 3, TH = Gm::TH, NT = 9, XCH = Gm::XCH, XBYTES = Gm::XBYTES, HI = Gm::HI, TPIX = Gm::TPIX;
+  using Gm = WgGeom<TW, S, 3>;   // S = 1: plain 3x3 layers; S = 2: conv-transpose k3 s2 (X = the output gradient on the fine grid)
+  static_assert(S == 1 || TW == 16, "stride-2 tiles are 16 x 4");
+  constexpr int NTS = 3, TH = Gm::TH, NT = 9, XCH = Gm::XCH, XBYTES = Gm::XBYTES, TPIX = Gm::TPIX;
   constexpr int CB = 64, YROW = 128, NF = 4;
   constexpr int YCH = TPIX / 8, BUF = XBYTES + YCH * 1024;
   constexpr int XCW = (XCH + 3) / 4, YCW = (YCH + 3) / 4;   // DMA instructions per PRODUCER wave and tile
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(512) void wgrad_group_ws_kernel(const WgGroupK p) {
     const int ubeg = (int)jr[2], N = (int)jr[3], H = (int)jr[4], W = (int)jr[5], Cx = (int)jr[6], Cy = (int)jr[7];
     const int tiles_x = (int)jr[8], tiles_y = (int)jr[9], want_ysum = (int)jr[10], gb0 = (int)jr[11];
     (void)N;
-    const int XH = H, XW = W;
+    const int XH = S * H, XW = S * W;
     const int tiles = tiles_x * tiles_y * N;
     const int b_blocks = (Cy + CB - 1) / CB, blocks = ((Cx + 63) >> 6) * b_blocks;
     const int local = u - ubeg;
@@ -500,13 +501,16 @@ __global__ __launch_bounds__(512) void wgrad_group_ws_kernel(const WgGroupK p) {
         // k-loop, software-pipelined by hand (left to itself the compiler hoists every fragment read of the tile above the first
         // MFMA: 316 spilled registers).  A k-step is 32 pixels; its X fragments are pairs of HALF fragments ("slots"): TW = 16:
         // slot j = patch row 2s + j (4 per k-step, tap row dy uses slots dy, dy + 1); TW = 32: slot 2r + h = half h of row s + r (6 per
-        // k-step, tap row dy uses slots 2dy, 2dy + 1).  Order per k-step: [reads for dy 1 | 12 MFMAs of dy 0] [reads for dy 2 | MFMAs
+        // k-step, tap row dy uses slots 2dy, 2dy + 1); stride 2: slot j = patch row 4s + j (5 per k-step, tap row dy uses slots dy,
+        // dy + 2).  Order per k-step: [reads for dy 1 | 12 MFMAs of dy 0] [reads for dy 2 | MFMAs
         // of dy 1] [Y fragments and dy-0 slots of the NEXT k-step | MFMAs of dy 2] - every read has 12 MFMAs (~200 cycles) to land.
-        constexpr int NS = TW == 16 ? 4 : 6;
+        constexpr int NS = S == 2 ? 5 : TW == 16 ? 4 : 6;
         auto slot_off = [](int s_, int j) {   // byte offset of slot j of k-step s_ (compile-time after unrolling)
-          return TW == 16 ? (2 * s_ + j) * Gm::PITCH * 128 : (s_ + j / 2) * Gm::PITCH * 128 + (j % 2) * 16 * 128;
+          return S == 2 ? (4 * s_ + j) * Gm::PITCH * 128
+                        : TW == 16 ? (2 * s_ + j) * Gm::PITCH * 128 : (s_ + j / 2) * Gm::PITCH * 128 + (j % 2) * 16 * 128;
         };
-        auto lo_slot = [](int dy) { return TW == 16 ? dy : 2 * dy; };
+        auto lo_slot = [](int dy) { return (S == 2 || TW == 16) ? dy : 2 * dy; };
+        auto hi_slot = [](int dy) { return S == 2 ? dy + 2 : TW == 16 ? dy + 1 : 2 * dy + 1; };
         s16x4 xs[2][NS][NTS];
         s16x4 ys[2][NF][2];
         auto read_y = [&](int s_) {
@@ -529,15 +533,18 @@ __global__ __launch_bounds__(512) void wgrad_group_ws_kernel(const WgGroupK p) {
           return __builtin_bit_cast(bf16x8, c);
         };
         read_y(0);
-        read_slot(0, 0);
-        read_slot(0, 1);
+        read_slot(0, lo_slot(0));
+        read_slot(0, hi_slot(0));
 #pragma unroll
         for (int s_ = 0; s_ < Gm::KSTEPS; ++s_) {
 #pragma unroll
           for (int dy = 0; dy < NTS; ++dy) {
             // reads that the NEXT group of MFMAs needs
             if (dy + 1 < NTS) {
-              if (TW == 16) {
+              if (S == 2) {
+                if (dy == 0) read_slot(s_, 1);   // tap row 1: slots 1, 3; tap row 2: slots 2 (in registers since row 0), 4
+                read_slot(s_, dy == 0 ? 3 : 4);
+              } else if (TW == 16) {
                 read_slot(s_, dy + 2);
               } else {
                 read_slot(s_, 2 * dy + 2);
@@ -545,13 +552,13 @@ __global__ __launch_bounds__(512) void wgrad_group_ws_kernel(const WgGroupK p) {
               }
             } else if (s_ + 1 < Gm::KSTEPS) {
               read_y(s_ + 1);
-              read_slot(s_ + 1, 0);
-              read_slot(s_ + 1, 1);
+              read_slot(s_ + 1, lo_slot(0));
+              read_slot(s_ + 1, hi_slot(0));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int dx = 0; dx < NTS; ++dx) {
-              const bf16x8 af = cat8(xs[s_ & 1][lo_slot(dy)][dx], xs[s_ & 1][lo_slot(dy) + 1][dx]);
+              const bf16x8 af = cat8(xs[s_ & 1][lo_slot(dy)][dx], xs[s_ & 1][hi_slot(dy)][dx]);
 #pragma unroll
               for (int b = 0; b < NF; ++b)
                 acc[dy * NTS + dx][b] = Mma16<T>::run(af, cat8(ys[s_ & 1][b][0], ys[s_ & 1][b][1]), acc[dy * NTS + dx][b]);
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(512) void wgrad_group_ws_kernel(const WgGroupK p) {
 #pragma unroll
         for (int c = 0; c < XCW; ++c) {
           if (pw + 4 * c < XCH) {  // wave-uniform
-            const int iy = ty0 - 1 + xpy[c], ix = tx0 - 1 + xpx[c];
+            const int iy = S * ty0 - 1 + xpy[c], ix = S * tx0 - 1 + xpx[c];
             const bool ok = (unsigned)iy < (unsigned)XH && (unsigned)ix < (unsigned)XW;
             glds16(ok ? xo + xrel[c] : zero, lx + (pw + 4 * c) * 1024);
           }
@@ -689,10 +696,10 @@ __global__ __launch_bounds__(512) void wgrad_group_ws_kernel(const WgGroupK p) {
   }
 }
 
-template <typename T, int TW>
+template <typename T, int TW, int S = 1>
 int launch_group_ws(const WgGroupK& k, int nwg, hipStream_t st) {
-  auto fn = wgrad_group_ws_kernel<T, TW>;
-  constexpr int lds = 2 * (WgGeom<TW, 1, 3>::XBYTES + WgGeom<TW, 1, 3>::TPIX * 128);
+  auto fn = wgrad_group_ws_kernel<T, TW, S>;
+  constexpr int lds = 2 * (WgGeom<TW, S, 3>::XBYTES + WgGeom<TW, S, 3>::TPIX * 128);
   static_assert(lds <= 160 * 1024, "two LDS buffers must fit");
   static std::atomic<bool> attr_done{false};
   if (!attr_done) {
@@ -732,6 +739,10 @@ int dispatch_group(int variant, int tile_w, const WgGroupK& k, int nwg, hipStrea
   if (variant == TG_WGROUP_C3 && k.per_wg >= 12)
     return tile_w == 32 ? launch_group_ws<T, 32>(k, nwg, st) : launch_group_ws<T, 16>(k, nwg, st);
   if (variant == TG_WGROUP_C3) return tile_w == 32 ? launch_group<T, 32, 1, 3>(k, nwg, st) : launch_group<T, 16, 1, 3>(k, nwg, st);
+#ifdef WG_CT_WS   // the conv-transpose kind (S = 2, 64-pixel tiles of two k-steps) on the wave-specialised kernel: parity green, measured
+                  // slightly SLOWER than the unified kernel (G backward alone 1.316 -> 1.335 ms, profiles/r04_z_wgrad_ws.log) - opt-in build
+  if (variant == TG_WGROUP_CT && k.per_wg >= 24) return launch_group_ws<T, 16, 2>(k, nwg, st);
+#endif
 #endif
 #ifdef TG_EXPERIMENTS   // 64 x 128 channel blocks: 1.1-2.5x slower (spills), profiles/r03_m_wgrad_b128.log
   if (variant == TG_WGROUP_C3_B128)
