@@ -39,7 +39,7 @@ KNOBS = OrderedDict((k.attr, k) for k in (
        "issue the collectives even with one rank (test hook)"),
     # ---- persistent launches: workgroup caps (kernels.persist_wgs*)
     _k("PERSIST_WGS", "persist_wgs", "oint", None, "profiles/r02_q_persist_wgs_sweep.log",
-       "cap of every persistent launch (unset: G 160, D 96, D real half 72 for steps of <= 4096 LR pixels)"),
+       "cap of every persistent launch (unset: G 160, D 96; for steps of <= 4096 LR pixels per pass G 144, its forward launches 192, D real half 72)"),
     _k("PERSIST_WGS_G", "persist_wgs_g", "oint", None, "profiles/r03_r_rw_dma_ab.log", "generator's cap (unset: 144 for steps of <= 4096 LR pixels per pass, else 160)"),
     _k("PERSIST_WGS_D", "persist_wgs_d", "oint", None, "profiles/r02_q_persist_wgs_sweep.log", "discriminator's cap (unset: 96)"),
     _k("PERSIST_WGS_DREAL", "persist_wgs_dreal", "oint", None, "profiles/r03_r_rw_dma_ab.log",
