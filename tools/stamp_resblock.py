@@ -5,8 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import pytorch_tecogan_amd
 from pytorch_tecogan_amd import _lib as L, kernels as K
 lib = L.load()
-lib.tg_debug_read_rb_stamps.restype = ctypes.c_int
-lib.tg_debug_read_rb_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+STAMPS = hasattr(lib, "tg_debug_read_rb_stamps")   # (a library built without -DTG_STAMP: only the launch time at the end)
+if STAMPS:
+    lib.tg_debug_read_rb_stamps.restype = ctypes.c_int
+    lib.tg_debug_read_rb_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 dt = torch.bfloat16
 N, H, NB = 4, 32, 16
 spec = K.ConvSpec("c3", 64, 64)
@@ -17,7 +19,7 @@ bs = [torch.zeros(64, device="cuda") for _ in range(NB)]
 a = [torch.randn(N, H, H, 64, device="cuda").to(dt) for _ in range(NB + 1)]
 h = [torch.empty(N, H, H, 64, dtype=dt, device="cuda") for _ in range(NB)]
 names = ["issue loads", "addr+wait+LDS stores", "barrier", "conv1 MFMA", "epilogue1", "barrier", "conv2 prologue", "conv2 MFMA", "epilogue2"]
-for rep in range(4):
+for rep in range(4 if STAMPS else 0):
     for i in range(NB):
         K.resblock_fwd(a[i], wps[i][0], bs[i], wps[i][1], h[i], a[i + 1], next_w=(wps[i + 1] if i + 1 < NB and os.environ.get('RB_PREFETCH', '1') == '1' else None))
     torch.cuda.synchronize()
