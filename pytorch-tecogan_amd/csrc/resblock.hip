@@ -36,6 +36,16 @@ __device__ long long tg_rb_stamps[16];
 extern "C" int tg_debug_read_rb_stamps(long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_rb_stamps), sizeof(long long) * n);
 }
+// ... and every wave of workgroup 0 at [0 kernel start | 1 conv1 begins | 2 conv1 done | 3 exchange barrier passed | 4 conv2 done]
+__device__ long long tg_rb_wstamps[8 * 5];
+#define RB_WSTAMP(i)                                                                         \
+  do {                                                                                       \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                          \
+      tg_rb_wstamps[(threadIdx.x >> 6) * 5 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+extern "C" int tg_debug_read_rb_wstamps(long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tg_rb_wstamps), sizeof(long long) * n);
+}
 #else
 #define RB_STAMP(i) do {} while (0)
 #endif
@@ -142,6 +152,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
   const char* in_n = p.in + (size_t)n * p.H * p.W * 128;
 
   RB_STAMP(0);
+  RB_WSTAMP(0);
   // ---- phase 1.  Patch loads are unconditional from a clamped address and zeroed afterwards: a load under a divergent
   // `if` makes the compiler wait for each one before issuing the next.
   u32x4 va[NU];
@@ -219,6 +230,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
   RB_STAMP(2);
   lds_barrier();
   RB_STAMP(3);
+  RB_WSTAMP(1);
 
   char* myx = lds_x + (wid * 4 * 64 + lane) * 16;               // exchange slots of this wave
   const char* px_ = lds_x + ((wid ^ 4) * 4 * 64 + lane) * 16;   // ... of the partner (same row tile, other K half)
@@ -245,6 +257,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     RB_STAMP(4);
+    RB_WSTAMP(2);
     // exchange: K half 0 finalises tiles 0 .. F1-1, K half 1 the rest; each wave hands the other tiles to its partner
     auto finish1 = [&](auto T0, auto NT) {
       constexpr int t0 = decltype(T0)::value, nt = decltype(NT)::value, o0 = t0 ? 0 : F1, no = NT1 - nt;
@@ -253,6 +266,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
       RB_STAMP(10);
       lds_barrier();
       RB_STAMP(11);
+      RB_WSTAMP(3);
 #pragma unroll
       for (int j = 0; j < nt; ++j) {
         const int t = t0 + j;
@@ -318,6 +332,7 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     RB_STAMP(8);
+    RB_WSTAMP(4);
     // L2 prefetch for the next residual block: its 147 KB of weights were evicted from this XCD's L2 since the previous
     // frame used them (they come back from the Infinity Cache at ~1 us latency, which is what paces the weight stream
     // above).  The workgroups of one XCD (blockIdx.x % 8) each touch one eighth of the two images - two or three 1-KiB

@@ -28,6 +28,15 @@ for rep in range(4 if STAMPS else 0):
     t = list(buf)
     print(" | ".join(f"{n} {t[i+1]-t[i]}" for i, n in enumerate(names)), "| total", t[9] - t[0], "ticks;",
           f"epilogue1 = exchange writes {t[10]-t[4]} + barrier {t[11]-t[10]} + finalise {t[5]-t[11]}")
+    if hasattr(lib, "tg_debug_read_rb_wstamps") and rep == 3:
+        wb = (ctypes.c_longlong * 40)()
+        lib.tg_debug_read_rb_wstamps(wb, 40)
+        w = list(wb)
+        t0 = min(w[k * 5] for k in range(8))
+        for k in range(8):
+            a_ = w[k * 5:k * 5 + 5]
+            print(f"   wave {k} (row tile {k & 3}, K half {k >> 2}): start +{a_[0]-t0}, conv1 begins +{a_[1]-t0}, conv1 done +{a_[2]-t0} (k-loop {a_[2]-a_[1]}), "
+                  f"exchange barrier passed +{a_[3]-t0} (waited {a_[3]-a_[2]}), conv2 done +{a_[4]-t0}")
 
 # wall time per launch of the same 16-launch trunk replayed as a hipGraph (what the step does; eager launches are host-bound)
 def trunk():
