@@ -48,6 +48,7 @@ extern "C" int tg_debug_read_rb_wstamps(long long* out, int n) {
 }
 #else
 #define RB_STAMP(i) do {} while (0)
+#define RB_WSTAMP(i) do {} while (0)
 #endif
 
 namespace {
