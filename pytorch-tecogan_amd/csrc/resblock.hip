@@ -381,6 +381,227 @@ __global__ __launch_bounds__(512) void resblock_kernel(const ResblockK p) {
   RB_STAMP(9);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Three-way K split for the 8 x 4-tile forward launch (round 4; the recurrent pass: 160 launches per training step).
+// Per-wave stamps of the kernel above (tools/stamp_resblock.py, profiles/r04_z_stamp_resblock.log): conv1 takes 2400 ticks for the
+// older wave of each SIMD and 3950 for the younger one - with or without weight loads in the k-loop - for 576 cycles of MFMA: it
+// is bound by its LDS fragment reads.  A wave there owns ONE 16-channel row tile and half of K, so each fragment it reads feeds one
+// MFMA, and the four row-tile waves of a K half read the same 36 fragments (288 KB per workgroup).  Here a compute wave owns TWO
+// row tiles (32 output channels) and ONE tap row (a third of K: 3 taps x 2 channel chunks = 6 k-steps): every fragment feeds two
+// MFMAs, 144 KB instead of 288 for conv1 and 72 instead of 144 for conv2, the weight stream is the same 144 fragments but over six
+// waves (24 each).  Waves 6 and 7 do not multiply; all eight share the patch load and the two finalising passes, which add the
+// three K partials from the exchange buffer (conv1: 16 (row tile, pixel tile) pairs, two per wave; conv2: 8, one per wave).
+// MEASURED SLOWER and not dispatched by default (-DRB_K3 builds it in): 6.58 vs 6.20 us per launch of the 16-launch trunk, chain
+// 1.53 vs 1.47 ms, step 3.79 vs 3.70 ms (profiles/r04_z_rb_k3.log) at every depth of the weight stream (4 / 8 / 12 / 16 / 24 fragments
+// ahead: 6.68 / 6.58 / 6.86 / 7.20 / 7.65).  The fragment reads are halved, but a compute wave now issues 24 weight loads instead of
+// 18 (~130 ticks each, in order, nothing else can issue them for it) and two waves issue none: the longest per-wave issue chain
+// grows from 2340 to 3120 ticks, which is what the workgroup then waits for.
+constexpr int kLdsX3 = 6 * 8 * 1024;   // exchange: [compute wave][2 row tiles x 4 pixel tiles][lane][16 B]
+#ifndef RB_K3_AHEAD
+#define RB_K3_AHEAD 8                   // weight fragments in flight ahead of their k-step (two per k-step)
+#endif
+template <typename T>
+__global__ __launch_bounds__(512) void resblock_k3_kernel(const ResblockK p) {
+  constexpr int TH = 4;
+  using G_ = Geo<TH>;
+  constexpr int kInPix = G_::kInPix, kInRows = G_::kInRows, kHPix = G_::kHPix, kHRows = G_::kHRows;
+  constexpr int kLdsIn = G_::kLdsIn, kLdsH = G_::kLdsH, NT1 = G_::NT1, NT2 = G_::NT2, NU = G_::NU;
+  static_assert(NT1 == 4 && NT2 == 2, "8 x 4 tiles: 60 region pixels, 32 output pixels");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_in = smem;
+  char* lds_h = smem + kLdsIn;
+  char* lds_x = smem + kLdsIn + kLdsH;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool comp = wid < 6;                 // compute waves
+  const int rp = wid & 1, dy = wid >> 1;     // ... row-tile pair (row tiles 2rp, 2rp + 1), tap row
+  const int fw = wid & 3, fq = wid >> 2;     // finalising role: row tile fw; conv1 pixel tiles 2fq, 2fq + 1; conv2 pixel tile fq
+  const int idx = lane & 15, g = lane >> 4;
+  int bx = blockIdx.x;
+  if (p.xcd_blocks) bx = (bx & 7) * p.xcd_blocks + (bx >> 3);
+  const int txb = bx % p.tiles_x;
+  bx /= p.tiles_x;
+  const int tyb = bx % p.tiles_y;
+  const int n = bx / p.tiles_y;
+  const int y0 = tyb * TH, x0 = txb * 8;
+  const char* in_n = p.in + (size_t)n * p.H * p.W * 128;
+
+  // ---- phase 1: patch loads (unconditional from a clamped address, zeroed afterwards), head of the weight stream
+  u32x4 va[NU];
+  int da[NU];
+  bool ok[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int i = min(tid + u * 512, 2 * kInPix * 4 - 1);
+    const int s_ = i & 3, r = i >> 2;
+    const int cc = r >= kInPix ? 1 : 0, prow = r - cc * kInPix;
+    const int py = (prow * 171) >> 11, px = prow - py * kInW;  // prow / 12, exact for prow <= 144
+    const int iy = y0 - 2 + py, ix = x0 - 2 + px;
+    da[u] = (tid + u * 512 < 2 * kInPix * 4) ? cc * kInRows * kRow + lds_off(py * kInP + px, s_) : -1;
+    ok[u] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+    va[u] = *reinterpret_cast<const u32x4*>(in_n + ((size_t)cy * p.W + cx) * 128 + cc * 64 + s_ * 16);
+  }
+  // A-fragments of row tiles 2rp, 2rp + 1 for the k-steps of tap row dy: step s = (chunk s / 3, column tap s % 3); fragment
+  // j = 12 * conv + 2 * s + row tile.  Packed image: [tap][chunk][64 rows][64 B]; lane (idx, g): bytes 16g .. 16g + 15 of its row.
+  const char* const w1l = p.w1 + (size_t)dy * 3 * 8192 + (rp * 32 + idx) * 64 + g * 16;
+  const char* const w2l = p.w2 + (size_t)dy * 3 * 8192 + (rp * 32 + idx) * 64 + g * 16;
+  bf16x8 wfr[24];
+  auto issue_w = [&](int j) {  // compile-time j after unrolling
+    const int s_ = (j % 12) / 2, rtl = j & 1;
+    wfr[j] = *reinterpret_cast<const bf16x8*>((j < 12 ? w1l : w2l) + (s_ % 3) * 8192 + ((s_ / 3) * 64 + rtl * 16) * 64);
+  };
+  constexpr int kAhead = RB_K3_AHEAD;
+  if (comp) {
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) issue_w(j);
+  }
+  // finalising role: lane (idx, g) of row tile fw ends up with channels ch0 .. ch0 + 3 of pixel idx
+  const int chunk = fw >> 1, half = fw & 1;
+  const int ch0 = 32 * chunk + 8 * g + 4 * half;
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(p.b1 + ch0);
+  // fragment offsets of conv1 inside one chunk image: pixel tile t (region pixels 16t .. 16t + 15, row-major, 10 wide; the last
+  // tile is partial: its spare lanes read a clamped pixel) under column tap dx of this wave's tap row
+  Packed16<NT1 * 3> xa;
+#pragma unroll
+  for (int t = 0; t < NT1; ++t) {
+    int hp = t * 16 + idx;
+    hp = hp < kHPix ? hp : kHPix - 1;
+    const int hy = (hp * 205) >> 11, hx = hp - hy * kHW;  // hp / 10
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) xa.set(t * 3 + dx, lds_off((hy + dy) * kInP + hx + dx, g));
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+    if (da[u] >= 0) *reinterpret_cast<u32x4*>(lds_in + da[u]) = ok[u] ? va[u] : u32x4{0u, 0u, 0u, 0u};
+  lds_barrier();
+
+  // ---- phase 2: conv1, six k-steps per compute wave; the fragments of step s + 1 are read before the MFMAs of step s
+  if (comp) {
+    f32x4 acc[2][NT1];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int t = 0; t < NT1; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[2][NT1];
+    auto frags = [&](int s_, int buf) {
+      const char* img = lds_in + (s_ / 3) * kInRows * kRow;
+#pragma unroll
+      for (int t = 0; t < NT1; ++t) xf[buf][t] = *reinterpret_cast<const bf16x8*>(img + xa.get(t * 3 + s_ % 3));
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int s_ = 0; s_ < 6; ++s_) {
+      if (s_ + 1 < 6) frags(s_ + 1, (s_ + 1) & 1);
+      if (kAhead + 2 * s_ < 24) issue_w(kAhead + 2 * s_);
+      if (kAhead + 2 * s_ + 1 < 24) issue_w(kAhead + 2 * s_ + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) acc[a][t] = mma<T>(wfr[2 * s_ + a], xf[s_ & 1][t], acc[a][t]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    char* myx = lds_x + (wid * 8 * 64 + lane) * 16;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int t = 0; t < NT1; ++t) *reinterpret_cast<f32x4*>(myx + (a * 4 + t) * 1024) = acc[a][t];
+  }
+  lds_barrier();
+  // finalise: sum of the three tap-row partials + bias, relu, zero outside the image (conv2 pads h with zeros), h -> LDS (bf16,
+  // exactly what the unfused path would read back) and -> global (the backward pass needs it)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int t = 2 * fq + j;
+    const char* px_ = lds_x + (((fw >> 1) * 8 + (fw & 1) * 4 + t) * 64 + lane) * 16;
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(px_);
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(px_ + 2 * 8 * 1024);
+    const f32x4 s2 = *reinterpret_cast<const f32x4*>(px_ + 4 * 8 * 1024);
+    const int hp = t * 16 + idx;
+    if (hp < kHPix) {
+      const int hy = (hp * 205) >> 11, hx = hp - hy * kHW;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      const bool inside = y >= 0 && y < p.H && x >= 0 && x < p.W;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = fmaxf((s0[e] + s1[e]) + s2[e] + bias[e], 0.f);
+        v[e] = inside ? v[e] : 0.f;
+      }
+      const uint2 pk = pack4<T>(v);
+      *reinterpret_cast<uint2*>(lds_h + chunk * kHRows * kRow + lds_off(hy * kHP + hx, g) + half * 8) = pk;
+      if (p.out_h && inside && hy >= 1 && hy <= TH && hx >= 1 && hx <= 8)   // (out_h null: inference, nobody reads h)
+        *reinterpret_cast<uint2*>(p.out_h + (((size_t)n * p.H + y) * p.W + x) * 128 + ch0 * 2) = pk;
+    }
+  }
+  lds_barrier();  // h complete (and every partial of conv1 has been read: the exchange buffer is free again)
+
+  // ---- phase 3: conv2 on the 8 x 4 tile from the LDS copy of h; pixel tile t = output rows 2t, 2t + 1
+  if (comp) {
+    Packed16<NT2 * 3> xb;
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+      const int op = t * 16 + idx;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) xb.set(t * 3 + dx, lds_off(((op >> 3) + dy) * kHP + (op & 7) + dx, g));
+    }
+    f32x4 acc[2][NT2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[2][NT2];
+    auto frags = [&](int s_, int buf) {
+      const char* img = lds_h + (s_ / 3) * kHRows * kRow;
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) xf[buf][t] = *reinterpret_cast<const bf16x8*>(img + xb.get(t * 3 + s_ % 3));
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int s_ = 0; s_ < 6; ++s_) {
+      if (s_ + 1 < 6) frags(s_ + 1, (s_ + 1) & 1);
+      if (12 + kAhead + 2 * s_ < 24) issue_w(12 + kAhead + 2 * s_);
+      if (12 + kAhead + 2 * s_ + 1 < 24) issue_w(12 + kAhead + 2 * s_ + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) acc[a][t] = mma<T>(wfr[12 + 2 * s_ + a], xf[s_ & 1][t], acc[a][t]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    char* myx = lds_x + (wid * 4 * 64 + lane) * 16;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) *reinterpret_cast<f32x4*>(myx + (a * 2 + t) * 1024) = acc[a][t];
+  }
+  lds_barrier();
+  {
+    const int t = fq;
+    const char* px_ = lds_x + (((fw >> 1) * 4 + (fw & 1) * 2 + t) * 64 + lane) * 16;
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(px_);
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(px_ + 2 * 4 * 1024);
+    const f32x4 s2 = *reinterpret_cast<const f32x4*>(px_ + 4 * 4 * 1024);
+    const int op = t * 16 + idx;
+    const int oy = op >> 3, ox = op & 7;
+    const int y = y0 + oy, x = x0 + ox;
+    if (y < p.H && x < p.W) {
+      // the skip connection comes from the LDS patch
+      const uint2 rr = *reinterpret_cast<const uint2*>(lds_in + chunk * kInRows * kRow + lds_off((oy + 2) * kInP + ox + 2, g) + half * 8);
+      const float sk = p.skip ? 1.f : 0.f;
+      float v[4];
+      v[0] = (s0[0] + s1[0]) + s2[0] + sk * bits16_to_f32<T>((unsigned short)(rr.x & 0xffffu));
+      v[1] = (s0[1] + s1[1]) + s2[1] + sk * bits16_to_f32<T>((unsigned short)(rr.x >> 16));
+      v[2] = (s0[2] + s1[2]) + s2[2] + sk * bits16_to_f32<T>((unsigned short)(rr.y & 0xffffu));
+      v[3] = (s0[3] + s1[3]) + s2[3] + sk * bits16_to_f32<T>((unsigned short)(rr.y >> 16));
+      *reinterpret_cast<uint2*>(p.out_a + (((size_t)n * p.H + y) * p.W + x) * 128 + ch0 * 2) = pack4<T>(v);
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -411,6 +632,8 @@ int resblock_launch(bool bwd, const void* in, const void* wa, const float* b1, c
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::kLdsTotal));
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_kernel<true, T, 4>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::kLdsTotal));
+    TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resblock_k3_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Geo<4>::kLdsIn + Geo<4>::kLdsH + kLdsX3));
     attr_done = true;
   }
   static const int xcd = [] { const char* e = kTgExperiments ? getenv("TECOGAN_RB_XCD") : nullptr; return e ? atoi(e) : 0; }();
@@ -419,7 +642,11 @@ int resblock_launch(bool bwd, const void* in, const void* wa, const float* b1, c
   hipStream_t st = (hipStream_t)stream;
   if (th == 4) {
     if (bwd) hipLaunchKernelGGL((resblock_kernel<true, T, 4>), grid, blk, Geo<4>::kLdsTotal, st, k);
+#ifdef RB_K3   // opt-in build (tools/build_variant.sh): the three-way K split above - parity green, 6.58 vs 6.20 us per launch
+    else hipLaunchKernelGGL((resblock_k3_kernel<T>), grid, blk, Geo<4>::kLdsIn + Geo<4>::kLdsH + kLdsX3, st, k);   // (no L2 prefetch hint)
+#else
     else hipLaunchKernelGGL((resblock_kernel<false, T, 4>), grid, blk, Geo<4>::kLdsTotal, st, k);
+#endif
   } else {
     if (bwd) hipLaunchKernelGGL((resblock_kernel<true, T, 8>), grid, blk, Geo<8>::kLdsTotal, st, k);
     else hipLaunchKernelGGL((resblock_kernel<false, T, 8>), grid, blk, Geo<8>::kLdsTotal, st, k);
