@@ -594,6 +594,7 @@ def other_config5(dev, frames, reps, log):
         return r
     K.resblock_fwd = rec
     try:
+        G._rec._flows(1)
         G._rec._frame(1)   # (slot 1 of the staging ring: any frame but the sequence's first)
     finally:
         K.resblock_fwd = orig

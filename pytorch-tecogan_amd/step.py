@@ -774,11 +774,12 @@ class RecurrentGenerator:
         n = self.n = self.FR + 1
         self.sin = torch.empty(B, n, 3, h, w, **f32)
         self.sout = torch.zeros(B, n, 3, H, W, **f32)
-        self.flow = torch.empty(B, 2, H, W, **f32)
+        # the up-sampled pseudo-flow of every frame of a chunk: it depends on the LR inputs only (channels 0, 1 of the PREVIOUS LR
+        # frame, code/train.py:77-80), so ONE launch per chunk computes all of them instead of one per frame inside the recurrence
+        self.flow = torch.empty(self.FR, B, 2, H, W, **f32)
         hh, HH = h * w, H * W
-        # planes (x, y displacement = channels 0, 1 of the PREVIOUS LR frame, the pseudo-flow of code/train.py:77-80) of slot s
         self.fsrc = _i64([((b * n + s) * 3 + c) * hh for s in range(n) for b in range(B) for c in range(2)], device).view(n, 2 * B)
-        self.fdst = _i64([(b * 2 + c) * HH for b in range(B) for c in range(2)], device)
+        self.fdst = _i64([((s * B + b) * 2 + c) * HH for s in range(self.FR) for b in range(B) for c in range(2)], device).view(self.FR, 2 * B)
         G.sets.pin((B, h, w))   # the chunk graphs hold addresses of this buffer set (engine.ShapeSets)
         G.alloc(B, h, w)
         self.graphs = {}        # frames in the chunk -> graph
@@ -795,12 +796,16 @@ class RecurrentGenerator:
         """the frame in slot s >= 1: previous LR / HR frames in slot s - 1, result into slot s of the output ring"""
         G, B, h, w, n = self.G, self.B, self.h, self.w, self.n
         hh, HH = h * w, 16 * h * w
-        K.up4_planes(self.sin, self.fsrc[s - 1], self.flow, self.fdst, 2 * B, h, w, pre=4.0)
-        K.gen_input(self.sin, s * 3 * hh, n * 3 * hh, self.sout, (s - 1) * 3 * HH, n * 3 * HH, self.flow, 0, 2 * HH,
+        K.gen_input(self.sin, s * 3 * hh, n * 3 * hh, self.sout, (s - 1) * 3 * HH, n * 3 * HH, self.flow, (s - 1) * B * 2 * HH, 2 * HH,
                     G.act["in0"], B, h, w)
         G.forward(0, B, self.sout, s * 3 * HH, n * 3 * HH, keep_h=False)
 
+    def _flows(self, nf):
+        """pseudo-flow of slots 1..nf (from the LR frames in slots 0..nf-1) in one launch"""
+        K.up4_planes(self.sin, self.fsrc[:nf].reshape(-1), self.flow, self.fdst[:nf].reshape(-1), 2 * self.B * nf, self.h, self.w, pre=4.0)
+
     def _chunk(self, nf):
+        self._flows(nf)
         for s in range(1, nf + 1):
             self._frame(s)
 
