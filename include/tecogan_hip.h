@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 1
+#define TG_ABI_VERSION 2   /* 2 (round 5): + tg_resblock_fwd_ws; round 4 removed tg_wgrad_group / tg_absdiff_nchw and moved the
+                           * rejected variants behind TG_EXPERIMENTS without a bump */
 
 enum { TG_F32 = 0, TG_BF16 = 1, TG_F16 = 2 };  /* TG_F16: IEEE half, same layouts as TG_BF16 (loss scaling: tg_adam) */
 
@@ -258,6 +259,13 @@ int tg_conv3x3_rgb_bwd(int dtype, const void* dpre4, const void* x, const float*
 int tg_resblock_fwd(int dtype, const void* in, const void* w1_packed, const float* b1, const void* w2_packed, void* out_h,
                     void* out_a, int N, int H, int W, int C, int add_skip, const void* next_w1_packed,
                     const void* next_w2_packed, void* stream);
+
+/* The same block, same arguments and results up to the fp32 summation order (conv1's K is ONE accumulator chain here, two added
+ * halves there), as the wave-specialised, stream-first kernel of round 5 (csrc/resblock_ws.hip): patch and W1 by LDS-DMA from
+ * tick 0, conv1 as v_mfma_f32_32x32x16 tiles on four compute waves without a split-K exchange, W2 straight into registers.
+ * The default of the recurrent pass and of inference (TECOGAN_RB_WS=0: tg_resblock_fwd). */
+int tg_resblock_fwd_ws(int dtype, const void* in, const void* w1_packed, const float* b1, const void* w2_packed, void* out_h,
+                       void* out_a, int N, int H, int W, int C, int add_skip, void* stream);
 
 #ifdef TG_EXPERIMENTS
 /* TWO consecutive residual blocks in ONE launch (8 x 4 output tiles, halo recomputed: h1 on 14 x 10, a1 on 12 x 8, h2 on 10 x 6

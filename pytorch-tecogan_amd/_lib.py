@@ -65,6 +65,7 @@ _PROTOS = {
     "tg_nchw_to_nhwc": (_I, [_I, _P, _L, _P, _I, _I, _I, _I, _I, _P]),
     "tg_nhwc_to_nchw": (_I, [_I, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "tg_resblock_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "tg_resblock_fwd_ws": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "tg_conv3x3_rgb": (_I, [_I, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "tg_conv3x3_rgb_bwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "tg_conv3x3_rgb_bwd_slot_floats": (_L, []),
@@ -117,6 +118,7 @@ _PROTOS_EXPERIMENTS = {
 }
 
 EXPORTED = tuple(_PROTOS.keys())
+ABI_VERSION = 2   # TG_ABI_VERSION of include/tecogan_hip.h
 _lib = None
 
 
@@ -134,12 +136,19 @@ def load():
             f"{LIB_PATH} is missing: build it with pytorch-tecogan_amd/csrc/build.sh (or __graft_entry__.build()). "
             "There is no CPU fallback for the HIP path.")
     lib = C.CDLL(LIB_PATH)
+    # the version first: a stale library must fail with this message, not with an AttributeError on a missing symbol
+    try:
+        lib.tg_abi_version.restype = C.c_int
+        ver = lib.tg_abi_version()
+    except AttributeError:
+        ver = None
+    if ver != ABI_VERSION:
+        raise TecoganHipError(f"{LIB_PATH}: ABI version {ver}, this package needs {ABI_VERSION} - rebuild it with "
+                              "pytorch-tecogan_amd/csrc/build.sh")
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError here means header and library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.tg_abi_version() != 1:
-        raise TecoganHipError("libtecogan_hip.so ABI version mismatch")
     if lib.tg_has_experiments():
         for name, (res, args) in _PROTOS_EXPERIMENTS.items():
             fn = getattr(lib, name)

@@ -763,6 +763,8 @@ class GeneratorEngine:
         # Infinity Cache every pass); since the 16 blocks' 2.4 MB stay in the XCDs' L2s between passes it only costs issue slots and
         # traffic - chain 1.970 -> 1.862 ms alone, step 4.008 -> 3.898 ms without it (profiles/r04_p_resblock_prefetch_ab.log)
         self.rb_prefetch = TU().rb_prefetch
+        # round 5: the wave-specialised, stream-first form of the fused block (csrc/resblock_ws.hip); no prefetch hint there
+        self.rb_ws = TU().rb_ws
         self.fused_rb_bwd = self.fused_rb and TU().fused_resblock_bwd
         self.rb_pair = self.fused_rb and TU().rb_pair
         if self.rb_pair:
@@ -854,7 +856,7 @@ class GeneratorEngine:
                 continue
             if self.fused_rb:  # conv-relu-conv-skip in one launch (csrc/resblock.hip)
                 nxt = (self.rb[i + 1][0].wf, self.rb[i + 1][1].wf) if (self.rb_prefetch and i + 1 < self.nrb) else None
-                K.resblock_fwd(a["a"][i][sl], c1.wf, c1.bias, c2.wf, hbuf(a["h"][i]), a["a"][i + 1][sl], next_w=nxt)
+                K.resblock_fwd(a["a"][i][sl], c1.wf, c1.bias, c2.wf, hbuf(a["h"][i]), a["a"][i + 1][sl], next_w=nxt, ws=self.rb_ws)
                 continue
             c1.fwd(a["a"][i][sl], a["h"][i][sl], act=L.ACT_RELU)
             c2.fwd(a["h"][i][sl], a["a"][i + 1][sl], res=a["a"][i][sl])
@@ -863,7 +865,7 @@ class GeneratorEngine:
         # launches of the register-weights kernel are faster (config 5: 256 x 256, profiles/r04_x_rw_fwd_routing.log)
         npix2 = B * a["u0"].shape[1] * a["u0"].shape[2]
         if self.fused_rb and not (0 < TU().pair_rw_min <= npix2 and K.rw_eligible(self.dt, 64, 64, B, a["u0"].shape[1], a["u0"].shape[2])):
-            K.resblock_fwd(a["u0"][sl], self.c20.wf, self.c20.bias, self.c22.wf, hbuf(a["hh"]), a["u1"][sl], skip=False)
+            K.resblock_fwd(a["u0"][sl], self.c20.wf, self.c20.bias, self.c22.wf, hbuf(a["hh"]), a["u1"][sl], skip=False, ws=self.rb_ws)
         else:
             self.c20.fwd(a["u0"][sl], a["hh"][sl], act=L.ACT_RELU)
             self.c22.fwd(a["hh"][sl], a["u1"][sl])

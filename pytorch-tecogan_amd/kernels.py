@@ -348,9 +348,14 @@ def nhwc_to_nchw(src, dst, n_stride, N, C_, H, W):
             "tg_nhwc_to_nchw")
 
 
-def resblock_fwd(x, w1, b1, w2, out_h, out_a, next_w=None, skip=True):
-    """next_w: (w1, w2) packed weights of the block launched next (L2 prefetch hint) or None; skip=False: conv-relu-conv"""
+def resblock_fwd(x, w1, b1, w2, out_h, out_a, next_w=None, skip=True, ws=False):
+    """next_w: (w1, w2) packed weights of the block launched next (L2 prefetch hint) or None; skip=False: conv-relu-conv;
+    ws: the wave-specialised kernel of round 5 (csrc/resblock_ws.hip; no prefetch hint)"""
     N, H, W, C_ = x.shape
+    if ws:
+        L.check(L.load().tg_resblock_fwd_ws(tg_dtype(x.dtype), _ptr(x), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(out_h), _ptr(out_a),
+                                            N, H, W, C_, int(skip), _stream()), "tg_resblock_fwd_ws")
+        return
     n1, n2 = next_w if next_w is not None else (None, None)
     L.check(L.load().tg_resblock_fwd(tg_dtype(x.dtype), _ptr(x), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(out_h), _ptr(out_a),
                                      N, H, W, C_, int(skip), _ptr(n1), _ptr(n2), _stream()), "tg_resblock_fwd")

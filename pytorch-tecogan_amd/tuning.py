@@ -80,6 +80,9 @@ KNOBS = OrderedDict((k.attr, k) for k in (
     _k("RGB_BWD_WGS", "rgb_bwd_wgs", "int", 256, "profiles/r03_o_rgb_bwd_ab.log", "its workgroups (160 / 256 / 512 / 1024 measured)"),
     _k("FUSED_RESBLOCK", "fused_resblock", "on", True, "profiles/r01_h_bench_6p1ms.json",
        "conv-relu-conv(+skip) of the trunk in one launch (resblock.hip)"),
+    _k("RB_WS", "rb_ws", "on", True, "profiles/r05_a_resblock_ws_ab.log",
+       "the fused trunk block as the wave-specialised, stream-first kernel (resblock_ws.hip: LDS-DMA patch and W1, 32x32x16 tiles "
+       "without a split-K exchange, W2 in registers; 0: resblock.hip)"),
     _k("RB_PREFETCH", "rb_prefetch", "flag", False, "profiles/r04_p_resblock_prefetch_ab.log (chain 1.97 -> 1.86 ms, step 4.01 -> 3.90 ms without)",
        "a fused trunk block touches the NEXT block's weights (L2 prefetch hint of tg_resblock_fwd); paid in round 2, costs now"),
     _k("FUSED_RESBLOCK_BWD", "fused_resblock_bwd", "flag", False, "DESIGN.md 'resblock' (15 x 28.2 vs 30 x 14.9 us: equal)",

@@ -42,7 +42,7 @@ def test_capi_library_exports_every_declared_symbol():
     if nm.returncode == 0 and not lib.tg_has_experiments():
         exported = {ln.split()[-1] for ln in nm.stdout.splitlines() if " T tg_" in ln}
         assert exported == declared, exported ^ declared
-    assert lib.tg_abi_version() == 1
+    assert lib.tg_abi_version() == L.ABI_VERSION == 2
     assert lib.tg_error_string(-2) == b"unsupported shape"
 
 
@@ -531,8 +531,8 @@ def test_tuning_defaults_equal_the_documented_optimum(monkeypatch):
     assert (t.rw, t.rw_extra, t.rw_extra_dreal, t.rw_dhalf_off) == ("1", "trunk,c30,m128,s3,s1", None, "")
     assert (t.wgrad_list, t.wgrad_groups, t.defer_finalize, t.fold_items, t.pack_blocks, t.stats_replicas) == \
         (True, True, True, True, 48, 4)
-    assert (t.fused_resblock, t.fused_resblock_bwd, t.subpix_ct, t.fast_c4s2, t.rgb_out, t.rgb_bwd, t.rgb_bwd_wgs, t.rb_prefetch) == \
-        (True, False, True, True, True, True, 256, False)
+    assert (t.fused_resblock, t.fused_resblock_bwd, t.subpix_ct, t.fast_c4s2, t.rgb_out, t.rgb_bwd, t.rgb_bwd_wgs, t.rb_prefetch, t.rb_ws) == \
+        (True, False, True, True, True, True, 256, False, True)
     assert t.dtype == "bf16"
     # every rejected experiment is off, and is marked as needing the experiments build
     exp = [k for k in tuning.KNOBS.values() if k.experiment]

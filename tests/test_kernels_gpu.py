@@ -1013,9 +1013,11 @@ def test_fnet_resampling_kernels(N, H, W, C_, dt):
 
 
 # (launches of up to 128 8x8 tiles run 8x4 tiles, larger ones 8x8: both geometries, each with ragged edges)
-@pytest.mark.parametrize("N,H,W", [(4, 32, 32), (1, 8, 8), (2, 20, 12), (1, 9, 17), (9, 32, 32), (6, 36, 44)])
-def test_fused_resblock_forward(N, H, W):
-    """tg_resblock_fwd == conv-relu-conv-skip of code/ops.py:45-54 as two tg_conv launches (bf16), and close to torch"""
+@pytest.mark.parametrize("ws", [False, True], ids=["unified", "ws"])
+@pytest.mark.parametrize("N,H,W", [(4, 32, 32), (1, 8, 8), (2, 20, 12), (1, 9, 17), (9, 32, 32), (6, 36, 44), (1, 128, 128), (3, 5, 3)])
+def test_fused_resblock_forward(N, H, W, ws):
+    """tg_resblock_fwd / tg_resblock_fwd_ws (round 5: wave-specialised) == conv-relu-conv-skip of code/ops.py:45-54 as two tg_conv
+    launches (bf16), and close to torch"""
     dt = torch.bfloat16
     spec = K.ConvSpec("c3", 64, 64)
     x = q(rnd((N, 64, H, W), 80), dt)
@@ -1029,7 +1031,7 @@ def test_fused_resblock_forward(N, H, W):
     bd = b1.to(DEV)
     h_f = torch.full((N, H, W, 64), float("nan"), dtype=dt, device=DEV)
     a_f = torch.full((N, H, W, 64), float("nan"), dtype=dt, device=DEV)
-    K.resblock_fwd(xd, wp1, bd, wp2, h_f, a_f)
+    K.resblock_fwd(xd, wp1, bd, wp2, h_f, a_f, ws=ws)
     # the same block as two launches
     h_u, a_u = torch.empty_like(h_f), torch.empty_like(a_f)
     d1 = K.make_conv_desc(spec.fwd_geom(), L.TG_BF16, N, H, W, 64, H, W, 64, act=L.ACT_RELU)
@@ -1048,12 +1050,21 @@ def test_fused_resblock_forward(N, H, W):
     torch.testing.assert_close(K.to_nchw(a_f, 64).cpu(), ref_a, **tol(dt))
     assert L.load().tg_resblock_fwd(L.TG_F32, xd.data_ptr(), wp1.data_ptr(), bd.data_ptr(), wp2.data_ptr(),
                                     h_f.data_ptr(), a_f.data_ptr(), N, H, W, 64, 1, None, None, None) == -2
+    assert L.load().tg_resblock_fwd_ws(L.TG_F32, xd.data_ptr(), wp1.data_ptr(), bd.data_ptr(), wp2.data_ptr(),
+                                       h_f.data_ptr(), a_f.data_ptr(), N, H, W, 64, 1, None) == -2
     # add_skip = 0: conv-relu-conv (conv_trans.2 of the generator)
     a_n = torch.empty_like(a_f)
-    K.resblock_fwd(xd, wp1, bd, wp2, h_p := torch.empty_like(h_f), a_n, skip=False)
+    K.resblock_fwd(xd, wp1, bd, wp2, h_p := torch.empty_like(h_f), a_n, skip=False, ws=ws)
     torch.cuda.synchronize()
     assert torch.equal(h_p, h_f)
     torch.testing.assert_close(K.to_nchw(a_n, 64).cpu(), ref_a - x, **tol(dt))
+    # out_h = null (inference): the same output, nothing else written
+    a_i = torch.empty_like(a_f)
+    K.resblock_fwd(xd, wp1, bd, wp2, None, a_i, ws=ws)
+    torch.cuda.synchronize()
+    assert torch.equal(a_i, a_f)
+    if ws:
+        return
     # the L2 prefetch hint for the next block must not change anything
     h_p, a_p = torch.empty_like(h_f), torch.empty_like(a_f)
     K.resblock_fwd(xd, wp1, bd, wp2, h_p, a_p, next_w=(wp2, wp1))
