@@ -276,6 +276,17 @@ int tg_resblock_fwd_ws(int dtype, const void* in, const void* w1_packed, const f
 int tg_resblock2_fwd(int dtype, const void* in, const void* w1a_packed, const float* b1a, const void* w2a_packed,
                      const void* w1b_packed, const float* b1b, const void* w2b_packed, void* out_h1, void* out_a1, void* out_h2,
                      void* out_a2, int N, int H, int W, int C, const void* const* next_w4, void* stream);
+
+/* TWO consecutive residual blocks in ONE launch of the same stream-first structure (csrc/resblock2_ws.hip; 8 x 4 output tiles, halo
+ * recomputed: h1 on 14 x 10, a1 on 12 x 8, h2 on 10 x 6 pixels from a 16 x 12 patch): out_h1 = relu(conv(in, w1a) + b1a), out_a1 = in +
+ * conv(out_h1, w2a), out_h2 = relu(conv(out_a1, w1b) + b1b), out_a2 = out_a1 + conv(out_h2, w2b) - bit-identical to two
+ * tg_resblock_fwd_ws launches; one launch boundary and one start-up of the weight stream fewer per pair on the recurrent pass's serial
+ * chain - in theory: measured 6.1 us per block against 5.05 for tg_resblock_fwd_ws (profiles/r05_b_resblock2_ws_ab.log), so it
+ * is an experiments-build entry point.  out_h1 / out_h2 may be null (inference).  Meant for launches of up to 128 8 x 8 tiles (the shapes tg_resblock_fwd_ws runs
+ * on 8 x 4 tiles); correct for any size.  Same dtype / channel limits. */
+int tg_resblock2_fwd_ws(int dtype, const void* in, const void* w1a_packed, const float* b1a, const void* w2a_packed,
+                        const void* w1b_packed, const float* b1b, const void* w2b_packed, void* out_h1, void* out_a1, void* out_h2,
+                        void* out_a2, int N, int H, int W, int C, void* stream);
 #endif
 
 /* Input-gradient of the same block in ONE launch (aten::convolution_backward x2 + threshold_backward, code/train.py:336):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds libtecogan_hip.so for gfx950 in-tree (next to this script).  Usage: build.sh [--experiments] [extra hipcc flags]
-#   --experiments   also compile the variants that were built, measured slower and rejected (-DTG_EXPERIMENTS: resblock2.hip,
+#   --experiments   also compile the variants that were built, measured slower and rejected (-DTG_EXPERIMENTS: resblock2.hip, resblock2_ws.hip,
 #                   the 64 x 128 work-list blocks, tg_bn_bwd_fused, tg_conv's stats_mode 3, the item-walking fold, the forced
 #                   trunk tile) into libtecogan_hip_experiments.so - objects under exp/, the default library is untouched.
 #                   Load it with TECOGAN_LIB=.../libtecogan_hip_experiments.so; tests: pytest -m experiments.
@@ -13,7 +13,7 @@ OBJ=.
 EXTRA=""
 if [ "${1:-}" = "--experiments" ]; then
   shift
-  SRCS="$SRCS resblock2"
+  SRCS="$SRCS resblock2 resblock2_ws"
   OUT=libtecogan_hip_experiments.so
   OBJ=exp
   EXTRA="-DTG_EXPERIMENTS"
@@ -25,7 +25,7 @@ objs=""
 for f in $SRCS; do
   o=$OBJ/$f.o
   objs="$objs $o"
-  if [ ! -f $o ] || [ $f.hip -nt $o ] || [ common.h -nt $o ] || [ ../../include/tecogan_hip.h -nt $o ]; then
+  if [ ! -f $o ] || [ $f.hip -nt $o ] || [ common.h -nt $o ] || [ rbw_common.h -nt $o ] || [ ../../include/tecogan_hip.h -nt $o ]; then
     rm -f $o   # a failed compile must not leave the previous object behind for the link below
     # conv3_rw: the producer waves' epilogue arithmetic shares a SIMD with the consumer's MFMA stream; SLP-packed f32 operations
     # (v_pk_add_f32 / v_pk_mul_f32) cost ~+25 cycles each beside MFMAs (MI355X_MICROARCH.md, 'price of one filler')

@@ -40,10 +40,9 @@
 //     the row is 8 (l / 8) + l % 8 + const = l + const (mod 16): conflict-free the same way.
 // tests/test_resblock_ws_maps_cpu.py restates these maps on the CPU and checks every read and every lane group.
 #include "common.h"
+#include "rbw_common.h"
 #include <cstdlib>
 #include <type_traits>
-
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #ifdef TG_STAMP
 // Diagnostic build only (-DTG_STAMP, tools/stamp_resblock.py): every wave of workgroup 0 records s_memtime at
@@ -62,21 +61,10 @@ extern "C" int tg_debug_read_rbw_stamps(long long* out, int n) {
 #endif
 
 // out-of-image patch positions and the unused rows of the patch image are DMA'd from here
+// (every lane of an out-of-image position reads the SAME 16 bytes; a page with 16 bytes per lane measured the same: r05_b log)
 __device__ __attribute__((aligned(16))) unsigned int tg_rbw_zero_page[4];
 
 namespace {
-
-template <typename T> struct Mma32;
-template <> struct Mma32<BF16> {
-  __device__ __forceinline__ static f32x16 run(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mma32<F16> {
-  __device__ __forceinline__ static f32x16 run(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  }
-};
 
 constexpr int kW1Bytes = 18 * 4096;   // [tap][chunk][64 rows in matrix order][64 B]
 
@@ -107,14 +95,6 @@ __device__ __forceinline__ int patch_row(int py, int px, int kMain) {
   const int v = 10 * py + px;
   return px < 10 ? v : kMain + 16 * (py >> 3) + (v & 15);
 }
-// byte offset of 16-byte piece `piece` of row `row` in the W1 / h images
-__device__ __forceinline__ int img_off(int row, int piece) { return row * 64 + ((piece ^ ((row >> 2) & 3)) << 4); }
-// ... of patch pixel `prow` (patch_row), 32-channel chunk c: a KiB of the image holds 8 pixels, chunk 0 rows then chunk 1 rows, so
-// that one DMA instruction reads 8 WHOLE pixels (128-byte lines); the row is still = prow mod 4 and the swizzle key prow / 4 mod 4
-__device__ __forceinline__ int patch_off(int prow, int c, int piece) {
-  return (16 * (prow >> 3) + 8 * c + (prow & 7)) * 64 + ((piece ^ ((prow >> 2) & 3)) << 4);
-}
-
 struct RbwK {
   const char* in;
   const char* w1;
@@ -126,24 +106,6 @@ struct RbwK {
   int N, H, W, tiles_x, tiles_y;
   int skip;           // 1: out_a = in + conv2(h); 0: out_a = conv2(h)
 };
-
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
-}
-// LDS-only barrier: __syncthreads() would also drain vmcnt (the weight stream, the h stores)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
-template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi);
-template <> __device__ __forceinline__ unsigned pack2<BF16>(float lo, float hi) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
-}
-template <> __device__ __forceinline__ unsigned pack2<F16>(float lo, float hi) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));
-}
 
 // conv1 meets W1 in three instalments: taps [0, 3) (with the patch), [3, 6), [6, 9)
 constexpr int kStageTaps[3] = {3, 6, 9};
@@ -172,7 +134,11 @@ __global__ __launch_bounds__(512) void resblock_ws_kernel(const RbwK p) {
   auto issue_patch = [&](auto NP) {
 #pragma unroll
     for (int k = 0; k < decltype(NP)::value; ++k) {
+#ifdef RBW_ISSUE4   // diagnostic (profiles/r05_b_resblock2_ws_ab.log): only the four conv1 waves issue the patch and W1
+      const int j = wid + 4 * k;
+#else
       const int j = wid + 8 * k;   // wave-uniform
+#endif
       const int lrow = lane >> 2, cc = lrow >> 3;
       const int row = 8 * j + (lrow & 7);   // patch_row of the lane's pixel
       int py, px;
@@ -206,16 +172,29 @@ __global__ __launch_bounds__(512) void resblock_ws_kernel(const RbwK p) {
     const int piece = (lane & 3) ^ ((mp >> 2) & 3);
     const char* src = p.w1 + cw * 4096 + R * 64 + piece * 16;
     const unsigned dst = lds0 + cw * 4096 + u * 1024;
+#ifdef RBW_ISSUE4
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      glds16(src - cw * 4096 + t * 8192, dst - cw * 4096 + t * 8192);
+      glds16(src - cw * 4096 + t * 8192 + 4096, dst - cw * 4096 + t * 8192 + 4096);
+    }
+#else
 #pragma unroll
     for (int t = 0; t < 9; ++t) glds16(src + t * 8192, dst + t * 8192);
+#endif
   };
 
   if (wid >= 4) {
     // ============================================================== CONV2 WAVES: (rt, kc) = 32 output channels x K half (input chunk)
     const int rt = wid & 1, kc = (wid >> 1) & 1;
     const int l32 = lane & 31, hi = lane >> 5;
+#ifndef RBW_ISSUE4
     issue_patch(std::integral_constant<int, G::kNPH>{});
     issue_w1();
+    constexpr int kD0 = 6, kD1 = 3;   // W1 taps of this wave still on their way at the first / second barrier
+#else
+    constexpr int kD0 = 0, kD1 = 0;
+#endif
     RBW_STAMP(1);
     // A-fragments of conv2: per tap the chunk's two halves; lane (l32, hi): matrix row l32 of row tile rt - the packed row that makes
     // its 16 accumulator registers 16 consecutive channels (as W1 above) - bytes 16 (2 half + hi) ..
@@ -255,11 +234,11 @@ __global__ __launch_bounds__(512) void resblock_ws_kernel(const RbwK p) {
 #endif
     constexpr int kA = RBW_KA, kB = RBW_KB, kC = RBW_KC;   // taps [0, kA) before the first barrier, [kA, kB) behind it, [kB, kC), [kC, 9)
     load_w2(std::integral_constant<int, 0>{}, std::integral_constant<int, kA>{});
-    wait_vm<6 + 2 * kA>();    // patch + taps 0-2 of W1
+    wait_vm<kD0 + 2 * kA>();    // patch + taps 0-2 of W1
     lds_barrier();
     RBW_STAMP(2);
     load_w2(std::integral_constant<int, kA>{}, std::integral_constant<int, kB>{});
-    wait_vm<3 + 2 * kB>();   // taps 3-5
+    wait_vm<kD1 + 2 * kB>();   // taps 3-5
     lds_barrier();
     load_w2(std::integral_constant<int, kB>{}, std::integral_constant<int, kC>{});
     wait_vm<2 * kC>();   // taps 6-8
@@ -360,7 +339,13 @@ __global__ __launch_bounds__(512) void resblock_ws_kernel(const RbwK p) {
   // ================================================================ CONV1 WAVES: (rt, pg) = 32 output channels x half of the pixel tiles
   const int rt = wid & 1, pg = wid >> 1;
   const int l32 = lane & 31, hi = lane >> 5;
+#ifdef RBW_ISSUE4
+  issue_patch(std::integral_constant<int, G::kNPD / 4>{});
+  constexpr int kPerTap = 2;
+#else
   issue_patch(std::integral_constant<int, G::kNPC>{});
+  constexpr int kPerTap = 1;
+#endif
   issue_w1();
   f32x4 bias4[4];   // bias of the lane's 16 channels
 #pragma unroll
@@ -412,14 +397,14 @@ __global__ __launch_bounds__(512) void resblock_ws_kernel(const RbwK p) {
     }
   };
   // vmcnt arithmetic (oldest first): kNPC patch blocks, 9 W1 taps, 4 bias loads
-  wait_vm<4 + 9 - kStageTaps[0]>();
+  wait_vm<4 + kPerTap * (9 - kStageTaps[0])>();
   lds_barrier();
   RBW_STAMP(2);
   run_steps(std::integral_constant<int, 0>{}, std::integral_constant<int, 4 * kStageTaps[0]>{});
-  wait_vm<4 + 9 - kStageTaps[1]>();
+  wait_vm<4 + kPerTap * (9 - kStageTaps[1])>();
   lds_barrier();
   run_steps(std::integral_constant<int, 4 * kStageTaps[0]>{}, std::integral_constant<int, 4 * kStageTaps[1]>{});
-  wait_vm<4 + 9 - kStageTaps[2]>();
+  wait_vm<4 + kPerTap * (9 - kStageTaps[2])>();
   lds_barrier();
   run_steps(std::integral_constant<int, 4 * kStageTaps[1]>{}, std::integral_constant<int, 4 * kStageTaps[2]>{});
   RBW_STAMP(3);

@@ -765,6 +765,9 @@ class GeneratorEngine:
         self.rb_prefetch = TU().rb_prefetch
         # round 5: the wave-specialised, stream-first form of the fused block (csrc/resblock_ws.hip); no prefetch hint there
         self.rb_ws = TU().rb_ws
+        self.rb_pair_ws = self.rb_ws and TU().rb_pair_ws
+        if self.rb_pair_ws:
+            tuning.need_experiments("rb_pair_ws")
         self.fused_rb_bwd = self.fused_rb and TU().fused_resblock_bwd
         self.rb_pair = self.fused_rb and TU().rb_pair
         if self.rb_pair:
@@ -841,6 +844,9 @@ class GeneratorEngine:
         self.conv0.fwd(a["in0"][sl], a["a"][0][sl], act=L.ACT_RELU)
         # small launches (the recurrent pass: <= 128 tiles of 8 x 8): TWO blocks per launch, halo recomputed (csrc/resblock2.hip)
         pair = self.rb_pair and B * ((a["in0"].shape[1] + 7) // 8) * ((a["in0"].shape[2] + 7) // 8) <= 128
+        # round 5: the same for the stream-first kernel - again slower than one block per launch (profiles/r05_b_resblock2_ws_ab.log)
+        pair_ws = self.fused_rb and self.rb_pair_ws and not pair and \
+            B * ((a["in0"].shape[1] + 7) // 8) * ((a["in0"].shape[2] + 7) // 8) <= 128
         skip_next = False
         for i, (c1, c2) in enumerate(self.rb):
             if skip_next:
@@ -854,7 +860,13 @@ class GeneratorEngine:
                                 a["h"][i + 1][sl], a["a"][i + 2][sl], next_w=nxt)
                 skip_next = True
                 continue
-            if self.fused_rb:  # conv-relu-conv-skip in one launch (csrc/resblock.hip)
+            if pair_ws and i + 1 < self.nrb:   # two blocks in one launch (csrc/resblock2_ws.hip)
+                c3, c4 = self.rb[i + 1]
+                K.resblock2_fwd_ws(a["a"][i][sl], c1.wf, c1.bias, c2.wf, c3.wf, c3.bias, c4.wf, hbuf(a["h"][i]), a["a"][i + 1][sl],
+                                   hbuf(a["h"][i + 1]), a["a"][i + 2][sl])
+                skip_next = True
+                continue
+            if self.fused_rb:  # conv-relu-conv-skip in one launch (csrc/resblock_ws.hip / resblock.hip)
                 nxt = (self.rb[i + 1][0].wf, self.rb[i + 1][1].wf) if (self.rb_prefetch and i + 1 < self.nrb) else None
                 K.resblock_fwd(a["a"][i][sl], c1.wf, c1.bias, c2.wf, hbuf(a["h"][i]), a["a"][i + 1][sl], next_w=nxt, ws=self.rb_ws)
                 continue

@@ -418,6 +418,14 @@ def convt_fwd(x, w_packed, bias, out, act=L.ACT_NONE):
                                   out.shape[3], act, _stream()), "tg_convt_fwd")
 
 
+def resblock2_fwd_ws(x, w1a, b1a, w2a, w1b, b1b, w2b, out_h1, out_a1, out_h2, out_a2):
+    """two consecutive residual blocks in one launch of the stream-first kernel (csrc/resblock2_ws.hip); out_h1 / out_h2 may be None"""
+    N, H, W, C_ = x.shape
+    L.check(L.load().tg_resblock2_fwd_ws(tg_dtype(x.dtype), _ptr(x), _ptr(w1a), _ptr(b1a), _ptr(w2a), _ptr(w1b), _ptr(b1b), _ptr(w2b),
+                                         _ptr(out_h1), _ptr(out_a1), _ptr(out_h2), _ptr(out_a2), N, H, W, C_, _stream()),
+            "tg_resblock2_fwd_ws")
+
+
 def resblock2_fwd(x, w1a, b1a, w2a, w1b, b1b, w2b, out_h1, out_a1, out_h2, out_a2, next_w=None):
     """two consecutive residual blocks in one launch (csrc/resblock2.hip); next_w: the four packed weight images of the next
     launch (L2 prefetch hint) or None"""

@@ -105,6 +105,8 @@ KNOBS = OrderedDict((k.attr, k) for k in (
     # ---- rejected experiments: need the -DTG_EXPERIMENTS library (csrc/build.sh --experiments)
     _k("RB_PAIR", "rb_pair", "flag", False, "profiles/r03_t_resblock2_ab.log (chain 1.56 -> 1.71 ms)",
        "two trunk blocks per launch, halo recomputed (resblock2.hip)", True),
+    _k("RB_PAIR_WS", "rb_pair_ws", "flag", False, "profiles/r05_b_resblock2_ws_ab.log (6.1 vs 5.05 us per block)",
+       "two trunk blocks per launch of the stream-first kernel (resblock2_ws.hip, halo recomputed)", True),
     _k("BN_FUSE", "bn_fuse", "flag", False, "profiles/r03_g_bn_fuse_ab.log (step 4.43 -> 4.46 ms)",
        "batch-norm backward sums in the producing input-gradient's epilogue (stats_mode 3)", True),
     _k("BN_BWD_FUSED", "bn_bwd_fused", "flag", False, "profiles/r03_l_bn_bwd_fused_ab.log (step 4.405 -> 4.42 ms)",

@@ -1138,6 +1138,46 @@ def test_two_resblocks_per_launch_bit_identical(N, H, W, dt):
                                      g[3].data_ptr(), N, H, W, 64, None, None) == -2
 
 
+@pytest.mark.experiments
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W", [(4, 32, 32), (1, 8, 8), (2, 20, 12), (1, 9, 17), (3, 5, 3), (1, 2, 2), (2, 36, 44)])
+def test_two_resblocks_per_launch_ws_bit_identical(N, H, W, dt):
+    """tg_resblock2_fwd_ws (round 5: two residual blocks per launch of the stream-first kernel, halo recomputed on 14x10 / 12x8 / 10x6
+    pixel regions from a 16x12 patch) writes exactly the four tensors two tg_resblock_fwd_ws launches write - images smaller than the
+    halo, ragged tiles, both 16-bit types, with and without the intermediate stores - and the pair agrees with torch"""
+    spec = K.ConvSpec("c3", 64, 64)
+    x = q(rnd((N, 64, H, W), 90), dt)
+    ws = [rnd(spec.weight_shape, 91 + i, -0.05, 0.05) for i in range(4)]
+    b1a, b1b = rnd((64,), 95, -0.1, 0.1).to(DEV), rnd((64,), 96, -0.1, 0.1).to(DEV)
+    xd = K.to_nhwc(x.to(DEV), dt)
+    rows, Kd, s_row, s_k = spec.fwd_pack()
+    slots = K.slot_table(9, DEV)
+    wp = [K.pack_weights(dt, w.to(DEV), rows, Kd, s_row, s_k, 9, slots) for w in ws]
+    mk = lambda: torch.full((N, H, W, 64), float("nan"), dtype=dt, device=DEV)  # noqa: E731
+    h1, a1, h2, a2 = mk(), mk(), mk(), mk()
+    K.resblock_fwd(xd, wp[0], b1a, wp[1], h1, a1, ws=True)
+    K.resblock_fwd(a1, wp[2], b1b, wp[3], h2, a2, ws=True)
+    g = [mk() for _ in range(4)]
+    K.resblock2_fwd_ws(xd, wp[0], b1a, wp[1], wp[2], b1b, wp[3], *g)
+    torch.cuda.synchronize()
+    for name, got, ref in zip(("h1", "a1", "h2", "a2"), g, (h1, a1, h2, a2)):
+        assert not torch.isnan(got.float()).any(), name
+        assert torch.equal(got, ref), (name, float((got.float() - ref.float()).abs().max()))
+    # inference: no intermediate stores, the same block outputs
+    a1i, a2i = mk(), mk()
+    K.resblock2_fwd_ws(xd, wp[0], b1a, wp[1], wp[2], b1b, wp[3], None, a1i, None, a2i)
+    torch.cuda.synchronize()
+    assert torch.equal(a1i, a1) and torch.equal(a2i, a2)
+    r_h1 = F.relu(F.conv2d(x, q(ws[0], dt), b1a.cpu(), 1, 1))
+    r_a1 = q(x + F.conv2d(q(r_h1, dt), q(ws[1], dt), None, 1, 1), dt)
+    r_h2 = F.relu(F.conv2d(r_a1, q(ws[2], dt), b1b.cpu(), 1, 1))
+    r_a2 = r_a1 + F.conv2d(q(r_h2, dt), q(ws[3], dt), None, 1, 1)
+    torch.testing.assert_close(K.to_nchw(g[3], 64).cpu(), r_a2, **tol(dt))
+    assert L.load().tg_resblock2_fwd_ws(L.TG_F32, xd.data_ptr(), wp[0].data_ptr(), b1a.data_ptr(), wp[1].data_ptr(), wp[2].data_ptr(),
+                                        b1b.data_ptr(), wp[3].data_ptr(), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
+                                        g[3].data_ptr(), N, H, W, 64, None) == -2
+
+
 def _random_conv_cases(n, seed):
     rng = np.random.default_rng(seed)
     cases = []

@@ -152,3 +152,132 @@ def check(TH):
 def test_resblock_ws_lds_maps():
     """csrc/resblock_ws.hip: the patch image has no wasted row for 8 x 4 tiles (96 rows = 96 pixels), 160 for 8 x 8"""
     assert check(4) == 96 and check(8) == 160
+
+
+def patch_off(prow, c, piece):
+    return (16 * (prow >> 3) + 8 * c + (prow & 7)) * 64 + ((piece ^ ((prow >> 2) & 3)) << 4)
+
+
+def conflict_free(addrs):
+    for g in GROUPS:
+        slots = {}
+        for l in g:
+            slots.setdefault((addrs[l] // 16) % 16, set()).add(addrs[l])
+        if not all(len(v) == 1 for v in slots.values()):
+            return False
+    return True
+
+
+def check_pair():
+    """csrc/resblock2_ws.hip (two blocks per launch, 8 x 4 tiles): patch (16 x 12, read by the 14-wide h1 region), h1 (pitch 28, read by
+    the 12-wide a1 region), a1 (12 x 8 image written by conv2A's epilogue, read by the 10-wide h2 region), h2 (pitch 24)"""
+    TH = 4
+    div = {8: lambda n: n >> 3, 10: lambda n: (n * 205) >> 11, 12: lambda n: (n * 171) >> 11, 14: lambda n: (n * 4682) >> 16}
+    for wr, top in ((10, 96), (12, 144), (14, 224)):
+        assert all(div[wr](n) == n // wr for n in range(top))
+    def src_row(wr, py, px, main):
+        v = wr * py + px
+        return v if px < wr else main + 16 * (py >> 3) + (v & 15)
+    # ---- patch DMA (reader WR = 14)
+    kP0H = TH + 8; kP0Main = (14 * kP0H + 15) // 16 * 16; kP0Rows = 224; kNPD = kP0Rows // 8
+    assert kP0Main == 176 and kNPD == 28
+    lds = {}
+    for wid in range(8):
+        NP = (kNPD + 7) // 8 if wid < 4 else (kNPD + 3) // 8
+        for k in range(NP):
+            j = wid + 8 * k
+            assert j < kNPD
+            for lane in range(64):
+                lrow = lane >> 2; cc = lrow >> 3
+                row = 8 * j + (lrow & 7)
+                if row < kP0Main:
+                    py = div[14](row); px = row - 14 * py; valid = row < 14 * kP0H
+                else:
+                    e = row - kP0Main; e4 = e & 15
+                    py = 8 * (e >> 4) + ((7 * (e4 >> 1) + 7) & 7); px = 14 + (e4 & 1); valid = py < kP0H
+                piece = (lane & 3) ^ ((row >> 2) & 3)
+                addr = j * 1024 + lane * 16
+                assert addr not in lds
+                lds[addr] = (cc, py, px, piece) if valid else None
+    assert len(lds) == kP0Rows * 8
+    assert {v for v in lds.values() if v} == {(cc, py, px, pc) for cc in range(2) for py in range(kP0H) for px in range(16) for pc in range(4)}
+    for (py, px) in [(py, px) for py in range(kP0H) for px in range(16)]:
+        for cc in range(2):
+            for pc in range(4):
+                assert lds[patch_off(src_row(14, py, px, kP0Main), cc, pc)] == (cc, py, px, pc)
+    # ---- conv1 of block A: region 14 x 10 = 140 pixels, tiles 0-2 / 3-4
+    kH1Pix = 140
+    for t0, ntw in ((0, 3), (3, 2)):
+        for tw in range(ntw):
+            for t in range(9):
+                for kc in range(2):
+                    for s16 in range(2):
+                        addrs = []
+                        for lane in range(64):
+                            l32, hi = lane & 31, lane >> 5
+                            n0 = 32 * (t0 + tw) + l32; nn = n0 if n0 < kH1Pix else n0 - 32
+                            hy = div[14](nn); hx = nn - 14 * hy
+                            a = kc * 512 + (patch_off(src_row(14, hy + t // 3, hx + t % 3, kP0Main), 0, hi) ^ (32 * s16))
+                            assert lds[a] == (kc, hy + t // 3, hx + t % 3, 2 * s16 + hi)
+                            addrs.append(a)
+                        assert conflict_free(addrs), ("conv1A", t0, tw, t)
+    # ---- h1 (pitch 28): written at img_off(28 hy + hx, pieces 2 hi, 2 hi + 1) of chunk rt; conv2A lanes = a1 region pixels (12 wide)
+    kH1Chunk = 28 * 10 * 64
+    h1 = {}
+    for rt in range(2):
+        for n0 in range(kH1Pix):
+            hy, hx = n0 // 14, n0 % 14
+            for pc in range(4):
+                a = rt * kH1Chunk + img_off(hy * 28 + hx, pc)
+                assert a not in h1 and a + 16 <= 2 * kH1Chunk
+                h1[a] = (rt, hy, hx, pc)
+    a1 = {}
+    kA1Main = 80
+    for kc in range(2):
+        for t in range(3):
+            for tt in range(9):
+                for s16 in range(2):
+                    addrs = []
+                    for lane in range(64):
+                        l32, hi = lane & 31, lane >> 5
+                        nn = 32 * t + l32; oy = div[12](nn); ox = nn - 12 * oy
+                        assert oy < 8
+                        a = kc * kH1Chunk + (img_off((oy + tt // 3) * 28 + ox + tt % 3, hi) ^ (32 * s16))
+                        assert h1[a] == (kc, oy + tt // 3, ox + tt % 3, 2 * s16 + hi)
+                        addrs.append(a)
+                        for rt in range(2):   # skip read from the patch, a1 write
+                            assert lds[patch_off(14 * (oy + 2) + ox + 2, rt, 2 * hi + kc)] == (rt, oy + 2, ox + 2, 2 * hi + kc)
+                            a1[patch_off(src_row(10, oy, ox, kA1Main), rt, 2 * hi + kc)] = (rt, oy, ox, 2 * hi + kc)
+                    assert conflict_free(addrs), ("conv2A", t, tt)
+    assert len(a1) == 96 * 8 and max(a1) + 16 <= 96 * 128
+    # ---- conv1 of block B: region 10 x 6 from the a1 image, one tile per wave
+    for pg in range(2):
+        for t in range(9):
+            for kc in range(2):
+                for s16 in range(2):
+                    addrs = []
+                    for lane in range(64):
+                        l32, hi = lane & 31, lane >> 5
+                        n0 = 32 * pg + l32; nn = n0 if n0 < 60 else n0 - 32
+                        hy = div[10](nn); hx = nn - 10 * hy
+                        a = kc * 512 + (patch_off(src_row(10, hy + t // 3, hx + t % 3, kA1Main), 0, hi) ^ (32 * s16))
+                        assert a1[a] == (kc, hy + t // 3, hx + t % 3, 2 * s16 + hi)
+                        addrs.append(a)
+                    assert conflict_free(addrs), ("conv1B", pg, t)
+    # skip read of block B: a1 pixel (oy + 2, ox + 2)
+    for lane in range(64):
+        l32, hi = lane & 31, lane >> 5
+        oy, ox = l32 >> 3, l32 & 7
+        for rt in range(2):
+            for kc in range(2):
+                assert a1[patch_off(10 * (oy + 2) + ox + 2, rt, 2 * hi + kc)] == (rt, oy + 2, ox + 2, 2 * hi + kc)
+    # LDS budget
+    kP0 = 18 * 4096; kH1 = kP0 + kP0Rows * 128; kA1 = kH1 + 2 * kH1Chunk
+    assert kA1 + 96 * 128 == 150528 <= 160 * 1024
+    for base in (kP0, kH1, kA1, kH1 + kH1Chunk, kH1 + 24 * 6 * 64):
+        assert base & 32 == 0   # (fragment offsets toggle the chunk half with XOR 32)
+    return True
+
+
+def test_resblock2_ws_lds_maps():
+    assert check_pair()

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import pytorch_tecogan_amd
 from pytorch_tecogan_amd import _lib as L, kernels as K
 lib = L.load()
+PAIR = os.environ.get("RB_PAIR") == "1"   # two blocks per launch (csrc/resblock2_ws.hip)
 WS = os.environ.get("RB_WS", "1") == "1"   # round 5: the wave-specialised kernel (csrc/resblock_ws.hip); RB_WS=0: resblock.hip
 STAMPS = hasattr(lib, "tg_debug_read_rb_stamps") and not WS   # (a library built without -DTG_STAMP: only the launch time at the end)
 WSTAMPS = WS and hasattr(lib, "tg_debug_read_rbw_stamps")
@@ -43,7 +44,26 @@ for rep in range(4 if STAMPS else 0):
             print(f"   wave {k} (row tile {k & 3}, K half {k >> 2}): start +{a_[0]-t0}, conv1 begins +{a_[1]-t0}, conv1 done +{a_[2]-t0} (k-loop {a_[2]-a_[1]}), "
                   f"exchange barrier passed +{a_[3]-t0} (waited {a_[3]-a_[2]}), conv2 done +{a_[4]-t0}")
 
-if WSTAMPS:
+if PAIR and hasattr(lib, "tg_debug_read_rbw2_stamps"):
+    lib.tg_debug_read_rbw2_stamps.restype = ctypes.c_int
+    lib.tg_debug_read_rbw2_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    for rep in range(2):
+        for i in range(0, NB, 2):
+            K.resblock2_fwd_ws(a[i], wps[i][0], bs[i], wps[i][1], wps[i + 1][0], bs[i + 1], wps[i + 1][1], h[i], a[i + 1], h[i + 1], a[i + 2])
+        torch.cuda.synchronize()
+        wb = (ctypes.c_longlong * 96)()
+        lib.tg_debug_read_rbw2_stamps(wb, 96)
+        w = list(wb)
+        t0 = min(w[k * 12] for k in range(8))
+        names1 = ["start", "DMA issued", "conv1A done", "[H1] passed", "h1 stored, W1b issued", "conv1B done", "[H2] passed", "end"]
+        names2 = ["start", "DMA issued", "[S2A] passed, W2a issued", "conv2A loop done", "a1 written", "[S2B] passed", "conv2B loop done", "end"]
+        print(f"-- pass {rep} (last pair's workgroup 0, ticks after the first wave's start)")
+        for k in range(8):
+            s_ = [x - t0 for x in w[k * 12:k * 12 + 8]]
+            print(f"   {'conv1' if k < 4 else 'conv2'} wave {k}: " + ", ".join(f"{n_} +{v}" for n_, v in zip(names1 if k < 4 else names2, s_)))
+            e_ = [x - t0 for x in w[k * 12 + 8:k * 12 + 10]]
+            print(f"        " + (f"a1 seen complete +{e_[0]}" if k < 4 else f"all through with h1 +{e_[0]}, exchange A met +{e_[1]}"))
+elif WSTAMPS:
     # [0 start | 1 DMA issued | 2 first stage passed | 3 conv1 done | 4 h barrier passed | 5 conv2 done | 6 end] per wave of workgroup 0
     lib.tg_debug_read_rbw_stamps.restype = ctypes.c_int
     lib.tg_debug_read_rbw_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -67,6 +87,10 @@ if WSTAMPS:
 
 # wall time per launch of the same 16-launch trunk replayed as a hipGraph (what the step does; eager launches are host-bound)
 def trunk():
+    if PAIR:
+        for i in range(0, NB, 2):
+            K.resblock2_fwd_ws(a[i], wps[i][0], bs[i], wps[i][1], wps[i + 1][0], bs[i + 1], wps[i + 1][1], h[i], a[i + 1], h[i + 1], a[i + 2])
+        return
     for i in range(NB):
         if WS:
             K.resblock_fwd(a[i], wps[i][0], bs[i], wps[i][1], h[i], a[i + 1], ws=True)
@@ -86,4 +110,4 @@ with torch.cuda.stream(side):
     e1.record(side)
 torch.cuda.synchronize()
 print(f"{e0.elapsed_time(e1) * 1e3 / (50 * NB):.2f} us per launch (hipGraph replay of the 16-launch trunk, N = {N}, {H} x {H}, "
-      f"{'resblock_ws.hip' if WS else 'resblock.hip'})")
+      f"{'resblock2_ws.hip: PER BLOCK, two per launch' if PAIR else 'resblock_ws.hip' if WS else 'resblock.hip'})")
