@@ -24,6 +24,26 @@ def dist_info():
 
 
 _SYNC_ORDERED = {}
+_WARMED = set()
+
+
+def warm_backend(group, device):
+    """one synchronous and one ASYNCHRONOUS all-reduce of a tiny tensor, once per process group, before the first step is built.
+    The RCCL backend creates its internal stream at the first asynchronous collective; when that happened AFTER a step had been
+    built and replayed with synchronous collectives only (the inline mode), a bucket-mode step built next in the same process
+    replayed at 12.5-13.4 ms instead of 3.9 - with 8, 16 or 24 hardware queues alike - and at 3.9 when the asynchronous path had
+    been used once beforehand (tools/pg_tax_probe.py, profiles/r05_c_pg_tax_probe.log).  A collective: every rank builds its first
+    data-parallel step at the same point.  No-op for gloo (its device buffers take the staged path)."""
+    if group is None or not (dist.is_available() and dist.is_initialized()) or id(group) in _WARMED:
+        return
+    _WARMED.add(id(group))
+    if dist.get_backend(group) == "gloo":
+        return
+    t = torch.zeros(8, dtype=torch.float32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    w.wait()
+    torch.cuda.synchronize(device)
 
 
 def sync_allreduce_stream_ordered(group, device):
@@ -56,6 +76,14 @@ def sync_allreduce_stream_ordered(group, device):
         out = t * 2.0                                          # the consumer, on the same stream
     s.synchronize()
     ok = bool((out == 2.0 * world).all().item())
+    # the verdict picks the collective SCHEDULE (one synchronous all-reduce per network, or asynchronous buckets): it has to be the
+    # same on every rank - a backend that is not stream-ordered gives a racy, rank-local answer, and ranks that disagreed would
+    # issue collectives of different sizes.  MIN over the group: everybody falls back together.
+    if world > 1:
+        v = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=device)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN, group=group)
+        torch.cuda.synchronize(device)
+        ok = bool(v.item() >= 1.0)
     _SYNC_ORDERED[key] = ok
     _SYNC_ORDERED[(key, "host_ms")] = host_ms                  # (diagnostic: a stream-ordered call returns long before the sleep ends)
     return ok

@@ -206,6 +206,8 @@ class TecoGANStep:
         # 4.64 with the two buckets per network of TECOGAN_DP_INLINE=0 (profiles/r03_q_dp_inline.log).  What the inline form
         # gives up is overlap of the first bucket (~4 MB of 7 / 13 MB) with the rest of the backward pass - worth less than
         # the hops as long as a bucket's all-reduce is shorter than ~0.3 ms.
+        if process_group is not None:
+            parallel.warm_backend(process_group, device)   # (the backend's asynchronous path exists before the lanes' graphs do)
         self.dp_inline = process_group is not None and tu.dp_inline
         # The inline form relies on a synchronous all-reduce being ordered on the issuing stream (true of this torch build's RCCL
         # backend); checked once per process group on a 2-element tensor, with the asynchronous form as fallback.

@@ -1,4 +1,4 @@
-"""Worker of tests/test_dp_gpu.py (not a test module): ONE rank of a 2-rank data-parallel run whose ranks share cuda:0.
+"""Worker of tests/test_dp_gpu.py (not a test module): ONE rank of a 2- (or 4-) rank data-parallel run whose ranks share cuda:0.
 Launched by torch.distributed.run with the gloo backend (RCCL refuses two ranks on one device), before anything touches
 the GPU.  Each rank owns one sequence; 2 steps through FRVSR_Train (step 0 eager + capture, step 1 hipGraph replay with
 the collectives between the lane graphs).  Rank 0 then replays the same two steps on the CPU oracle as "two shards with
@@ -57,13 +57,13 @@ def main(out_path):
         sums.append([float(v) for v in out.update_list])
     import pytorch_tecogan_amd.train as hip_train
     st = next(iter(hip_train._STEPS.values()))
-    assert st.world == 2 and st.graphs is not None, (st.world, st.graphs)
+    assert st.world == world and st.graphs is not None, (st.world, st.graphs)
     w_g = torch.cat([p.detach().flatten() for p in G.parameters()]).cpu()
     w_d = torch.cat([p.detach().flatten() for p in D.parameters()]).cpu()
     digest = torch.stack([w_g.double().sum(), w_g.double().abs().sum(), w_d.double().sum(), w_d.double().abs().sum()])
     both = [torch.zeros(4, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(both, digest)
-    res = {"rank": rank, "replicas_bit_equal": bool(torch.equal(both[0], both[1])), "scalars": sums}
+    res = {"rank": rank, "replicas_bit_equal": all(bool(torch.equal(both[0], b)) for b in both[1:]), "scalars": sums, "world": world}
     if rank == 0:
         torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
         # the HIP side's view of the LAST step: flat gradient buffers hold the SUM over ranks (1/world lives in tg_adam)

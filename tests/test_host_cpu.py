@@ -401,6 +401,11 @@ def test_bench_launch_logic_spawns_its_ranks_and_refuses_mismatches():
     assert line["n_gpus"] == 2 and line["pg_world_size"] == 2 and line["config"] == {"parallelism": "dp2", "global_batch": 8}
     r = subprocess.run([sys.executable, bench, "--dry"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    # the driver's scaling run goes to 8 ranks: the same launch logic at that size (configs[2]: global batch 32)
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--dry"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["pg_world_size"] == 8 and line["config"] == {"parallelism": "dp8", "global_batch": 32}
     import torch
     if torch.cuda.device_count() < 2:
         r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)

@@ -201,3 +201,73 @@ def test_broadcast_state_makes_replicas_of_rank0():
 def test_broadcast_state_is_a_noop_without_a_process_group():
     from pytorch_tecogan_amd import parallel
     assert parallel.broadcast_state((torch.nn.Linear(2, 2),)) == 0
+
+
+def _world8_worker(rank, world, port, q):
+    """the data-parallel HOST logic at the driver's scaling-run size: shard bounds, rank-0 broadcast (ranks draw different weights),
+    flat-buffer averaging with a rank-dependent gradient, Adam on the averaged gradient, replica check - no oracle evaluation (eight of
+    those do not fit this box's time budget; world 2 above does the numerics)"""
+    try:
+        if ROOT not in sys.path:
+            sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        torch.set_num_threads(1)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import argparse
+        import pytorch_tecogan_amd  # noqa: F401
+        from pytorch_tecogan_amd import models as M, parallel
+        lo, hi = parallel.shard_bounds(32, world, rank)        # configs[2]: global batch 32 -> 4 sequences per GPU
+        assert (lo, hi) == (4 * rank, 4 * rank + 4)
+        lo16, hi16 = parallel.shard_bounds(16, world, rank)    # configs[3]: global batch 16 -> 2 per GPU
+        assert hi16 - lo16 == 2
+        args = argparse.Namespace(num_resblock=1, discrim_resblocks=1, discrim_channels=128, crop_size=32)
+        torch.manual_seed(500 + rank)
+        G, D = M.generator(3, args), M.discriminator(args)
+        og = torch.optim.Adam(G.parameters(), 1e-4)
+        group, w = parallel.dist_info()
+        assert w == world and group is not None
+        before = parallel.replicas_equal((G, D), group)        # every rank drew its own weights
+        n = parallel.broadcast_state((G, D), (og,), group)
+        after = parallel.replicas_equal((G, D), group)
+        # the flat gradient buffers the engines all-reduce: rank r holds (r + 1) * pattern; the average is (world + 1) / 2 * pattern
+        gflat = torch.cat([p.detach().flatten() for p in G.parameters()])
+        pat = torch.arange(gflat.numel(), dtype=torch.float32).remainder(97.0) / 97.0 - 0.5
+        bufs = [(rank + 1.0) * pat.clone(), (rank + 1.0) * 2.0 * pat[:1000].clone()]
+        parallel.average_gradients_(bufs, group, w)
+        err = float((bufs[0] - (world + 1) / 2.0 * pat).abs().max()), float((bufs[1] - (world + 1.0) * pat[:1000]).abs().max())
+        # a step on the averaged gradient keeps the replicas equal
+        off = 0
+        for p in G.parameters():
+            p.grad = bufs[0][off:off + p.numel()].view_as(p).clone()
+            off += p.numel()
+        og.step()
+        still = parallel.replicas_equal((G, D), group)
+        q.put({"rank": rank, "before": before, "after": after, "still": still, "n": n, "err": err})
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put({"rank": rank, "error": traceback.format_exc()})
+        raise
+
+
+@pytest.mark.timeout(600)
+def test_world_size_8_rehearsal_over_gloo():
+    """nothing had ever run at the world size of the driver's scaling run.  Eight gloo ranks on this box's CPUs:
+    shard bounds of configs[2] / configs[3], broadcast of rank 0's state, averaging of the flat gradient buffers, replica equality
+    before (False: every rank initialises by itself), after the broadcast and after an update on the averaged gradient (True)."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=500) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert "error" not in r, r.get("error")
+        assert r["before"] is False and r["after"] is True and r["still"] is True, r
+        assert r["n"] > 50 and max(r["err"]) < 1e-5, r
+    assert sorted(r["rank"] for r in results) == list(range(world))
