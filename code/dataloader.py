@@ -39,7 +39,12 @@ class FrameCache:
             self.hits += 1
             return ent[0]
         self.misses += 1
-        img = Image.open(path).convert("RGB")
+        img = Image.open(path)
+        if as_array or img.mode == "RGB":
+            img = img.convert("RGB")     # (decode-only workers: the GPU resize is PIL's bilinear on RGB - "auto" picks it for RGB datasets only)
+        else:
+            img.load()                   # the reference resizes the frame AS OPENED and converts afterwards (_to_tensor): a palette or
+                                         # grey frame is resized in its own mode (PIL uses NEAREST for 'P'), so it is cached unconverted
         val = np.asarray(img) if as_array else img
         size = img.size[0] * img.size[1] * 3
         if self.budget > 0:
@@ -154,7 +159,7 @@ class train_dataset(Dataset):
     def __init__(self, args, decode_only=False):
         """decode_only: __getitem__ returns the window's DECODED frames as one uint8 tensor (10,H,W,3); the resize to the LR
         and HR sizes then happens on the GPU (frames_to_batches) - the PNG decode is all the workers do.  "auto": decode-only when
-        the dataset's frames share one size (probed on the first and last scene), else the reference pipeline.
+        the dataset's frames share one size and are RGB (probed on the first frame of every scene), else the reference pipeline.
         args.tg_frame_cache_mb (default 512): per-worker budget of the decoded-frame cache, 0 = off."""
         self.decode_only = decode_only
         self.cache = None   # per process: created on first use, i.e. inside each DataLoader worker
@@ -177,13 +182,13 @@ class train_dataset(Dataset):
             self.scenes += 1
             self.windows += [frames[i:i + 10] for i in range(110)]
         if self.decode_only == "auto":
+            # one header read per SCENE (a scene's frames share a size; 110 windows per scene): a differently sized or non-RGB scene
+            # in the middle of the dataset must not surface as a collate error halfway through an epoch
             sizes = set()
-            for w in (self.windows[:1] + self.windows[-1:]):
+            for w in self.windows[::110]:
                 with Image.open(w[0]) as im:
-                    sizes.add(im.size)
-                with Image.open(w[-1]) as im:
-                    sizes.add(im.size)
-            self.decode_only = len(sizes) == 1
+                    sizes.add((im.size, im.mode))
+            self.decode_only = len(sizes) == 1 and next(iter(sizes))[1] == "RGB"
 
     def _frame(self, path, as_array):
         if self.cache is None:

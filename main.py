@@ -215,6 +215,10 @@ def main(argv=None):
             g_loss = g_loss + (output.gen_loss.data - g_loss) / (batch_idx + 1)   # running means stay on the device
             d_loss = d_loss + (output.d_loss.data - d_loss) / (batch_idx + 1)
             n_batches += 1
+        # the fused Adam launch updates the weights without ever calling optimizer.step(): tell the schedulers so, or torch warns every
+        # epoch that lr_scheduler.step() came before optimizer.step() (the LR itself is read from param_groups at every step)
+        for o_ in (opt_d, opt_g) + ((opt_f,) if sch_f is not None else ()):
+            o_._opt_called = True
         sch_d.step()
         sch_g.step()
         if sch_f is not None:

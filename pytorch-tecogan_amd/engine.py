@@ -161,6 +161,7 @@ class Conv:
         self.fin_job = None
         self.persist_wgs = K.PERSIST_WGS  # workgroups of this layer's persistent launches (the engines set their network's cap)
         self.persist_rw = 0               # ... of its register-weights conv launches, when different (0: the same)
+        self.persist_dgrad = 0            # ... of its register-weights INPUT-GRADIENT launches only (GeneratorEngine.set_trunk_cap)
         self.persist_fwd = 0              # ... of its FORWARD register-weights launches, when different again (0: the same)
         self.rw_off = False               # route this conv's launches past the register-weights kernel (A/B knob of the D halves)
         self.rw_extra = ""                # more launch classes of kernels.rw_eligible for this conv (set per D half)
@@ -199,7 +200,7 @@ class Conv:
             K.conv3x3_rgb(x, self.wf, self.bias, nchw[0], nchw[1], nchw[2], nchw[3], act)
             return
         if self.spec.kind == "c3" and nchw is None and self.tile == L.TILE_AUTO and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) \
-                and not self.rw_off and K.rw_eligible(self.dt, self.cin_p, self.cout_p, N, H, W, extra=self.rw_extra):
+                and not self.rw_off and K.rw_eligible(self.dt, self.cin_p, self.cout_p, N, H, W, extra=self.rw_extra, tu=self.tu):
             self.last_desc, self.last_rw_nch = "rw", self.cin_p // 32  # persistent register-weights kernel (csrc/conv3_rw.hip)
             K.conv3x3_rw(x, self.wf, out, False, bias=self.bias, res=res, act=act, stats=stats, stats_mode=2, groups=groups,
                          stats_replicas=stats_r, max_workgroups=self.persist_fwd or self.persist_rw or self.persist_wgs)
@@ -270,10 +271,10 @@ class Conv:
         st = bias_grad_of.gbias if bias_grad_of is not None else None
         if self.spec.kind == "c3" and self.tile == L.TILE_AUTO and \
                 not self.rw_off and K.rw_eligible(self.dt, self.cout_p, self.cin_p, N, H, W, masked=mask is not None,
-                                                  extra=self.rw_extra, dgrad=True):
+                                                  extra=self.rw_extra, dgrad=True, tu=self.tu):
             self.last_desc, self.last_rw_nch = "rw", self.cout_p // 32  # the input-gradient of a 3x3 conv is the same conv with mirrored taps
             K.conv3x3_rw(dout, self.wb, out, True, res=res, mask=mask, mask_mode=mask_mode, stats=st, stats_mode=1,
-                         max_workgroups=self.persist_rw or self.persist_wgs)
+                         max_workgroups=self.persist_dgrad or self.persist_rw or self.persist_wgs)
             return
         key = ("d", N, OH, OW, mask_mode, res is not None, st is not None)
         ent = self._desc.get(key)
@@ -755,6 +756,7 @@ class GeneratorEngine:
                 dtype_t in (torch.bfloat16, torch.float16):
             self.hr_list, self.trunk_group = WgradList(K.persist_wgs("G")), WgradList(K.persist_wgs("G"))
         self._rgb_cache = {}
+        self.tu = TU()   # (the engine routes by what it was built with)
         self.fused_rb = dtype_t in (torch.bfloat16, torch.float16) and TU().fused_resblock
         # the fused input-gradient launch (tg_resblock_bwd) is numerically identical and was measured EQUAL in time on the
         # batched backward (15 x 28.2 us vs 30 x 14.9 us at 40 samples: 640 workgroups each re-read 147 KB of weights), so
@@ -781,7 +783,7 @@ class GeneratorEngine:
         from the generator's (0: the same)"""
         for pair in self.rb:
             for c in pair:
-                c.persist_rw = cap
+                c.persist_dgrad = cap    # (its own attribute: TECOGAN_PERSIST_RW_G stays in force, forward launches are not touched)
 
     def set_cap(self, cap, fwd=0):
         """workgroups of the generator's persistent launches (register-weights convs, weight-gradient work lists); a scheduling
@@ -876,7 +878,8 @@ class GeneratorEngine:
         # conv_trans.2 is conv-relu-conv without a skip: the same fused launch - up to TECOGAN_PAIR_RW_MIN pixels; beyond that two
         # launches of the register-weights kernel are faster (config 5: 256 x 256, profiles/r04_x_rw_fwd_routing.log)
         npix2 = B * a["u0"].shape[1] * a["u0"].shape[2]
-        if self.fused_rb and not (0 < TU().pair_rw_min <= npix2 and K.rw_eligible(self.dt, 64, 64, B, a["u0"].shape[1], a["u0"].shape[2])):
+        if self.fused_rb and not (0 < self.tu.pair_rw_min <= npix2 and
+                                  K.rw_eligible(self.dt, 64, 64, B, a["u0"].shape[1], a["u0"].shape[2], tu=self.tu)):
             K.resblock_fwd(a["u0"][sl], self.c20.wf, self.c20.bias, self.c22.wf, hbuf(a["hh"]), a["u1"][sl], skip=False, ws=self.rb_ws)
         else:
             self.c20.fwd(a["u0"][sl], a["hh"][sl], act=L.ACT_RELU)

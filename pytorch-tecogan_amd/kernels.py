@@ -183,7 +183,7 @@ def conv3x3_rw(x, w_packed, out, flip=False, bias=None, res=None, mask=None, mas
                                    max_workgroups or persist_wgs(None), _stream()), "tg_conv3x3_rw")
 
 
-def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False, extra="", dgrad=False):
+def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False, extra="", dgrad=False, tu=None):
     """launch shapes routed to the persistent register-weights 3x3 kernel (csrc/conv3_rw.hip).  cin_p = reduction channels.
     Measured against tg_conv on the step's dense shapes (tools/mb_rw.py, profiles/r02_c_mb_rw.log):
       64 -> 64  @64x64   N=40  32.7 -> 20.0 us      64 -> 128 @128x128 N=40  154 -> 106 us     128 -> 128 @64x64 N=40 78.5 -> 74.1
@@ -197,8 +197,8 @@ def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False, extra="", dgrad=F
     FORWARD launch of >= TECOGAN_RW_FWD_MIN = 4096 pixels (the chain's conv0 / c30 / c32 / c6, the discriminator's stage 1, config 5's
     HR stage: config 2 3.92 -> 3.80 ms, config 5 2840 -> 2946 frames/s at 160 workgroups, 3130 at 256) and stage 1's input-gradients
     in both halves (s1); with conv_trans.2's pair as two launches and the generator at 144 workgroups config 2 runs at 3.75 ms."""
-    TU = tuning.current()
-    _RW, _RW_EXTRA_ENV = TU.rw, TU.rw_extra   # 0: never, 1: where it measured faster, all | classes routed there for the STEP's sake
+    TU = tu if tu is not None else tuning.current()   # (tu: the caller's snapshot - engines route by what they were built with, and a
+    _RW, _RW_EXTRA_ENV = TU.rw, TU.rw_extra           #  re-parse of ~50 environment variables per launch decision cost ~30 us of host time)   # 0: never, 1: where it measured faster, all | classes routed there for the STEP's sake
     if _RW == "0" or dtype_t not in (torch.bfloat16, torch.float16) or cin_p not in (64, 128) or cout_p % 64:
         return False
     if _RW == "all":

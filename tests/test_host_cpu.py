@@ -307,6 +307,21 @@ def test_dataloader_semantics(tmp_path):
                                             crop_size=8))
     inf = DL.inference_dataset(argparse.Namespace(input_dir_LR=str(tmp_path), input_dir_HR=None, crop_size=8))
     assert len(inf) == 2 and inf[0].shape[1:] == (3, 8, 8)
+    # a PALETTE scene is resized as opened (PIL: NEAREST for mode 'P') and converted afterwards, like the reference's
+    # torchvision resize of the opened image (code/dataloader.py:88-93 there); the frame cache keeps it unconverted, and "auto" does
+    # not hand such a dataset (or one with a differently sized scene in the middle) to the decode-only / GPU-resize path
+    d = tmp_path / "pal" / "scene_2000"
+    d.mkdir(parents=True)
+    for k in range(120):
+        Image.fromarray(rng.integers(0, 255, (24, 24), dtype=np.uint8), mode="P").save(d / ("col_high_%04d.png" % k))
+    ap = argparse.Namespace(input_video_dir=str(tmp_path / "pal"), input_video_pre="scene", str_dir=2000, end_dir=2000, max_frm=119,
+                            crop_size=8)
+    dsp = DL.train_dataset(ap, decode_only="auto")
+    assert dsp.decode_only is False
+    lr_p, _ = dsp[0]
+    ref = Image.open(d / "col_high_0001.png").resize((8, 8), Image.BILINEAR).convert("RGB")
+    assert torch.equal(lr_p[1], torch.from_numpy(np.asarray(ref, dtype=np.float32) / 255.0).permute(2, 0, 1))
+    assert DL.train_dataset(a, decode_only="auto").decode_only is True      # the RGB tree above: one size, RGB
 
 
 def test_shape_sets_keep_pinned_sets_alive_and_drop_loose_ones():
