@@ -200,7 +200,7 @@ def roofline_pass(st, dtype):
     wrap(E.Conv, "wgrad", lambda self, *a, **k: f"wgrad_kernel<{T16}, {self.spec.nslots}, ..>",
          lambda self, x_in, dout, *a, **k: conv_flops(self.spec, x_in.shape[0], x_in.shape[1], x_in.shape[2]), "mfma")
     rb_fl = lambda x, *a, **k: 2 * 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * 9 * x.shape[3] * x.shape[3]  # noqa: E731
-    wrap(K, "resblock_fwd", lambda *a, **k: "resblock_kernel<false>", rb_fl, "mfma")
+    wrap(K, "resblock_fwd", lambda *a, **k: "resblock_ws_kernel" if k.get("ws") else "resblock_kernel<false>", rb_fl, "mfma")
     wrap(K, "resblock_bwd", lambda *a, **k: "resblock_kernel<true>", rb_fl, "mfma")
     wrap(K, "resblock2_fwd", lambda *a, **k: f"resblock2_kernel<{T16}>", lambda x, *a, **k: 2 * rb_fl(x), "mfma")  # two blocks
     def time_group(cls, label):
@@ -329,7 +329,7 @@ def usable_cores():
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are separate
     runs of this same command; they cannot be collected live).  gfx950 correction: FETCH_SIZE counts 64 B per 128-B request."""
-    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         try:
             tab = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
         except (OSError, ValueError, KeyError):
@@ -587,8 +587,11 @@ def other_config5(dev, frames, reps, log):
     calls, fl = [], [0.0]
     orig = K.resblock_fwd
 
+    ws_seen = []
+
     def rec(xa, *a, **k):
         r = orig(xa, *a, **k)
+        ws_seen.append(bool(k.get("ws")))
         calls.append(lambda: orig(xa, *a, **k))
         fl[0] += 2 * 2.0 * xa.shape[0] * xa.shape[1] * xa.shape[2] * 9 * xa.shape[3] * xa.shape[3]
         return r
@@ -608,7 +611,7 @@ def other_config5(dev, frames, reps, log):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
-        res["trunk_family"] = {"kernel": "resblock_kernel<false>", "launches_per_frame": len(calls), "ms_per_frame": round(ms, 4),
+        res["trunk_family"] = {"kernel": "resblock_ws_kernel" if all(ws_seen) else "resblock_kernel<false>", "launches_per_frame": len(calls), "ms_per_frame": round(ms, 4),
                                "tflops": round(fl[0] / (ms * 1e-3) / 1e12, 1),
                                "frac": round(fl[0] / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["bf16"], 5),
                                "share_of_frame": round(ms / (dt / frames * 1e3), 3)}
@@ -673,11 +676,10 @@ def main(argv=None):
     # TECOGAN_FORCE_COLLECTIVES=1) runs the same code path, so the fields below can be rehearsed on one GPU.
     from pytorch_tecogan_amd import parallel
     dp_live = parallel.dist_info()[0] is not None
-    # "both": buckets first.  A bucket-mode step built after an inline one in the same process replays at 13-14 ms when the inline
-    # step was the process's FIRST use of the communicator (host issue 0.8 ms/step, every piece alone and the step with its
-    # collectives skipped at their normal times, not reproduced under the kernel tracer: the time is in the asynchronous
-    # collectives' stream hand-overs; profiles/r04_w_rebuild_probe.log - buckets, inline, buckets runs 4.32 / 3.92 / 4.29).  The other
-    # order times both modes at their own rate, and leaves the inline step (the default) for the roofline pass below.
+    # "both": buckets first, so that the inline step (the default) is the one left for the roofline pass below.  (Until round 5 the
+    # order mattered: a bucket-mode step built after an inline one replayed at 13 ms when the backend's first ASYNCHRONOUS collective
+    # came after the first step's graphs; parallel.warm_backend() now uses that path once before the first step -
+    # profiles/r05_c_pg_tax_probe.log.)
     modes = (["buckets", "inline"] if a.dp_mode == "both" else [a.dp_mode or "env"]) if dp_live else [None]
     runs, first = [], 0
     for mode in modes:

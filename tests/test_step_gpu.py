@@ -507,9 +507,9 @@ def test_bench_contract_line_with_roofline_pass():
     # of this same command, and the in-step launch time agrees with that summary's average
     import csv
     import glob
-    stats = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_*kernel_stats*.csv"))) or \
-        sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*kernel_stats*.csv")))
-    assert stats, "profiles/r0[34]_*kernel_stats*.csv (rocprofv3 --kernel-trace --stats of bench.py) is missing"
+    stats = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_*kernel_stats*.csv"))) or \
+        sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_*kernel_stats*.csv")))
+    assert stats, "profiles/r0[45]_*kernel_stats*.csv (rocprofv3 --kernel-trace --stats of bench.py) is missing"
     rows = list(csv.DictReader(open(stats[-1])))
     import re
     short = lambda n: re.sub(r"^void |\(anonymous namespace\)::", "", n).split(">(")[0] + ">"  # noqa: E731
@@ -527,7 +527,7 @@ def test_bench_contract_line_with_roofline_pass():
     # profiled step has both lanes busy, 84 % of the unprofiled one - so its per-kernel average is the STAND-ALONE launch time)
     assert abs(rf["avg_launch_us_standalone"] / prof_us - 1.0) < 0.15, (rf["avg_launch_us_standalone"], prof_us)
     fam = rf["families"]
-    assert any(k.startswith("resblock_kernel<false") for k in fam) and any(k.startswith("conv_rgb_kernel") for k in fam)
+    assert any(k.startswith("resblock_ws_kernel") for k in fam) and any(k.startswith("conv_rgb_kernel") for k in fam)
     assert all(v["launches"] > 0 and v["ms"] > 0 for v in fam.values())
     assert rf["hbm_kernels"] and all(0.0 < v["frac_of_8TBps"] < 1.0 for v in rf["hbm_kernels"].values())
 

@@ -48,7 +48,7 @@ def main():
     busy = {s: sum(b - a for a, b, _ in v) for s, v in by.items()}
     lanes = sorted(busy, key=lambda s: -busy[s])[:2]
     # lane A is the stream of the generator chain
-    la = max(lanes, key=lambda s: sum(1 for _, _, n in by[s] if "resblock_kernel" in n))
+    la = max(lanes, key=lambda s: sum(1 for _, _, n in by[s] if "resblock_kernel" in n or "resblock_ws_kernel" in n))
     lb = [s for s in lanes if s != la][0]
     marks = sorted(b for a, b, n in by[la] if "pack_multi_kernel" in n)
     if len(marks) < nsteps + 1:
