@@ -76,6 +76,11 @@ template <int NCH> struct Geo {
   static constexpr int kAccBytes = kHalves * kAccHalf;           // 34 816 either way
   static constexpr int KS = kPix / 32;                           // 8-pixel store instructions per producer wave and tile
   static constexpr int kLds = 2 * kBufBytes + 2 * kAccBytes;       // (+ kRedBytes of statistics scratch behind it)
+  // Cin = 64 (round 5): the workgroup's 72 KB of weights are staged ONCE by LDS-DMA - in the accumulator images, which nobody uses
+  // before the first tile is through, the statistics scratch and 3 KB more - and the consumers take their fragments from there
+  static constexpr bool kStageW = NCH == 2;
+  static constexpr int kStage = 2 * kBufBytes, kStageBytes = 18 * 4096;
+  static constexpr int kLdsAll = kStageW ? (kStage + kStageBytes > kLds + 1024 ? kStage + kStageBytes : kLds + 1024) : kLds + 1024;
   static_assert(kChunkBytes % 1024 == 0, "a DMA block must not straddle two chunk images");
 };
 
@@ -148,6 +153,22 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
     tx0 = txb * 16;
   };
   RW_STAMP(0);
+#ifndef RW_NO_STAGE
+  if constexpr (G::kStageW) {
+    // Every consumer wave used to load its 36 A-fragments itself - the two waves of a channel half the same 36 KB: 144 KB through
+    // the CU's intake (~22 B/clk) in front of the first tile, of which 16 fragments up front and 20 inside the first tile's k-loop.
+    // Now all eight waves DMA the 72 KB once: block (tap so, chunk ci) = 64 rows x 64 B; wave (u = wid % 4, ci = wid / 4) brings rows
+    // 16 u .. + 15 of chunk ci for every tap; the lane's 16 bytes are physical piece lane % 4 of its row (swz is an involution).
+    const unsigned lds0w = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int u = wid & 3, ci = wid >> 2, row = 16 * u + (lane >> 2);
+    const char* src = p.w + ((size_t)co_base + row) * 64 + (((lane & 3) ^ ((row >> 1) & 2)) << 4);
+#pragma unroll
+    for (int so = 0; so < 9; ++so) {
+      const int slot = p.flip ? 8 - so : so;
+      glds16(src + (size_t)(slot * NCH + ci) * p.Cout * 64, lds0w + G::kStage + (so * 2 + ci) * 4096 + u * 1024);
+    }
+  }
+#endif
 
   if (wid < 4) {
     // ============================================================ CONSUMER: weights in registers, k-loop, accumulators -> LDS
@@ -173,9 +194,16 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
       for (int a = 0; a < 2; ++a)
         wfr[ci][so][a] = *reinterpret_cast<const bf16x8*>(wl + ((size_t)(slot * NCH + chunk) * p.Cout + a * 16) * 64);
     };
-    constexpr int kEarly = RW_EARLY_STEPS;
+#ifndef RW_NO_STAGE
+    constexpr bool kStaged = G::kStageW;
+#else
+    constexpr bool kStaged = false;
+#endif
+    constexpr int kEarly = kStaged ? 18 : RW_EARLY_STEPS;
+    if constexpr (!kStaged) {
 #pragma unroll
-    for (int s_ = 0; s_ < kEarly; ++s_) wload(s_);
+      for (int s_ = 0; s_ < kEarly; ++s_) wload(s_);
+    }
     RW_STAMP(1);
     // fragment addresses of the wave's rows inside one chunk image (column taps 0..2); row taps add multiples of the pitch
     // (two 16-bit offsets per register)
@@ -191,7 +219,18 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
     // lane (idx, g) ends with channels 32*wc + 8g .. + 7 (two row-interleaved MFMA tiles, common.h) of pixel (r0 + b, idx)
     const int acc_off = kh * G::kAccHalf + (r0 * 16 + idx) * kAccPitch + (wc * 32 + 8 * g) * 4;
     RW_STAMP(2);
-    lds_barrier();   // patch 0 is in LDS
+    if constexpr (kStaged) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the weights has landed
+      lds_barrier();                                     // ... everybody's
+#pragma unroll
+      for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int so = 0; so < 9; ++so)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+            wfr[ci][so][a] = *reinterpret_cast<const bf16x8*>(smem + G::kStage + (so * 2 + ci) * 4096 + swz(wc * 32 + a * 16 + idx, g));
+    }
+    lds_barrier();   // patch 0 is in LDS (staged weights: and every consumer has its fragments - the area is the accumulators' again)
     RW_STAMP(3);
     for (int i = 0; i <= ntl; ++i) {
       RW_STAMP(4 + 6 * i + 0);
@@ -341,7 +380,12 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
   // (Per-wave global atomics - 8 instructions of 8 lanes each - took 147 us instead of 34 on c20's input-gradient: 5120 atomic
   // instructions on the same four cache lines serialise at ~25 ns each; profiles/r04_i_g_bwd_anatomy_v2e.log.)
   float* const red = reinterpret_cast<float*>(smem + G::kLds);   // [2][64] sums, [128] the ticket
-  if constexpr (STATS) {
+#ifndef RW_NO_STAGE
+  constexpr bool kStagedP = G::kStageW;
+#else
+  constexpr bool kStagedP = false;
+#endif
+  if constexpr (STATS && !kStagedP) {
     if (tid - 256 < 132) red[tid - 256] = 0.f;   // published by the first barrier
   }
   auto flush_stats = [&](int grp) {
@@ -518,8 +562,17 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
   dma_patch(cur, 0);
   RW_STAMP(1);
   RW_STAMP(2);
+  if constexpr (kStagedP) {
+    // this wave's 9 weight blocks are older than its patch blocks (8, or 7 for the waves behind the buffer's last block)
+    if (pw < ((G::kBlocks & 3) ? (G::kBlocks & 3) : 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NB - 1) : "memory");
+    lds_barrier();   // the weights are staged; the consumers take their fragments while patch 0 is still landing
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // patch 0 has landed
   lds_barrier();
+  if constexpr (STATS && kStagedP) {
+    if (tid - 256 < 132) red[tid - 256] = 0.f;   // (the scratch was part of the staging area) published by the first tile's barrier
+  }
   RW_STAMP(3);
   int tile = (int)blockIdx.x;
   for (int i = 0; i <= ntl; ++i, tile += (int)gridDim.x) {
@@ -565,7 +618,7 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
 
 template <int NCH, int SM, typename T>
 int launch_rw(const RwK& k, dim3 grid, hipStream_t st) {
-  constexpr int lds = Geo<NCH>::kLds + kRedBytes;
+  constexpr int lds = Geo<NCH>::kLdsAll;   // (kLds + kRedBytes; Cin = 64: + the tail of the weight staging area)
   auto fn = conv3_rw_kernel<NCH, SM, T>;
   static std::atomic<bool> attr_done{false};  // one-time function attribute (benign race: idempotent)
   if (!attr_done) {

@@ -221,6 +221,50 @@ def test_step_extension_config4_shape_vs_oracle(monkeypatch):
     assert float(og.state[next(iter(G.parameters()))]["step"]) == 1.0
 
 
+def test_step_odd_shape_b3_crop48_vs_oracle(monkeypatch):
+    """parity at a shape nothing was tuned on - B = 3 sequences, crop 48 (48 -> 192; fc = 3 * 6 * 6 = 108 inputs, the
+    tg_extend shapes; LR area and tile counts that are not powers of two: 3 x 48 x 48 = 6912 LR pixels per pass, 6 x 12 tiles of 8 x 4
+    per sample ...), fp32, eager and then under hipGraph replay, against the oracle."""
+    over = dict(crop_size=48, tg_extend=True, num_resblock=4, discrim_resblocks=1)
+    args = orc.default_args(**over)
+    args.tg_dtype = "fp32"
+    gp = orc.init_params(orc.generator_param_shapes(4), 117)
+    dp = orc.init_params(orc.discriminator_param_shapes(1, 128, fc_in=108), 217)
+    x, y = synth(3, 10, 48, 17)
+    torch.set_num_threads(max(1, os.cpu_count() // 2))
+    f = orc.tecogan_forward(gp, dp, orc.init_bn_buffers(dp, 1), x, y, args, 0)
+    exp = np.array([float(v) for v in f["update_list"]])
+    for graph in ("0", "1"):
+        monkeypatch.setenv("TECOGAN_GRAPH", graph)
+        G, D = models.generator(3, args), models.discriminator(args)
+        G.load_state_dict(gp)
+        D.load_state_dict(dp, strict=False)
+        G, D = G.cuda(), D.cuda()
+        og = torch.optim.Adam(G.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
+        od = torch.optim.Adam(D.parameters(), args.learning_rate, betas=(args.beta, 0.999), eps=args.adameps)
+        out = train.FRVSR_Train(x.cuda(), y.cuda(), args, D, G, 0, 0.0, 0.0, og, od)
+        got = np.array([float(v) for v in out.update_list])
+        np.testing.assert_allclose(got, exp, rtol=1e-3, atol=1e-6, err_msg=f"TECOGAN_GRAPH={graph}")
+        assert rel(out.gen_output.cpu(), f["gen"]) < 1e-4
+        assert out.target.shape == (9, 27, 192, 192) and rel(out.target.cpu(), f["real_in"]) < 1e-5
+
+
+@pytest.mark.timeout(900)
+def test_default_knobs_within_8_percent_of_the_cap_sweep_off_benchmark():
+    """the workgroup caps / routing thresholds were tuned on three shapes (configs 2, 4-shard, 5); tools/shape_sweep.py times the step
+    with the caps scaled (x 0.75, x 1.25) and lifted against the defaults - on the full grid B {1,2,4,8} x crop {32,48,64,96} the worst
+    regret of the default is 1.3 % (profiles/r05_e_shape_sweep.log).  Here: three off-benchmark shapes, default within 8 % of the best."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shape_sweep.py"), "--shapes", "1x48,2x64,8x32"],
+                       capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-1500:]
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("B=")]
+    assert len(rows) == 3, r.stdout[-1500:]
+    for ln in rows:
+        assert "regret of the default" in ln, ln
+        assert float(ln.split("regret of the default")[1].split("%")[0]) <= 8.0, ln
+
+
 def test_step_with_fnet_flow_option_vs_oracle(monkeypatch):
     """opt-in, NOT reference behaviour (the reference defines f_net but never calls it): args.tg_fnet = an f_net module makes
     the flow up4(4 * f_net(previous LR frame)) instead of the raw-frame pseudo-flow; the oracle states the same option."""
