@@ -268,6 +268,16 @@ int tg_resblock_fwd_ws(int dtype, const void* in, const void* w1_packed, const f
                        void* out_a, int N, int H, int W, int C, int add_skip, void* stream);
 
 #ifdef TG_EXPERIMENTS
+/* The same two input-gradients as ONE PERSISTENT, tile-pipelined launch (csrc/resblock_pp.hip, round 5): min(tiles, max_workgroups)
+ * workgroups keep both weight sets for all their 8 x 4 tiles (W of stage 1 in an LDS image for 32x32x16 tiles, W of stage 2 in
+ * registers) and stream only the 12 x 8 patch and the relu mask per tile; the four conv1 waves work on tile i while the four conv2
+ * waves finish tile i - 1.  For launches with many tiles per workgroup (the batched generator backward: 40 x 32 x 32 = 1280 tiles).
+ * MEASURED SLOWER than two register-weights launches (22.5 vs 20.5 us per block at 40 x 32 x 32, 55 vs 41 at 32 x 64 x 64, 144 workgroups:
+ * ~4300 ticks per 8 x 4 tile of which ~1150 are matrix work - profiles/r05_h_resblock_pp_ab.log): experiments build only.
+ * max_workgroups: 0 = one per CU (256).  Same operands, results (up to the fp32 summation order) and limits as tg_resblock_bwd. */
+int tg_resblock_bwd_pp(int dtype, const void* dout, const void* w2_dgrad_packed, const void* h, const void* w1_dgrad_packed,
+                       void* out_dh, void* out_din, int N, int H, int W, int C, int max_workgroups, void* stream);
+
 /* TWO consecutive residual blocks in ONE launch (8 x 4 output tiles, halo recomputed: h1 on 14 x 10, a1 on 12 x 8, h2 on 10 x 6
  * pixels from a 16 x 12 patch): out_h1 = relu(conv(in, w1a) + b1a), out_a1 = in + conv(out_h1, w2a), out_h2 = relu(conv(out_a1, w1b)
  * + b1b), out_a2 = out_a1 + conv(out_h2, w2b) - bit-identical to two tg_resblock_fwd launches, one launch boundary and one
@@ -296,6 +306,7 @@ int tg_resblock2_fwd_ws(int dtype, const void* in, const void* w1a_packed, const
 int tg_resblock_bwd(int dtype, const void* dout, const void* w2_dgrad_packed, const void* h, const void* w1_dgrad_packed,
                     void* out_dh, void* out_din, int N, int H, int W, int C, const void* next_wa_packed,
                     const void* next_wb_packed, void* stream);
+
 
 /* ---- layout converters ------------------------------------------------------------------------------- */
 /* NCHW fp32 (strided samples) -> NHWC `dtype` with zero channel padding. */

@@ -114,6 +114,7 @@ _PROTOS_EXPERIMENTS = {
     "tg_bn_bwd_coop": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "tg_resblock2_fwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "tg_resblock2_fwd_ws": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "tg_resblock_bwd_pp": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "tg_bn_bwd_fused": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "tg_bn_bwd_fused_max_pixels": (_I, []),
 }

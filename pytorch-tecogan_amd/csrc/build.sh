@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds libtecogan_hip.so for gfx950 in-tree (next to this script).  Usage: build.sh [--experiments] [extra hipcc flags]
-#   --experiments   also compile the variants that were built, measured slower and rejected (-DTG_EXPERIMENTS: resblock2.hip, resblock2_ws.hip,
+#   --experiments   also compile the variants that were built, measured slower and rejected (-DTG_EXPERIMENTS: resblock2.hip, resblock2_ws.hip, resblock_pp.hip,
 #                   the 64 x 128 work-list blocks, tg_bn_bwd_fused, tg_conv's stats_mode 3, the item-walking fold, the forced
 #                   trunk tile) into libtecogan_hip_experiments.so - objects under exp/, the default library is untouched.
 #                   Load it with TECOGAN_LIB=.../libtecogan_hip_experiments.so; tests: pytest -m experiments.
@@ -13,7 +13,7 @@ OBJ=.
 EXTRA=""
 if [ "${1:-}" = "--experiments" ]; then
   shift
-  SRCS="$SRCS resblock2 resblock2_ws"
+  SRCS="$SRCS resblock2 resblock2_ws resblock_pp"
   OUT=libtecogan_hip_experiments.so
   OBJ=exp
   EXTRA="-DTG_EXPERIMENTS"

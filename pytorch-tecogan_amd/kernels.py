@@ -438,6 +438,13 @@ def resblock2_fwd(x, w1a, b1a, w2a, w1b, b1b, w2b, out_h1, out_a1, out_h2, out_a
             "tg_resblock2_fwd")
 
 
+def resblock_bwd_pp(dout, w2b, h, w1b, out_dh, out_din, max_workgroups=0):
+    """both input-gradients of a residual block as one persistent, tile-pipelined launch (csrc/resblock_pp.hip)"""
+    N, H, W, C_ = dout.shape
+    L.check(L.load().tg_resblock_bwd_pp(tg_dtype(dout.dtype), _ptr(dout), _ptr(w2b), _ptr(h), _ptr(w1b), _ptr(out_dh), _ptr(out_din),
+                                        N, H, W, C_, int(max_workgroups), _stream()), "tg_resblock_bwd_pp")
+
+
 def resblock_bwd(dout, w2b, h, w1b, out_dh, out_din, next_w=None):
     """input-gradient of conv-relu-conv-skip in one launch; w*b = dgrad packings, h = saved forward activation"""
     N, H, W, C_ = dout.shape

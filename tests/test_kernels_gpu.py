@@ -1072,9 +1072,12 @@ def test_fused_resblock_forward(N, H, W, ws):
     assert torch.equal(h_p, h_f) and torch.equal(a_p, a_f)
 
 
-@pytest.mark.parametrize("N,H,W", [(5, 32, 32), (1, 8, 8), (2, 20, 12), (9, 32, 32), (6, 36, 44)])
-def test_fused_resblock_backward(N, H, W):
-    """tg_resblock_bwd == the two masked input-gradient launches of the block, and close to torch autograd"""
+@pytest.mark.parametrize("pp", [0, pytest.param(256, marks=pytest.mark.experiments), pytest.param(7, marks=pytest.mark.experiments),
+                                pytest.param(1, marks=pytest.mark.experiments)], ids=["unified", "pp256", "pp7", "pp1"])
+@pytest.mark.parametrize("N,H,W", [(5, 32, 32), (1, 8, 8), (2, 20, 12), (9, 32, 32), (6, 36, 44), (40, 32, 32), (3, 5, 3)])
+def test_fused_resblock_backward(N, H, W, pp):
+    """tg_resblock_bwd / tg_resblock_bwd_pp (round 5: one persistent, tile-pipelined launch; pp = its workgroup cap - 7 and 1 make a
+    workgroup walk many tiles, odd and even counts) == the two masked input-gradient launches of the block, and close to torch autograd"""
     dt = torch.bfloat16
     spec = K.ConvSpec("c3", 64, 64)
     dout = q(rnd((N, 64, H, W), 90), dt)
@@ -1087,7 +1090,10 @@ def test_fused_resblock_backward(N, H, W):
     wb2 = K.pack_weights(dt, w2.to(DEV), rows, Kd, s_row, s_k, 9, slots)
     dh_f = torch.full((N, H, W, 64), float("nan"), dtype=dt, device=DEV)
     da_f = torch.full((N, H, W, 64), float("nan"), dtype=dt, device=DEV)
-    K.resblock_bwd(dd, wb2, hd, wb1, dh_f, da_f)
+    if pp:
+        K.resblock_bwd_pp(dd, wb2, hd, wb1, dh_f, da_f, max_workgroups=pp)
+    else:
+        K.resblock_bwd(dd, wb2, hd, wb1, dh_f, da_f)
     dh_u, da_u = torch.empty_like(dh_f), torch.empty_like(da_f)
     d2 = K.make_conv_desc(spec.dgrad_geom(), L.TG_BF16, N, H, W, 64, H, W, 64, mask_mode=L.MASK_RELU)
     d1 = K.make_conv_desc(spec.dgrad_geom(), L.TG_BF16, N, H, W, 64, H, W, 64)
