@@ -489,7 +489,11 @@ extern "C" int tg_resblock_fwd_ws(int dtype, const void* in, const void* w1_pack
   k.tiles_x = (W + 7) / 8;
   // 8x4 tiles while 8x8 tiles would leave half of the chip's CUs without a workgroup (resblock.hip's rule)
   const long long blocks8 = (long long)k.tiles_x * ((H + 7) / 8) * N;
+#ifdef RBW_TH8_MIN   // A/B build: 8 x 8 tiles from this many 8 x 8 tiles on (default rule: above 128)
+  const int th = blocks8 < RBW_TH8_MIN ? 4 : 8;
+#else
   const int th = blocks8 <= 128 ? 4 : 8;
+#endif
   k.tiles_y = (H + th - 1) / th;
   const long long blocks = (long long)k.tiles_x * k.tiles_y * N;
   if (blocks > 0x7fffffffLL) return TG_E_UNSUPPORTED;

@@ -746,7 +746,7 @@ class GeneratorEngine:
         self.shape = None
         self.sets = ShapeSets()
         for c in self.convs:
-            c.persist_wgs, c.persist_rw, c.persist_fwd = K.persist_wgs("G"), TU().persist_rw_g, TU().persist_fwd_g
+            c.persist_wgs, c.persist_fwd = K.persist_wgs("G"), TU().persist_fwd_g
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
         self.trunk_group = WgradGroup() if TU().wgrad_groups else None
@@ -783,7 +783,7 @@ class GeneratorEngine:
         from the generator's (0: the same)"""
         for pair in self.rb:
             for c in pair:
-                c.persist_dgrad = cap    # (its own attribute: TECOGAN_PERSIST_RW_G stays in force, forward launches are not touched)
+                c.persist_dgrad = cap    # (its own attribute: forward launches are not touched)
 
     def set_cap(self, cap, fwd=0):
         """workgroups of the generator's persistent launches (register-weights convs, weight-gradient work lists); a scheduling
@@ -1293,7 +1293,7 @@ class DiscriminatorEngine:
                                                                              self.res[st] for c in (c1, c2)]
         self.shape = None
         for c in self.convs:
-            c.persist_wgs, c.persist_rw = K.persist_wgs("D"), TU().persist_rw_d
+            c.persist_wgs = K.persist_wgs("D")
         self.repacker = Repacker(self.convs, dtype_t, flat.device)
         self.finalizer = Finalizer(self.convs, flat.device) if _defer_finalize() else None
         self.res_group = WgradGroup() if TU().wgrad_groups else None
@@ -1304,10 +1304,7 @@ class DiscriminatorEngine:
         # lane B has slack there (it waits for the chain's last frame), the fake half is on the step's critical path
         self.cap = {None: K.persist_wgs("D"), 1: K.persist_wgs("D"),
                     0: TU().cap_dreal_default()}
-        # ... and of the FORWARD register-weights launches of a half when different (0: the same)
-        self.fwd_cap = {0: TU().persist_fwd_dreal, 1: TU().persist_fwd_dfake}
         self.rw_extra_real = TU().rw_extra_dreal or ""
-        self.rw_dhalf_off = TU().rw_dhalf_off
         self.bn_fuse = TU().bn_fuse
         if self.bn_fuse:
             tuning.need_experiments("bn_fuse")
@@ -1318,11 +1315,8 @@ class DiscriminatorEngine:
 
     def _set_cap(self, half):
         cap = self.cap[half]
-        off = self.rw_dhalf_off   # "1": the fake half's convs on tg_conv, "0": the real half's, "01": both
-        fwd = self.fwd_cap.get(half, 0)
         for c in self.convs:
-            c.persist_wgs, c.persist_fwd = cap, fwd
-            c.rw_off = half is not None and str(half) in off
+            c.persist_wgs = cap
             c.rw_extra = self.rw_extra_real if half == 0 else ""
         if isinstance(self.res_group, WgradList):
             self.res_group.cap = cap

@@ -44,16 +44,12 @@ KNOBS = OrderedDict((k.attr, k) for k in (
     _k("PERSIST_WGS_D", "persist_wgs_d", "oint", None, "profiles/r02_q_persist_wgs_sweep.log", "discriminator's cap (unset: 96)"),
     _k("PERSIST_WGS_DREAL", "persist_wgs_dreal", "oint", None, "profiles/r03_r_rw_dma_ab.log",
        "cap of the discriminator's REAL half, which runs beside the chain (unset: 72 for chain-bound steps, else the D cap)"),
-    _k("PERSIST_RW_G", "persist_rw_g", "int", 0, "profiles/r02_q_persist_wgs_sweep.log",
-       "separate cap for the generator's register-weights conv launches (0: the same cap)"),
     _k("PERSIST_FWD_G", "persist_fwd_g", "int", 0, "profiles/r04_z_fwd_cap.log",
        "cap of the generator's FORWARD register-weights launches (the chain, beside the real half); 0: 192 for steps of <= 4096 LR pixels per pass, else the generator's"),
     _k("PERSIST_TRUNK_G", "persist_trunk_g", "int", 0, "profiles/r04_z_trunk_cap.log",
        "cap of the trunk's 32 input-gradient launches in the batched G backward (0: the generator's)"),
-    _k("PERSIST_FWD_DREAL", "persist_fwd_dreal", "int", 0, "profiles/r04_z_d_fwd_caps.log",
-       "cap of the real half's FORWARD register-weights launches when different (0: the half's cap)"),
-    _k("PERSIST_FWD_DFAKE", "persist_fwd_dfake", "int", 0, "profiles/r04_z_d_fwd_caps.log", "... of the fake half's"),
-    _k("PERSIST_RW_D", "persist_rw_d", "int", 0, "profiles/r02_q_persist_wgs_sweep.log", "... the discriminator's"),
+    # (round 5 pruned five knobs that every sweep of rounds 2-4 had left at their defaults: PERSIST_RW_G / _D - a separate cap for the
+    #  register-weights launches, r02_q -, PERSIST_FWD_DREAL / _DFAKE - r04_z_d_fwd_caps - and RW_DHALF_OFF - r03_r)
     # ---- kernel routing (engine.Conv, kernels.rw_eligible)
     _k("RW", "rw", "str", "1", "profiles/r02_c_mb_rw.log", "register-weights 3x3 kernel: 0 never, 1 where measured faster, all"),
     _k("RW_EXTRA", "rw_extra", "str", "trunk,c30,m128,s3,s1", "profiles/r03_r_rw_dma_ab.log, r04_l_rw_extra_s3.log, r04_x_rw_fwd_routing.log",
@@ -69,8 +65,6 @@ KNOBS = OrderedDict((k.attr, k) for k in (
        "frames per hipGraph (and per staging copy) in RecurrentGenerator"),
     _k("INFER_WGS", "infer_wgs", "int", 256, "profiles/r04_x_rw_fwd_routing.log",
        "workgroup cap of the generator's persistent launches inside RecurrentGenerator (no other lane to leave CUs to)"),
-    _k("RW_DHALF_OFF", "rw_dhalf_off", "str", "", "profiles/r03_r_rw_dma_ab.log",
-       "A/B: discriminator halves ('0', '1', '01') whose convs bypass the register-weights kernel"),
     _k("SUBPIX_CT", "subpix_ct", "on", True, "profiles/r01_h_bench_6p1ms.json (tools/mb_convt.py)",
        "conv-transpose forward as one four-class sub-pixel launch"),
     _k("FAST_C4S2", "fast_c4s2", "on", True, "profiles/r01_h_bench_6p1ms.json (tools/mb_c4s2.py)",

@@ -548,7 +548,7 @@ def test_tuning_defaults_equal_the_documented_optimum(monkeypatch):
     assert (t.cap_fwd_g_for(4096), t.cap_fwd_g_for(8192)) == (192, 0)
     assert (t.graph, t.lanes, t.dreal_bwd, t.dp_inline, t.dp_buckets, t.cu_reserve, t.force_collectives) == \
         (True, True, True, True, True, 0, False)
-    assert (t.rw, t.rw_extra, t.rw_extra_dreal, t.rw_dhalf_off) == ("1", "trunk,c30,m128,s3,s1", None, "")
+    assert (t.rw, t.rw_extra, t.rw_extra_dreal) == ("1", "trunk,c30,m128,s3,s1", None)
     assert (t.wgrad_list, t.wgrad_groups, t.defer_finalize, t.fold_items, t.pack_blocks, t.stats_replicas) == \
         (True, True, True, True, 48, 4)
     assert (t.fused_resblock, t.fused_resblock_bwd, t.subpix_ct, t.fast_c4s2, t.rgb_out, t.rgb_bwd, t.rgb_bwd_wgs, t.rb_prefetch, t.rb_ws) == \
