@@ -27,8 +27,11 @@ __device__ __forceinline__ int patch_off(int prow, int c, int piece) {
   return (16 * (prow >> 3) + 8 * c + (prow & 7)) * 64 + ((piece ^ ((prow >> 2) & 3)) << 4);
 }
 
+#ifndef RBW_DMA_AUX   // A/B builds: cache-policy bits on the LDS-DMA (" nt", " sc1", ...): profiles/r05_j_dma_policy_ab.log
+#define RBW_DMA_AUX ""
+#endif
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" RBW_DMA_AUX : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
 // LDS-only barrier: __syncthreads() would also drain vmcnt (the weight stream, the h stores)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
