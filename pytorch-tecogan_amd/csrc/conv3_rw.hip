@@ -132,7 +132,16 @@ template <> __device__ __forceinline__ unsigned pack2<F16>(float lo, float hi) {
 
 // SM: statistics of the stored values - 0 none, 1 per-channel sums (a bias gradient), 2 sums and sums of squares (batch norm).
 template <int NCH, int SM, typename T = BF16>
-__global__ __launch_bounds__(512) void conv3_rw_kernel(const RwK p) {
+// (arguments one by one, the ones a wave needs first in front: the first 16 dwords are preloaded into SGPRs with the wave -
+// csrc/build.sh, -amdgpu-kernarg-preload-count; profiles/r05_k_kernarg_preload_ab.log)
+__global__ __launch_bounds__(512) void conv3_rw_kernel(const char* a_in, const char* a_w, const char* a_zero, int a_H, int a_W, int a_Cout,
+                                                       int a_tiles_x, int a_tiles_y, int a_ntiles, int a_flip, int a_N, char* a_out,
+                                                       const char* a_mask, const char* a_res, const float* a_bias, float* a_stats,
+                                                       int a_act, int a_mask_mode, int a_stats_groups, int a_stats_mode, int a_stats_replicas) {
+  RwK p;
+  p.in = a_in; p.w = a_w; p.zero = a_zero; p.H = a_H; p.W = a_W; p.Cout = a_Cout; p.tiles_x = a_tiles_x; p.tiles_y = a_tiles_y;
+  p.ntiles = a_ntiles; p.flip = a_flip; p.N = a_N; p.out = a_out; p.mask = a_mask; p.res = a_res; p.bias = a_bias; p.stats = a_stats;
+  p.act = a_act; p.mask_mode = a_mask_mode; p.stats_groups = a_stats_groups; p.stats_mode = a_stats_mode; p.stats_replicas = a_stats_replicas;
   using G = Geo<NCH>;
   static_assert(NCH == 2 || NCH == 4, "Cin = 64 or 128");
   constexpr bool STATS = SM > 0;
@@ -625,7 +634,8 @@ int launch_rw(const RwK& k, dim3 grid, hipStream_t st) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(fn, grid, dim3(512), lds, st, k);
+  hipLaunchKernelGGL(fn, grid, dim3(512), lds, st, k.in, k.w, k.zero, k.H, k.W, k.Cout, k.tiles_x, k.tiles_y, k.ntiles, k.flip, k.N, k.out,
+                     k.mask, k.res, k.bias, k.stats, k.act, k.mask_mode, k.stats_groups, k.stats_mode, k.stats_replicas);
   return tg_launch_status();
 }
 

@@ -113,8 +113,16 @@ constexpr int kStageTaps[3] = {3, 6, 9};
 // do not all ask its L2 for the same two 4-KB blocks at once - 9.1 instead of 5.0 us per launch: requests for the same lines at the
 // same time are what the L2 serves best.  profiles/r05_a_resblock_ws_ab.log)
 
+// The arguments are passed one by one, the ones a wave needs first in front: with -mllvm -amdgpu-kernarg-preload-count=16 (csrc/build.sh)
+// the first 16 dwords arrive in SGPRs with the wave instead of through an s_load round trip at its first instruction - which sits in
+// front of the very first DMA address of every workgroup of every launch (profiles/r05_k_kernarg_preload_ab.log).
 template <typename T, int TH>
-__global__ __launch_bounds__(512) void resblock_ws_kernel(const RbwK p) {
+__global__ __launch_bounds__(512) void resblock_ws_kernel(const char* a_in, const char* a_w1, const char* a_zero, int a_H, int a_W,
+                                                          int a_tiles_x, int a_tiles_y, const char* a_w2, const float* a_b1,
+                                                          char* a_out_h, char* a_out_a, int a_N, int a_skip) {
+  RbwK p;
+  p.in = a_in; p.w1 = a_w1; p.zero = a_zero; p.H = a_H; p.W = a_W; p.tiles_x = a_tiles_x; p.tiles_y = a_tiles_y;
+  p.w2 = a_w2; p.b1 = a_b1; p.out_h = a_out_h; p.out_a = a_out_a; p.N = a_N; p.skip = a_skip;
   using G = GeoW<TH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -463,7 +471,8 @@ int launch_rbw(const RbwK& k, unsigned blocks, hipStream_t st) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, GeoW<TH>::kLds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), GeoW<TH>::kLds, st, k);
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), GeoW<TH>::kLds, st, k.in, k.w1, k.zero, k.H, k.W, k.tiles_x, k.tiles_y, k.w2, k.b1,
+                     k.out_h, k.out_a, k.N, k.skip);
   return tg_launch_status();
 }
 
