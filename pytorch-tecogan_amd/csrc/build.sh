@@ -20,7 +20,9 @@ if [ "${1:-}" = "--experiments" ]; then
   mkdir -p exp
 fi
 pids=""
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $EXTRA"
+# -amdgpu-kernarg-preload-count: kernels whose arguments are passed one by one (everything but the by-value launch structs) get their
+# first 16 dwords preloaded into SGPRs with the wave - no s_load round trip in front of a workgroup's first address (r05_k log)
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=16 $EXTRA"
 objs=""
 for f in $SRCS; do
   o=$OBJ/$f.o
@@ -29,10 +31,7 @@ for f in $SRCS; do
     rm -f $o   # a failed compile must not leave the previous object behind for the link below
     # conv3_rw: the producer waves' epilogue arithmetic shares a SIMD with the consumer's MFMA stream; SLP-packed f32 operations
     # (v_pk_add_f32 / v_pk_mul_f32) cost ~+25 cycles each beside MFMAs (MI355X_MICROARCH.md, 'price of one filler')
-    per_file=""; [ $f = conv3_rw ] && per_file="-fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16"
-    # kernels whose arguments are passed one by one get the first 16 dwords preloaded into SGPRs with the wave (no s_load round trip
-    # in front of a workgroup's first address): profiles/r05_k_kernarg_preload_ab.log
-    [ $f = resblock_ws ] && per_file="-mllvm -amdgpu-kernarg-preload-count=16"
+    per_file=""; [ $f = conv3_rw ] && per_file="-fno-slp-vectorize"
     $HIPCC $FLAGS $per_file "$@" -c $f.hip -o $o &
     pids="$pids $!"
   fi

@@ -10,8 +10,7 @@ objs=""
 for f in conv_mfma wgrad_mfma wgrad_group warp elementwise fnet resblock resblock_ws convt_mfma conv4s2_mfma runtime conv3_rw vgg conv_rgb rgb_bwd; do
   if [[ ",$stems," == *",$f,"* ]]; then
     per_file=""; [ $f = conv3_rw ] && per_file="-fno-slp-vectorize"   # (as csrc/build.sh)
-    [ $f = conv3_rw ] && [ -z "${NO_PRELOAD:-}" ] && per_file="$per_file -mllvm -amdgpu-kernarg-preload-count=16"
-    [ $f = resblock_ws ] && [ -z "${NO_PRELOAD:-}" ] && per_file="-mllvm -amdgpu-kernarg-preload-count=16"
+    [ -z "${NO_PRELOAD:-}" ] && per_file="$per_file -mllvm -amdgpu-kernarg-preload-count=16"   # (as csrc/build.sh's FLAGS)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $per_file "$@" -c $f.hip -o $out/$name/$f.o
     objs="$objs $out/$name/$f.o"
   else
