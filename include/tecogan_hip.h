@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 2   /* 2 (round 5): + tg_resblock_fwd_ws; round 4 removed tg_wgrad_group / tg_absdiff_nchw and moved the
+#define TG_ABI_VERSION 3   /* 3 (round 5): + tg_convt_fwd_cw; 2 (round 5): + tg_resblock_fwd_ws; round 4 removed tg_wgrad_group / tg_absdiff_nchw and moved the
                            * rejected variants behind TG_EXPERIMENTS without a bump */
 
 enum { TG_F32 = 0, TG_BF16 = 1, TG_F16 = 2 };  /* TG_F16: IEEE half, same layouts as TG_BF16 (loss scaling: tg_adam) */
@@ -132,6 +132,14 @@ int tg_conv3x3_rw(int dtype, const void* in, const void* w_packed, const float* 
  * +bias, act in {NONE, RELU, LRELU}.  TG_E_UNSUPPORTED unless Cout % 64 == 0 (use tg_conv then). */
 int tg_convt_fwd(int dtype, const void* in, const void* w_packed, const float* bias, void* out, int N, int IH, int IW,
                  int Cin, int Cout, int act, void* stream);
+
+/* The same layer (same arguments, same results up to the fp32 summation order) with CLASS-SPECIALISED waves (csrc/convt_cw.hip,
+ * round 5): min(tiles, max_workgroups / (Cout/64)) x Cout/64 persistent workgroups walk 4 x 16 INPUT tiles; each of the eight waves
+ * keeps the slots of ONE sub-pixel class x 32 of the 64 output channels in registers for the workgroup's lifetime and stores its
+ * class's results straight from the accumulators (no accumulator image, one barrier per tile; the patch comes by LDS-DMA).
+ * bf16 / fp16, Cin in {64, 128}, Cout % 64 == 0, else TG_E_UNSUPPORTED (use tg_convt_fwd).  max_workgroups: 0 = one per CU. */
+int tg_convt_fwd_cw(int dtype, const void* in, const void* w_packed, const float* bias, void* out, int N, int IH, int IW,
+                    int Cin, int Cout, int act, int max_workgroups, void* stream);
 
 /* 4x4 stride-2 padding-1 conv forward (the discriminator's down-sampling convs, code/models.py:90-94) with compile-time
  * taps and pipelined chunk staging; in [N][IH][IW][Cin] (IH, IW even) -> out [N][IH/2][IW/2][Cout]; w_packed = the 16-slot

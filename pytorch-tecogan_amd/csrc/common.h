@@ -81,7 +81,11 @@ template <> struct Vec<BF16> {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       t[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+#ifdef TG_VEC_NT   // A/B only (profiles/r05_o_nt_store_ab.log)
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
+#else
     *reinterpret_cast<u32x4*>(p) = t;
+#endif
   }
 };
 

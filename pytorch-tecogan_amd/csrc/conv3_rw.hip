@@ -562,8 +562,16 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const char* a_in, const c
 #pragma unroll
     for (int k = 0; k < G::KS; ++k) {
       const int pl = pl0 + 8 * k;
-      if ((okm >> k) & 1u)
-        *reinterpret_cast<u32x4*>(out_t + (unsigned)(((pl >> 4) * p.W + (pl & 15)) * p.Cout + ch0) * 2u) = ov[k];
+      if ((okm >> k) & 1u) {
+        u32x4* const dst = reinterpret_cast<u32x4*>(out_t + (unsigned)(((pl >> 4) * p.W + (pl & 15)) * p.Cout + ch0) * 2u);
+#ifdef RW_NT_BYTES   // A/B (profiles/r05_o_nt_store_ab.log): outputs too large for the L2s leave them early - no gain, off
+        // (inline asm: the optimiser merges a plain and a __builtin_nontemporal_store branch into one plain store)
+        if ((size_t)p.N * p.H * p.W * p.Cout * 2 >= (size_t)RW_NT_BYTES)
+          asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(ov[k]) : "memory");
+        else
+#endif
+          *dst = ov[k];
+      }
     }
   };
 

@@ -179,6 +179,13 @@ class Conv:
         stats: `stats_r` replica blocks of [groups][2][cout_p] (the consumer, BatchNorm.apply, folds them)."""
         N, H, W, _ = x.shape
         OH, OW = self.spec.out_hw(H, W)
+        if self.spec.kind == "ct" and self.cout_p % 64 == 0 and self.cin_p in (64, 128) and res is None and stats is None and \
+                nchw is None and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and self.tile == L.TILE_AUTO and \
+                self.dt in (torch.bfloat16, torch.float16) and self.tu.ct_cw:
+            # persistent workgroups, one sub-pixel class per wave, weights in registers (csrc/convt_cw.hip, round 5)
+            self.last_desc = None
+            K.convt_fwd_cw(x, self.wf, self.bias, out, act, max_workgroups=self.persist_fwd or self.persist_rw or self.persist_wgs)
+            return
         if self.spec.kind == "ct" and self.cout_p % 64 == 0 and res is None and stats is None and nchw is None and \
                 act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and self.tile == L.TILE_AUTO and self.tu.subpix_ct and \
                 N * ((H + 7) // 8) * ((W + 15) // 16) * (self.cout_p // 64) >= 128:

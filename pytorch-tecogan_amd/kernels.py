@@ -420,6 +420,13 @@ def convt_fwd(x, w_packed, bias, out, act=L.ACT_NONE):
                                   out.shape[3], act, _stream()), "tg_convt_fwd")
 
 
+def convt_fwd_cw(x, w_packed, bias, out, act=L.ACT_NONE, max_workgroups=0):
+    """the same layer with class-specialised waves (csrc/convt_cw.hip): Cin in {64, 128}, Cout % 64 == 0"""
+    N, H, W, cin = x.shape
+    L.check(L.load().tg_convt_fwd_cw(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), N, H, W, cin,
+                                     out.shape[3], act, max_workgroups or persist_wgs(None), _stream()), "tg_convt_fwd_cw")
+
+
 def resblock2_fwd_ws(x, w1a, b1a, w2a, w1b, b1b, w2b, out_h1, out_a1, out_h2, out_a2):
     """two consecutive residual blocks in one launch of the stream-first kernel (csrc/resblock2_ws.hip); out_h1 / out_h2 may be None"""
     N, H, W, C_ = x.shape

@@ -1274,6 +1274,41 @@ def test_convt_subpixel_forward(cin, cout, N, H, W, act, dt):
                                  K.pad32(cin), 32, act, None) == -2
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cap", [0, 24, 7])
+@pytest.mark.parametrize("cin,cout,N,H,W,act", [(64, 64, 4, 32, 32, L.ACT_RELU), (128, 128, 4, 64, 64, L.ACT_RELU),
+                                                (64, 128, 2, 9, 21, L.ACT_NONE), (128, 64, 3, 7, 40, L.ACT_LRELU),
+                                                (64, 64, 1, 1, 1, L.ACT_RELU), (128, 128, 1, 5, 17, L.ACT_NONE),
+                                                (64, 64, 1, 128, 128, L.ACT_RELU)])
+def test_convt_forward_class_waves(cin, cout, N, H, W, act, cap, dt):
+    """tg_convt_fwd_cw (persistent workgroups, class-specialised waves: csrc/convt_cw.hip) == F.conv_transpose2d(k3, s2, p1, op1) and
+    == tg_convt_fwd, for any workgroup cap (1 .. many tiles per workgroup)"""
+    if cap and H * W * N > 20000:
+        pytest.skip("caps are covered on the smaller shapes")
+    spec = K.ConvSpec("ct", cin, cout)
+    x = q(rnd((N, cin, H, W), 113), dt)
+    w = q(rnd(spec.weight_shape, 114, -0.1, 0.1), dt)
+    b = rnd((cout,), 115)
+    ref = ref_conv(spec, x, w, b)
+    ref = F.relu(ref) if act == L.ACT_RELU else (F.leaky_relu(ref, 0.2) if act == L.ACT_LRELU else ref)
+    xd = K.to_nhwc(x.to(DEV), dt)
+    rows, Kd, s_row, s_k = spec.fwd_pack()
+    wp = K.pack_weights(dt, w.to(DEV).contiguous(), rows, Kd, s_row, s_k, 9, K.slot_table(9, DEV))
+    bd = torch.zeros(K.pad32(cout), device=DEV)
+    bd[:cout] = b.to(DEV)
+    out = torch.full((N, 2 * H, 2 * W, K.pad32(cout)), float("nan"), dtype=dt, device=DEV)
+    K.convt_fwd_cw(xd, wp, bd, out, act, max_workgroups=cap)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(K.to_nchw(out, cout).cpu(), ref, **tol(dt))
+    other = torch.full_like(out, float("nan"))
+    K.convt_fwd(xd, wp, bd, other, act)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.float().cpu(), other.float().cpu(), rtol=2 ** -7, atol=1e-3)
+    fn = L.load().tg_convt_fwd_cw
+    assert fn(K.tg_dtype(dt), xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), N, H, W, 32, 64, act, 0, None) == -2
+    assert fn(K.tg_dtype(dt), xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), N, H, W, K.pad32(cin), 32, act, 0, None) == -2
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("cin,cout,N,H,W,G", [(64, 64, 4, 32, 32, 2), (64, 128, 2, 16, 16, 1), (128, 128, 2, 8, 8, 2),
                                               (128, 64, 3, 16, 16, 1), (27, 64, 1, 2, 2, 1), (64, 64, 2, 20, 44, 1)])
