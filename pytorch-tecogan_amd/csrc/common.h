@@ -53,7 +53,20 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
   return __builtin_bit_cast(unsigned short, h);
 }
 
-// Load/store `kVec` consecutive elements (16 bytes) as floats.
+// A 16-byte store to GLOBAL memory.  -DTG_ST_AUX="sc1" (csrc/build.sh): written THROUGH the L2 at agent scope.  Every kernel boundary
+// writes the XCDs' dirty L2 lines back (the next launch's workgroups run on other XCDs) - whoever dirtied them: with write-back stores
+// the 210 dependent launches of the recurrent pass paid at each of their boundaries for the lines the discriminator's launches on the
+// other lane had just written (profiles/r05_u_write_through_ab.log).  (Inline asm: a store the compiler's vmcnt bookkeeping does not see
+// only makes its waits conservative - the counter is in order.)
+__device__ __forceinline__ void tg_store16(void* p, u32x4 v) {
+#ifdef TG_ST_AUX
+  asm volatile("global_store_dwordx4 %0, %1, off " TG_ST_AUX ::"v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<u32x4*>(p) = v;
+#endif
+}
+
+// Load/store `kVec` consecutive elements (16 bytes) as floats (store: to global memory; pack: anywhere).
 template <typename T> struct Vec;
 template <> struct Vec<F32> {
   static constexpr int N = 4;
@@ -61,9 +74,13 @@ template <> struct Vec<F32> {
     f32x4 t = *reinterpret_cast<const f32x4*>(p);
     v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
   }
-  __device__ __forceinline__ static void store(void* p, const float* v) {
+  __device__ __forceinline__ static void pack(void* p, const float* v) {
     f32x4 t = {v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(p) = t;
+  }
+  __device__ __forceinline__ static void store(void* p, const float* v) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    tg_store16(p, __builtin_bit_cast(u32x4, t));
   }
 };
 template <> struct Vec<BF16> {
@@ -76,17 +93,15 @@ template <> struct Vec<BF16> {
       v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
     }
   }
-  __device__ __forceinline__ static void store(void* p, const float* v) {
+  __device__ __forceinline__ static u32x4 bits(const float* v) {
     u32x4 t;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       t[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
-#ifdef TG_VEC_NT   // A/B only (profiles/r05_o_nt_store_ab.log)
-    __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
-#else
-    *reinterpret_cast<u32x4*>(p) = t;
-#endif
+    return t;
   }
+  __device__ __forceinline__ static void pack(void* p, const float* v) { *reinterpret_cast<u32x4*>(p) = bits(v); }
+  __device__ __forceinline__ static void store(void* p, const float* v) { tg_store16(p, bits(v)); }
 };
 
 template <> struct Vec<F16> {
@@ -96,11 +111,17 @@ template <> struct Vec<F16> {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
   }
-  __device__ __forceinline__ static void store(void* p, const float* v) {
+  __device__ __forceinline__ static void pack(void* p, const float* v) {
     f16x8 t;
 #pragma unroll
     for (int i = 0; i < 8; ++i) t[i] = (_Float16)v[i];
     *reinterpret_cast<f16x8*>(p) = t;
+  }
+  __device__ __forceinline__ static void store(void* p, const float* v) {
+    f16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (_Float16)v[i];
+    tg_store16(p, __builtin_bit_cast(u32x4, t));
   }
 };
 

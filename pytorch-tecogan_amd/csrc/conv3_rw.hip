@@ -27,6 +27,9 @@
 //
 // Replaces aten::conv2d / convolution_backward(input) of the 3x3 layers (code/models.py:54-58,68,73-76,102 via
 // code/ops.py:57-63; autograd of code/train.py:336,340) where tg_conv is the general entry point.
+#ifndef TG_ST_AUX
+#define TG_ST_AUX "sc1"   // this kernel's results are written THROUGH the L2 (common.h, tg_store16; profiles/r05_u_write_through_ab.log)
+#endif
 #include "common.h"
 #include <type_traits>
 
@@ -562,16 +565,7 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const char* a_in, const c
 #pragma unroll
     for (int k = 0; k < G::KS; ++k) {
       const int pl = pl0 + 8 * k;
-      if ((okm >> k) & 1u) {
-        u32x4* const dst = reinterpret_cast<u32x4*>(out_t + (unsigned)(((pl >> 4) * p.W + (pl & 15)) * p.Cout + ch0) * 2u);
-#ifdef RW_NT_BYTES   // A/B (profiles/r05_o_nt_store_ab.log): outputs too large for the L2s leave them early - no gain, off
-        // (inline asm: the optimiser merges a plain and a __builtin_nontemporal_store branch into one plain store)
-        if ((size_t)p.N * p.H * p.W * p.Cout * 2 >= (size_t)RW_NT_BYTES)
-          asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(ov[k]) : "memory");
-        else
-#endif
-          *dst = ov[k];
-      }
+      if ((okm >> k) & 1u) tg_store16(out_t + (unsigned)(((pl >> 4) * p.W + (pl & 15)) * p.Cout + ch0) * 2u, ov[k]);
     }
   };
 

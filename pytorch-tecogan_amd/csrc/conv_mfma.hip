@@ -504,7 +504,7 @@ __global__ __launch_bounds__(64 * WC * WP) void conv_gather_kernel(const ConvK p
           float zz[E], vr[E];
           Vec<T>::load(&pre[b][a], zz);
           u32x4 rt;
-          Vec<T>::store(&rt, v);
+          Vec<T>::pack(&rt, v);
           Vec<T>::load(&rt, vr);
 #pragma unroll
           for (int e = 0; e < E; ++e) {

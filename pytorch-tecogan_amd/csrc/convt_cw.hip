@@ -19,6 +19,9 @@
 //   * the (4+1) x (16+1) patch is brought by LDS-DMA (all eight waves, 2 - 4 one-KiB blocks each; positions outside the image read
 //     a page of zeros) into a double buffer one tile ahead; ONE barrier per tile.
 // LDS image (64-byte rows per 32-channel chunk, pitch 24, piece XOR) and packed weights are those of conv3_rw.hip / conv_mfma.hip.
+#ifndef TG_ST_AUX
+#define TG_ST_AUX "sc1"   // this kernel's results are written THROUGH the L2 (common.h, tg_store16; profiles/r05_u_write_through_ab.log)
+#endif
 #include "rbw_common.h"
 #include <atomic>
 #include <type_traits>
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(512) void convt_cw_kernel(const char* a_in, const c
             }
             o[e] = pack2<T>(lo, hi);
           }
-          if (okx && mine.ty0 + b < p.H) *reinterpret_cast<u32x4*>(out_t + (unsigned)((b * 4 * p.W + idx * 2) * p.Cout) * 2u) = o;
+          if (okx && mine.ty0 + b < p.H) tg_store16(out_t + (unsigned)((b * 4 * p.W + idx * 2) * p.Cout) * 2u, o);
         }
       };
       if (p.act == TG_ACT_RELU) finish(std::true_type{});

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(512) void resblock_ws_kernel(const char* a_in, cons
           const float s0 = bits16_to_f32<T>((unsigned short)(rr[e] & 0xffffu)), s1 = bits16_to_f32<T>((unsigned short)(rr[e] >> 16));
           o[e] = pack2<T>(v[2 * e] + sk * s0, v[2 * e + 1] + sk * s1);
         }
-        *reinterpret_cast<u32x4*>(p.out_a + (((size_t)n * p.H + y) * p.W + x) * 128 + (32 * rt + 16 * hi + 8 * kc) * 2) = o;
+        tg_store16(p.out_a + (((size_t)n * p.H + y) * p.W + x) * 128 + (32 * rt + 16 * hi + 8 * kc) * 2, o);
       }
     }
     RBW_STAMP(6);
@@ -453,8 +453,8 @@ __global__ __launch_bounds__(512) void resblock_ws_kernel(const char* a_in, cons
     for (int tw = 0; tw < G::NTW; ++tw) {
       if (st_h[tw]) {
         char* dst = p.out_h + (((size_t)n * p.H + (y0 - 1 + hyv[tw])) * p.W + (x0 - 1 + hxv[tw])) * 128 + (32 * rt + 16 * hi) * 2;
-        *reinterpret_cast<u32x4*>(dst) = pk[tw][0];
-        *reinterpret_cast<u32x4*>(dst + 16) = pk[tw][1];
+        tg_store16(dst, pk[tw][0]);
+        tg_store16(dst + 16, pk[tw][1]);
       }
     }
   }

@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void rgb_bwd_kernel(const RgbBwdK p) {
       }
       if (y < p.H && x < p.W) {
         char* o = p.dx + (((size_t)n * p.H + y) * p.W + x) * 128 + g * 32;
-        *reinterpret_cast<u32x4*>(o) = o0;
-        *reinterpret_cast<u32x4*>(o + 16) = o1;
+        tg_store16(o, o0);
+        tg_store16(o + 16, o1);
       }
     }
     // ---- weight gradient: wave `wid` owns channels 16 wid .. 16 wid + 15, both k-row tiles; K = the tile's 256 pixels

@@ -39,13 +39,13 @@ KNOBS = OrderedDict((k.attr, k) for k in (
        "issue the collectives even with one rank (test hook)"),
     # ---- persistent launches: workgroup caps (kernels.persist_wgs*)
     _k("PERSIST_WGS", "persist_wgs", "oint", None, "profiles/r02_q_persist_wgs_sweep.log",
-       "cap of every persistent launch (unset: G 160, D 96; for steps of <= 4096 LR pixels per pass G 144, its forward launches 192, D real half 80)"),
+       "cap of every persistent launch (unset: G 160, D 96; for steps of <= 4096 LR pixels per pass G 144, its forward launches 160, D real half 80)"),
     _k("PERSIST_WGS_G", "persist_wgs_g", "oint", None, "profiles/r03_r_rw_dma_ab.log", "generator's cap (unset: 144 for steps of <= 4096 LR pixels per pass, else 160)"),
     _k("PERSIST_WGS_D", "persist_wgs_d", "oint", None, "profiles/r02_q_persist_wgs_sweep.log", "discriminator's cap (unset: 96)"),
     _k("PERSIST_WGS_DREAL", "persist_wgs_dreal", "oint", None, "profiles/r05_l_caps_resweep.log",
        "cap of the discriminator's REAL half, which runs beside the chain (unset: 80 for chain-bound steps, else the D cap)"),
-    _k("PERSIST_FWD_G", "persist_fwd_g", "int", 0, "profiles/r04_z_fwd_cap.log",
-       "cap of the generator's FORWARD register-weights launches (the chain, beside the real half); 0: 192 for steps of <= 4096 LR pixels per pass, else the generator's"),
+    _k("PERSIST_FWD_G", "persist_fwd_g", "int", 0, "profiles/r04_z_fwd_cap.log, r05_v_caps_write_through.log",
+       "cap of the generator's FORWARD register-weights launches (the chain, beside the real half); 0: 160 for steps of <= 4096 LR pixels per pass, else the generator's"),
     _k("PERSIST_TRUNK_G", "persist_trunk_g", "int", 0, "profiles/r04_z_trunk_cap.log",
        "cap of the trunk's 32 input-gradient launches in the batched G backward (0: the generator's)"),
     # (round 5 pruned five knobs that every sweep of rounds 2-4 had left at their defaults: PERSIST_RW_G / _D - a separate cap for the
@@ -165,10 +165,12 @@ class Tuning:
     def cap_fwd_g_for(self, lr_pixels):
         """cap of the generator's FORWARD register-weights launches for such a step (0: the generator's cap): the chain's launches
         run beside the real half (80 workgroups; 72 through round 4) and may take more of the chip than the backward pass beside the fake half's 96 -
-        176 / 192 / 208 / 256: 3.727 / 3.735 / 3.763 / 3.751 vs 3.762-3.780 ms at the generator's 144 (profiles/r04_z_fwd_cap.log)"""
+        176 / 192 / 208 / 256: 3.727 / 3.735 / 3.763 / 3.751 vs 3.762-3.780 ms at the generator's 144 (profiles/r04_z_fwd_cap.log).
+        Round 5, with the register-weights kernels' results written through the L2: 128 / 144 / 160 / 176 / 192 / 224 = 3.41-3.42 / 3.41 /
+        3.404-3.406 / 3.42-3.44 / 3.44 / 3.44-3.45 ms (profiles/r05_v_caps_write_through.log)"""
         if self.persist_fwd_g:
             return self.persist_fwd_g
-        return 192 if lr_pixels <= 4096 else 0
+        return 160 if lr_pixels <= 4096 else 0
 
     def cap_dreal_for(self, lr_pixels):
         """cap of the discriminator's REAL half for such a step, or None (environment fixes it / step is not chain-bound)"""
