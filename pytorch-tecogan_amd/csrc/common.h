@@ -66,6 +66,14 @@ __device__ __forceinline__ void tg_store16(void* p, u32x4 v) {
 #endif
 }
 
+__device__ __forceinline__ void tg_store4(float* p, float v) {   // one float, the same way
+#ifdef TG_ST_AUX
+  asm volatile("global_store_dword %0, %1, off " TG_ST_AUX ::"v"(p), "v"(v) : "memory");
+#else
+  *p = v;
+#endif
+}
+
 // Load/store `kVec` consecutive elements (16 bytes) as floats (store: to global memory; pack: anywhere).
 template <typename T> struct Vec;
 template <> struct Vec<F32> {

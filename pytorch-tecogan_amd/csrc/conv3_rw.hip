@@ -437,6 +437,12 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const char* a_in, const c
       }
     }
   };
+  // (Round 5, profiles/r05_x_rw_producer_diag.log: every byte the producers move goes through the CU's vector-memory pipe at ~25 B/clk -
+  // 64 KB per tile of a masked input-gradient = 2600 ticks in the issue queue, THEN 1300 of arithmetic: 4350 against the consumers'
+  // 3300-3600; without the stores, the DMA or the row loads the launch is consumer-bound (147 -> 116 us on c6's input-gradient).  Two
+  // re-orderings that would overlap the arithmetic with the queueing were built and measured SLOWER: group-wise interleaving of store /
+  // DMA / row load / arithmetic (203 us: a dozen uniform branches and their joins per group) and two waves computing first and
+  // storing last from a second register set (163 us).)
   // The epilogue of a tile is split over two iterations: COMPUTE (accumulator image -> 16-bit results in registers) while the
   // consumers multiply the next tile, and the STORES of those registers at the top of the following iteration.  That way the only
   // vector-memory operations an iteration issues behind its DMA are loads whose data is needed an iteration later, so the wait in
@@ -589,7 +595,9 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const char* a_in, const c
   for (int i = 0; i <= ntl; ++i, tile += (int)gridDim.x) {
     st_it = i;
     RW_STAMP(4 + 6 * i + 0);
+#ifndef RW_DIAG_NOSTORE   // (diagnostic builds, tools/stamp_rw.py + profiles/r05_x_rw_producer_diag.log: what does each part of the producers' issue phase cost?)
     if (i >= 2) store_results();   // tile i - 2, computed during iteration i - 1
+#endif
     // the previous tile's mask / residual rows arrived during iteration i - 1 (its vmcnt(0)); taken over into registers the compiler
     // does not connect with a load any more, so that nothing below waits on the vector-memory counter
     u32x4 mk[G::KS];
@@ -602,9 +610,13 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const char* a_in, const c
     prev = cur;
     if (i + 1 < ntl) {
       cur = tile_of(tile + (int)gridDim.x);
+#ifndef RW_DIAG_NODMA
       dma_patch(cur, (i + 1) & 1);
+#endif
     }
+#ifndef RW_DIAG_NOROWS
     if (i < ntl) issue_pre(prev);
+#endif
     RW_STAMP(4 + 6 * i + 1);
     // the previous tile's accumulators were published by the barrier that ended iteration i - 1
     if (i >= 1) {

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512) void wgrad_group_kernel(const WgGroupK p) {
       for (int b = 0; b < NF; ++b) {
         const int bch = (wb * NF + b) * 16 + idx;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) slab[(t * 64 + wa * 16 + 4 * g + j) * CB + bch] = acc[t][b][j];
+        for (int j = 0; j < 4; ++j) tg_store4(&slab[(t * 64 + wa * 16 + 4 * g + j) * CB + bch], acc[t][b][j]);
       }
     __syncthreads();  // every wave is done with the LDS images (the next segment's DMA, or the sums below, overwrite them)
     if (want_ysum) {
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(512) void wgrad_group_ws_kernel(const WgGroupK p) {
 #pragma unroll
         for (int b = 0; b < NF; ++b) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) sl[(t * 64 + j) * CB + b * 16] = acc[t][b][j];
+          for (int j = 0; j < 4; ++j) tg_store4(&sl[(t * 64 + j) * CB + b * 16], acc[t][b][j]);
         }
     } else {
       // ======================================================================================================= PRODUCER

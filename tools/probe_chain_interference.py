@@ -34,6 +34,11 @@ one = torch.zeros(64, device=dev)
 empty = graph_of(lambda: [one.fill_(1.0) for _ in range(125)])
 big_a, big_b = torch.empty(64 << 20, device=dev), torch.empty(64 << 20, device=dev)   # 256 MB each
 stream8 = graph_of(lambda: [big_b.copy_(big_a) for _ in range(8)])                      # 8 x 512 MB of traffic
+writes8 = graph_of(lambda: [big_b.fill_(1.0) for _ in range(16)])                       # 16 x 256 MB written, nothing read (round 5)
+acc_r = torch.zeros(1, device=dev)
+reads8 = graph_of(lambda: [torch.sum(big_a, dim=0, keepdim=True, out=acc_r) for _ in range(16)])   # 16 x 256 MB read, nothing written
+small_w = torch.empty(1 << 20, device=dev)                                              # 4 MB: stays in the L2s
+writes_small = graph_of(lambda: [small_w.fill_(1.0) for _ in range(125)])               # 125 launches that dirty 4 MB each
 compute = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
 gemm = graph_of(lambda: [torch.mm(compute, compute) for _ in range(3)])
 
@@ -65,4 +70,7 @@ run("chain alone", None)
 run("chain || real half of D (prep + d_real graphs)", dreal)
 run("chain || 125 empty launches", empty.replay)
 run("chain || 8 x 256-MB device copies (4 GB of traffic)", stream8.replay)
+run("chain || 16 x 256-MB fills (writes only)", writes8.replay)
+run("chain || 16 x 256-MB sums (reads only)", reads8.replay)
+run("chain || 125 x 4-MB fills (dirty lines, many boundaries)", writes_small.replay)
 run("chain || 3 bf16 GEMMs 8192^3 (dense MFMA, few launches)", gemm.replay)
