@@ -156,6 +156,8 @@ def kernel_name(conv, dtype):
         return f"conv_s2_gather_kernel<{TAG[dtype]}, {4 if conv.last_desc == 'c4s2' else 3}>"
     if conv.last_desc == "rgb":  # csrc/conv_rgb.hip (the generator's output layer)
         return f"conv_rgb_kernel<{TAG[dtype]}>"
+    if conv.last_desc == "ctcw":  # csrc/convt_cw.hip (conv-transpose forward, class-specialised waves)
+        return f"convt_cw_kernel<{conv.last_rw_nch}, {TAG[dtype]}>"
     if conv.last_desc == "rw":  # csrc/conv3_rw.hip (NCH = input channels / 32; statistics variant not distinguished)
         return f"conv3_rw_kernel<{conv.last_rw_nch}, ..>"
     plan = L.load().tg_conv_pick_tile(ctypes.byref(conv.last_desc))

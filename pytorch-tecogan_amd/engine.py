@@ -183,7 +183,7 @@ class Conv:
                 nchw is None and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and self.tile == L.TILE_AUTO and \
                 self.dt in (torch.bfloat16, torch.float16) and self.tu.ct_cw:
             # persistent workgroups, one sub-pixel class per wave, weights in registers (csrc/convt_cw.hip, round 5)
-            self.last_desc = None
+            self.last_desc, self.last_rw_nch = "ctcw", self.cin_p // 32
             K.convt_fwd_cw(x, self.wf, self.bias, out, act, max_workgroups=self.persist_fwd or self.persist_rw or self.persist_wgs)
             return
         if self.spec.kind == "ct" and self.cout_p % 64 == 0 and res is None and stats is None and nchw is None and \
