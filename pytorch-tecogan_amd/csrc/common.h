@@ -94,7 +94,11 @@ template <> struct Vec<F32> {
 template <> struct Vec<BF16> {
   static constexpr int N = 8;
   __device__ __forceinline__ static void load(const void* p, float* v) {
+#ifdef TG_VEC_LD_NT   // A/B only (profiles/r05_u_write_through_ab.log, section 6): streaming reads that leave the L2 to the other lane
+    u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+#else
     u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       v[2 * i] = __uint_as_float(t[i] << 16);

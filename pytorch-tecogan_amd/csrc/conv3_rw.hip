@@ -343,6 +343,11 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const char* a_in, const c
         const int iy = tl.ty0 + dpy[u], ix = tl.tx0 + dpx[u];
         const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);   // (no short-circuit branches)
         const char* src = in_n + (unsigned)((iy * p.W + ix) * (int)pix_bytes + dof[u]);    // (an image is < 4 GB)
+#ifdef RW_DMA_NT_BYTES   // A/B only (profiles/r05_u_write_through_ab.log, section 6): inputs too large for the L2s are streamed past them
+        if ((size_t)p.N * p.H * p.W * pix_bytes >= (size_t)RW_DMA_NT_BYTES)
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(ok ? src : p.zero), "s"(dst0 + u * 4096) : "memory", "m0");
+        else
+#endif
         glds16(ok ? src : p.zero, dst0 + u * 4096);
       }
     }

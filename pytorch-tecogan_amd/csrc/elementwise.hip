@@ -3,6 +3,11 @@
 // All kernels move 16 bytes per lane per access; per-channel quantities are kept in registers because a thread's
 // channel vector is fixed for its whole grid-stride loop.
 #include "common.h"
+#ifdef TG_VEC_LD_NT   // A/B only: the tensors these kernels stream are read once (profiles/r05_u_write_through_ab.log, section 6)
+#define TG_LDG16(p) __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p))
+#else
+#define TG_LDG16(p) (*reinterpret_cast<const u32x4*>(p))
+#endif
 #include <type_traits>
 
 namespace {
@@ -81,8 +86,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ 
   for (int u = 0; u < 4; ++u) {
     const long long pix = p + u * step < npix ? p + u * step : npix - 1;
     const long long off = ((base + pix) * C + vec * E) * TR::kBytes;
-    rz[u] = *reinterpret_cast<const u32x4*>(z + off);
-    if (skip) rs[u] = *reinterpret_cast<const u32x4*>(skip + off);
+    rz[u] = TG_LDG16(z + off);
+    if (skip) rs[u] = TG_LDG16(skip + off);
   }
   float scale[E], shift[E], sum1[E], sum2[E];
   load_folded<E>(stats_rep + (grp * 2 + 0) * C + vec * E, R, rblock, sum1);
@@ -244,9 +249,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const char* __restric
   for (int u = 0; u < 4; ++u) {
     const long long pix = p + u * step < npix ? p + u * step : npix - 1;
     const long long off = ((base + pix) * C + vec * E) * TR::kBytes;
-    rd[u] = *reinterpret_cast<const u32x4*>(dy + off);
-    rz[u] = *reinterpret_cast<const u32x4*>(z + off);
-    if (act == TG_ACT_LRELU) ra[u] = *reinterpret_cast<const u32x4*>(yact + off);
+    rd[u] = TG_LDG16(dy + off);
+    rz[u] = TG_LDG16(z + off);
+    if (act == TG_ACT_LRELU) ra[u] = TG_LDG16(yact + off);
   }
   float mean[E], invstd[E], k0[E], m1[E], m2[E];
   load_folded<E>(red_rep + (grp * 2 + 0) * C + vec * E, R, rblock, m1);
@@ -351,9 +356,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
   for (int u = 0; u < U; ++u) {   // every load of the launch goes out before anything is used (raw, from clamped addresses)
     const long long pix = p + u * step < npix ? p + u * step : npix - 1;
     const long long off = ((base + pix) * C + vec * E) * TR::kBytes;
-    rd[u] = *reinterpret_cast<const u32x4*>(dy + off);
-    rz[u] = *reinterpret_cast<const u32x4*>(z + off);
-    if (act == TG_ACT_LRELU) ra[u] = *reinterpret_cast<const u32x4*>(yact + off);
+    rd[u] = TG_LDG16(dy + off);
+    rz[u] = TG_LDG16(z + off);
+    if (act == TG_ACT_LRELU) ra[u] = TG_LDG16(yact + off);
   }
   float mean[E], invstd[E], k0[E], s1[E], s2[E];
 #pragma unroll
@@ -486,9 +491,9 @@ __global__ __launch_bounds__(kBfThreads) void bn_bwd_fused_kernel(const char* __
   for (int u = 0; u < kBfTrips; ++u) {  // every load of the launch goes out before anything is used
     const int pix = threadIdx.x + u * kBfThreads;
     const long long off = ((base + (pix < npix ? pix : npix - 1)) * C + vec * E) * TR::kBytes;
-    rd[u] = *reinterpret_cast<const u32x4*>(dy + off);
-    rz[u] = *reinterpret_cast<const u32x4*>(z + off);
-    if (act == TG_ACT_LRELU) ra[u] = *reinterpret_cast<const u32x4*>(yact + off);
+    rd[u] = TG_LDG16(dy + off);
+    rz[u] = TG_LDG16(z + off);
+    if (act == TG_ACT_LRELU) ra[u] = TG_LDG16(yact + off);
   }
   float mean[E], invstd[E], k0[E], s[2 * E];
 #pragma unroll
