@@ -60,7 +60,9 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
 // only makes its waits conservative - the counter is in order.)
 __device__ __forceinline__ void tg_store16(void* p, u32x4 v) {
 #ifdef TG_ST_AUX
-  asm volatile("global_store_dwordx4 %0, %1, off " TG_ST_AUX ::"v"(p), "v"(v) : "memory");
+  // (s_nop 1: a store of more than 8 bytes whose data registers the NEXT vector instruction overwrites needs wait states; the compiler
+  // inserts them for its own stores and cannot see into this one)
+  asm volatile("global_store_dwordx4 %0, %1, off " TG_ST_AUX "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #else
   *reinterpret_cast<u32x4*>(p) = v;
 #endif
