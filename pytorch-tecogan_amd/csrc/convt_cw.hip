@@ -91,7 +91,12 @@ __global__ __launch_bounds__(512) void convt_cw_kernel(const char* a_in, const c
   const int idx = lane & 15, g = lane >> 4;
   const int wc = wid & 1;                                     // channel half: packed rows 32 wc .. + 31
   // waves w and w + 4 share a SIMD: SIMDs 0 / 1 run classes 3 (w < 4) and 0, SIMDs 2 / 3 classes 1 and 2
-  const int cls = ((wid >> 1) & 1) ? ((wid >> 2) ? 2 : 1) : ((wid >> 2) ? 0 : 3);
+#ifndef CW_PAIRING
+#define CW_PAIRING 0   // A/B (profiles/r05_r_convt_cw_ab.log, section 5): 1 = classes 3 + 1 / 2 + 0 per SIMD pair, 2 = 3 + 2 / 1 + 0
+#endif
+  const int cls = CW_PAIRING == 0 ? (((wid >> 1) & 1) ? ((wid >> 2) ? 2 : 1) : ((wid >> 2) ? 0 : 3))
+                  : CW_PAIRING == 1 ? (((wid >> 1) & 1) ? ((wid >> 2) ? 0 : 2) : ((wid >> 2) ? 1 : 3))
+                                    : (((wid >> 1) & 1) ? ((wid >> 2) ? 0 : 1) : ((wid >> 2) ? 2 : 3));
   const int co_base = blockIdx.y * 64;
   const int ntl = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -188,7 +193,10 @@ __global__ __launch_bounds__(512) void convt_cw_kernel(const char* a_in, const c
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{bias_r[4 * a], bias_r[4 * a + 1], bias_r[4 * a + 2], bias_r[4 * a + 3]};
       // k-loop: NS steps of 4 B-fragment reads + 8 MFMAs, the fragments of steps s + 1 and s + 2 in flight while step s multiplies
-      bf16x8 xf[3][4];
+#ifndef CW_DEPTH
+#define CW_DEPTH 3   // fragment sets in flight (A/B: 2)
+#endif
+      bf16x8 xf[CW_DEPTH][4];
       auto frags = [&](int s_, int buf) {   // compile-time arguments after unrolling
         const int ci = s_ / NT, t = s_ % NT;
 #pragma unroll
@@ -196,16 +204,20 @@ __global__ __launch_bounds__(512) void convt_cw_kernel(const char* a_in, const c
           xf[buf][b] = *reinterpret_cast<const bf16x8*>(img + ci * kChunkBytes + xb[b][TP::dx[t]] + TP::dy[t] * kPitch * kRow);
       };
       frags(0, 0);
-      if (NS > 1) frags(1, 1);
+      if (NS > 1 && CW_DEPTH > 2) frags(1, 1);
 #pragma unroll
       for (int s_ = 0; s_ < NS; ++s_) {
-        if (s_ + 2 < NS) frags(s_ + 2, (s_ + 2) % 3);
+        if (s_ + CW_DEPTH - 1 < NS) frags(s_ + CW_DEPTH - 1, (s_ + CW_DEPTH - 1) % CW_DEPTH);
+#ifdef CW_SCHED_BARRIER   // (A/B: fencing every k-step as conv3_rw does costs 1-5 % here - two waves per SIMD fill each other's gaps)
         __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-          for (int a = 0; a < 2; ++a) acc[a][b] = mma<T>(wfr[s_ / NT][s_ % NT][a], xf[s_ % 3][b], acc[a][b]);
+          for (int a = 0; a < 2; ++a) acc[a][b] = mma<T>(wfr[s_ / NT][s_ % NT][a], xf[s_ % CW_DEPTH][b], acc[a][b]);
+#ifdef CW_SCHED_BARRIER   // (A/B: fencing every k-step as conv3_rw does costs 1-5 % here - two waves per SIMD fill each other's gaps)
         __builtin_amdgcn_sched_barrier(0);
+#endif
       }
       if (i < 6) CW_STAMP(4 + 4 * i + 2);
       // epilogue from the accumulators: input pixel (ty0 + b, tx0 + idx) -> output pixel (2 y + oy, 2 x + ox), 8 channels = 16 bytes
