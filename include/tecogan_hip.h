@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 3   /* 3 (round 5): + tg_convt_fwd_cw; 2 (round 5): + tg_resblock_fwd_ws; round 4 removed tg_wgrad_group / tg_absdiff_nchw and moved the
+#define TG_ABI_VERSION 3   /* 3 (round 5): + tg_convt_fwd_cw, tg_conv3x3_cw; 2 (round 5): + tg_resblock_fwd_ws; round 4 removed tg_wgrad_group / tg_absdiff_nchw and moved the
                            * rejected variants behind TG_EXPERIMENTS without a bump */
 
 enum { TG_F32 = 0, TG_BF16 = 1, TG_F16 = 2 };  /* TG_F16: IEEE half, same layouts as TG_BF16 (loss scaling: tg_adam) */
@@ -123,6 +123,14 @@ int tg_conv(const tg_conv_desc* d, const void* in, const void* w_packed, const f
  * [stats_groups][2][Cout], ACCUMULATED - see "replica blocks" at tg_bn_apply).
  * max_workgroups: 0 = one per CU (256); the grid is min(tiles, max_workgroups / (Cout/64)) x Cout/64. */
 int tg_conv3x3_rw(int dtype, const void* in, const void* w_packed, const float* bias, const void* res, const void* mask,
+                  void* out, float* stats, int N, int H, int W, int Cin, int Cout, int flip, int act, int mask_mode,
+                  int stats_mode, int stats_groups, int stats_replicas, int max_workgroups, void* stream);
+
+/* The same operation, arguments and results (up to the fp32 summation order of the statistics) for Cin = 64 with EIGHT EQUAL WAVES
+ * (csrc/conv3_cw.hip, round 5): every wave keeps the 9 taps' weights of 32 output channels in registers, multiplies 2 of the tile's
+ * 8 rows, brings its share of the next patch by LDS-DMA and finishes its pixels straight from the accumulators - no producer /
+ * consumer roles, no accumulator image, one barrier per tile.  TG_E_UNSUPPORTED unless Cin == 64 (tg_conv3x3_rw takes 128). */
+int tg_conv3x3_cw(int dtype, const void* in, const void* w_packed, const float* bias, const void* res, const void* mask,
                   void* out, float* stats, int N, int H, int W, int Cin, int Cout, int flip, int act, int mask_mode,
                   int stats_mode, int stats_groups, int stats_replicas, int max_workgroups, void* stream);
 

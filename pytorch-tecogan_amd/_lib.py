@@ -54,6 +54,7 @@ _PROTOS = {
     "tg_conv_pick_tile": (_I, [C.POINTER(ConvDesc)]),
     "tg_conv": (_I, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "tg_conv3x3_rw": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "tg_conv3x3_cw": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "tg_wgrad_slab_floats": (_L, [C.POINTER(WgradDesc)]),
     "tg_wgrad": (_I, [C.POINTER(WgradDesc), _P, _P, _P, _P]),
     "tg_wgrad_multi": (_I, [C.POINTER(WgradDesc), _P, _I, _P]),

@@ -210,7 +210,7 @@ class Conv:
                 and not self.rw_off and K.rw_eligible(self.dt, self.cin_p, self.cout_p, N, H, W, extra=self.rw_extra, tu=self.tu):
             self.last_desc, self.last_rw_nch = "rw", self.cin_p // 32  # persistent register-weights kernel (csrc/conv3_rw.hip)
             K.conv3x3_rw(x, self.wf, out, False, bias=self.bias, res=res, act=act, stats=stats, stats_mode=2, groups=groups,
-                         stats_replicas=stats_r, max_workgroups=self.persist_fwd or self.persist_rw or self.persist_wgs)
+                         stats_replicas=stats_r, max_workgroups=self.persist_fwd or self.persist_rw or self.persist_wgs, cw=self.tu.c3_cw)
             return
         key = ("f", N, H, W, act, res is not None, stats is not None, groups, nchw is not None and nchw[2:], stats_r)
         ent = self._desc.get(key)
@@ -281,7 +281,7 @@ class Conv:
                                                   extra=self.rw_extra, dgrad=True, tu=self.tu):
             self.last_desc, self.last_rw_nch = "rw", self.cout_p // 32  # the input-gradient of a 3x3 conv is the same conv with mirrored taps
             K.conv3x3_rw(dout, self.wb, out, True, res=res, mask=mask, mask_mode=mask_mode, stats=st, stats_mode=1,
-                         max_workgroups=self.persist_dgrad or self.persist_rw or self.persist_wgs)
+                         max_workgroups=self.persist_dgrad or self.persist_rw or self.persist_wgs, cw=self.tu.c3_cw)
             return
         key = ("d", N, OH, OW, mask_mode, res is not None, st is not None)
         ent = self._desc.get(key)

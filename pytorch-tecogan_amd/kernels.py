@@ -172,15 +172,25 @@ def conv(desc, x, w_packed, out, bias=None, res=None, mask=None, stats=None):
                              _ptr(stats), _stream()), "tg_conv")
 
 
+C3_CW_FORCE = None   # tests: True / False overrides TECOGAN_C3_CW for conv3x3_rw's Cin = 64 launches
+
+
 def conv3x3_rw(x, w_packed, out, flip=False, bias=None, res=None, mask=None, mask_mode=L.MASK_NONE, act=L.ACT_NONE,
-               stats=None, stats_mode=2, groups=1, max_workgroups=0, stats_replicas=1):
+               stats=None, stats_mode=2, groups=1, max_workgroups=0, stats_replicas=1, cw=None):
     """3x3 stride-1 conv / input-gradient through the persistent register-weights kernel (csrc/conv3_rw.hip):
     x [N,H,W,Cin] -> out [N,H,W,Cout], bf16, Cin in {64,128}, Cout % 64 == 0"""
     N, H, W, cin = x.shape
-    L.check(L.load().tg_conv3x3_rw(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(res), _ptr(mask), _ptr(out),
-                                   _ptr(stats), N, H, W, cin, out.shape[3], int(flip), act,
-                                   mask_mode if mask is not None else L.MASK_NONE, stats_mode, groups, stats_replicas,
-                                   max_workgroups or persist_wgs(None), _stream()), "tg_conv3x3_rw")
+    # 64 reduction channels: the eight-equal-waves form (csrc/conv3_cw.hip, round 5) unless TECOGAN_C3_CW=0
+    if C3_CW_FORCE is not None:
+        cw = C3_CW_FORCE
+    elif cw is None:
+        cw = tuning.current().c3_cw
+    cw = cw and cin == 64 and (stats is None or C3_CW_FORCE)   # (launches with statistics: 17.9 vs 17.0 us - they stay on conv3_rw)
+    fn, name = (L.load().tg_conv3x3_cw, "tg_conv3x3_cw") if cw else (L.load().tg_conv3x3_rw, "tg_conv3x3_rw")
+    L.check(fn(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(res), _ptr(mask), _ptr(out),
+               _ptr(stats), N, H, W, cin, out.shape[3], int(flip), act,
+               mask_mode if mask is not None else L.MASK_NONE, stats_mode, groups, stats_replicas,
+               max_workgroups or persist_wgs(None), _stream()), name)
 
 
 def rw_eligible(dtype_t, cin_p, cout_p, N, H, W, masked=False, extra="", dgrad=False, tu=None):

@@ -18,6 +18,15 @@ DEV = "cuda:0"
 BF = torch.bfloat16
 
 
+@pytest.fixture(autouse=True, params=["rw", "cw"])
+def which_kernel(request):
+    """every case runs on csrc/conv3_rw.hip (producer / consumer waves) and, for 64 reduction channels, on csrc/conv3_cw.hip (eight
+    equal waves, round 5): K.conv3x3_rw routes by K.C3_CW_FORCE"""
+    K.C3_CW_FORCE = request.param == "cw"
+    yield request.param
+    K.C3_CW_FORCE = None
+
+
 def rnd(shape, seed, lo=-1.0, hi=1.0):
     return torch.from_numpy(np.random.default_rng(seed).uniform(lo, hi, size=shape).astype(np.float32))
 
