@@ -186,6 +186,9 @@ __global__ __launch_bounds__(512) void conv3_cw_kernel(const char* a_in, const c
                     : (p.mask_mode == TG_MASK_RELU && !p.res && !p.bias && p.act == TG_ACT_NONE) ? 1
                     : (p.mask_mode == TG_MASK_NONE && p.res && !p.bias && p.act == TG_ACT_NONE) ? 2 : 3;
   const float act_slope = p.act == TG_ACT_RELU ? 0.f : p.act == TG_ACT_LRELU ? 0.2f : 1.f;   // activation as max(v, slope * v)
+  float acc0[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc0[e] = (!STATS && emode == 0) ? bias_r[e] : 0.f;   // (the statistics instantiations have no registers to spare)
 
   // per-channel statistics of the stored values: lanes (the 16 pixels of a row) -> wave -> the eight waves through an LDS accumulator
   // -> ONE global atomic per channel and workgroup, issued by whichever wave arrives last (a ticket in LDS)
@@ -280,11 +283,11 @@ __global__ __launch_bounds__(512) void conv3_cw_kernel(const char* a_in, const c
       }
     }
     const char* img = smem + (i & 1) * kBufBytes;
-    f32x4 acc[2][2];
+    f32x4 acc[2][2];   // the forward form starts from the bias (acc0: zeros in every other form)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{acc0[4 * a], acc0[4 * a + 1], acc0[4 * a + 2], acc0[4 * a + 3]};
     // k-loop: 18 steps (2 chunks x 9 taps) of 2 B-fragment reads + 4 MFMAs, kDepth - 1 steps' fragments in flight
     bf16x8 xf[kDepth][2];
     auto frags = [&](int s_, int buf) {   // compile-time arguments after unrolling
@@ -339,11 +342,17 @@ __global__ __launch_bounds__(512) void conv3_cw_kernel(const char* a_in, const c
           v[e] = acc[0][b][e];
           v[4 + e] = acc[1][b][e];
         }
-        if constexpr (M == 0) {
+        if constexpr (M == 0) {   // (the bias is in the accumulators already; the vector instructions of an epilogue are not hidden by
+          if constexpr (STATS) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            v[e] += bias_r[e];                         // (zeros without a bias)
-            v[e] = fmaxf(v[e], act_slope * v[e]);
+            for (int e = 0; e < 8; ++e) v[e] += bias_r[e];
+          }
+          if (p.act == TG_ACT_RELU) {   //  the matrix stream: one max instead of multiply + max per value where the activation allows)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          } else if (p.act == TG_ACT_LRELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.2f * v[e]);
           }
         } else if constexpr (M == 1) {
           // mask value > 0 on its 16-bit pattern (sign clear, not zero): the low half as the sign of word << 16, the high half as word > 0xffff
