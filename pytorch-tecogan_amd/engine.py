@@ -208,7 +208,8 @@ class Conv:
             return
         if self.spec.kind == "c3" and nchw is None and self.tile == L.TILE_AUTO and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) \
                 and not self.rw_off and K.rw_eligible(self.dt, self.cin_p, self.cout_p, N, H, W, extra=self.rw_extra, tu=self.tu):
-            self.last_desc, self.last_rw_nch = "rw", self.cin_p // 32  # persistent register-weights kernel (csrc/conv3_rw.hip)
+            # persistent register-weights kernel (csrc/conv3_rw.hip; 64 input channels without statistics: csrc/conv3_cw.hip)
+            self.last_desc, self.last_rw_nch = ("c3cw" if (self.tu.c3_cw and self.cin_p == 64 and stats is None) else "rw"), self.cin_p // 32
             K.conv3x3_rw(x, self.wf, out, False, bias=self.bias, res=res, act=act, stats=stats, stats_mode=2, groups=groups,
                          stats_replicas=stats_r, max_workgroups=self.persist_fwd or self.persist_rw or self.persist_wgs, cw=self.tu.c3_cw)
             return
@@ -279,7 +280,8 @@ class Conv:
         if self.spec.kind == "c3" and self.tile == L.TILE_AUTO and \
                 not self.rw_off and K.rw_eligible(self.dt, self.cout_p, self.cin_p, N, H, W, masked=mask is not None,
                                                   extra=self.rw_extra, dgrad=True, tu=self.tu):
-            self.last_desc, self.last_rw_nch = "rw", self.cout_p // 32  # the input-gradient of a 3x3 conv is the same conv with mirrored taps
+            # the input-gradient of a 3x3 conv is the same conv with mirrored taps
+            self.last_desc, self.last_rw_nch = ("c3cw" if (self.tu.c3_cw and self.cout_p == 64 and st is None) else "rw"), self.cout_p // 32
             K.conv3x3_rw(dout, self.wb, out, True, res=res, mask=mask, mask_mode=mask_mode, stats=st, stats_mode=1,
                          max_workgroups=self.persist_dgrad or self.persist_rw or self.persist_wgs, cw=self.tu.c3_cw)
             return

@@ -563,8 +563,9 @@ def test_bench_contract_line_with_roofline_pass():
         return [r for r in rows if short(r["Name"]).startswith(st + ",") or short(r["Name"]).startswith(st + ">")]
     tot = {k: sum(float(r["TotalDurationNs"]) for r in fam_rows(k)) for k in rf["families"] if "wgrad" not in k}
     top = max(tot, key=tot.get)
-    # round 4: since the chain's forward convolutions moved to it the register-weights family (Cin = 64) is the largest, in the
-    # bench's brackets and in the profiler's rows alike (the fused trunk block was, through round 3)
+    # round 4: since the chain's forward convolutions moved to it the register-weights family (Cin = 64) was the largest, in the
+    # bench's brackets and in the profiler's rows alike (the fused trunk block was, through round 3); round 5: most of its launches
+    # run on conv3_cw_kernel now, and the Cin = 128 family of conv3_rw is the largest
     assert top == rf["kernel"], (top, rf["kernel"], sorted(tot.items(), key=lambda kv: -kv[1])[:4])
     prof_us = tot[top] / sum(float(r["Calls"]) for r in fam_rows(top)) / 1e3
     # (rocprofv3's kernel trace dispatches the two lanes' kernels almost serially - profiles/r03_overlap.json: 12 % of the
