@@ -342,7 +342,8 @@ __global__ __launch_bounds__(512) void conv3_cw_kernel(const char* a_in, const c
           v[e] = acc[0][b][e];
           v[4 + e] = acc[1][b][e];
         }
-        if constexpr (M == 0) {   // (the bias is in the accumulators already; the vector instructions of an epilogue are not hidden by
+        if constexpr (M < 0) {    // (C3_DIAG_NOEPI)
+        } else if constexpr (M == 0) {   // (the bias is in the accumulators already; the vector instructions of an epilogue are not hidden by
           if constexpr (STATS) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += bias_r[e];
@@ -410,10 +411,15 @@ __global__ __launch_bounds__(512) void conv3_cw_kernel(const char* a_in, const c
         if (ok) tg_store16(out_t + (unsigned)((b * p.W + idx) * p.Cout) * 2u, o);
       }
     };
+#ifdef C3_DIAG_NOEPI   // diagnostic (timing only, results wrong): no epilogue arithmetic - what would fewer vector instructions buy?
+    if (emode < 0) finish(std::integral_constant<int, 0>{});
+    else finish(std::integral_constant<int, -1>{});
+#else
     if (emode == 0) finish(std::integral_constant<int, 0>{});
     else if (emode == 1) finish(std::integral_constant<int, 1>{});
     else if (emode == 2) finish(std::integral_constant<int, 2>{});
     else finish(std::integral_constant<int, 3>{});
+#endif
     // (the next tile's patch has landed: it was requested before this tile's rows, and those have been waited for - the counter is in order)
     if (i < 6) C3_STAMP(4 + 4 * i + 3);
   }
