@@ -158,6 +158,8 @@ def kernel_name(conv, dtype):
         return f"conv_rgb_kernel<{TAG[dtype]}>"
     if conv.last_desc == "ctcw":  # csrc/convt_cw.hip (conv-transpose forward, class-specialised waves)
         return f"convt_cw_kernel<{conv.last_rw_nch}, {TAG[dtype]}>"
+    if conv.last_desc == "c4dcw":  # csrc/conv4s2d_cw.hip (input-gradient of the 4x4 stride-2 convs, class-specialised waves)
+        return f"conv4s2d_cw_kernel<{conv.last_rw_nch}, {TAG[dtype]}>"
     if conv.last_desc == "c3cw":  # csrc/conv3_cw.hip (64 reduction channels, no statistics: eight equal waves)
         return f"conv3_cw_kernel<0, {TAG[dtype]}>"
     if conv.last_desc == "rw":  # csrc/conv3_rw.hip (NCH = input channels / 32; statistics variant not distinguished)

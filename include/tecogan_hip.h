@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 3   /* 3 (round 5): + tg_convt_fwd_cw, tg_conv3x3_cw; 2 (round 5): + tg_resblock_fwd_ws; round 4 removed tg_wgrad_group / tg_absdiff_nchw and moved the
+#define TG_ABI_VERSION 3   /* 3 (round 5): + tg_convt_fwd_cw, tg_conv3x3_cw, tg_conv4s2_dgrad_cw; 2 (round 5): + tg_resblock_fwd_ws; round 4 removed tg_wgrad_group / tg_absdiff_nchw and moved the
                            * rejected variants behind TG_EXPERIMENTS without a bump */
 
 enum { TG_F32 = 0, TG_BF16 = 1, TG_F16 = 2 };  /* TG_F16: IEEE half, same layouts as TG_BF16 (loss scaling: tg_adam) */
@@ -163,6 +163,14 @@ int tg_conv4s2_fwd(int dtype, const void* in, const void* w_packed, const float*
  * below, the result is multiplied by act'(mask) (TG_MASK_*).  TG_E_UNSUPPORTED unless Cin % 64 == 0 (use tg_conv then). */
 int tg_conv4s2_dgrad(int dtype, const void* dout, const void* w_dgrad_packed, void* din, int N, int OH, int OW, int Cout,
                      int Cin, const void* mask, int mask_mode, void* stream);
+
+/* The same input-gradient (same arguments and results up to the fp32 summation order) with CLASS-SPECIALISED waves
+ * (csrc/conv4s2d_cw.hip, round 5; the structure of tg_convt_fwd_cw): persistent workgroups over 4 x 16 tiles of dout, one
+ * sub-pixel class x 32 output channels per wave with its 4 slots' weights in registers, act'(mask) and the stores straight
+ * from the accumulators.  bf16 / fp16, Cout (the reduction) in {64, 128}, Cin % 64 == 0, else TG_E_UNSUPPORTED.
+ * max_workgroups: 0 = one per CU. */
+int tg_conv4s2_dgrad_cw(int dtype, const void* dout, const void* w_dgrad_packed, void* din, int N, int OH, int OW, int Cout,
+                        int Cin, const void* mask, int mask_mode, int max_workgroups, void* stream);
 
 /* Input-gradient of the conv-transpose layers (autograd of code/ops.py:45-54) with the same kernel structure (3x3-window
  * stride-2 gather): dout [N][OH][OW][Cout] (OH, OW even) -> din [N][OH/2][OW/2][Cin]; w_dgrad_packed = the role-swapped

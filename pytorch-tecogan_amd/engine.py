@@ -268,6 +268,15 @@ class Conv:
             self.last_desc = "ctd"  # 3x3-window stride-2 gather (csrc/conv4s2_mfma.hip, KS = 3)
             K.convt_dgrad(dout, self.wb, out)
             return
+        if self.spec.kind == "c4s2" and self.cin_p % 64 == 0 and self.cout_p in (64, 128) and res is None and bias_grad_of is None and \
+                self.tu.c4d_cw and self.dt in (torch.bfloat16, torch.float16) and H == 2 * OH and W == 2 * OW and \
+                mask_mode in (L.MASK_NONE, L.MASK_RELU, L.MASK_LRELU) and \
+                N * ((OH + 3) // 4) * ((OW + 15) // 16) * (self.cin_p // 64) >= 48:
+            # persistent workgroups, one sub-pixel class per wave (csrc/conv4s2d_cw.hip, round 5)
+            self.last_desc, self.last_rw_nch = "c4dcw", self.cout_p // 32
+            K.conv4s2_dgrad_cw(dout, self.wb, out, mask, mask_mode if mask is not None else L.MASK_NONE,
+                               max_workgroups=self.persist_dgrad or self.persist_rw or self.persist_wgs)
+            return
         if self.spec.kind == "c4s2" and self.cin_p % 64 == 0 and res is None and bias_grad_of is None and \
                 self.tu.fast_c4s2 and H == 2 * OH and W == 2 * OW and N * ((OH + 7) // 8) * ((OW + 15) // 16) * (self.cin_p // 64) >= 64:
             # four-class sub-pixel launch (csrc/convt_mfma.hip, PAT 1).  Measured (tools/mb_c4s2_dgrad.py, 24 samples):

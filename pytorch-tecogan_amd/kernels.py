@@ -416,6 +416,14 @@ def conv4s2_dgrad(dout, wb_packed, din, mask=None, mask_mode=L.MASK_NONE):
                                       din.shape[3], _ptr(mask), mask_mode, _stream()), "tg_conv4s2_dgrad")
 
 
+def conv4s2_dgrad_cw(dout, wb_packed, din, mask=None, mask_mode=L.MASK_NONE, max_workgroups=0):
+    """the same input-gradient on persistent workgroups with class-specialised waves (csrc/conv4s2d_cw.hip): reduction channels 64 / 128"""
+    N, OH, OW, cout = dout.shape
+    L.check(L.load().tg_conv4s2_dgrad_cw(tg_dtype(dout.dtype), _ptr(dout), _ptr(wb_packed), _ptr(din), N, OH, OW, cout,
+                                         din.shape[3], _ptr(mask), mask_mode, max_workgroups or persist_wgs(None), _stream()),
+            "tg_conv4s2_dgrad_cw")
+
+
 def convt_dgrad(dout, wb_packed, din):
     """input-gradient of conv-transpose k3 s2: dout [N,2H,2W,Cout] -> din [N,H,W,Cin] (3x3-window stride-2 gather)"""
     N, OH, OW, cout = dout.shape

@@ -69,6 +69,8 @@ KNOBS = OrderedDict((k.attr, k) for k in (
        "conv-transpose forward as one four-class sub-pixel launch"),
     _k("C3_CW", "c3_cw", "on", True, "profiles/r05_z_conv3_cw_ab.log",
        "register-weights 3x3 launches with 64 reduction channels on the eight-equal-waves kernel (conv3_cw.hip; 0: conv3_rw.hip's producer / consumer form)"),
+    _k("C4D_CW", "c4d_cw", "on", True, "profiles/r05_zz_conv4s2d_cw_ab.log",
+       "input-gradients of the 4x4 stride-2 convolutions (64 / 128 reduction channels, 16-bit) on the persistent class-waves kernel (conv4s2d_cw.hip; 0: the sub-pixel launch)"),
     _k("CT_CW", "ct_cw", "on", True, "profiles/r05_r_convt_cw_ab.log",
        "conv-transpose FORWARD launches (Cin 64 / 128, 16-bit) on the persistent class-waves kernel (convt_cw.hip; 0: the sub-pixel / four-class launches)"),
     _k("FAST_C4S2", "fast_c4s2", "on", True, "profiles/r01_h_bench_6p1ms.json (tools/mb_c4s2.py)",

@@ -1366,6 +1366,43 @@ def test_convt_input_gradient_fast_path(cin, cout, N, H, W, dt):
     torch.testing.assert_close(K.to_nchw(dx, cin).cpu(), x.grad, rtol=t["rtol"], atol=t["atol"] * max(1.0, scale))
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cap", [0, 5])
+@pytest.mark.parametrize("cin,cout,N,H,W", [(64, 64, 2, 32, 32), (64, 128, 1, 16, 16), (128, 128, 2, 8, 8), (128, 64, 1, 2, 6),
+                                            (64, 64, 12, 128, 128), (64, 128, 3, 10, 38), (128, 64, 2, 6, 6)])
+def test_conv4s2_input_gradient_class_waves(cin, cout, N, H, W, cap, dt):
+    """tg_conv4s2_dgrad_cw (persistent workgroups, one sub-pixel class per wave: csrc/conv4s2d_cw.hip) == autograd of
+    F.conv2d(k4, s2, p1) w.r.t. its input and == tg_conv4s2_dgrad, without and with the LeakyReLU / ReLU mask of the layer below"""
+    if cap and N * H * W > 20000:
+        pytest.skip("caps are covered on the smaller shapes")
+    spec = K.ConvSpec("c4s2", cin, cout)
+    x = q(rnd((N, cin, H, W), 150), dt).requires_grad_(True)
+    w = q(rnd(spec.weight_shape, 151, -0.1, 0.1), dt)
+    dout = q(rnd((N, cout, H // 2, W // 2), 152), dt)
+    ref_conv(spec, x, w, None).backward(dout)
+    dd = K.to_nhwc(dout.to(DEV), dt)
+    rows, Kd, s_row, s_k = spec.dgrad_pack()
+    wb = K.pack_weights(dt, w.to(DEV).contiguous(), rows, Kd, s_row, s_k, 16, K.slot_table(16, DEV))
+    dx = torch.full((N, H, W, K.pad32(cin)), float("nan"), dtype=dt, device=DEV)
+    K.conv4s2_dgrad_cw(dd, wb, dx, max_workgroups=cap)
+    torch.cuda.synchronize()
+    t = tol(dt)
+    scale = float(x.grad.abs().max()) + 1e-6
+    torch.testing.assert_close(K.to_nchw(dx, cin).cpu(), x.grad, rtol=t["rtol"], atol=t["atol"] * max(1.0, scale))
+    other = torch.full_like(dx, float("nan"))
+    K.conv4s2_dgrad(dd, wb, other)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dx.float().cpu(), other.float().cpu(), rtol=2 ** -7, atol=1e-3 * max(1.0, scale))
+    act_below = q(rnd((N, cin, H, W), 153), dt)
+    for mode, slope in ((L.MASK_LRELU, 0.2), (L.MASK_RELU, 0.0)):
+        K.conv4s2_dgrad_cw(dd, wb, dx, mask=K.to_nhwc(act_below.to(DEV), dt), mask_mode=mode, max_workgroups=cap)
+        torch.cuda.synchronize()
+        exp = x.grad * torch.where(act_below > 0, 1.0, slope)
+        torch.testing.assert_close(K.to_nchw(dx, cin).cpu(), exp, rtol=t["rtol"], atol=t["atol"] * max(1.0, scale))
+    assert L.load().tg_conv4s2_dgrad_cw(K.tg_dtype(dt), dd.data_ptr(), wb.data_ptr(), dx.data_ptr(), N, H // 2, W // 2, 256, K.pad32(cin),
+                                        None, 0, 0, None) == -2
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("cin,cout,N,H,W", [(64, 64, 2, 32, 32), (64, 128, 1, 16, 16), (128, 128, 2, 8, 8), (128, 64, 1, 2, 6)])
 def test_conv4s2_input_gradient_subpixel(cin, cout, N, H, W, dt):
