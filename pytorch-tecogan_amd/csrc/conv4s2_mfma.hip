@@ -37,6 +37,7 @@ struct C4K {
   float* stats;
   int N, IH, IW, Cin, OH, OW, Cout, tiles_x, tiles_y, nchunks, stats_groups, stats_replicas;
   int gx, ny;  // pixel tiles, output-channel tiles (ny > 1: the grid is one-dimensional, see the kernel)
+  int total;   // units (pixel tile x channel tile, padded to groups of 8 x ny) a workgroup may walk
 };
 
 template <typename T> struct MmaT;
@@ -81,12 +82,16 @@ __global__ __launch_bounds__(NTHR) void conv_s2_gather_kernel(const C4K p) {
   // other, so a 168-MB input (conv_trans.4's input-gradient, 40 samples) came from HBM once per channel tile (PMC: 351 MB
   // for 210 MB algorithmic).  One-dimensional grid instead: workgroups b and b + 8 - same XCD, dispatched together -
   // are the channel tiles of one pixel tile.
-  int bx = blockIdx.x, by = 0;
+  // (round 5: the grid may be SMALLER than the number of (pixel tile, channel tile) units - max_workgroups of the entry points; a
+  // workgroup then walks units vb = blockIdx.x, + gridDim.x, ...: a capped launch leaves the step's other lane its CUs)
+  for (int vb = (int)blockIdx.x; vb < p.total; vb += (int)gridDim.x) {
+  if (vb != (int)blockIdx.x) __syncthreads();   // the previous unit's LDS reads (fragments, statistics scratch) are done
+  int bx = vb, by = 0;
   if (p.ny > 1) {
     const int r = bx % (8 * p.ny), grp = bx / (8 * p.ny);
     by = r >> 3;
     bx = grp * 8 + (r & 7);
-    if (bx >= p.gx) return;  // padding of the last group (uniform per workgroup, before any barrier)
+    if (bx >= p.gx) continue;  // padding of the last group (uniform per workgroup)
   }
   const int txb = bx % p.tiles_x;
   bx /= p.tiles_x;
@@ -250,10 +255,11 @@ __global__ __launch_bounds__(NTHR) void conv_s2_gather_kernel(const C4K p) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < WP; ++w) s += red[(w * 2 + which) * CO_TILE + chn];
-      const size_t rep = (size_t)(blockIdx.x & (p.stats_replicas - 1)) * p.stats_groups * 2 * p.Cout;
+      const size_t rep = (size_t)(vb & (p.stats_replicas - 1)) * p.stats_groups * 2 * p.Cout;
       atomicAdd(p.stats + rep + ((size_t)grp * 2 + which) * p.Cout + co_base + chn, s);
     }
   }
+  }   // units of this workgroup
 }
 
 }  // namespace
@@ -274,7 +280,11 @@ int launch_s2(int dtype, const void* in, const void* w_packed, const float* bias
   const long long total = k.ny > 1 ? (gx + 7) / 8 * 8 * k.ny : gx;
   if (total > 0x7fffffffLL) return TG_E_UNSUPPORTED;
   k.gx = (int)gx;
-  dim3 grid((unsigned)total, 1);
+  k.total = (int)total;
+  // A/B hook (profiles/r05_zz_s2_cap_ab.log): TECOGAN_S2_CAP = workgroups of these launches (0 / unset: one per unit)
+  static const int cap = [] { const char* e = getenv("TECOGAN_S2_CAP"); return e ? atoi(e) : 0; }();
+  const long long ngrid = cap > 0 && cap < total ? (long long)((cap + 7) / 8 * 8) : total;   // (a multiple of 8: units b and b + 8 stay on one XCD)
+  dim3 grid((unsigned)ngrid, 1);
   hipStream_t st = (hipStream_t)stream;
   constexpr int lds = Geo<KS>::kLds;
   static std::atomic<bool> attr_done{false};
