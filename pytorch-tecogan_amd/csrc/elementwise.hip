@@ -832,6 +832,12 @@ inline int grid_for(long long total, int per_block, int cap) {
   return (int)std::max<long long>(1, std::min<long long>((total + per_block - 1) / per_block, cap));
 }
 
+// A/B hook (profiles/r05_zz_bn_cap_ab.log): TECOGAN_BN_WGS caps the batch-norm launches' grids (0 / unset: the built-in caps)
+inline int bn_grid_cap(int builtin) {
+  static const int cap = [] { const char* e = getenv("TECOGAN_BN_WGS"); return e ? atoi(e) : 0; }();
+  return cap > 0 && cap < builtin ? cap : builtin;
+}
+
 inline bool bn_shape_ok(int dtype, int C) {
   const int e = dtype == TG_F32 ? 4 : 8;
   const int vpp = C / e;
@@ -856,7 +862,7 @@ extern "C" int tg_bn_apply(int dtype, const void* z, const float* stats, int sta
   if (stats_replicas < 1 || (stats_replicas & (stats_replicas - 1))) return TG_E_BADARG;
   if (!bn_shape_ok(dtype, C)) return TG_E_UNSUPPORTED;
   const int rows = 256 / (C / (dtype == TG_F32 ? 4 : 8));
-  dim3 grid(grid_for((long long)(N / groups) * HW, rows * 4, 1024), groups);
+  dim3 grid(grid_for((long long)(N / groups) * HW, rows * 4, bn_grid_cap(1024)), groups);
   TG_DISPATCH(dtype, bn_apply_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)z, stats, stats_replicas, gamma, beta,
               (const char*)skip, (char*)y, running_mean, running_var, save, N, HW, C, groups, act, eps, momentum,
               (long long*)num_batches_tracked);
@@ -870,7 +876,7 @@ extern "C" int tg_bn_bwd_reduce(int dtype, const void* dy, const void* yact, con
   if (act == TG_ACT_LRELU && !yact) return TG_E_BADARG;
   if (!bn_shape_ok(dtype, C)) return TG_E_UNSUPPORTED;
   const int rows = 256 / (C / (dtype == TG_F32 ? 4 : 8));
-  dim3 grid(grid_for((long long)(N / groups) * HW, rows * 8, 512), groups);  // two trips of four pixels per thread
+  dim3 grid(grid_for((long long)(N / groups) * HW, rows * 8, bn_grid_cap(512)), groups);  // two trips of four pixels per thread
   TG_DISPATCH(dtype, bn_bwd_reduce_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)dy, (const char*)yact,
               (const char*)z, save, red, red_replicas, N, HW, C, groups, act);
   return tg_launch_status();
@@ -885,7 +891,7 @@ extern "C" int tg_bn_bwd_apply(int dtype, const void* dy, const void* yact, cons
   if (red_replicas < 1 || (red_replicas & (red_replicas - 1))) return TG_E_BADARG;
   if (!bn_shape_ok(dtype, C)) return TG_E_UNSUPPORTED;
   const int rows = 256 / (C / (dtype == TG_F32 ? 4 : 8));
-  dim3 grid(grid_for((long long)(N / groups) * HW, rows * 4, 1024), groups);
+  dim3 grid(grid_for((long long)(N / groups) * HW, rows * 4, bn_grid_cap(1024)), groups);
   TG_DISPATCH(dtype, bn_bwd_apply_kernel, grid, dim3(256), (hipStream_t)stream, (const char*)dy, (const char*)yact,
               (const char*)z, save, red, red_replicas, gamma, (char*)dz, dgamma, dbeta, N, HW, C, groups, act, red_raw);
   return tg_launch_status();
