@@ -413,11 +413,13 @@ class TecoGANStep:
         D, B, T, h, H, tb = self.D, self.B, self.T, self.h, self.H, self.tb
         backward = self.dreal_bwd_early if backward is None else backward
         K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"][:tb], B, T, self.K, h, self.border, half=0)
-        K.nhwc_to_nchw(D.act["in"][:tb], self.target, 27 * H * H, tb, 27, H, H)
         D.forward(update_stats=True, half=0)
         if backward:
             K.dlogit_real(D.prob, D.dlogit, tb, self.cfg, self.loss_scale)
             D.backward(groups=2, half=0)
+        # the returned `target` (the real half's input as fp32 NCHW, code/train.py:368) is read by the host only: converted at the END of
+        # the piece, where lane B waits for the chain anyway (the fake half writes D.act["in"][tb:], not this half's rows)
+        K.nhwc_to_nchw(D.act["in"][:tb], self.target, 27 * H * H, tb, 27, H, H)
 
     def _chain(self, t0=0, t1=None, loss=False):
         """recurrent generator passes t0..t1-1 (each: warp + pack, conv0, residual trunk, up-sampling stage).  The piece
