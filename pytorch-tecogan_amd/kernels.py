@@ -319,7 +319,8 @@ def persist_wgs_dreal_for(lr_pixels):
     workgroups than the fake half's 96 it loads the memory system less while the chain runs and still ends before the chain does -
     96 -> 80: 4.36 -> 4.32 ms/step; after the register-weights change 80 / 72 / 64 = 4.238 4.226 4.218 (48: +0.18 ms, the real half
     becomes the long pole).  Round 5: the chain got 0.05 ms shorter (resblock_ws), the real half became the phase's long pole at 72 and
-    80 is the optimum again (3.54-3.56 -> 3.485-3.50 ms, profiles/r05_l_caps_resweep.log).  The configs[3] shard is not chain-bound:
+    80 was the optimum again (3.54-3.56 -> 3.485-3.50 ms, profiles/r05_l_caps_resweep.log); at the end of round 5 the fake half's 96
+    (3.37 -> 3.31-3.32 ms, profiles/r05_v_caps_write_through.log).  The configs[3] shard is not chain-bound:
     no gain there."""
     return tuning.current().cap_dreal_for(lr_pixels)
 

@@ -39,11 +39,11 @@ KNOBS = OrderedDict((k.attr, k) for k in (
        "issue the collectives even with one rank (test hook)"),
     # ---- persistent launches: workgroup caps (kernels.persist_wgs*)
     _k("PERSIST_WGS", "persist_wgs", "oint", None, "profiles/r02_q_persist_wgs_sweep.log",
-       "cap of every persistent launch (unset: G 160, D 96; for steps of <= 4096 LR pixels per pass G 144, its forward launches 160, D real half 80)"),
+       "cap of every persistent launch (unset: G 160, D 96; for steps of <= 4096 LR pixels per pass G 144, its forward launches 160)"),
     _k("PERSIST_WGS_G", "persist_wgs_g", "oint", None, "profiles/r03_r_rw_dma_ab.log", "generator's cap (unset: 144 for steps of <= 4096 LR pixels per pass, else 160)"),
     _k("PERSIST_WGS_D", "persist_wgs_d", "oint", None, "profiles/r02_q_persist_wgs_sweep.log", "discriminator's cap (unset: 96)"),
     _k("PERSIST_WGS_DREAL", "persist_wgs_dreal", "oint", None, "profiles/r05_l_caps_resweep.log",
-       "cap of the discriminator's REAL half, which runs beside the chain (unset: 80 for chain-bound steps, else the D cap)"),
+       "cap of the discriminator's REAL half, which runs beside the chain (unset: the D cap; 72 / 80 for chain-bound steps until the end of round 5)"),
     _k("PERSIST_FWD_G", "persist_fwd_g", "int", 0, "profiles/r04_z_fwd_cap.log, r05_v_caps_write_through.log",
        "cap of the generator's FORWARD register-weights launches (the chain, beside the real half); 0: 160 for steps of <= 4096 LR pixels per pass, else the generator's"),
     _k("PERSIST_TRUNK_G", "persist_trunk_g", "int", 0, "profiles/r04_z_trunk_cap.log",
@@ -168,7 +168,7 @@ class Tuning:
 
     def cap_fwd_g_for(self, lr_pixels):
         """cap of the generator's FORWARD register-weights launches for such a step (0: the generator's cap): the chain's launches
-        run beside the real half (80 workgroups; 72 through round 4) and may take more of the chip than the backward pass beside the fake half's 96 -
+        run beside the real half (96 workgroups; 72 / 80 earlier) and may take more of the chip than the backward pass beside the fake half's 96 -
         176 / 192 / 208 / 256: 3.727 / 3.735 / 3.763 / 3.751 vs 3.762-3.780 ms at the generator's 144 (profiles/r04_z_fwd_cap.log).
         Round 5, with the register-weights kernels' results written through the L2: 128 / 144 / 160 / 176 / 192 / 224 = 3.41-3.42 / 3.41 /
         3.404-3.406 / 3.42-3.44 / 3.44 / 3.44-3.45 ms (profiles/r05_v_caps_write_through.log)"""
@@ -181,8 +181,10 @@ class Tuning:
         if self.persist_wgs is not None or self.persist_wgs_d is not None or self.persist_wgs_dreal is not None:
             return None
         # 72 through round 4; 80 since the chain got 0.2 ms shorter (round 5: the real half, not the chain, bounds phase 1 now):
-        # 64 / 72 / 80 / 88 / 96 / 112: 3.56-3.57 / 3.54-3.56 / 3.485-3.50 / 3.50-3.51 / 3.555 / 3.57 ms (profiles/r05_l_caps_resweep.log)
-        return 80 if lr_pixels <= 4096 else None
+        # 64 / 72 / 80 / 88 / 96 / 112: 3.56-3.57 / 3.54-3.56 / 3.485-3.50 / 3.50-3.51 / 3.555 / 3.57 ms (profiles/r05_l_caps_resweep.log).
+        # End of round 5 (write-through stores, the stride-2 input-gradients persistent at this cap): 80 / 88 / 96 / 104 / 112 / 128 =
+        # 3.37 / 3.34-3.36 / 3.31-3.32 / 3.33-3.34 / 3.34 / 3.38 ms (profiles/r05_v_caps_write_through.log) - the discriminator's own cap
+        return 96 if lr_pixels <= 4096 else None
 
     def cap_dreal_default(self):
         return self.persist_wgs_dreal if self.persist_wgs_dreal is not None else self.cap("D")

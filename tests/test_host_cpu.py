@@ -476,7 +476,7 @@ def test_step_aware_caps_and_register_weights_routing(monkeypatch):
         monkeypatch.delenv(k, raising=False)
     K = importlib.reload(K)
     assert K.persist_wgs_g_for(4 * 32 * 32) == 144 and K.persist_wgs_g_for(2 * 64 * 64) == 160   # (round 4: r04_x)
-    assert K.persist_wgs_dreal_for(4 * 32 * 32) == 80 and K.persist_wgs_dreal_for(2 * 64 * 64) is None
+    assert K.persist_wgs_dreal_for(4 * 32 * 32) == 96 and K.persist_wgs_dreal_for(2 * 64 * 64) is None
     monkeypatch.setenv("TECOGAN_PERSIST_WGS_DREAL", "96")
     assert K.persist_wgs_dreal_for(4096) is None
     monkeypatch.delenv("TECOGAN_PERSIST_WGS_DREAL")
@@ -543,7 +543,7 @@ def test_tuning_defaults_equal_the_documented_optimum(monkeypatch):
     t = tuning.current()
     assert not t.explicit
     assert (t.cap("G"), t.cap("D"), t.cap(None), t.cap_g_for(4096), t.cap_dreal_for(4096), t.cap_dreal_for(8192)) == \
-        (160, 96, 160, 144, 80, None)
+        (160, 96, 160, 144, 96, None)
     assert (t.cap_g_for(8192), t.rw_fwd_min, t.pair_rw_min, t.infer_wgs, t.infer_chunk) == (160, 4096, 16384, 256, 16)
     assert (t.cap_fwd_g_for(4096), t.cap_fwd_g_for(8192)) == (160, 0)
     assert (t.graph, t.lanes, t.dreal_bwd, t.dp_inline, t.dp_buckets, t.cu_reserve, t.force_collectives) == \

@@ -28,7 +28,7 @@ def variant_env(variant, lr_pixels):
         return {"TECOGAN_PERSIST_WGS": "256"}
     f = float(variant[1:])
     chain_bound = lr_pixels <= 4096
-    g, gf, d, dr = (144, 160, 96, 80) if chain_bound else (160, 160, 96, 96)
+    g, gf, d, dr = (144, 160, 96, 96) if chain_bound else (160, 160, 96, 96)
     r8 = lambda v: str(max(8, int(round(v * f / 8.0)) * 8))  # noqa: E731
     return {"TECOGAN_PERSIST_WGS_G": r8(g), "TECOGAN_PERSIST_FWD_G": r8(gf), "TECOGAN_PERSIST_WGS_D": r8(d), "TECOGAN_PERSIST_WGS_DREAL": r8(dr)}
 
