@@ -90,7 +90,7 @@ struct C3K {
 
 // SM: statistics of the stored values - 0 none, 1 per-channel sums (a bias gradient), 2 sums and sums of squares (batch norm).
 // (arguments one by one, the ones a wave needs first in front: the first 16 dwords are preloaded into SGPRs with the wave)
-template <int SM, typename T>
+template <int SM, typename T, int NCH = 2>   // NCH: 32-channel chunks of the reduction (2: 64 channels; 1: 32 - the discriminator's first layer)
 __global__ __launch_bounds__(512) void conv3_cw_kernel(const char* a_in, const char* a_w, const char* a_zero, int a_H, int a_W, int a_Cout,
                                                        int a_tiles_x, int a_tiles_y, int a_ntiles, int a_flip, int a_N, char* a_out,
                                                        const char* a_mask, const char* a_res, const float* a_bias, float* a_stats,
@@ -116,10 +116,12 @@ __global__ __launch_bounds__(512) void conv3_cw_kernel(const char* a_in, const c
   {
     const int u = wid & 3, ci = wid >> 2, row = 16 * u + (lane >> 2);
     const char* src = p.w + ((size_t)co_base + row) * 64 + (((lane & 3) ^ ((row >> 1) & 2)) << 4);
+    if (ci < NCH) {   // (wave-uniform; one chunk: waves 0-3 bring it)
 #pragma unroll
-    for (int so = 0; so < 9; ++so) {
-      const int slot = p.flip ? 8 - so : so;
-      glds16(src + (size_t)(slot * 2 + ci) * p.Cout * 64, lds0 + kStage + (so * 2 + ci) * 4096 + u * 1024);
+      for (int so = 0; so < 9; ++so) {
+        const int slot = p.flip ? 8 - so : so;
+        glds16(src + (size_t)(slot * NCH + ci) * p.Cout * 64, lds0 + kStage + (so * 2 + ci) * 4096 + u * 1024);
+      }
     }
   }
   // ---- patch DMA: block j = wid + 8 u of a buffer = 16 rows (row block wid + 8 (u & 1)) of chunk u >> 1; the lane's 16 bytes: row
@@ -148,15 +150,15 @@ __global__ __launch_bounds__(512) void conv3_cw_kernel(const char* a_in, const c
     return r;
   };
   auto dma_patch = [&](const Tile& tl, int buf) {   // asynchronous: vmcnt + barrier before anyone reads it.  EXACTLY 4 requests per wave
-    const char* in_n = p.in + (size_t)tl.n * p.H * p.W * 128;
+    const char* in_n = p.in + (size_t)tl.n * p.H * p.W * (NCH * 64);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int iy = tl.ty0 + dpy[e], ix = tl.tx0 + dpx[e];
       const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);   // (no short-circuit branches)
-      const char* src = in_n + (unsigned)((iy * p.W + ix) * 128 + dof);                    // (an image is < 4 GB)
+      const char* src = in_n + (unsigned)((iy * p.W + ix) * (NCH * 64) + dof);             // (an image is < 4 GB)
       const unsigned dst = lds0 + buf * kBufBytes + (wid + 8 * e) * 1024;
       glds16(ok ? src : p.zero, dst);
-      glds16(ok ? src + 64 : p.zero, dst + kChunkBytes);
+      if constexpr (NCH == 2) glds16(ok ? src + 64 : p.zero, dst + kChunkBytes);
     }
   };
   int tile = (int)blockIdx.x;
@@ -244,13 +246,13 @@ __global__ __launch_bounds__(512) void conv3_cw_kernel(const char* a_in, const c
     }
   };
 
-  // this wave's 9 weight blocks are older than its 4 patch blocks
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  // this wave's weight blocks are older than its 2 NCH patch blocks
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCH) : "memory");
   lds_barrier();   // the weights are staged
   // A-fragments of packed rows 32 wc + 16 a + idx for 9 taps x 2 chunks
-  bf16x8 wfr[2][9][2];
+  bf16x8 wfr[NCH][9][2];
 #pragma unroll
-  for (int ci = 0; ci < 2; ++ci)
+  for (int ci = 0; ci < NCH; ++ci)
 #pragma unroll
     for (int so = 0; so < 9; ++so)
 #pragma unroll
@@ -299,8 +301,8 @@ __global__ __launch_bounds__(512) void conv3_cw_kernel(const char* a_in, const c
 #pragma unroll
     for (int s_ = 0; s_ < kDepth - 1; ++s_) frags(s_, s_);
 #pragma unroll
-    for (int s_ = 0; s_ < 18; ++s_) {
-      if (s_ + kDepth - 1 < 18) frags(s_ + kDepth - 1, (s_ + kDepth - 1) % kDepth);
+    for (int s_ = 0; s_ < 9 * NCH; ++s_) {
+      if (s_ + kDepth - 1 < 9 * NCH) frags(s_ + kDepth - 1, (s_ + kDepth - 1) % kDepth);
 #ifndef C3_NO_SCHED_BARRIER   // (left to itself the compiler reads a fragment pair, waits for it, issues two MFMAs: one step in flight)
       __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -429,9 +431,9 @@ __global__ __launch_bounds__(512) void conv3_cw_kernel(const char* a_in, const c
   C3_STAMP(28);
 }
 
-template <int SM, typename T>
+template <int SM, typename T, int NCH = 2>
 int launch_c3cw(const C3K& k, dim3 grid, hipStream_t st) {
-  auto fn = conv3_cw_kernel<SM, T>;
+  auto fn = conv3_cw_kernel<SM, T, NCH>;
   static std::atomic<bool> attr_done{false};  // one-time function attribute (benign race: idempotent)
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
@@ -449,7 +451,8 @@ extern "C" int tg_conv3x3_cw(int dtype, const void* in, const void* w_packed, co
                              int act, int mask_mode, int stats_mode, int stats_groups, int stats_replicas, int max_workgroups,
                              void* stream) {
   if (!in || !w_packed || !out || N <= 0 || H <= 0 || W <= 0) return TG_E_BADARG;
-  if ((dtype != TG_BF16 && dtype != TG_F16) || Cin != 64 || Cout <= 0 || Cout % 64) return TG_E_UNSUPPORTED;
+  if ((dtype != TG_BF16 && dtype != TG_F16) || (Cin != 64 && Cin != 32) || Cout <= 0 || Cout % 64) return TG_E_UNSUPPORTED;
+  if (Cin == 32 && stats) return TG_E_UNSUPPORTED;   // (the 32-channel form is built without statistics: the discriminator's first layer has none)
   if (act != TG_ACT_NONE && act != TG_ACT_RELU && act != TG_ACT_LRELU) return TG_E_UNSUPPORTED;
   if (mask_mode != TG_MASK_NONE && !mask) return TG_E_BADARG;
   if (stats && (stats_groups <= 0 || N % stats_groups || stats_mode < 1 || stats_mode > 2)) return TG_E_BADARG;
@@ -485,6 +488,7 @@ extern "C" int tg_conv3x3_cw(int dtype, const void* in, const void* w_packed, co
   hipStream_t st = (hipStream_t)stream;
   const int sm = k.stats_mode;
 #define C3_GO(TAG) (sm == 2 ? launch_c3cw<2, TAG>(k, grid, st) : sm == 1 ? launch_c3cw<1, TAG>(k, grid, st) : launch_c3cw<0, TAG>(k, grid, st))
+  if (Cin == 32) return dtype == TG_F16 ? launch_c3cw<0, F16, 1>(k, grid, st) : launch_c3cw<0, BF16, 1>(k, grid, st);
   if (dtype == TG_F16) return C3_GO(F16);
   return C3_GO(BF16);
 #undef C3_GO

@@ -12,6 +12,7 @@ Reference behaviour reproduced (file:line into the reference):
 """
 from collections import OrderedDict
 
+import os
 import torch
 
 from . import _lib as L
@@ -205,6 +206,15 @@ class Conv:
                 self.dt in (torch.bfloat16, torch.float16):
             self.last_desc = "rgb"  # one 16-row MFMA tile + fp32 NCHW store (csrc/conv_rgb.hip)
             K.conv3x3_rgb(x, self.wf, self.bias, nchw[0], nchw[1], nchw[2], nchw[3], act)
+            return
+        if self.spec.kind == "c3" and nchw is None and self.tile == L.TILE_AUTO and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) \
+                and self.cin_p == 32 and self.cout_p % 64 == 0 and stats is None and self.tu.c3_cw and not self.rw_off \
+                and self.dt in (torch.bfloat16, torch.float16) and 0 < self.tu.rw_fwd_min <= N * H * W:
+            # the discriminator's first layer (27 -> 64 at HR size): the eight-equal-waves kernel's 32-channel form, a capped persistent
+            # launch instead of 1536 workgroups beside the other lane (csrc/conv3_cw.hip)
+            self.last_desc, self.last_rw_nch = "c3cw", 1
+            K.conv3x3_rw(x, self.wf, out, False, bias=self.bias, res=res, act=act,
+                         max_workgroups=self.persist_fwd or self.persist_rw or self.persist_wgs, cw=True)
             return
         if self.spec.kind == "c3" and nchw is None and self.tile == L.TILE_AUTO and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) \
                 and not self.rw_off and K.rw_eligible(self.dt, self.cin_p, self.cout_p, N, H, W, extra=self.rw_extra, tu=self.tu):

@@ -185,7 +185,8 @@ def conv3x3_rw(x, w_packed, out, flip=False, bias=None, res=None, mask=None, mas
         cw = C3_CW_FORCE
     elif cw is None:
         cw = tuning.current().c3_cw
-    cw = cw and cin == 64 and (stats is None or C3_CW_FORCE)   # (launches with statistics: 17.9 vs 17.0 us - they stay on conv3_rw)
+    cw = (cw and cin == 64 and (stats is None or C3_CW_FORCE)) or cin == 32   # (launches with statistics: 17.9 vs 17.0 us - they stay on
+    #                                                                         conv3_rw; 32 reduction channels exist on conv3_cw only)
     fn, name = (L.load().tg_conv3x3_cw, "tg_conv3x3_cw") if cw else (L.load().tg_conv3x3_rw, "tg_conv3x3_rw")
     L.check(fn(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(res), _ptr(mask), _ptr(out),
                _ptr(stats), N, H, W, cin, out.shape[3], int(flip), act,

@@ -52,6 +52,21 @@ CASES = [  # cin, cout, N, H, W, max_workgroups
 ]
 
 
+@pytest.mark.parametrize("cout,N,H,W,cap,act", [(64, 2, 32, 32, 0, L.ACT_LRELU), (64, 3, 40, 24, 4, L.ACT_RELU), (128, 2, 20, 50, 6, L.ACT_NONE),
+                                                (64, 1, 8, 16, 0, L.ACT_LRELU), (64, 5, 7, 9, 2, L.ACT_LRELU), (64, 12, 128, 128, 96, L.ACT_LRELU)])
+def test_cw_forward_27_input_channels(cout, N, H, W, cap, act, which_kernel):
+    """the 32-channel form of csrc/conv3_cw.hip (the discriminator's first layer, 27 -> 64, code/models.py:102): + bias, activation"""
+    if which_kernel != "cw":
+        pytest.skip("32 reduction channels exist on conv3_cw only")
+    spec = K.ConvSpec("c3", 27, cout)
+    x, w, b = q(rnd((N, 27, H, W), 31)), q(rnd(spec.weight_shape, 32, -0.1, 0.1)), rnd((cout,), 33)
+    y = F.conv2d(x, w, b, 1, 1)
+    ref = F.relu(y) if act == L.ACT_RELU else (F.leaky_relu(y, 0.2) if act == L.ACT_LRELU else y)
+    out = torch.empty(N, H, W, cout, dtype=BF, device=DEV)
+    K.conv3x3_rw(K.to_nhwc(x.to(DEV), BF), packed(spec, w, False), out, False, bias=b.to(DEV), act=act, max_workgroups=cap)
+    torch.testing.assert_close(K.to_nchw(out, cout).cpu(), ref, rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("cin,cout,N,H,W,cap", CASES)
 def test_rw_forward_bias_relu(cin, cout, N, H, W, cap):
     spec = K.ConvSpec("c3", cin, cout)
