@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 3   /* 3 (round 5): + tg_convt_fwd_cw, tg_conv3x3_cw, tg_conv4s2_dgrad_cw; 2 (round 5): + tg_resblock_fwd_ws; round 4 removed tg_wgrad_group / tg_absdiff_nchw and moved the
+#define TG_ABI_VERSION 3   /* 3 (round 5): + tg_convt_fwd_cw, tg_conv3x3_cw, tg_conv4s2_dgrad_cw, tg_conv4s2_fwd_capped; 2 (round 5): + tg_resblock_fwd_ws; round 4 removed tg_wgrad_group / tg_absdiff_nchw and moved the
                            * rejected variants behind TG_EXPERIMENTS without a bump */
 
 enum { TG_F32 = 0, TG_BF16 = 1, TG_F16 = 2 };  /* TG_F16: IEEE half, same layouts as TG_BF16 (loss scaling: tg_adam) */
@@ -156,6 +156,12 @@ int tg_convt_fwd_cw(int dtype, const void* in, const void* w_packed, const float
  * Cout % 64 == 0 (use tg_conv then). */
 int tg_conv4s2_fwd(int dtype, const void* in, const void* w_packed, const float* bias, void* out, float* stats,
                    int stats_groups, int stats_replicas, int N, int IH, int IW, int Cin, int Cout, void* stream);
+
+/* The same launch with at most max_workgroups workgroups (rounded up to a multiple of 8; 0: one per (pixel tile, channel tile) unit):
+ * a workgroup walks its units.  The step passes the discriminator's cap - no faster alone, 0.015 ms of the step beside the other lane. */
+int tg_conv4s2_fwd_capped(int dtype, const void* in, const void* w_packed, const float* bias, void* out, float* stats,
+                          int stats_groups, int stats_replicas, int N, int IH, int IW, int Cin, int Cout, int max_workgroups,
+                          void* stream);
 
 /* Input-gradient of the 4x4 stride-2 convs (autograd of code/models.py:90-94) as one four-class sub-pixel launch (the
  * tg_convt_fwd kernel with a 3x3 window and 16 (class, tap) pairs): dout [N][OH][OW][Cout] -> din [N][2OH][2OW][Cin];

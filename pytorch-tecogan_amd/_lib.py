@@ -71,6 +71,7 @@ _PROTOS = {
     "tg_conv3x3_rgb_bwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "tg_conv3x3_rgb_bwd_slot_floats": (_L, []),
     "tg_conv4s2_fwd": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "tg_conv4s2_fwd_capped": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "tg_conv4s2_dgrad": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "tg_conv4s2_dgrad_cw": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "tg_convt_dgrad": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(NTHR) void conv_s2_gather_kernel(const C4K p) {
 namespace {
 template <int KS>
 int launch_s2(int dtype, const void* in, const void* w_packed, const float* bias, void* out, float* stats, int stats_groups,
-              int stats_replicas, int N, int IH, int IW, int Cin, int Cout, void* stream) {
+              int stats_replicas, int N, int IH, int IW, int Cin, int Cout, void* stream, int max_workgroups = 0) {
   C4K k;
   k.in = (const char*)in; k.w = (const char*)w_packed; k.bias = bias; k.out = (char*)out; k.stats = stats;
   k.N = N; k.IH = IH; k.IW = IW; k.Cin = Cin; k.OH = IH / 2; k.OW = IW / 2; k.Cout = Cout;
@@ -281,8 +281,10 @@ int launch_s2(int dtype, const void* in, const void* w_packed, const float* bias
   if (total > 0x7fffffffLL) return TG_E_UNSUPPORTED;
   k.gx = (int)gx;
   k.total = (int)total;
-  // A/B hook (profiles/r05_zz_s2_cap_ab.log): TECOGAN_S2_CAP = workgroups of these launches (0 / unset: one per unit)
-  static const int cap = [] { const char* e = getenv("TECOGAN_S2_CAP"); return e ? atoi(e) : 0; }();
+  // max_workgroups (tg_conv4s2_fwd_capped: the discriminator's cap) or the A/B hooks TECOGAN_S2_CAP_CT (KS 3: the conv-transposes'
+  // input-gradients, lane A - every cap costs) / TECOGAN_S2_CAP (KS 4) (profiles/r05_zz_s2_cap_ab.log); 0: one workgroup per unit
+  static const int env_cap = [] { const char* e = getenv(KS == 3 ? "TECOGAN_S2_CAP_CT" : "TECOGAN_S2_CAP"); return e ? atoi(e) : 0; }();
+  const int cap = env_cap > 0 ? env_cap : max_workgroups;
   const long long ngrid = cap > 0 && cap < total ? (long long)((cap + 7) / 8 * 8) : total;   // (a multiple of 8: units b and b + 8 stay on one XCD)
   dim3 grid((unsigned)ngrid, 1);
   hipStream_t st = (hipStream_t)stream;
@@ -322,6 +324,17 @@ extern "C" int tg_conv4s2_fwd(int dtype, const void* in, const void* w_packed, c
   if (stats && (stats_groups <= 0 || N % stats_groups)) return TG_E_BADARG;
   if (stats && (stats_replicas < 1 || (stats_replicas & (stats_replicas - 1)))) return TG_E_BADARG;  // a power of two
   return launch_s2<4>(dtype, in, w_packed, bias, out, stats, stats_groups, stats_replicas, N, IH, IW, Cin, Cout, stream);
+}
+
+extern "C" int tg_conv4s2_fwd_capped(int dtype, const void* in, const void* w_packed, const float* bias, void* out, float* stats,
+                                     int stats_groups, int stats_replicas, int N, int IH, int IW, int Cin, int Cout,
+                                     int max_workgroups, void* stream) {
+  const int rc = check_s2(dtype, in, w_packed, bias, out, N, IH, IW, Cin, Cout);
+  if (rc != TG_OK) return rc;
+  if (stats && (stats_groups <= 0 || N % stats_groups)) return TG_E_BADARG;
+  if (stats && (stats_replicas < 1 || (stats_replicas & (stats_replicas - 1)))) return TG_E_BADARG;  // a power of two
+  return launch_s2<4>(dtype, in, w_packed, bias, out, stats, stats_groups, stats_replicas, N, IH, IW, Cin, Cout, stream,
+                      max_workgroups > 0 ? max_workgroups : 0);
 }
 
 extern "C" int tg_convt_dgrad(int dtype, const void* dout, const void* w_dgrad_packed, void* din, int N, int OH, int OW,

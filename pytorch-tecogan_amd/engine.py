@@ -199,7 +199,9 @@ class Conv:
                 self.tile == L.TILE_AUTO and self.tu.fast_c4s2 and H % 2 == 0 and W % 2 == 0 and \
                 (stats is None or K.stats_replicas_for(N * OH * OW) == 1):
             self.last_desc = "c4s2"  # compile-time-tap stride-2 kernel (csrc/conv4s2_mfma.hip)
-            K.conv4s2_fwd(x, self.wf, self.bias, out, stats, groups, stats_replicas=stats_r)
+            # (capped at the network's workgroups since round 5: no faster alone, better beside the other lane - profiles/r05_zz_s2_cap_ab.log)
+            K.conv4s2_fwd(x, self.wf, self.bias, out, stats, groups, stats_replicas=stats_r,
+                          max_workgroups=(self.persist_wgs if self.dt in (torch.bfloat16, torch.float16) else 0))
             return
         if self.spec.kind == "c3" and nchw is not None and self.cin_p == 64 and self.spec.cout <= 4 and res is None and \
                 stats is None and act in (L.ACT_NONE, L.ACT_SIGMOID) and self.tile == L.TILE_AUTO and self.tu.rgb_out and \

@@ -403,11 +403,13 @@ def conv3x3_rgb_bwd(dpre4, x, w_master, dx, slab, cap):
                                    _stream()), "tg_conv3x3_rgb_bwd")
 
 
-def conv4s2_fwd(x, w_packed, bias, out, stats=None, groups=1, stats_replicas=1):
-    """conv k4 s2 p1 forward with compile-time taps; stats: `stats_replicas` blocks of [groups][2][Cout], accumulated"""
+def conv4s2_fwd(x, w_packed, bias, out, stats=None, groups=1, stats_replicas=1, max_workgroups=0):
+    """conv k4 s2 p1 forward with compile-time taps; stats: `stats_replicas` blocks of [groups][2][Cout], accumulated;
+    max_workgroups: 0 = one workgroup per unit, else a capped grid whose workgroups walk the units"""
     N, H, W, cin = x.shape
-    L.check(L.load().tg_conv4s2_fwd(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(stats),
-                                    groups, stats_replicas, N, H, W, cin, out.shape[3], _stream()), "tg_conv4s2_fwd")
+    L.check(L.load().tg_conv4s2_fwd_capped(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(stats),
+                                           groups, stats_replicas, N, H, W, cin, out.shape[3], max_workgroups, _stream()),
+            "tg_conv4s2_fwd_capped")
 
 
 def conv4s2_dgrad(dout, wb_packed, din, mask=None, mask_mode=L.MASK_NONE):
