@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 3   /* 3 (round 5): + tg_convt_fwd_cw, tg_conv3x3_cw, tg_conv4s2_dgrad_cw, tg_conv4s2_fwd_capped; 2 (round 5): + tg_resblock_fwd_ws; round 4 removed tg_wgrad_group / tg_absdiff_nchw and moved the
+#define TG_ABI_VERSION 4   /* 4 (round 6): + tg_conv4s2_fwd_cw, tg_convt_dgrad_cw; 3 (round 5): + tg_convt_fwd_cw, tg_conv3x3_cw, tg_conv4s2_dgrad_cw, tg_conv4s2_fwd_capped; 2 (round 5): + tg_resblock_fwd_ws; round 4 removed tg_wgrad_group / tg_absdiff_nchw and moved the
                            * rejected variants behind TG_EXPERIMENTS without a bump */
 
 enum { TG_F32 = 0, TG_BF16 = 1, TG_F16 = 2 };  /* TG_F16: IEEE half, same layouts as TG_BF16 (loss scaling: tg_adam) */
@@ -183,6 +183,18 @@ int tg_conv4s2_dgrad_cw(int dtype, const void* dout, const void* w_dgrad_packed,
  * 9-slot packing.  TG_E_UNSUPPORTED unless Cin % 64 == 0 (use tg_conv then). */
 int tg_convt_dgrad(int dtype, const void* dout, const void* w_dgrad_packed, void* din, int N, int OH, int OW, int Cout,
                    int Cin, void* stream);
+
+/* The two stride-2 gathers above with the WEIGHTS IN REGISTERS (csrc/conv_s2_cw.hip, round 6; same arguments and results up to the
+ * fp32 summation order): persistent workgroups over 4 x 16 output tiles; the reduction (taps x channels) is split between four wave
+ * groups whose partial sums meet through an LDS exchange; the patch arrives by LDS-DMA with its columns de-interleaved by parity.
+ * tg_conv4s2_fwd_cw replaces aten::conv2d of code/models.py:90-94 (statistics as tg_conv4s2_fwd); tg_convt_dgrad_cw the input
+ * gradient of code/ops.py:45-54.  bf16 / fp16, reduction channels (Cin / Cout of the respective signature) in {64, 128}, output
+ * channels % 64 == 0, else TG_E_UNSUPPORTED (use the launches above).  max_workgroups: 0 = one per CU. */
+int tg_conv4s2_fwd_cw(int dtype, const void* in, const void* w_packed, const float* bias, void* out, float* stats,
+                      int stats_groups, int stats_replicas, int N, int IH, int IW, int Cin, int Cout, int max_workgroups,
+                      void* stream);
+int tg_convt_dgrad_cw(int dtype, const void* dout, const void* w_dgrad_packed, void* din, int N, int OH, int OW, int Cout,
+                      int Cin, int max_workgroups, void* stream);
 
 /* Weight gradient: slab[split][t][a][b] = sum over the split's pixels of X[n, y*S+dy[t], x*S+dx[t]][a] * Y[n,y,x][b].
  * (aten::convolution_backward weight path, code/train.py:336,340.) */

@@ -75,6 +75,8 @@ _PROTOS = {
     "tg_conv4s2_dgrad": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "tg_conv4s2_dgrad_cw": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "tg_convt_dgrad": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "tg_conv4s2_fwd_cw": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "tg_convt_dgrad_cw": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "tg_convt_fwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "tg_convt_fwd_cw": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "tg_resblock_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
@@ -124,7 +126,7 @@ _PROTOS_EXPERIMENTS = {
 }
 
 EXPORTED = tuple(_PROTOS.keys())
-ABI_VERSION = 3   # TG_ABI_VERSION of include/tecogan_hip.h
+ABI_VERSION = 4   # TG_ABI_VERSION of include/tecogan_hip.h
 _lib = None
 
 

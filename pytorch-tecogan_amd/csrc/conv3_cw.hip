@@ -426,6 +426,10 @@ __global__ __launch_bounds__(512) void conv3_cw_kernel(const char* a_in, const c
     if (i < 6) C3_STAMP(4 + 4 * i + 3);
   }
   if constexpr (STATS) {
+    // a barrier between the loop's last flush and this one: when a workgroup's LAST tile is the first of a new statistics group, that
+    // tile's epilogue has just flushed the old group, and without the barrier a fast wave could add its new-group sums into `red` and
+    // take a second ticket before a slow wave has contributed to (or the last wave has read and zeroed) the first flush
+    lds_barrier();
     if (cur_grp >= 0) flush_stats(cur_grp);
   }
   C3_STAMP(28);

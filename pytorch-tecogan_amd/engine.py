@@ -12,7 +12,6 @@ Reference behaviour reproduced (file:line into the reference):
 """
 from collections import OrderedDict
 
-import os
 import torch
 
 from . import _lib as L
@@ -195,6 +194,14 @@ class Conv:
             self.last_desc = None
             K.convt_fwd(x, self.wf, self.bias, out, act)
             return
+        if self.spec.kind == "c4s2" and res is None and nchw is None and act == L.ACT_NONE and self.tile == L.TILE_AUTO and \
+                self.tu.s2_cw and K.s2_cw_ok(self.dt, self.cin_p, self.cout_p, H, W) and \
+                (stats is None or K.stats_replicas_for(N * OH * OW) == 1):
+            # persistent workgroups, the weights in registers, four-way split of the reduction (csrc/conv_s2_cw.hip, round 6)
+            self.last_desc, self.last_rw_nch = "s2cw", self.cin_p // 32
+            K.conv4s2_fwd_cw(x, self.wf, self.bias, out, stats, groups, stats_replicas=stats_r,
+                             max_workgroups=self.persist_fwd or self.persist_rw or self.persist_wgs)
+            return
         if self.spec.kind == "c4s2" and self.cout_p % 64 == 0 and res is None and nchw is None and act == L.ACT_NONE and \
                 self.tile == L.TILE_AUTO and self.tu.fast_c4s2 and H % 2 == 0 and W % 2 == 0 and \
                 (stats is None or K.stats_replicas_for(N * OH * OW) == 1):
@@ -274,6 +281,11 @@ class Conv:
                                                        mask_mode=L.MASK_BNZ, stats_mode=3, stats_groups=groups, stats_replicas=R)
             self.last_desc = d
             K.conv(d, dout, self.wb, out, res=res, mask=z, stats=red)
+            return
+        if self.spec.kind == "ct" and mask is None and res is None and bias_grad_of is None and self.tu.s2_cw and \
+                K.s2_cw_ok(self.dt, self.cout_p, self.cin_p, OH, OW) and OH == 2 * H and OW == 2 * W:
+            self.last_desc, self.last_rw_nch = "s2cw", self.cout_p // 32   # register-weights stride-2 gather (csrc/conv_s2_cw.hip, KS = 3)
+            K.convt_dgrad_cw(dout, self.wb, out, max_workgroups=self.persist_dgrad or self.persist_rw or self.persist_wgs)
             return
         if self.spec.kind == "ct" and self.cin_p % 64 == 0 and mask is None and res is None and bias_grad_of is None and \
                 self.tu.fast_c4s2 and OH == 2 * H and OW == 2 * W:

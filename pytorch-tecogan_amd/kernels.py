@@ -412,6 +412,19 @@ def conv4s2_fwd(x, w_packed, bias, out, stats=None, groups=1, stats_replicas=1, 
             "tg_conv4s2_fwd_capped")
 
 
+def conv4s2_fwd_cw(x, w_packed, bias, out, stats=None, groups=1, stats_replicas=1, max_workgroups=0):
+    """the same layer with the weights in registers (csrc/conv_s2_cw.hip, round 6): Cin in {64, 128}, Cout % 64 == 0, 16-bit types"""
+    N, H, W, cin = x.shape
+    L.check(L.load().tg_conv4s2_fwd_cw(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(stats), groups,
+                                       stats_replicas, N, H, W, cin, out.shape[3], max_workgroups or persist_wgs(None), _stream()),
+            "tg_conv4s2_fwd_cw")
+
+
+def s2_cw_ok(dtype, c_red, c_out, H, W):
+    """shapes csrc/conv_s2_cw.hip takes: 16-bit elements, 64 / 128 reduction channels, output channels % 64, even input size"""
+    return dtype in (torch.bfloat16, torch.float16) and c_red in (64, 128) and c_out % 64 == 0 and H % 2 == 0 and W % 2 == 0
+
+
 def conv4s2_dgrad(dout, wb_packed, din, mask=None, mask_mode=L.MASK_NONE):
     """input-gradient of conv k4 s2 p1: dout [N,OH,OW,Cout] -> din [N,2OH,2OW,Cin] (four sub-pixel classes in one launch),
     optionally times act'(mask)"""
@@ -433,6 +446,13 @@ def convt_dgrad(dout, wb_packed, din):
     N, OH, OW, cout = dout.shape
     L.check(L.load().tg_convt_dgrad(tg_dtype(dout.dtype), _ptr(dout), _ptr(wb_packed), _ptr(din), N, OH, OW, cout,
                                     din.shape[3], _stream()), "tg_convt_dgrad")
+
+
+def convt_dgrad_cw(dout, wb_packed, din, max_workgroups=0):
+    """the same input-gradient with the weights in registers (csrc/conv_s2_cw.hip, round 6): Cout (the reduction) in {64, 128}"""
+    N, OH, OW, cout = dout.shape
+    L.check(L.load().tg_convt_dgrad_cw(tg_dtype(dout.dtype), _ptr(dout), _ptr(wb_packed), _ptr(din), N, OH, OW, cout,
+                                       din.shape[3], max_workgroups or persist_wgs(None), _stream()), "tg_convt_dgrad_cw")
 
 
 def convt_fwd(x, w_packed, bias, out, act=L.ACT_NONE):

@@ -176,13 +176,26 @@ class generator(_HipModule):
 
     def recurrent(self, frames, use_graph=False):
         """(B,T,3,h,w) LR frames -> (B,T,3,4h,4w): the whole inference loop of main.py:171-219 on device."""
-        eng = self.engine()
         B, T, _, h, w = frames.shape
+        return self._rec_for(B, h, w, frames.device, use_graph).run(frames.contiguous().float())
+
+    def _rec_for(self, B, h, w, device, use_graph):
         if self._rec is None or (self._rec.B, self._rec.h, self._rec.w, self._rec.use_graph) != (B, h, w, use_graph):
             if self._rec is not None:
                 self._rec.close()
-            self._rec = RecurrentGenerator(eng, B, h, w, frames.device, use_graph)
-        return self._rec.run(frames.contiguous().float())
+            self._rec = RecurrentGenerator(self.engine(), B, h, w, device, use_graph)
+        return self._rec
+
+    def recurrent_step(self, frame, use_graph=False, reset=False):
+        """ONE frame of a live stream: (B,3,h,w) LR frame -> (B,3,4h,4w) HR frame, carrying the previous LR / HR frame across calls
+        (the per-frame body of /root/reference/experimental/live.py:100-128 and main.py:191-219: flow from the previous LR frame, warp of
+        the previous output, (x+1)/2, space-to-depth, generator).  reset=True (or a new frame shape) starts a new sequence: zeros as
+        the previous output (main.py:189-196).  A whole-sequence recurrent() call in between also restarts the stream."""
+        B, _, h, w = frame.shape
+        rec = self._rec_for(B, h, w, frame.device, use_graph)
+        if reset:
+            rec.reset()
+        return rec.step(frame.contiguous().float())
 
 
 class discriminator(_HipModule):

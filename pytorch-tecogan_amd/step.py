@@ -157,7 +157,7 @@ class TecoGANStep:
         self.gen = torch.empty(B, T, 3, H, H, **f32)
         self.flow = torch.empty(B, T - 1, 2, H, H, **f32)
         self.tvel = torch.empty(B * self.tsize, H, H, 2, **f32)
-        self.target = torch.empty(self.tb, 27, H, H, **f32)
+        self.target = self.out_gen = None   # the last call's fresh result tensors (_emit_target / _emit_gen)
         self.acc = torch.zeros(16, **f32)
         self.scalars = torch.zeros(64, **f32)
         # per-step host parameters (loss config, Adam bias corrections, lr) travel through ONE small async copy from a
@@ -417,9 +417,25 @@ class TecoGANStep:
         if backward:
             K.dlogit_real(D.prob, D.dlogit, tb, self.cfg, self.loss_scale)
             D.backward(groups=2, half=0)
-        # the returned `target` (the real half's input as fp32 NCHW, code/train.py:368) is read by the host only: converted at the END of
-        # the piece, where lane B waits for the chain anyway (the fake half writes D.act["in"][tb:], not this half's rows)
-        K.nhwc_to_nchw(D.act["in"][:tb], self.target, 27 * H * H, tb, 27, H, H)
+        # (the returned `target` - this half's input as fp32 NCHW, code/train.py:368 - is converted by _emit_target right behind this
+        # piece, where lane B waits for the chain anyway)
+
+    def _emit_target(self):
+        """Network.target of this call: a NEW tensor every call, as in the reference (code/train.py:357-370 builds its results
+        afresh), written on the current stream - lane B, behind the real half, outside the hipGraphs (their addresses are fixed).
+        The fake half writes D.act["in"][tb:], not the real half's rows, so this reads what the real half's forward saw."""
+        H, tb = self.H, self.tb
+        out = torch.empty(tb, 27, H, H, dtype=torch.float32, device=self.dev)
+        out.record_stream(self._caller)   # allocated on lane B's stream, read by the caller's
+        K.nhwc_to_nchw(self.D.act["in"][:tb], out, 27 * H * H, tb, 27, H, H)
+        self.target = out
+
+    def _emit_gen(self):
+        """Network.gen_output of this call: a fresh copy of the step's frame buffer (which the next call's graphs overwrite)"""
+        out = torch.empty_like(self.gen)
+        out.record_stream(self._caller)
+        out.copy_(self.gen, non_blocking=True)
+        self.out_gen = out
 
     def _chain(self, t0=0, t1=None, loss=False):
         """recurrent generator passes t0..t1-1 (each: warp + pack, conv0, residual trunk, up-sampling stage).  The piece
@@ -594,6 +610,7 @@ class TecoGANStep:
                     w_f.wait()
                 fn["update_f"]()
             fn["d_real"]()
+            self._emit_target()
         if sBm is not sB:
             ev["dreal"].record(sBm)
             sB.wait_event(ev["dreal"])
@@ -649,6 +666,7 @@ class TecoGANStep:
             if tm:
                 tm["B1"].record(sB)
             fn["update_d"]()
+            self._emit_gen()   # (the frames are final since the tail event this lane waited for; 8 MB, beside lane A's update)
             ev["d"].record(sB)
         for w in works_g:
             if w is not None:
@@ -687,6 +705,8 @@ class TecoGANStep:
 
     def _run_single(self, fwd_bwd, update):
         fwd_bwd()
+        self._emit_target()
+        self._emit_gen()
         works = [self._allreduce(self.G.flat.g), self._allreduce(self.D.flat.g)]
         if self.F_train:
             works.append(self._allreduce(self.F.flat.g))
@@ -724,8 +744,9 @@ class TecoGANStep:
     # ----------------------------------------------------------------------------------------------------------
     def run(self, x, y, global_step, lr_g, lr_d, betas_g=(0.9, 0.999), betas_d=(0.9, 0.999), eps_g=1e-8, eps_d=1e-8,
             f_hyper=None):
-        """x (B,T,3,h,h), y (B,T,3,H,H) fp32 device tensors.  Returns nothing; results live in self.gen / self.scalars /
-        self.target and the parameter / optimiser buffers are updated in place."""
+        """x (B,T,3,h,h), y (B,T,3,H,H) fp32 device tensors.  Returns nothing; results: self.out_gen / self.target (fresh tensors
+        every call), self.scalars, self.gen (the internal frame buffer, overwritten by the next call); the parameter / optimiser
+        buffers are updated in place."""
         Ti = self.T_in
         if tuple(x.shape) != (self.B, Ti, 3, self.h, self.h) or tuple(y.shape) != (self.B, Ti, 3, self.H, self.H):
             raise ValueError(f"step built for B={self.B}, T={Ti}, crop {self.h}; got {tuple(x.shape)} / {tuple(y.shape)}")
@@ -741,7 +762,7 @@ class TecoGANStep:
             self._stage_inputs_b()
         eager = (lambda: self._run_lanes(self._piece_fns())) if self.lanes else \
             (lambda: self._run_single(self._fork_join, self._update_all))
-        caller = torch.cuda.current_stream()
+        caller = self._caller = torch.cuda.current_stream()
         laneA = self.sA if self.sA is not None else caller
         if laneA is not caller:
             laneA.wait_stream(caller)
@@ -826,8 +847,56 @@ class RecurrentGenerator:
         finally:
             self.G.set_cap(cap0, fwd0)
 
+    # ---- one frame per call: the live loop (experimental/live.py:100-128 of the reference; the same recurrence as main.py:191-219)
+    def reset(self):
+        """forget the previous frame: the next step() is a sequence's first frame (zeros as "previous", main.py:189-196)"""
+        self._live = False
+
+    def step(self, frame):
+        """frame (B,3,h,w) fp32 device -> the HR frame (B,3,4h,4w), a new tensor.  STATEFUL: the previous LR / HR frames stay in slot 0
+        of the rings between calls, so a caller can feed a camera one frame at a time - what run() computes for a whole sequence, in
+        the same arithmetic (bit-identical: tests/test_inference_gpu.py).  With use_graph the frame step (flow -> warp + pack -> G)
+        is the one-frame chunk graph; per call: one LR copy in, one replay, one HR copy out, two copies that carry slot 1 to slot 0."""
+        B, h, w = self.B, self.h, self.w
+        if tuple(frame.shape) != (B, 3, h, w):
+            raise ValueError(f"recurrent step built for frames of {(B, 3, h, w)}, got {tuple(frame.shape)}")
+        self.G.alloc(B, h, w)
+        cap0, fwd0 = self.G.convs[0].persist_wgs, self.G.convs[0].persist_fwd
+        self.G.set_cap(tuning.current().infer_wgs)
+        try:
+            n, hh, HH = self.n, h * w, 16 * h * w
+            if not getattr(self, "_live", False):
+                self.sin[:, 0].copy_(frame)
+                K.gen_input(self.sin, 0, n * 3 * hh, None, 0, 0, None, 0, 0, self.G.act["in0"], B, h, w)
+                self.G.forward(0, B, self.sout, 0, n * 3 * HH, keep_h=False)
+                self._live = True
+                return self.sout[:, 0].clone()
+            self.sin[:, 1].copy_(frame)
+            self._replay_chunk(1)
+            out = self.sout[:, 1].clone()
+            self.sin[:, 0].copy_(self.sin[:, 1])
+            self.sout[:, 0].copy_(self.sout[:, 1])
+            return out
+        finally:
+            self.G.set_cap(cap0, fwd0)
+
+    def _replay_chunk(self, nf):
+        if not self.use_graph:
+            self._chunk(nf)
+            return
+        g = self.graphs.get(nf)
+        if g is None:
+            self._chunk(nf)           # warm-up: workspace growth, launch plans
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._chunk(nf)
+            self.graphs[nf] = g
+        g.replay()
+
     def _run(self, frames, B, T, h, w):
         n, hh, HH = self.n, h * w, 16 * h * w
+        self._live = False   # (a whole-sequence run uses the same rings: a live stream restarts afterwards)
         outs = torch.empty(B, T, 3, 4 * h, 4 * w, dtype=torch.float32, device=self.dev)
         # frame 0 has no previous frame (main.py:189-196: zeros): it goes through slot 0, the first chunk's "previous" slot
         self.sin[:, 0].copy_(frames[:, 0])
@@ -838,18 +907,7 @@ class RecurrentGenerator:
         while t < T:
             nf = min(self.FR, T - t)
             self.sin[:, 1:nf + 1].copy_(frames[:, t:t + nf])
-            if self.use_graph:
-                g = self.graphs.get(nf)
-                if g is None:
-                    self._chunk(nf)           # warm-up: workspace growth, launch plans
-                    torch.cuda.synchronize()
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        self._chunk(nf)
-                    self.graphs[nf] = g
-                g.replay()
-            else:
-                self._chunk(nf)
+            self._replay_chunk(nf)
             outs[:, t:t + nf].copy_(self.sout[:, 1:nf + 1])
             t += nf
             if t < T:   # the chunk's last frame becomes the next chunk's "previous"

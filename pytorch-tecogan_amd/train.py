@@ -170,7 +170,7 @@ def _network(st, args, global_step, counter1, counter2):
     avg += [tb, torch.tensor(st.dt_ratio), counter1, counter2]
     names_all = names + ["t_balance", "Dst_ratio", "withD_counter", "w_o_D_counter"]
     gen_loss = s[5]
-    return Network(gen_output=st.gen, learning_rate=args.learning_rate, update_list=vals, update_list_name=names_all,
+    return Network(gen_output=st.out_gen, learning_rate=args.learning_rate, update_list=vals, update_list_name=names_all,
                    update_list_avg=avg, global_step=global_step, d_loss=s[8], gen_loss=gen_loss, fnet_loss=gen_loss,
                    tb=tb, target=st.target)
 

@@ -73,6 +73,9 @@ KNOBS = OrderedDict((k.attr, k) for k in (
        "input-gradients of the 4x4 stride-2 convolutions (64 / 128 reduction channels, 16-bit) on the persistent class-waves kernel (conv4s2d_cw.hip; 0: the sub-pixel launch)"),
     _k("CT_CW", "ct_cw", "on", True, "profiles/r05_r_convt_cw_ab.log",
        "conv-transpose FORWARD launches (Cin 64 / 128, 16-bit) on the persistent class-waves kernel (convt_cw.hip; 0: the sub-pixel / four-class launches)"),
+    _k("S2_CW", "s2_cw", "on", True, "profiles/r06_b_conv_s2_cw_ab.log",
+       "4x4 stride-2 FORWARD launches and the conv-transposes' input-gradients (64 / 128 reduction channels, 16-bit) on the persistent "
+       "register-weights kernel (conv_s2_cw.hip; 0: conv4s2_mfma.hip's per-tile staging)"),
     _k("FAST_C4S2", "fast_c4s2", "on", True, "profiles/r01_h_bench_6p1ms.json (tools/mb_c4s2.py)",
        "dedicated stride-2 kernels (4x4 s2 forward / input-gradient, conv-transpose input-gradient)"),
     _k("RGB_OUT", "rgb_out", "on", True, "profiles/r02_i_bench_5p25ms.json", "output layer forward on conv_rgb.hip"),

@@ -13,12 +13,20 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: runs only with TECOGAN_SLOW=1 (sweeps, second variants of the multi-process tests)")
     config.addinivalue_line("markers", "experiments: a rejected variant; needs the experiments build of the library "
                                        "(csrc/build.sh --experiments, TECOGAN_LIB=.../libtecogan_hip_experiments.so) - skipped otherwise")
 
 
 def pytest_collection_modifyitems(config, items):
-    """tests of the rejected variants run only against the experiments library (never loaded by default)"""
+    """tests of the rejected variants run only against the experiments library (never loaded by default); `slow` tests (sweeps and
+    second variants of multi-process tests: minutes of box time, no parity row depends on them) only with TECOGAN_SLOW=1 - the
+    default `-m gpu` run has to stay well inside the driver's 900-s budget (447 s and growing)"""
+    if os.environ.get("TECOGAN_SLOW", "0") != "1":
+        skip_slow = pytest.mark.skip(reason="slow: set TECOGAN_SLOW=1")
+        for it in items:
+            if it.get_closest_marker("slow"):
+                it.add_marker(skip_slow)
     exp = [it for it in items if it.get_closest_marker("experiments")]
     if not exp:
         return

@@ -98,7 +98,10 @@ def test_rw_input_gradient_with_residual_and_mask(cin, cout, N, H, W, cap):
 
 
 @pytest.mark.parametrize("cin,cout,N,H,W,cap,groups", [(64, 64, 4, 24, 32, 5, 2), (64, 128, 6, 16, 16, 0, 1),
-                                                       (128, 128, 4, 16, 24, 7, 2), (64, 64, 12, 8, 8, 3, 2)])
+                                                       (128, 128, 4, 16, 24, 7, 2), (64, 64, 12, 8, 8, 3, 2),
+                                                       # every workgroup's LAST tile is the first of a new statistics group (6 tiles
+                                                       # on 3 workgroups: b, b + 3): two flushes with no tile between them
+                                                       (64, 64, 2, 24, 16, 4, 2)])
 def test_rw_statistics_groups_and_lrelu(cin, cout, N, H, W, cap, groups):
     """the discriminator's residual convs: per-channel sum / sum of squares of the STORED values per BN group
     (code/ops.py:75-77 via batch_norm's batch statistics); bias-gradient mode (sums only) leaves the second row untouched"""

@@ -36,7 +36,8 @@ def _launch(script_args, port, env_extra, cwd, timeout=900, nproc=2):
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("mode", [{}, {"TECOGAN_DP_INLINE": "0"}], ids=["one-allreduce-per-network", "two-buckets-per-network"])
+@pytest.mark.parametrize("mode", [{}, pytest.param({"TECOGAN_DP_INLINE": "0"}, marks=pytest.mark.slow)],   # (the option, not the default: 33 s)
+                         ids=["one-allreduce-per-network", "two-buckets-per-network"])
 def test_two_rank_step_equals_two_shards_with_local_bn_and_averaged_gradients(tmp_path, mode):
     out = tmp_path / "dp"
     r = _launch([os.path.join(ROOT, "tests", "dp_worker.py"), str(out)], _free_port(), dict(mode), ROOT)

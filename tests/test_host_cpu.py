@@ -42,7 +42,7 @@ def test_capi_library_exports_every_declared_symbol():
     if nm.returncode == 0 and not lib.tg_has_experiments():
         exported = {ln.split()[-1] for ln in nm.stdout.splitlines() if " T tg_" in ln}
         assert exported == declared, exported ^ declared
-    assert lib.tg_abi_version() == L.ABI_VERSION == 3
+    assert lib.tg_abi_version() == L.ABI_VERSION == 4
     assert lib.tg_error_string(-2) == b"unsupported shape"
 
 

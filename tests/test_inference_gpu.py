@@ -63,6 +63,33 @@ def test_config5_sequence_of_120_frames_graph_equals_eager_bf16():
     assert float((alone[:, 0] - graph[:, 119]).abs().max()) > 0.0
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_live_per_frame_step_carries_the_previous_frame_across_calls(graph):
+    """generator.recurrent_step(frame): the stateful per-frame entry point of the live loop
+    (/root/reference/experimental/live.py:100-128, main.py:191-219).  Feeding a sequence one frame per call gives, bit for bit, what
+    the whole-sequence recurrent() gives (which is gated against the oracle above); the results are new tensors; reset=True and an
+    intervening whole-sequence call both start a new stream."""
+    G, _ = _gen("bf16")
+    x = torch.from_numpy(np.random.default_rng(8).random((2, 7, 3, 32, 48), dtype=np.float32)).cuda()
+    ref = G.recurrent(x, use_graph=False).clone()
+    outs = [G.recurrent_step(x[:, t], use_graph=graph, reset=(t == 0)) for t in range(7)]
+    assert len({o.data_ptr() for o in outs}) == 7
+    for t, o in enumerate(outs):
+        assert o.shape == (2, 3, 128, 192) and float((o - ref[:, t]).abs().max()) == 0.0, t
+    # a second stream on the same object: reset, then the same frames again
+    again = [G.recurrent_step(x[:, t], use_graph=graph, reset=(t == 0)) for t in range(3)]
+    assert all(float((a - ref[:, t]).abs().max()) == 0.0 for t, a in enumerate(again))
+    # without a reset the stream continues: frame 0 fed as the 4th frame of the stream is NOT a first frame
+    cont = G.recurrent_step(x[:, 0], use_graph=graph)
+    assert float((cont - ref[:, 0]).abs().max()) > 0.0
+    # a whole-sequence call restarts the stream
+    G.recurrent(x[:, :2].contiguous(), use_graph=graph)
+    first = G.recurrent_step(x[:, 0], use_graph=graph)
+    assert float((first - ref[:, 0]).abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        G._rec.step(x[:, 0, :, :16].contiguous())
+
+
 @pytest.mark.parametrize("chunk", ["16", "4", "1"])
 def test_chunked_inference_batch_of_two_ragged_length_graph_equals_eager(chunk, monkeypatch):
     """RecurrentGenerator runs the sequence in chunks of TECOGAN_INFER_CHUNK frames (one staging copy in, one hipGraph, one strided

@@ -249,6 +249,7 @@ def test_step_odd_shape_b3_crop48_vs_oracle(monkeypatch):
         assert out.target.shape == (9, 27, 192, 192) and rel(out.target.cpu(), f["real_in"]) < 1e-5
 
 
+@pytest.mark.slow   # (a three-shape cap sweep in a child process: 31 s of the default run's budget; tools/shape_sweep.py is the full form)
 @pytest.mark.timeout(900)
 def test_default_knobs_within_8_percent_of_the_cap_sweep_off_benchmark():
     """the workgroup caps / routing thresholds were tuned on three shapes (configs 2, 4-shard, 5); tools/shape_sweep.py times the step
@@ -597,3 +598,90 @@ def test_persistent_workgroup_cap_is_a_scheduling_knob_only():
     # (d_loss five steps into GAN training amplifies the last bits of the atomically accumulated BatchNorm sums: runs of ONE setting
     #  spread over 0.207 ... 0.219, profiles/r04_z_cap_losses.log - a changed cap must stay inside that band, not inside 5 %)
     np.testing.assert_allclose(res[0]["d_loss"], res[1]["d_loss"], rtol=0.12, atol=2e-3)
+
+
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_frvsr_train_returns_fresh_tensors_every_call(graph, monkeypatch):
+    """the reference builds `gen_output` / `target` anew on every call (/root/reference/code/train.py:357-370): what call k returned
+    must survive call k + 1 (round 5 handed out the step's internal buffers, which the next call's graphs overwrite)"""
+    monkeypatch.setenv("TECOGAN_GRAPH", graph)
+    args, G, D, og, od, _, _ = build(7, "bf16", num_resblock=2, discrim_resblocks=1)
+    outs, keep = [], []
+    for k in range(3):     # (graph mode: call 0 runs eager + captures, calls 1 and 2 replay)
+        x, y = synth(2, 10, 32, 70 + k)
+        out = train.FRVSR_Train(x.cuda(), y.cuda(), args, D, G, k, 0.0, 0.0, og, od)
+        torch.cuda.synchronize()
+        outs.append(out)
+        keep.append((out.gen_output.clone(), out.target.clone(), y))
+    ptrs = {o.gen_output.data_ptr() for o in outs} | {o.target.data_ptr() for o in outs}
+    assert len(ptrs) == 6
+    for o, (g, t, y) in zip(outs, keep):
+        assert torch.equal(o.gen_output, g) and torch.equal(o.target, t)
+        # target[:, 0:9] = the HR frames of this call's batch (code/train.py:175-179), not a later call's
+        assert rel(o.target[:, 0:9].cpu().reshape(2, 3, 3, 3, 128, 128), y[:, :9].reshape(2, 3, 3, 3, 128, 128)) < 4e-3
+    assert not torch.equal(outs[0].gen_output, outs[1].gen_output)
+
+
+def test_reference_written_checkpoint_resumes_through_main_py(tmp_path, monkeypatch):
+    """tests/golden/ref_generator.pt.xz / ref_discrim.pt.xz were saved by the REFERENCE's modules and optimisers with its own
+    statements (/root/reference/main.py:308-317; oracle/make_ckpt_golden.py).  (1) Loaded with main.py's resume statements into the
+    build's modules on the GPU and bound to the engines, parameters, BN buffers and both Adam moments are exactly the file's; one
+    training step then moves every weight by at most ~lr.  (2) `main.py --pre_trained_model true` resumes from them: epoch and Adam
+    step count continue (7 -> 8 epochs, step 2 -> 3), and what it writes goes to gpurun_out/r06_ckpt for the build container's
+    load-into-the-reference check (tests/test_checkpoint_cpu.py)."""
+    import importlib.util
+    import lzma
+    import shutil
+    paths = {}
+    for tag in ("generator", "discrim"):
+        raw = lzma.decompress(open(os.path.join(ROOT, "tests", "golden", f"ref_{tag}.pt.xz"), "rb").read())
+        paths[tag] = tmp_path / f"ref_{tag}.pt"
+        paths[tag].write_bytes(raw)
+    exp = np.load(os.path.join(ROOT, "tests", "golden", "ckpt_expect.npz"))
+    args, G, D, og, od, _, _ = build(9, "bf16", num_resblock=2, discrim_resblocks=1)
+    g_ck = torch.load(paths["generator"], map_location=DEV)
+    G.load_state_dict(g_ck["model_state_dict"])
+    og.load_state_dict(g_ck["optimizer_state_dict"])
+    d_ck = torch.load(paths["discrim"], map_location=DEV)
+    D.load_state_dict(d_ck["model_state_dict"])
+    od.load_state_dict(d_ck["optimizer_state_dict"])
+    G.engine(), D.engine()                                     # bind: parameters become views of the flat buffers
+    hip_train._bind_optimizer(og, G)
+    hip_train._bind_optimizer(od, D)
+    for tag, mod, opt, ck in (("generator", G, og, g_ck), ("discrim", D, od, d_ck)):
+        assert list(mod.state_dict().keys()) == list(exp[tag + "_state_keys"])
+        for k, v in mod.state_dict().items():
+            assert torch.equal(v.float().cpu(), ck["model_state_dict"][k].float().cpu()), k
+        flat = mod.flat_params()
+        for i, (n, p) in enumerate(mod.named_parameters()):
+            s_ck = ck["optimizer_state_dict"]["state"][i]
+            assert torch.equal(flat.view(flat.m, n).cpu(), s_ck["exp_avg"].cpu()) and torch.equal(flat.view(flat.v, n).cpu(), s_ck["exp_avg_sq"].cpu()), n
+            assert opt.state[p]["exp_avg"].data_ptr() == flat.view(flat.m, n).data_ptr() and float(opt.state[p]["step"]) == 2.0
+    before = {k: v.clone() for k, v in G.state_dict().items()}
+    x, y = synth(2, 10, 32, 90)
+    hip_train._STEPS.clear()
+    out = train.FRVSR_Train(x.cuda(), y.cuda(), args, D, G, 0, 0.0, 0.0, og, od)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out.gen_output).all()) and np.isfinite(float(out.d_loss))
+    moved = max(float((G.state_dict()[k] - v).abs().max()) for k, v in before.items())
+    # the file's third Adam step: |update| <= lr * (1 - beta1) / sqrt(1 - beta2) = 3.2 lr whatever the gradient
+    assert 0.0 < moved <= 3.2e-4 and float(og.state_dict()["state"][0]["step"]) == 3.0
+    # ---- (2) main.py
+    spec = importlib.util.spec_from_file_location("tg_main_ck", os.path.join(ROOT, "main.py"))
+    tg_main = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tg_main)
+    monkeypatch.chdir(tmp_path)
+    hip_train._STEPS.clear()
+    tg_main.main(["--synthetic", "4", "--max_epochs", "8", "--num_resblock", "2", "--discrim_resblocks", "1", "--tg_dtype", "bf16",
+                  "--pre_trained_model", "true", "--g_checkpoint", str(paths["generator"]), "--d_checkpoint", str(paths["discrim"])])
+    g2, d2 = torch.load(tmp_path / "generator.pt"), torch.load(tmp_path / "discrim.pt")
+    assert g2["epoch"] == 7 and float(g2["optimizer_state_dict"]["state"][0]["step"]) == 3.0
+    assert list(g2["model_state_dict"].keys()) == list(exp["generator_state_keys"])
+    assert list(d2["model_state_dict"].keys()) == list(exp["discrim_state_keys"])
+    assert int(d2["model_state_dict"]["block1.1.num_batches_tracked"]) == 6      # 4 in the file + 2 forward calls of one step
+    assert sorted(g2["optimizer_state_dict"]["param_groups"][0].keys()) == list(exp["generator_opt_group_keys"])
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):   # (the GPU box's copy is merged back into the build container's tree)
+        os.makedirs(os.path.join(out_dir, "r06_ckpt"), exist_ok=True)
+        for f in ("generator.pt", "discrim.pt"):
+            shutil.copy(tmp_path / f, os.path.join(out_dir, "r06_ckpt", f))
