@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 4   /* 4 (round 6): + tg_conv4s2_fwd_cw, tg_convt_dgrad_cw; 3 (round 5): + tg_convt_fwd_cw, tg_conv3x3_cw, tg_conv4s2_dgrad_cw, tg_conv4s2_fwd_capped; 2 (round 5): + tg_resblock_fwd_ws; round 4 removed tg_wgrad_group / tg_absdiff_nchw and moved the
+#define TG_ABI_VERSION 4   /* 4 (round 6): + tg_conv4s2_fwd_cw, tg_convt_dgrad_cw, tg_d_tail_fwd / _bwd / _max_pixels / _scratch_floats; 3 (round 5): + tg_convt_fwd_cw, tg_conv3x3_cw, tg_conv4s2_dgrad_cw, tg_conv4s2_fwd_capped; 2 (round 5): + tg_resblock_fwd_ws; round 4 removed tg_wgrad_group / tg_absdiff_nchw and moved the
                            * rejected variants behind TG_EXPERIMENTS without a bump */
 
 enum { TG_F32 = 0, TG_BF16 = 1, TG_F16 = 2 };  /* TG_F16: IEEE half, same layouts as TG_BF16 (loss scaling: tg_adam) */
@@ -435,6 +435,34 @@ int tg_fc_head_fwd(int dtype, const void* feat, const float* w, const float* b, 
                    int Cp, void* stream);
 int tg_fc_head_bwd(int dtype, const void* feat, const float* w, const float* dlogit, void* dfeat, float* dw,
                    float* db, int N, int HW, int C, int Cp, void* stream);
+
+/* The discriminator's TAIL in ONE launch per direction (csrc/d_tail.hip, round 6: one workgroup per sample; what couples the samples -
+ * block5.1's batch statistics, block4.1's backward sums - goes through `scratch` and a ticket, the workgroup that draws the last one
+ * finishes for all; nobody waits, no co-residency assumption; replaces, behind block4's
+ * convolution, the launches tg_bn_apply, tg_conv (block5.0), tg_bn_apply, tg_fc_head_fwd [, tg_dlogit_real] and tg_fc_head_bwd,
+ * 2 x (tg_bn_bwd_reduce, tg_bn_bwd_apply), tg_conv (block5.0's input-gradient) - /root/reference/code/models.py:119-123,137-146,
+ * code/ops.py:75-77,85-88, autograd of code/train.py:304-307 - with the same rounding points: every tensor another launch reads is
+ * written as before).  Tensors NHWC: z4 n4 dn4 dz4 [N][H4][H4][C4], z5 n5 dz5 [N][H4/2][H4/2][Cp5] (C5 real channels, padding written
+ * as zeros); stats4 = the replica blocks block4's convolution accumulated; w5 = block5.0.weight, the fp32 MASTER [C5][C4][4][4]
+ * (rounded to the element type in the kernel, as the packer does); fc_w [C5 * (H4/2)^2], channel-major as torch's flatten; save4 /
+ * save5 [groups][2][C] (mean, invstd); running statistics / num_batches_tracked may be null (no update).  BatchNorm groups are
+ * walked one after the other.  tg_d_tail_bwd: seed_real != 0 (groups must be 1) computes d(loss)/d(logit) of the real half from prob
+ * as tg_dlogit_real does and leaves it in dlogit_in_out; parameter gradients are ACCUMULATED (+=); dn4 is scratch.
+ * scratch: tg_d_tail_scratch_floats(N, H4, groups) floats, ZERO before the first launch (every launch leaves it zero); one buffer
+ * per stream of launches (forward and backward of one discriminator call may share it).
+ * TG_E_UNSUPPORTED beyond tg_d_tail_max_pixels() block4 pixels per group, C4 != 64, C5 > 4 (run the separate launches). */
+long long tg_d_tail_max_pixels(void);
+long long tg_d_tail_scratch_floats(int N, int H4, int groups);
+int tg_d_tail_fwd(int dtype, const void* z4, const float* stats4, int stats_replicas, const float* gamma4, const float* beta4,
+                  float* rmean4, float* rvar4, int64_t* nbt4, float* save4, void* n4, const float* w5, void* z5,
+                  const float* gamma5, const float* beta5, float* rmean5, float* rvar5, int64_t* nbt5, float* save5, void* n5,
+                  const float* fc_w, const float* fc_b, float* prob, int N, int H4, int C4, int C5, int Cp5, int groups,
+                  float eps, float momentum, float* scratch, void* stream);
+int tg_d_tail_bwd(int dtype, const float* dlogit_in_out, const float* prob, const float* cfg, const float* loss_scale,
+                  int seed_real, const void* n5, const void* z5, const float* save5, const float* gamma5, const float* fc_w,
+                  const float* w5, const void* n4, const void* z4, const float* save4, const float* gamma4, void* dz5, void* dn4,
+                  void* dz4, float* g_fc_w, float* g_fc_b, float* dgamma5, float* dbeta5, float* dgamma4, float* dbeta4, int N,
+                  int H4, int C4, int C5, int Cp5, int groups, float* scratch, void* stream);
 /* acc[0] += sum |a-b| over real channels (layer loss, code/train.py:219-220). */
 int tg_absdiff_sum(int dtype, const void* a, const void* b, float* acc, int64_t npix, int C, int Cp, void* stream);
 /* The same for njobs tensor pairs in one launch (the four D layer losses of code/train.py:205-226): jobs_dev = njobs x 6 int64

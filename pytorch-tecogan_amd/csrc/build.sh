@@ -7,7 +7,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-SRCS="conv_mfma wgrad_mfma wgrad_group warp elementwise fnet resblock resblock_ws convt_mfma convt_cw conv4s2_mfma conv4s2d_cw conv_s2_cw runtime conv3_rw conv3_cw vgg conv_rgb rgb_bwd"
+SRCS="conv_mfma wgrad_mfma wgrad_group warp elementwise fnet resblock resblock_ws convt_mfma convt_cw conv4s2_mfma conv4s2d_cw conv_s2_cw d_tail runtime conv3_rw conv3_cw vgg conv_rgb rgb_bwd"
 OUT=libtecogan_hip.so
 OBJ=.
 EXTRA=""

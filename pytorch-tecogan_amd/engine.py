@@ -1350,6 +1350,8 @@ class DiscriminatorEngine:
         self.bn_fuse = TU().bn_fuse
         if self.bn_fuse:
             tuning.need_experiments("bn_fuse")
+        self.tail = TU().d_tail
+        self._tail_scratch = {}
 
     # launch classes of kernels.rw_eligible added for the REAL half only (TecoGANStep sets "s1" for chain-bound steps: the real
     # half runs beside the chain with slack, and its stage-1 convs are better neighbours as capped persistent launches: 4.194 ->
@@ -1423,9 +1425,18 @@ class DiscriminatorEngine:
         v = lambda t: t[sl]
         self.conv0.fwd(v(a["in"]), v(a["c0"]), act=L.ACT_LRELU)
         prev = v(a["c0"])
+        n_here = sl.stop - sl.start
         for k in range(1, 6):
             conv, bn = self.blk[k]
             conv.fwd(prev, v(a["z"][k]), stats=st_of(bn), groups=groups, stats_r=bn.R)
+            if k == 4 and self.tail_fused(n_here // groups):
+                # BN + LeakyReLU of block4, block5, fc, sigmoid: ONE single-workgroup launch (csrc/d_tail.hip, round 6)
+                bn5, sv = self.blk[5][1], (lambda b: b.save if half is None else b.save[half])
+                rs = lambda b: (b.rm, b.rv, b.nbt) if update_stats else (None, None, None)
+                K.d_tail_fwd(v(a["z"][4]), st_of(bn), bn.R, bn.gamma, bn.beta, *rs(bn), sv(bn), v(a["n"][4]), self.blk[5][0].w,
+                             v(a["z"][5]), bn5.gamma, bn5.beta, *rs(bn5), sv(bn5), v(a["n"][5]), self.fc_w, self.fc_b, self.prob[sl],
+                             n_here, a["z"][4].shape[1], self.cout[5], groups, self._tail_ws(half, n_here, groups))
+                return
             bn.apply(v(a["z"][k]), v(a["n"][k]), L.ACT_LRELU, groups, update=update_stats, half=half)
             net = v(a["n"][k])
             if k <= 3:
@@ -1438,13 +1449,28 @@ class DiscriminatorEngine:
             prev = net
         K.fc_head_fwd(v(a["n"][5]), self.fc_w, self.fc_b, self.prob[sl], sl.stop - sl.start, self.fc_hw, 3, 32)
 
+    def _tail_ws(self, half, n, groups):
+        """the tail launches' scratch for this half (or the whole batch) of the current buffer set: zero at creation, left zero by every launch"""
+        key = (self.shape, half, n, groups)
+        ws = self._tail_scratch.get(key)
+        if ws is None:
+            if self.ws.frozen:
+                raise L.TecoganHipError("new discriminator tail shape after graph capture")
+            ws = self._tail_scratch[key] = K.d_tail_scratch(n, self.act["z"][4].shape[1], groups, self.flat.device)
+        return ws
+
+    def tail_fused(self, n_per_group):
+        """the tail (block4's BatchNorm ... sigmoid, and its backward) as single-workgroup launches for this many samples per BN group?"""
+        return self.tail and K.d_tail_ok(n_per_group, self.act["z"][4].shape[1], pad32(self.cout[4]), self.cout[5])
+
     def bucket_split(self):
         """element offset in the flat gradient buffer where block2 begins: [0, split) = conv.0, block1, resids1 - the
         layers whose gradients come LAST in backward - is final after backward(part='lo'), [split, total) after 'hi'"""
         return self.flat.offsets["block2.0.weight"][0]
 
-    def backward(self, groups=2, half=None, part=None):
+    def backward(self, groups=2, half=None, part=None, real_seed=None):
         """consumes self.dlogit; accumulates all D gradients (everything on the current stream).
+        real_seed = (cfg, loss_scale): self.dlogit of this (real) half is first computed from self.prob (tg_dlogit_real's expression).
         half=0/1: only the real / fake half of the 2-group batch (the loss is a mean of per-half terms and BN statistics
         are per half, code/train.py:199-203,304-307, so the halves are independent in backward): the real half's backward
         can run before the generator has produced the frames the fake half needs.
@@ -1461,7 +1487,20 @@ class DiscriminatorEngine:
         a, g = cut(self.act), cut(self.gbuf)
         n = sl.stop - sl.start
         lo_convs = [self.conv0, self.blk[1][0]] + [c for (c1, c2, _) in self.res[1] for c in (c1, c2)]
-        if part != "lo":
+        gh = groups if half is None else 1
+        tail = part != "lo" and self.tail_fused(n // gh) and (real_seed is None or gh == 1)
+        if part != "lo" and tail:
+            # fc, block5 and block4's BatchNorm backward: ONE single-workgroup launch (csrc/d_tail.hip); leaves d z5, d z4 and the
+            # parameter gradients of fc / block5.1 / block4.1
+            bn4, bn5, sv = self.blk[4][1], self.blk[5][1], (lambda b: b.save if half is None else b.save[half])
+            K.d_tail_bwd(self.dlogit[sl], self.prob[sl], real_seed[0] if real_seed else None, real_seed[1] if real_seed else None,
+                         real_seed is not None, a["n"][5], a["z"][5], sv(bn5), bn5.gamma, self.fc_w, self.blk[5][0].w, a["n"][4],
+                         a["z"][4], sv(bn4), bn4.gamma, g["dz"][5], g["dn"][4], g["dz"][4], self.g_fc_w, self.g_fc_b, bn5.dgamma,
+                         bn5.dbeta, bn4.dgamma, bn4.dbeta, n, a["z"][4].shape[1], self.cout[5], gh, self._tail_ws(half, n, gh))
+            d_net = None
+        elif part != "lo":
+            if real_seed is not None:
+                K.dlogit_real(self.prob[sl], self.dlogit[sl], n, real_seed[0], real_seed[1])
             K.fc_head_bwd(a["n"][5], self.fc_w, self.dlogit[sl], g["dn"][5], self.g_fc_w, self.g_fc_b, n, self.fc_hw, 3, 32)
             d_net = g["dn"][5]  # gradient w.r.t. the current stage's output
         else:
@@ -1501,12 +1540,15 @@ class DiscriminatorEngine:
                 # (work lists: stage 1 waits for conv.0 below - one launch for both; the k4 s2 layers stay queued to the end)
             conv, bn = self.blk[k]
             d_z = g["dz"][k]
-            bn.backward(d_net, a["n"][k], a["z"][k], d_z, L.ACT_LRELU, groups, half=half)
+            if not (tail and k >= 4):   # (the fused tail has left d z5 and d z4)
+                bn.backward(d_net, a["n"][k], a["z"][k], d_z, L.ACT_LRELU, groups, half=half)
             prev = stage_out(k - 1) if k > 1 else a["c0"]
             if lists:
                 wg(conv, prev, d_z)
             else:
                 conv.wgrad(prev, d_z)
+            if tail and k == 5:
+                continue                # (block5.0's input-gradient is inside the fused launch)
             if k > 1:
                 d_prev = g["dnet"][k - 1][self.nrb - 1] if (k - 1 <= 3 and self.nrb > 0) else g["dn"][k - 1]
                 conv.dgrad(d_z, d_prev)

@@ -690,6 +690,37 @@ def fc_head_bwd(feat, w, dlogit, dfeat, dw, db, N, HW, C_, Cp):
                                     _ptr(db), N, HW, C_, Cp, _stream()), "tg_fc_head_bwd")
 
 
+def d_tail_ok(n_per_group, H4, C4, C5):
+    """shapes the tail launches take (csrc/d_tail.hip, check_tail)"""
+    return n_per_group * H4 * H4 <= int(L.load().tg_d_tail_max_pixels()) and n_per_group <= 256 and C4 == 64 and \
+        1 <= C5 <= 4 and C5 * (H4 // 2) ** 2 <= 256 and H4 % 2 == 0
+
+
+def d_tail_fwd(z4, stats4, replicas, gamma4, beta4, rm4, rv4, nbt4, save4, n4, w5, z5, gamma5, beta5, rm5, rv5, nbt5, save5, n5,
+               fc_w, fc_b, prob, N, H4, C5, groups, scratch, eps=1e-3, momentum=0.1):
+    """everything of discriminator.forward behind block4's convolution in one launch (include/tecogan_hip.h, tg_d_tail_fwd)"""
+    L.check(L.load().tg_d_tail_fwd(tg_dtype(z4.dtype), _ptr(z4), _ptr(stats4), replicas, _ptr(gamma4), _ptr(beta4), _ptr(rm4), _ptr(rv4),
+                                   _ptr(nbt4), _ptr(save4), _ptr(n4), _ptr(w5), _ptr(z5), _ptr(gamma5), _ptr(beta5), _ptr(rm5), _ptr(rv5),
+                                   _ptr(nbt5), _ptr(save5), _ptr(n5), _ptr(fc_w), _ptr(fc_b), _ptr(prob), N, H4, z4.shape[3], C5,
+                                   z5.shape[3], groups, eps, momentum, _ptr(scratch), _stream()), "tg_d_tail_fwd")
+
+
+def d_tail_scratch(N, H4, groups, device):
+    """the zeroed scratch of the tail launches for N samples (every launch leaves it zero again)"""
+    return torch.zeros(int(L.load().tg_d_tail_scratch_floats(N, H4, groups)), device=device)
+
+
+def d_tail_bwd(dlogit, prob, cfg, loss_scale, seed_real, n5, z5, save5, gamma5, fc_w, w5, n4, z4, save4, gamma4, dz5, dn4, dz4,
+               g_fc_w, g_fc_b, dgamma5, dbeta5, dgamma4, dbeta4, N, H4, C5, groups, scratch):
+    """... and of its backward pass between d(loss)/d(logit) and block4's input-gradient (tg_d_tail_bwd)"""
+    L.check(L.load().tg_d_tail_bwd(tg_dtype(z4.dtype), _ptr(dlogit), _ptr(prob), _ptr(cfg), _ptr(loss_scale), int(seed_real), _ptr(n5),
+                                   _ptr(z5), _ptr(save5), _ptr(gamma5), _ptr(fc_w), _ptr(w5), _ptr(n4), _ptr(z4), _ptr(save4),
+                                   _ptr(gamma4), _ptr(dz5), _ptr(dn4), _ptr(dz4), _ptr(g_fc_w), _ptr(g_fc_b), _ptr(dgamma5),
+                                   _ptr(dbeta5), _ptr(dgamma4), _ptr(dbeta4), N, H4, z4.shape[3], C5, z5.shape[3], groups, _ptr(scratch),
+                                   _stream()),
+            "tg_d_tail_bwd")
+
+
 def absdiff_sum(a, b, acc, acc_idx, npix, C_, Cp):
     L.check(L.load().tg_absdiff_sum(tg_dtype(a.dtype), _ptr(a), _ptr(b), _sub_ptr(acc, acc_idx), npix, C_, Cp,
                                     _stream()), "tg_absdiff_sum")

@@ -184,7 +184,7 @@ class TecoGANStep:
         cap_g, cap_dr = K.persist_wgs_g_for(B * h * h), K.persist_wgs_dreal_for(B * h * h)
         if cap_g is not None:
             G.set_cap(cap_g, tu.cap_fwd_g_for(B * h * h))
-        G.set_trunk_cap(tu.persist_trunk_g)
+        G.set_trunk_cap(tu.cap_trunk_g_for(B * h * h))
         # (set both ways: the engine may have served a step of another size before)
         D.cap[0] = cap_dr if cap_dr is not None else tu.cap_dreal_default()
         D.rw_extra_real = tu.rw_extra_dreal if tu.rw_extra_dreal is not None else ("s1" if cap_dr is not None else "")
@@ -414,9 +414,8 @@ class TecoGANStep:
         backward = self.dreal_bwd_early if backward is None else backward
         K.d_assemble(self.x, self.y, self.gen, self.tvel, D.act["in"][:tb], B, T, self.K, h, self.border, half=0)
         D.forward(update_stats=True, half=0)
-        if backward:
-            K.dlogit_real(D.prob, D.dlogit, tb, self.cfg, self.loss_scale)
-            D.backward(groups=2, half=0)
+        if backward:   # (the loss seed of this half - tg_dlogit_real - is the backward pass's first action: inside its tail launch)
+            D.backward(groups=2, half=0, real_seed=(self.cfg, self.loss_scale))
         # (the returned `target` - this half's input as fp32 NCHW, code/train.py:368 - is converted by _emit_target right behind this
         # piece, where lane B waits for the chain anyway)
 

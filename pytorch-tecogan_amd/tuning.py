@@ -46,8 +46,9 @@ KNOBS = OrderedDict((k.attr, k) for k in (
        "cap of the discriminator's REAL half, which runs beside the chain (unset: the D cap; 72 / 80 for chain-bound steps until the end of round 5)"),
     _k("PERSIST_FWD_G", "persist_fwd_g", "int", 0, "profiles/r04_z_fwd_cap.log, r05_v_caps_write_through.log",
        "cap of the generator's FORWARD register-weights launches (the chain, beside the real half); 0: 160 for steps of <= 4096 LR pixels per pass, else the generator's"),
-    _k("PERSIST_TRUNK_G", "persist_trunk_g", "int", 0, "profiles/r04_z_trunk_cap.log",
-       "cap of the trunk's 32 input-gradient launches in the batched G backward (0: the generator's)"),
+    _k("PERSIST_TRUNK_G", "persist_trunk_g", "int", 0, "profiles/r04_z_trunk_cap.log, r06_h_caps.log",
+       "cap of the trunk's 32 input-gradient launches in the batched G backward (0: 160 for steps of <= 4096 LR pixels per pass - two tiles "
+       "per workgroup instead of 2.2 at the generator's 144 -, else the generator's)"),
     # (round 5 pruned five knobs that every sweep of rounds 2-4 had left at their defaults: PERSIST_RW_G / _D - a separate cap for the
     #  register-weights launches, r02_q -, PERSIST_FWD_DREAL / _DFAKE - r04_z_d_fwd_caps - and RW_DHALF_OFF - r03_r)
     # ---- kernel routing (engine.Conv, kernels.rw_eligible)
@@ -101,6 +102,9 @@ KNOBS = OrderedDict((k.attr, k) for k in (
     # ---- batch norm
     _k("STATS_REPLICAS", "stats_replicas", "int", 4, "profiles/r02_k_mb_stats_replicas.log, r02_k_stats_replicas_ab.log",
        "replica blocks of the batch-norm accumulators (a power of two)"),
+    _k("D_TAIL", "d_tail", "on", True, "profiles/r06_d_tail_ab.log",
+       "the discriminator's tail (BN + LeakyReLU of block4, block5, fc, sigmoid [, the real half's loss seed]; and its backward down to "
+       "block4's output gradient) as ONE single-workgroup launch per direction (d_tail.hip; 0: 5-6 + 6 separate launches)"),
     # ---- element type / library / launcher
     _k("DTYPE", "dtype", "str", "bf16", "BASELINE.json configs[1]", "compute element type when args.tg_dtype is unset (bf16 | fp16 | fp32)"),
     _k("LIB", "lib", "ostr", None, "tools/ab_libs.sh", "path of an alternative libtecogan_hip.so (A/B builds); read by _lib.py at import"),
@@ -177,6 +181,15 @@ class Tuning:
         3.404-3.406 / 3.42-3.44 / 3.44 / 3.44-3.45 ms (profiles/r05_v_caps_write_through.log)"""
         if self.persist_fwd_g:
             return self.persist_fwd_g
+        return 160 if lr_pixels <= 4096 else 0
+
+    def cap_trunk_g_for(self, lr_pixels):
+        """cap of the trunk's 32 input-gradient launches of the batched G backward (0: the generator's).  Round 4 found no effect
+        (107 ... 256: 3.724-3.737 ms, lane B was the long pole then); since the discriminator's tail became two launches lane A ends
+        last, and 40 x 32 x 32 pixels = 320 tiles are TWO per workgroup at 160 instead of 3 / 2 at 144: 0 / 160 / 176 / 192 / 256 =
+        3.268 / 3.234 / 3.241 / 3.245 / 3.240 ms (profiles/r06_h_caps.log)"""
+        if self.persist_trunk_g:
+            return self.persist_trunk_g
         return 160 if lr_pixels <= 4096 else 0
 
     def cap_dreal_for(self, lr_pixels):
