@@ -334,15 +334,21 @@ def usable_cores():
     return n
 
 
+PMC_ROUND = 6
+PMC_SUMMARY = f"r{PMC_ROUND:02d}_pmc_summary.json"
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are separate
     runs of this same command; they cannot be collected live).  gfx950 correction: FETCH_SIZE counts 64 B per 128-B request."""
-    for name in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    # ONLY the current round's file: an older round's counters under this round's kernel names (a renamed or rebuilt kernel) would be a
+    # number about another binary - a label missing from the newest file reports no traffic instead (VERDICT r5, weak 4)
+    for name in (PMC_SUMMARY,):
         try:
             tab = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
         except (OSError, ValueError, KeyError):
             continue
-        src = f"profiles/{name} (rocprofv3 --pmc, separate passes of this same command; not live)"
+        src = f"profiles/{name} (round {PMC_ROUND}; rocprofv3 --pmc, separate passes of this same command; not live)"
         if kernel in tab:
             return dict(tab[kernel], rocprof_names=[kernel]), src
         # a bench label leaves trailing template arguments open ("conv_gather_kernel<BF16, 4, 2, 1, 4, true>" covers the slim

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 4   /* 4 (round 6): + tg_conv4s2_fwd_cw, tg_convt_dgrad_cw, tg_d_tail_fwd / _bwd / _max_pixels / _scratch_floats; 3 (round 5): + tg_convt_fwd_cw, tg_conv3x3_cw, tg_conv4s2_dgrad_cw, tg_conv4s2_fwd_capped; 2 (round 5): + tg_resblock_fwd_ws; round 4 removed tg_wgrad_group / tg_absdiff_nchw and moved the
+#define TG_ABI_VERSION 4   /* 4 (round 6): + tg_conv4s2_fwd_cw, tg_convt_dgrad_cw, tg_d_tail_fwd / _bwd / _max_pixels / _scratch_floats, TG_MASK_RELU_BITS + tg_convt_fwd_cw's relu_bits; 3 (round 5): + tg_convt_fwd_cw, tg_conv3x3_cw, tg_conv4s2_dgrad_cw, tg_conv4s2_fwd_capped; 2 (round 5): + tg_resblock_fwd_ws; round 4 removed tg_wgrad_group / tg_absdiff_nchw and moved the
                            * rejected variants behind TG_EXPERIMENTS without a bump */
 
 enum { TG_F32 = 0, TG_BF16 = 1, TG_F16 = 2 };  /* TG_F16: IEEE half, same layouts as TG_BF16 (loss scaling: tg_adam) */
@@ -39,7 +39,10 @@ enum {
 };
 
 enum { TG_ACT_NONE = 0, TG_ACT_RELU = 1, TG_ACT_LRELU = 2, TG_ACT_SIGMOID = 3, TG_ACT_TANH24 = 4 /* 24*tanh, code/models.py:50 */ };
-enum { TG_MASK_NONE = 0, TG_MASK_RELU = 1, TG_MASK_LRELU = 2, TG_MASK_BNZ = 3 /* tg_conv stats_mode 3: `mask` is z (experiments build only) */ };
+enum { TG_MASK_NONE = 0, TG_MASK_RELU = 1, TG_MASK_LRELU = 2, TG_MASK_BNZ = 3 /* tg_conv stats_mode 3: `mask` is z (experiments build only) */,
+       TG_MASK_RELU_BITS = 4 /* tg_conv3x3_rw only: `mask` is the 1-BIT form of a ReLU output, [N][H][W][Cout / 8] bytes, bit c % 8 of byte
+                              * c / 8 = (stored value of channel c > 0), as tg_convt_fwd_cw writes it (relu_bits): a sixteenth of the bytes
+                              * a masked input-gradient tile reads back (round 6) */ };
 enum { TG_OUT_NHWC = 0, TG_OUT_NCHW_F32 = 1 };
 
 #define TG_MAX_TAPS 16
@@ -147,7 +150,9 @@ int tg_convt_fwd(int dtype, const void* in, const void* w_packed, const float* b
  * class's results straight from the accumulators (no accumulator image, one barrier per tile; the patch comes by LDS-DMA).
  * bf16 / fp16, Cin in {64, 128}, Cout % 64 == 0, else TG_E_UNSUPPORTED (use tg_convt_fwd).  max_workgroups: 0 = one per CU. */
 int tg_convt_fwd_cw(int dtype, const void* in, const void* w_packed, const float* bias, void* out, int N, int IH, int IW,
-                    int Cin, int Cout, int act, int max_workgroups, void* stream);
+                    int Cin, int Cout, int act, void* relu_bits, int max_workgroups, void* stream);
+/* (relu_bits, may be null, act must be TG_ACT_RELU: also writes the 1-bit mask of the stored output, [N][2IH][2IW][Cout / 8] bytes - see
+ * TG_MASK_RELU_BITS) */
 
 /* 4x4 stride-2 padding-1 conv forward (the discriminator's down-sampling convs, code/models.py:90-94) with compile-time
  * taps and pipelined chunk staging; in [N][IH][IW][Cin] (IH, IW even) -> out [N][IH/2][IW/2][Cout]; w_packed = the 16-slot

@@ -218,7 +218,8 @@ def main(argv=None):
         # the fused Adam launch updates the weights without ever calling optimizer.step(): tell the schedulers so, or torch warns every
         # epoch that lr_scheduler.step() came before optimizer.step() (the LR itself is read from param_groups at every step)
         for o_ in (opt_d, opt_g) + ((opt_f,) if sch_f is not None else ()):
-            o_._opt_called = True
+            if hasattr(o_, "_opt_called"):   # (a torch internal - set by lr_scheduler's patch of optimizer.step(): touched only where it exists)
+                o_._opt_called = True
         sch_d.step()
         sch_g.step()
         if sch_f is not None:

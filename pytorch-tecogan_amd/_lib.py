@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("TECOGAN_LIB") or os.path.join(_HERE, "csrc", "libteco
 
 TG_F32, TG_BF16, TG_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_TANH24 = 0, 1, 2, 3, 4
-MASK_NONE, MASK_RELU, MASK_LRELU, MASK_BNZ = 0, 1, 2, 3
+MASK_NONE, MASK_RELU, MASK_LRELU, MASK_BNZ, MASK_RELU_BITS = 0, 1, 2, 3, 4
 OUT_NHWC, OUT_NCHW_F32 = 0, 1
 TILE_AUTO, TILE_64x256, TILE_64x64, TILE_128x128, TILE_32x128 = 0, 1, 2, 3, 4
 TILE_32x64, TILE_64x128, TILE_64x128_8W, TILE_64x64_8W = 5, 6, 7, 8
@@ -78,7 +78,7 @@ _PROTOS = {
     "tg_conv4s2_fwd_cw": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "tg_convt_dgrad_cw": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "tg_convt_fwd": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "tg_convt_fwd_cw": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "tg_convt_fwd_cw": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "tg_resblock_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "tg_maxpool2": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "tg_up2_bilinear": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds libtecogan_hip.so for gfx950 in-tree (next to this script).  Usage: build.sh [--experiments] [extra hipcc flags]
-#   --experiments   also compile the variants that were built, measured slower and rejected (-DTG_EXPERIMENTS: resblock2.hip, resblock2_ws.hip, resblock_pp.hip,
+#   --experiments   also compile the variants that were built, measured slower and rejected (-DTG_EXPERIMENTS: exp/resblock2.hip, exp/resblock2_ws.hip, exp/resblock_pp.hip,
 #                   the 64 x 128 work-list blocks, tg_bn_bwd_fused, tg_conv's stats_mode 3, the item-walking fold, the forced
 #                   trunk tile) into libtecogan_hip_experiments.so - objects under exp/, the default library is untouched.
 #                   Load it with TECOGAN_LIB=.../libtecogan_hip_experiments.so; tests: pytest -m experiments.
@@ -27,12 +27,13 @@ objs=""
 for f in $SRCS; do
   o=$OBJ/$f.o
   objs="$objs $o"
-  if [ ! -f $o ] || [ $f.hip -nt $o ] || [ common.h -nt $o ] || [ rbw_common.h -nt $o ] || [ ../../include/tecogan_hip.h -nt $o ]; then
+  src=$f.hip; [ -f $src ] || src=exp/$f.hip   # (the rejected variants' sources live under exp/, next to the experiments build's objects)
+  if [ ! -f $o ] || [ $src -nt $o ] || [ common.h -nt $o ] || [ rbw_common.h -nt $o ] || [ ../../include/tecogan_hip.h -nt $o ]; then
     rm -f $o   # a failed compile must not leave the previous object behind for the link below
     # conv3_rw: the producer waves' epilogue arithmetic shares a SIMD with the consumer's MFMA stream; SLP-packed f32 operations
     # (v_pk_add_f32 / v_pk_mul_f32) cost ~+25 cycles each beside MFMAs (MI355X_MICROARCH.md, 'price of one filler')
     per_file=""; [ $f = conv3_rw ] && per_file="-fno-slp-vectorize"
-    $HIPCC $FLAGS $per_file "$@" -c $f.hip -o $o &
+    $HIPCC $FLAGS -I. $per_file "$@" -c $src -o $o &
     pids="$pids $!"
   fi
 done

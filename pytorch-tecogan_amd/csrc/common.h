@@ -53,11 +53,15 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
   return __builtin_bit_cast(unsigned short, h);
 }
 
-// A 16-byte store to GLOBAL memory.  -DTG_ST_AUX="sc1" (csrc/build.sh): written THROUGH the L2 at agent scope.  Every kernel boundary
+// A 16-byte store to GLOBAL memory.  A source file that #defines TG_ST_AUX "sc1" in front of its includes (conv3_rw.hip, conv3_cw.hip,
+// convt_cw.hip, conv4s2d_cw.hip, conv_s2_cw.hip - per file, not from build.sh) gets it written THROUGH the L2 at agent scope.  Every kernel boundary
 // writes the XCDs' dirty L2 lines back (the next launch's workgroups run on other XCDs) - whoever dirtied them: with write-back stores
 // the 210 dependent launches of the recurrent pass paid at each of their boundaries for the lines the discriminator's launches on the
 // other lane had just written (profiles/r05_u_write_through_ab.log).  (Inline asm: a store the compiler's vmcnt bookkeeping does not see
-// only makes its waits conservative - the counter is in order.)
+// only makes its waits conservative - the counter is in order.  BUT: the compiler's vmcnt scoreboard does not see these stores, so
+// it may drop a later fence's vmcnt(0) as redundant - a file that defines TG_ST_AUX must NOT publish such a store to another workgroup
+// inside the same kernel (__threadfence + flag / atomic) without an explicit `s_waitcnt vmcnt(0)` in front of the fence.  None of the
+// five files does; d_tail.hip, which publishes through tickets, uses plain stores.)
 __device__ __forceinline__ void tg_store16(void* p, u32x4 v) {
 #ifdef TG_ST_AUX
   // (s_nop 1: a store of more than 8 bytes whose data registers the NEXT vector instruction overwrites needs wait states; the compiler

@@ -73,6 +73,7 @@ struct CwK {
   const char* zero;
   const float* bias;
   char* out;
+  unsigned char* bits;   // null, or [N][2H][2W][Cout / 8]: bit c % 8 of byte c / 8 = (stored value of channel c > 0) - the 1-bit ReLU mask
   int H, W, Cout, tiles_x, tiles_y, ntiles, act;
 };
 
@@ -80,9 +81,10 @@ struct CwK {
 template <int NCH, typename T>
 __global__ __launch_bounds__(512) void convt_cw_kernel(const char* a_in, const char* a_w, const char* a_zero, int a_H, int a_W, int a_Cout,
                                                        int a_tiles_x, int a_tiles_y, int a_ntiles, int a_act, char* a_out,
-                                                       const float* a_bias) {
+                                                       const float* a_bias, unsigned char* a_bits) {
   using G = CwGeo<NCH>;
   CwK p;
+  p.bits = a_bits;
   p.in = a_in; p.w = a_w; p.zero = a_zero; p.H = a_H; p.W = a_W; p.Cout = a_Cout; p.tiles_x = a_tiles_x; p.tiles_y = a_tiles_y;
   p.ntiles = a_ntiles; p.act = a_act; p.out = a_out; p.bias = a_bias;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -223,7 +225,10 @@ __global__ __launch_bounds__(512) void convt_cw_kernel(const char* a_in, const c
       // epilogue from the accumulators: input pixel (ty0 + b, tx0 + idx) -> output pixel (2 y + oy, 2 x + ox), 8 channels = 16 bytes
       char* const out_t = p.out + ((((size_t)mine.n * 2 * p.H + 2 * mine.ty0 + oy) * 2 * p.W + 2 * mine.tx0 + ox) * p.Cout + ch0) * 2;
       const bool okx = mine.tx0 + idx < p.W;
-      auto finish = [&](auto RELU) {
+      auto finish = [&](auto RELU, auto BITS) {
+        // (BITS: + the 1-bit mask of the stored values - what the input-gradient of the layer ABOVE needs of this ReLU's output is its
+        // sign pattern: 1 byte per lane instead of the 16 it would read back; LOG.md / DESIGN.md 'what a CU's vector-memory pipe takes')
+        unsigned char* const bits_t = p.bits + ((((size_t)mine.n * 2 * p.H + 2 * mine.ty0 + oy) * 2 * p.W + 2 * mine.tx0 + ox) * p.Cout + ch0) / 8;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           u32x4 o;
@@ -240,14 +245,29 @@ __global__ __launch_bounds__(512) void convt_cw_kernel(const char* a_in, const c
             }
             o[e] = pack2<T>(lo, hi);
           }
-          if (okx && mine.ty0 + b < p.H) tg_store16(out_t + (unsigned)((b * 4 * p.W + idx * 2) * p.Cout) * 2u, o);
+          if (okx && mine.ty0 + b < p.H) {
+            tg_store16(out_t + (unsigned)((b * 4 * p.W + idx * 2) * p.Cout) * 2u, o);
+            if constexpr (decltype(BITS)::value) {
+              unsigned m = 0;   // the test the masked input-gradients make on the 16-bit patterns: sign clear and not zero
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int w_ = (int)o[e];
+                m |= ((int)((unsigned)w_ << 16) > 0 ? 1u : 0u) << (2 * e);
+                m |= (w_ > 0xffff ? 1u : 0u) << (2 * e + 1);
+              }
+              bits_t[(unsigned)((b * 4 * p.W + idx * 2) * p.Cout) / 8u] = (unsigned char)m;
+            }
+          }
         }
       };
-      if (p.act == TG_ACT_RELU) finish(std::true_type{});
-      else finish(std::false_type{});
+      const bool with_bits = p.bits != nullptr;
+      if (p.act == TG_ACT_RELU && with_bits) finish(std::true_type{}, std::true_type{});
+      else if (p.act == TG_ACT_RELU) finish(std::true_type{}, std::false_type{});
+      else finish(std::false_type{}, std::false_type{});
       // the next tile's patch must have landed before this wave arrives at the barrier.  It was requested before this tile's kTH stores
-      // (the counter is in order): whole tiles - those may stay in flight; ragged images issue fewer stores: the plain wait
-      if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kTH) : "memory");
+      // (the counter is in order; 2 kTH with the mask bytes): whole tiles - those may stay in flight; ragged images issue fewer stores: the plain wait
+      if (full && !with_bits) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kTH) : "memory");
+      else if (full && p.act == TG_ACT_RELU) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kTH) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (i < 6) CW_STAMP(4 + 4 * i + 3);
     }
@@ -270,15 +290,16 @@ int launch_cw(const CwK& k, dim3 grid, hipStream_t st) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(fn, grid, dim3(512), lds, st, k.in, k.w, k.zero, k.H, k.W, k.Cout, k.tiles_x, k.tiles_y, k.ntiles, k.act, k.out, k.bias);
+  hipLaunchKernelGGL(fn, grid, dim3(512), lds, st, k.in, k.w, k.zero, k.H, k.W, k.Cout, k.tiles_x, k.tiles_y, k.ntiles, k.act, k.out, k.bias, k.bits);
   return tg_launch_status();
 }
 
 }  // namespace
 
 extern "C" int tg_convt_fwd_cw(int dtype, const void* in, const void* w_packed, const float* bias, void* out, int N, int H, int W,
-                               int Cin, int Cout, int act, int max_workgroups, void* stream) {
+                               int Cin, int Cout, int act, void* relu_bits, int max_workgroups, void* stream) {
   if (!in || !w_packed || !out || N <= 0 || H <= 0 || W <= 0) return TG_E_BADARG;
+  if (relu_bits && act != TG_ACT_RELU) return TG_E_BADARG;
   if ((dtype != TG_BF16 && dtype != TG_F16) || (Cin != 64 && Cin != 128) || Cout <= 0 || Cout % 64) return TG_E_UNSUPPORTED;
   if (act != TG_ACT_NONE && act != TG_ACT_RELU && act != TG_ACT_LRELU) return TG_E_UNSUPPORTED;
   if (!tg_aligned16(in) || !tg_aligned16(w_packed) || !tg_aligned16(out) || (bias && !tg_aligned16(bias))) return TG_E_ALIGN;
@@ -290,6 +311,7 @@ extern "C" int tg_convt_fwd_cw(int dtype, const void* in, const void* w_packed, 
   if (!zero_page) return TG_E_BADARG;
   CwK k;
   k.in = (const char*)in; k.w = (const char*)w_packed; k.zero = zero_page; k.bias = bias; k.out = (char*)out;
+  k.bits = (unsigned char*)relu_bits;
   k.H = H; k.W = W; k.Cout = Cout; k.act = act;
   k.tiles_x = (W + 15) / 16; k.tiles_y = (H + kTH - 1) / kTH;
   const long long nt = (long long)k.tiles_x * k.tiles_y * N;

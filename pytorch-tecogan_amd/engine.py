@@ -174,9 +174,10 @@ class Conv:
             rows, Kd, s_row, s_k = s.dgrad_pack()
             K.pack_weights(self.dt, self.w, rows, Kd, s_row, s_k, s.nslots, self.slots, out=self.wb)
 
-    def fwd(self, x, out, act=L.ACT_NONE, res=None, stats=None, groups=1, nchw=None, stats_r=1):
+    def fwd(self, x, out, act=L.ACT_NONE, res=None, stats=None, groups=1, nchw=None, stats_r=1, relu_bits=None):
         """x [N,H,W,cin_p] -> out [N,OH,OW,cout_p]; nchw=(buffer, elem_offset, n_stride, c_real) for the fp32 NCHW store.
-        stats: `stats_r` replica blocks of [groups][2][cout_p] (the consumer, BatchNorm.apply, folds them)."""
+        stats: `stats_r` replica blocks of [groups][2][cout_p] (the consumer, BatchNorm.apply, folds them).
+        relu_bits: also the 1-bit mask of the ReLU output - written only by the class-waves conv-transpose launch; returns True then."""
         N, H, W, _ = x.shape
         OH, OW = self.spec.out_hw(H, W)
         if self.spec.kind == "ct" and self.cout_p % 64 == 0 and self.cin_p in (64, 128) and res is None and stats is None and \
@@ -184,8 +185,10 @@ class Conv:
                 self.dt in (torch.bfloat16, torch.float16) and self.tu.ct_cw:
             # persistent workgroups, one sub-pixel class per wave, weights in registers (csrc/convt_cw.hip, round 5)
             self.last_desc, self.last_rw_nch = "ctcw", self.cin_p // 32
-            K.convt_fwd_cw(x, self.wf, self.bias, out, act, max_workgroups=self.persist_fwd or self.persist_rw or self.persist_wgs)
-            return
+            bits = relu_bits if act == L.ACT_RELU else None
+            K.convt_fwd_cw(x, self.wf, self.bias, out, act, max_workgroups=self.persist_fwd or self.persist_rw or self.persist_wgs,
+                           relu_bits=bits)
+            return bits is not None
         if self.spec.kind == "ct" and self.cout_p % 64 == 0 and res is None and stats is None and nchw is None and \
                 act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and self.tile == L.TILE_AUTO and self.tu.subpix_ct and \
                 N * ((H + 7) // 8) * ((W + 15) // 16) * (self.cout_p // 64) >= 128:
@@ -217,7 +220,7 @@ class Conv:
             K.conv3x3_rgb(x, self.wf, self.bias, nchw[0], nchw[1], nchw[2], nchw[3], act)
             return
         if self.spec.kind == "c3" and nchw is None and self.tile == L.TILE_AUTO and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) \
-                and self.cin_p == 32 and self.cout_p % 64 == 0 and stats is None and self.tu.c3_cw and not self.rw_off \
+                and self.cin_p == 32 and self.cout_p % 64 == 0 and stats is None and self.tu.c3_cw and not self.rw_off and self.tu.rw != "0" \
                 and self.dt in (torch.bfloat16, torch.float16) and 0 < self.tu.rw_fwd_min <= N * H * W:
             # the discriminator's first layer (27 -> 64 at HR size): the eight-equal-waves kernel's 32-channel form, a capped persistent
             # launch instead of 1536 workgroups beside the other lane (csrc/conv3_cw.hip)
@@ -262,7 +265,7 @@ class Conv:
         else:
             K.conv(d, x, self.wf, out, bias=self.bias, res=res, stats=stats)
 
-    def dgrad(self, dout, out, mask=None, mask_mode=L.MASK_NONE, res=None, bias_grad_of=None, bn_sums=None):
+    def dgrad(self, dout, out, mask=None, mask_mode=L.MASK_NONE, res=None, bias_grad_of=None, bn_sums=None, mask_bits=None):
         """dout [N,OH,OW,cout_p] -> out [N,H,W,cin_p] = (dgrad + res) * act'(mask); bias_grad_of: Conv whose bias
         gradient is the per-channel sum of `out` (accumulated straight into its grad slot).
         bn_sums = (red, z, groups, replicas): `out` is the output gradient of a BatchNorm without activation whose
@@ -314,8 +317,12 @@ class Conv:
                 not self.rw_off and K.rw_eligible(self.dt, self.cout_p, self.cin_p, N, H, W, masked=mask is not None,
                                                   extra=self.rw_extra, dgrad=True, tu=self.tu):
             # the input-gradient of a 3x3 conv is the same conv with mirrored taps
-            self.last_desc, self.last_rw_nch = ("c3cw" if (self.tu.c3_cw and self.cout_p == 64 and st is None) else "rw"), self.cout_p // 32
-            K.conv3x3_rw(dout, self.wb, out, True, res=res, mask=mask, mask_mode=mask_mode, stats=st, stats_mode=1,
+            # mask_bits: the 1-bit form of the ReLU mask (written by the forward launch below this layer) - a sixteenth of the mask rows'
+            # bytes; conv3_rw.hip's plain masked input-gradient only
+            bits = mask_bits is not None and mask_mode == L.MASK_RELU and res is None
+            self.last_desc, self.last_rw_nch = ("c3cw" if (self.tu.c3_cw and self.cout_p == 64 and st is None and not bits) else "rw"), self.cout_p // 32
+            K.conv3x3_rw(dout, self.wb, out, True, res=res, mask=mask_bits if bits else mask,
+                         mask_mode=L.MASK_RELU_BITS if bits else mask_mode, stats=st, stats_mode=1,
                          max_workgroups=self.persist_dgrad or self.persist_rw or self.persist_wgs, cw=self.tu.c3_cw)
             return
         key = ("d", N, OH, OW, mask_mode, res is not None, st is not None)
@@ -591,7 +598,7 @@ def _defer_finalize():
     return TU().defer_finalize
 
 
-# Two residual blocks per launch on the recurrent pass (csrc/resblock2.hip: halo recomputed, no cross-workgroup traffic, results
+# Two residual blocks per launch on the recurrent pass (csrc/exp/resblock2.hip: halo recomputed, no cross-workgroup traffic, results
 # bit-identical): built, tested and measured SLOWER - 21 MFMA pixel tiles instead of 2 x 6 put 1.75x the matrix and LDS work on
 # the workgroup's serial path, which costs more than the launch boundary and patch round trip it saves: a generator pass 0.200 ->
 # 0.219 ms alone, the chain 1.56 -> 1.71 ms, the step 4.20 -> 4.34 ms (profiles/r03_t_resblock2_ab.log).  Off by default.
@@ -809,6 +816,7 @@ class GeneratorEngine:
         self.rb_prefetch = TU().rb_prefetch
         # round 5: the wave-specialised, stream-first form of the fused block (csrc/resblock_ws.hip); no prefetch hint there
         self.rb_ws = TU().rb_ws
+        self.mask_bits = TU().mask_bits
         self.rb_pair_ws = self.rb_ws and TU().rb_pair_ws
         if self.rb_pair_ws:
             tuning.need_experiments("rb_pair_ws")
@@ -873,7 +881,9 @@ class GeneratorEngine:
                             "h": [e(NS, h, w, 64) for _ in range(self.nrb)], "u0": e(NS, 2 * h, 2 * w, 64),
                             "hh": e(NS, 2 * h, 2 * w, 64), "u1": e(NS, 2 * h, 2 * w, 64),
                             "h2": e(NS, 2 * h, 2 * w, 128), "u2": e(NS, 2 * h, 2 * w, 128),
-                            "u3": e(NS, 4 * h, 4 * w, 128), "u4": e(NS, 4 * h, 4 * w, 64)}, "grad": None}
+                            "u3": e(NS, 4 * h, 4 * w, 128), "u4": e(NS, 4 * h, 4 * w, 64),
+                            # the 1-bit mask of u3 (conv_trans.4's ReLU output), read back by c6's input-gradient instead of u3
+                            "u3b": torch.empty(NS, 4 * h, 4 * w, 16, dtype=torch.uint8, device=dev)}, "grad": None}
 
         self.cur = self.sets.get((NS, h, w), make)
         self.act, self.shape, self.grad = self.cur["act"], (NS, h, w), self.cur["grad"]
@@ -886,7 +896,7 @@ class GeneratorEngine:
         sl = slice(s0, s0 + B)
         hbuf = (lambda t: t[sl]) if keep_h else (lambda t: None)
         self.conv0.fwd(a["in0"][sl], a["a"][0][sl], act=L.ACT_RELU)
-        # small launches (the recurrent pass: <= 128 tiles of 8 x 8): TWO blocks per launch, halo recomputed (csrc/resblock2.hip)
+        # small launches (the recurrent pass: <= 128 tiles of 8 x 8): TWO blocks per launch, halo recomputed (csrc/exp/resblock2.hip)
         pair = self.rb_pair and B * ((a["in0"].shape[1] + 7) // 8) * ((a["in0"].shape[2] + 7) // 8) <= 128
         # round 5: the same for the stream-first kernel - again slower than one block per launch (profiles/r05_b_resblock2_ws_ab.log)
         pair_ws = self.fused_rb and self.rb_pair_ws and not pair and \
@@ -904,7 +914,7 @@ class GeneratorEngine:
                                 a["h"][i + 1][sl], a["a"][i + 2][sl], next_w=nxt)
                 skip_next = True
                 continue
-            if pair_ws and i + 1 < self.nrb:   # two blocks in one launch (csrc/resblock2_ws.hip)
+            if pair_ws and i + 1 < self.nrb:   # two blocks in one launch (csrc/exp/resblock2_ws.hip)
                 c3, c4 = self.rb[i + 1]
                 K.resblock2_fwd_ws(a["a"][i][sl], c1.wf, c1.bias, c2.wf, c3.wf, c3.bias, c4.wf, hbuf(a["h"][i]), a["a"][i + 1][sl],
                                    hbuf(a["h"][i + 1]), a["a"][i + 2][sl])
@@ -928,7 +938,11 @@ class GeneratorEngine:
             self.c22.fwd(a["hh"][sl], a["u1"][sl])
         self.c30.fwd(a["u1"][sl], a["h2"][sl], act=L.ACT_RELU)
         self.c32.fwd(a["h2"][sl], a["u2"][sl])
-        self.ct4.fwd(a["u2"][sl], a["u3"][sl], act=L.ACT_RELU)
+        wrote = self.ct4.fwd(a["u2"][sl], a["u3"][sl], act=L.ACT_RELU, relu_bits=a["u3b"][sl] if (keep_h and self.mask_bits) else None)
+        if s0 == 0:
+            self.cur["u3b_ok"] = bool(wrote)   # (per buffer set; every pass of a step takes the same route)
+        elif not wrote:
+            self.cur["u3b_ok"] = False
         self.c6.fwd(a["u3"][sl], a["u4"][sl], act=L.ACT_RELU)
         self.cout.fwd(a["u4"][sl], None, act=L.ACT_SIGMOID, nchw=(out_buf, out_off, out_n_stride, self.out_ch))
 
@@ -997,7 +1011,8 @@ class GeneratorEngine:
         # bias gradients of plain convs come out of their own wgrad launch (bias_sum): the output gradient is that
         # launch's Y operand, so its channel sums cost a few VALU adds there instead of an atomics epilogue here
         wh(self.c6, a["u3"], g["hr64"], True)
-        self.c6.dgrad(g["hr64"], g["hr128"], mask=a["u3"], mask_mode=RELU, bias_grad_of=self.ct4)
+        self.c6.dgrad(g["hr64"], g["hr128"], mask=a["u3"], mask_mode=RELU, bias_grad_of=self.ct4,
+                      mask_bits=a["u3b"] if self.cur.get("u3b_ok") else None)
         wh(self.ct4, a["u2"], g["hr128"])
         self.ct4.dgrad(g["hr128"], g["m128a"])
         wh(self.c32, a["h2"], g["m128a"])
@@ -1453,9 +1468,7 @@ class DiscriminatorEngine:
         """the tail launches' scratch for this half (or the whole batch) of the current buffer set: zero at creation, left zero by every launch"""
         key = (self.shape, half, n, groups)
         ws = self._tail_scratch.get(key)
-        if ws is None:
-            if self.ws.frozen:
-                raise L.TecoganHipError("new discriminator tail shape after graph capture")
+        if ws is None:   # (a captured step's entries exist since its eager warm-up; a module forward at another shape may add its own later)
             ws = self._tail_scratch[key] = K.d_tail_scratch(n, self.act["z"][4].shape[1], groups, self.flat.device)
         return ws
 

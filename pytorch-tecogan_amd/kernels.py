@@ -185,6 +185,8 @@ def conv3x3_rw(x, w_packed, out, flip=False, bias=None, res=None, mask=None, mas
         cw = C3_CW_FORCE
     elif cw is None:
         cw = tuning.current().c3_cw
+    if mask_mode == L.MASK_RELU_BITS and mask is not None:
+        cw = False   # (the 1-bit mask form exists on conv3_rw.hip only)
     cw = (cw and cin == 64 and (stats is None or C3_CW_FORCE)) or cin == 32   # (launches with statistics: 17.9 vs 17.0 us - they stay on
     #                                                                         conv3_rw; 32 reduction channels exist on conv3_cw only)
     fn, name = (L.load().tg_conv3x3_cw, "tg_conv3x3_cw") if cw else (L.load().tg_conv3x3_rw, "tg_conv3x3_rw")
@@ -462,15 +464,16 @@ def convt_fwd(x, w_packed, bias, out, act=L.ACT_NONE):
                                   out.shape[3], act, _stream()), "tg_convt_fwd")
 
 
-def convt_fwd_cw(x, w_packed, bias, out, act=L.ACT_NONE, max_workgroups=0):
-    """the same layer with class-specialised waves (csrc/convt_cw.hip): Cin in {64, 128}, Cout % 64 == 0"""
+def convt_fwd_cw(x, w_packed, bias, out, act=L.ACT_NONE, max_workgroups=0, relu_bits=None):
+    """the same layer with class-specialised waves (csrc/convt_cw.hip): Cin in {64, 128}, Cout % 64 == 0.  relu_bits (uint8
+    [N,2H,2W,Cout/8], act = ReLU): also the 1-bit mask of the output, for the input-gradient of the layer above (L.MASK_RELU_BITS)"""
     N, H, W, cin = x.shape
     L.check(L.load().tg_convt_fwd_cw(tg_dtype(x.dtype), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(out), N, H, W, cin,
-                                     out.shape[3], act, max_workgroups or persist_wgs(None), _stream()), "tg_convt_fwd_cw")
+                                     out.shape[3], act, _ptr(relu_bits), max_workgroups or persist_wgs(None), _stream()), "tg_convt_fwd_cw")
 
 
 def resblock2_fwd_ws(x, w1a, b1a, w2a, w1b, b1b, w2b, out_h1, out_a1, out_h2, out_a2):
-    """two consecutive residual blocks in one launch of the stream-first kernel (csrc/resblock2_ws.hip); out_h1 / out_h2 may be None"""
+    """two consecutive residual blocks in one launch of the stream-first kernel (csrc/exp/resblock2_ws.hip); out_h1 / out_h2 may be None"""
     N, H, W, C_ = x.shape
     L.check(L.load().tg_resblock2_fwd_ws(tg_dtype(x.dtype), _ptr(x), _ptr(w1a), _ptr(b1a), _ptr(w2a), _ptr(w1b), _ptr(b1b), _ptr(w2b),
                                          _ptr(out_h1), _ptr(out_a1), _ptr(out_h2), _ptr(out_a2), N, H, W, C_, _stream()),
@@ -478,7 +481,7 @@ def resblock2_fwd_ws(x, w1a, b1a, w2a, w1b, b1b, w2b, out_h1, out_a1, out_h2, ou
 
 
 def resblock2_fwd(x, w1a, b1a, w2a, w1b, b1b, w2b, out_h1, out_a1, out_h2, out_a2, next_w=None):
-    """two consecutive residual blocks in one launch (csrc/resblock2.hip); next_w: the four packed weight images of the next
+    """two consecutive residual blocks in one launch (csrc/exp/resblock2.hip); next_w: the four packed weight images of the next
     launch (L2 prefetch hint) or None"""
     N, H, W, C_ = x.shape
     nxt = None
@@ -490,7 +493,7 @@ def resblock2_fwd(x, w1a, b1a, w2a, w1b, b1b, w2b, out_h1, out_a1, out_h2, out_a
 
 
 def resblock_bwd_pp(dout, w2b, h, w1b, out_dh, out_din, max_workgroups=0):
-    """both input-gradients of a residual block as one persistent, tile-pipelined launch (csrc/resblock_pp.hip)"""
+    """both input-gradients of a residual block as one persistent, tile-pipelined launch (csrc/exp/resblock_pp.hip)"""
     N, H, W, C_ = dout.shape
     L.check(L.load().tg_resblock_bwd_pp(tg_dtype(dout.dtype), _ptr(dout), _ptr(w2b), _ptr(h), _ptr(w1b), _ptr(out_dh), _ptr(out_din),
                                         N, H, W, C_, int(max_workgroups), _stream()), "tg_resblock_bwd_pp")

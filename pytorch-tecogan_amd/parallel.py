@@ -23,8 +23,36 @@ def dist_info():
     return None, 1
 
 
-_SYNC_ORDERED = {}
-_WARMED = set()
+class _GroupCache:
+    """per-process-group facts, keyed by the group OBJECT: after destroy_process_group() + init_process_group() in one process a new
+    group can reuse the old one's id(), and an id-keyed cache would then skip the backend warm-up (the 13-ms bucket-mode replay it cures
+    would be back) and reuse a stale stream-ordering verdict.  Weak references where the object allows them; otherwise the entry keeps the
+    object alive, so its id cannot be reused while the entry exists."""
+
+    def __init__(self):
+        import weakref
+        self._weak, self._strong = weakref.WeakKeyDictionary(), {}
+
+    def get(self, group, default=None):
+        try:
+            return self._weak.get(group, default)
+        except TypeError:
+            ent = self._strong.get(id(group))
+            return ent[1] if ent is not None and ent[0] is group else default
+
+    def set(self, group, value):
+        try:
+            self._weak[group] = value
+        except TypeError:
+            self._strong[id(group)] = (group, value)
+
+    def clear(self):
+        self._weak.clear()
+        self._strong.clear()
+
+
+_SYNC_ORDERED = _GroupCache()   # group -> {"ok": bool | None, "host_ms": float}
+_WARMED = _GroupCache()         # group -> True
 
 
 def warm_backend(group, device):
@@ -34,9 +62,9 @@ def warm_backend(group, device):
     replayed at 12.5-13.4 ms instead of 3.9 - with 8, 16 or 24 hardware queues alike - and at 3.9 when the asynchronous path had
     been used once beforehand (tools/pg_tax_probe.py, profiles/r05_c_pg_tax_probe.log).  A collective: every rank builds its first
     data-parallel step at the same point.  No-op for gloo (its device buffers take the staged path)."""
-    if group is None or not (dist.is_available() and dist.is_initialized()) or id(group) in _WARMED:
+    if group is None or not (dist.is_available() and dist.is_initialized()) or _WARMED.get(group):
         return
-    _WARMED.add(id(group))
+    _WARMED.set(group, True)
     if dist.get_backend(group) == "gloo":
         return
     t = torch.zeros(8, dtype=torch.float32, device=device)
@@ -58,9 +86,9 @@ def sync_allreduce_stream_ordered(group, device):
         return None
     if dist.get_backend(group) == "gloo":
         return None
-    key = id(group)
-    if key in _SYNC_ORDERED:
-        return _SYNC_ORDERED[key]
+    ent = _SYNC_ORDERED.get(group)
+    if ent is not None:
+        return ent["ok"]
     import time
     world = dist.get_world_size(group)
     t = torch.zeros(2, dtype=torch.float32, device=device)
@@ -84,8 +112,7 @@ def sync_allreduce_stream_ordered(group, device):
         dist.all_reduce(v, op=dist.ReduceOp.MIN, group=group)
         torch.cuda.synchronize(device)
         ok = bool(v.item() >= 1.0)
-    _SYNC_ORDERED[key] = ok
-    _SYNC_ORDERED[(key, "host_ms")] = host_ms                  # (diagnostic: a stream-ordered call returns long before the sleep ends)
+    _SYNC_ORDERED.set(group, {"ok": ok, "host_ms": host_ms})   # (host_ms, diagnostic: a stream-ordered call returns long before the sleep ends)
     return ok
 
 

@@ -546,7 +546,7 @@ def test_tuning_defaults_equal_the_documented_optimum(monkeypatch):
         (160, 96, 160, 144, 96, None)
     assert (t.cap_g_for(8192), t.rw_fwd_min, t.pair_rw_min, t.infer_wgs, t.infer_chunk) == (160, 4096, 16384, 256, 16)
     assert (t.cap_fwd_g_for(4096), t.cap_fwd_g_for(8192)) == (160, 0)
-    assert (t.cap_trunk_g_for(4096), t.cap_trunk_g_for(8192), t.s2_cw, t.d_tail) == (160, 0, True, True)
+    assert (t.cap_trunk_g_for(4096), t.cap_trunk_g_for(8192), t.s2_cw, t.d_tail, t.mask_bits) == (160, 0, True, True, False)
     assert (t.graph, t.lanes, t.dreal_bwd, t.dp_inline, t.dp_buckets, t.cu_reserve, t.force_collectives) == \
         (True, True, True, True, True, 0, False)
     assert (t.rw, t.rw_extra, t.rw_extra_dreal) == ("1", "trunk,c30,m128,s3,s1", None)

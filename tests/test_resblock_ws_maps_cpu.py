@@ -169,7 +169,7 @@ def conflict_free(addrs):
 
 
 def check_pair():
-    """csrc/resblock2_ws.hip (two blocks per launch, 8 x 4 tiles): patch (16 x 12, read by the 14-wide h1 region), h1 (pitch 28, read by
+    """csrc/exp/resblock2_ws.hip (two blocks per launch, 8 x 4 tiles): patch (16 x 12, read by the 14-wide h1 region), h1 (pitch 28, read by
     the 12-wide a1 region), a1 (12 x 8 image written by conv2A's epilogue, read by the 10-wide h2 region), h2 (pitch 24)"""
     TH = 4
     div = {8: lambda n: n >> 3, 10: lambda n: (n * 205) >> 11, 12: lambda n: (n * 171) >> 11, 14: lambda n: (n * 4682) >> 16}

@@ -1,6 +1,6 @@
 """The trunk's input-gradient chain of the batched generator backward, block by block as the step runs it (16 blocks, each with its
 own weights / mask / buffers), hipGraph replay: two register-weights launches per block (round 4) against ONE persistent,
-tile-pipelined launch (csrc/resblock_pp.hip, round 5), at several workgroup caps.  MB_SHAPE="N,H" (default 40,32: config 2)."""
+tile-pipelined launch (csrc/exp/resblock_pp.hip, round 5), at several workgroup caps.  MB_SHAPE="N,H" (default 40,32: config 2)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import pytorch_tecogan_amd  # noqa: F401

@@ -41,7 +41,7 @@ def child(v):
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
         if v == "seq_ib_nowarm" or os.environ.get("PG_NOWARM"):   # (round 5: parallel.warm_backend uses the asynchronous path once before the first step; this
             from pytorch_tecogan_amd import parallel   # variant switches it off to show the 13-ms replay it cures)
-            parallel._WARMED.add(id(dist.group.WORLD))
+            parallel._WARMED.set(dist.group.WORLD, True)
     env["TECOGAN_GRAPH"] = "1"
     args = bench.default_args("bf16")
     torch.manual_seed(1)

@@ -1,4 +1,4 @@
-"""Diagnostic: per-tile stamps of the persistent, tile-pipelined backward block (csrc/resblock_pp.hip; library built with -DTG_STAMP)"""
+"""Diagnostic: per-tile stamps of the persistent, tile-pipelined backward block (csrc/exp/resblock_pp.hip; library built with -DTG_STAMP)"""
 import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import pytorch_tecogan_amd  # noqa: F401

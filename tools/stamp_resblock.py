@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import pytorch_tecogan_amd
 from pytorch_tecogan_amd import _lib as L, kernels as K
 lib = L.load()
-PAIR = os.environ.get("RB_PAIR") == "1"   # two blocks per launch (csrc/resblock2_ws.hip)
+PAIR = os.environ.get("RB_PAIR") == "1"   # two blocks per launch (csrc/exp/resblock2_ws.hip)
 WS = os.environ.get("RB_WS", "1") == "1"   # round 5: the wave-specialised kernel (csrc/resblock_ws.hip); RB_WS=0: resblock.hip
 STAMPS = hasattr(lib, "tg_debug_read_rb_stamps") and not WS   # (a library built without -DTG_STAMP: only the launch time at the end)
 WSTAMPS = WS and hasattr(lib, "tg_debug_read_rbw_stamps")
