@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 import pytorch_tecogan_amd  # noqa: E402,F401
 from pytorch_tecogan_amd import _lib as L  # noqa: E402
 from pytorch_tecogan_amd import kernels as K  # noqa: E402
+from parity import assert_rel_l2  # noqa: E402  (whole-tensor relative L2 <= 4e-3: tests/parity.py)
 
 DEV = "cuda:0"
 BF = torch.bfloat16
@@ -65,6 +66,7 @@ def test_cw_forward_27_input_channels(cout, N, H, W, cap, act, which_kernel):
     out = torch.empty(N, H, W, cout, dtype=BF, device=DEV)
     K.conv3x3_rw(K.to_nhwc(x.to(DEV), BF), packed(spec, w, False), out, False, bias=b.to(DEV), act=act, max_workgroups=cap)
     torch.testing.assert_close(K.to_nchw(out, cout).cpu(), ref, rtol=2e-2, atol=2e-2)
+    assert_rel_l2(K.to_nchw(out, cout).cpu(), ref, BF)
 
 
 @pytest.mark.parametrize("cin,cout,N,H,W,cap", CASES)
@@ -75,6 +77,7 @@ def test_rw_forward_bias_relu(cin, cout, N, H, W, cap):
     out = torch.empty(N, H, W, cout, dtype=BF, device=DEV)
     K.conv3x3_rw(K.to_nhwc(x.to(DEV), BF), packed(spec, w, False), out, False, bias=b.to(DEV), act=L.ACT_RELU, max_workgroups=cap)
     torch.testing.assert_close(K.to_nchw(out, cout).cpu(), ref, rtol=2e-2, atol=2e-2)
+    assert_rel_l2(K.to_nchw(out, cout).cpu(), ref, BF)
 
 
 @pytest.mark.parametrize("cin,cout,N,H,W,cap", CASES)
@@ -90,11 +93,13 @@ def test_rw_input_gradient_with_residual_and_mask(cin, cout, N, H, W, cap):
     K.conv3x3_rw(K.to_nhwc(dout.to(DEV), BF), packed(spec, w, True), out, True, res=K.to_nhwc(res.to(DEV), BF),
                  mask=K.to_nhwc(mask.to(DEV), BF), mask_mode=L.MASK_RELU, max_workgroups=cap)
     torch.testing.assert_close(K.to_nchw(out, cin).cpu(), ref, rtol=2e-2, atol=2e-2)
+    assert_rel_l2(K.to_nchw(out, cin).cpu(), ref, BF)
     # LeakyReLU mask, no residual
     ref2 = F.conv_transpose2d(dout, w, None, 1, 1) * torch.where(mask > 0, 1.0, 0.2)
     K.conv3x3_rw(K.to_nhwc(dout.to(DEV), BF), packed(spec, w, True), out, True, mask=K.to_nhwc(mask.to(DEV), BF),
                  mask_mode=L.MASK_LRELU, max_workgroups=cap)
     torch.testing.assert_close(K.to_nchw(out, cin).cpu(), ref2, rtol=2e-2, atol=2e-2)
+    assert_rel_l2(K.to_nchw(out, cin).cpu(), ref2, BF)
 
 
 @pytest.mark.parametrize("cin,cout,N,H,W,cap,groups", [(64, 64, 4, 24, 32, 5, 2), (64, 128, 6, 16, 16, 0, 1),
@@ -114,6 +119,7 @@ def test_rw_statistics_groups_and_lrelu(cin, cout, N, H, W, cap, groups):
                  groups=groups, max_workgroups=cap)
     got = K.to_nchw(out, cout).cpu()
     torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2)
+    assert_rel_l2(got, ref, BF)
     per = N // groups
     for gi in range(groups):
         r = got[gi * per:(gi + 1) * per].double()  # statistics are taken from the fp32 values before the bf16 store

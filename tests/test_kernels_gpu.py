@@ -15,6 +15,7 @@ import pytorch_tecogan_amd  # noqa: E402,F401
 from pytorch_tecogan_amd import _lib as L  # noqa: E402
 from pytorch_tecogan_amd import kernels as K  # noqa: E402
 import tecogan_oracle as orc  # noqa: E402
+from parity import assert_rel_l2  # noqa: E402  (whole-tensor relative L2: 4e-3 bf16, 1.5e-3 fp16, 1e-4 fp32 - tests/parity.py)
 
 DEV = "cuda:0"
 DTYPES = [torch.float32, torch.bfloat16]
@@ -381,6 +382,7 @@ def test_wgrad_group_work_list_vs_torch(cap, shapes, dt):
         scale = float(w.grad.abs().max())
         torch.testing.assert_close(grads[i].cpu(), w.grad, rtol=2e-2, atol=scale * 1e-2)
         assert rel_err(grads[i].cpu(), w.grad) < 2e-3, (i, rel_err(grads[i].cpu(), w.grad))   # fp32 accumulation of exact products
+        assert_rel_l2(grads[i].cpu(), w.grad, torch.float32, f"layer {i}", scale=5.0)       # (5e-4: fp32 sums of exact 16-bit products)
         if shapes[i][5]:
             torch.testing.assert_close(gbs[i][:sp.cout].cpu(), b.grad, rtol=1e-4, atol=1e-3)
         else:
@@ -433,6 +435,7 @@ def test_wgrad_group_stride2_kinds_vs_torch(kind, cap, layers, dt):
     torch.cuda.synchronize()
     for i in range(len(layers)):
         assert rel_err(grads[i].cpu(), refs[i]) < 2e-3, (i, layers[i], rel_err(grads[i].cpu(), refs[i]))
+        assert_rel_l2(grads[i].cpu(), refs[i], torch.float32, f"layer {i}", scale=5.0)   # (5e-4: fp32 sums of exact 16-bit products)
         torch.testing.assert_close(grads[i].cpu(), refs[i], rtol=2e-2, atol=float(refs[i].abs().max()) * 1e-2)
 
 
@@ -493,6 +496,7 @@ def test_wgrad_group_wide_channel_blocks_vs_torch(kind, cap, layers, dt):
     torch.cuda.synchronize()
     for i in range(len(layers)):
         assert rel_err(grads[i].cpu(), refs[i]) < 2e-3, (i, layers[i], rel_err(grads[i].cpu(), refs[i]))
+        assert_rel_l2(grads[i].cpu(), refs[i], torch.float32, f"layer {i}", scale=5.0)   # (5e-4: fp32 sums of exact 16-bit products)
         torch.testing.assert_close(grads[i].cpu(), refs[i], rtol=2e-2, atol=float(refs[i].abs().max()) * 1e-2)
         if layers[i][5]:
             torch.testing.assert_close(gbs[i][:specs[i].cout].cpu(), brefs[i], rtol=1e-4, atol=1e-3)
@@ -1048,6 +1052,8 @@ def test_fused_resblock_forward(N, H, W, ws):
     ref_a = x + F.conv2d(q(ref_h, dt), q(w2, dt), None, 1, 1)
     torch.testing.assert_close(K.to_nchw(h_f, 64).cpu(), ref_h, **tol(dt))
     torch.testing.assert_close(K.to_nchw(a_f, 64).cpu(), ref_a, **tol(dt))
+    assert_rel_l2(K.to_nchw(h_f, 64).cpu(), ref_h, dt, "h")
+    assert_rel_l2(K.to_nchw(a_f, 64).cpu(), ref_a, dt, "a")
     assert L.load().tg_resblock_fwd(L.TG_F32, xd.data_ptr(), wp1.data_ptr(), bd.data_ptr(), wp2.data_ptr(),
                                     h_f.data_ptr(), a_f.data_ptr(), N, H, W, 64, 1, None, None, None) == -2
     assert L.load().tg_resblock_fwd_ws(L.TG_F32, xd.data_ptr(), wp1.data_ptr(), bd.data_ptr(), wp2.data_ptr(),
@@ -1108,6 +1114,8 @@ def test_fused_resblock_backward(N, H, W, pp):
     da = dout + torch.nn.grad.conv2d_input((N, 64, H, W), q(w1, dt), q(dpre, dt), padding=1)
     torch.testing.assert_close(K.to_nchw(dh_f, 64).cpu(), dpre, **tol(dt))
     torch.testing.assert_close(K.to_nchw(da_f, 64).cpu(), da, **tol(dt))
+    assert_rel_l2(K.to_nchw(dh_f, 64).cpu(), dpre, dt, "d pre")
+    assert_rel_l2(K.to_nchw(da_f, 64).cpu(), da, dt, "d a")
 
 
 @pytest.mark.experiments
@@ -1300,13 +1308,14 @@ def test_convt_forward_class_waves(cin, cout, N, H, W, act, cap, dt):
     K.convt_fwd_cw(xd, wp, bd, out, act, max_workgroups=cap)
     torch.cuda.synchronize()
     torch.testing.assert_close(K.to_nchw(out, cout).cpu(), ref, **tol(dt))
+    assert_rel_l2(K.to_nchw(out, cout).cpu(), ref, dt, "conv-transpose forward")
     other = torch.full_like(out, float("nan"))
     K.convt_fwd(xd, wp, bd, other, act)
     torch.cuda.synchronize()
     torch.testing.assert_close(out.float().cpu(), other.float().cpu(), rtol=2 ** -7, atol=1e-3)
     fn = L.load().tg_convt_fwd_cw
-    assert fn(K.tg_dtype(dt), xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), N, H, W, 32, 64, act, 0, None) == -2
-    assert fn(K.tg_dtype(dt), xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), N, H, W, K.pad32(cin), 32, act, 0, None) == -2
+    assert fn(K.tg_dtype(dt), xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), N, H, W, 32, 64, act, None, 0, None) == -2
+    assert fn(K.tg_dtype(dt), xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), N, H, W, K.pad32(cin), 32, act, None, 0, None) == -2
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -1389,6 +1398,7 @@ def test_conv4s2_input_gradient_class_waves(cin, cout, N, H, W, cap, dt):
     t = tol(dt)
     scale = float(x.grad.abs().max()) + 1e-6
     torch.testing.assert_close(K.to_nchw(dx, cin).cpu(), x.grad, rtol=t["rtol"], atol=t["atol"] * max(1.0, scale))
+    assert_rel_l2(K.to_nchw(dx, cin).cpu(), x.grad, dt, "4x4 s2 input-gradient")
     other = torch.full_like(dx, float("nan"))
     K.conv4s2_dgrad(dd, wb, other)
     torch.cuda.synchronize()
@@ -1399,6 +1409,7 @@ def test_conv4s2_input_gradient_class_waves(cin, cout, N, H, W, cap, dt):
         torch.cuda.synchronize()
         exp = x.grad * torch.where(act_below > 0, 1.0, slope)
         torch.testing.assert_close(K.to_nchw(dx, cin).cpu(), exp, rtol=t["rtol"], atol=t["atol"] * max(1.0, scale))
+        assert_rel_l2(K.to_nchw(dx, cin).cpu(), exp, dt, "masked 4x4 s2 input-gradient")
     assert L.load().tg_conv4s2_dgrad_cw(K.tg_dtype(dt), dd.data_ptr(), wb.data_ptr(), dx.data_ptr(), N, H // 2, W // 2, 256, K.pad32(cin),
                                         None, 0, 0, None) == -2
 
