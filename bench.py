@@ -155,7 +155,7 @@ def kernel_name(conv, dtype):
     if conv.last_desc in ("c4s2", "ctd"):  # csrc/conv4s2_mfma.hip
         return f"conv_s2_gather_kernel<{TAG[dtype]}, {4 if conv.last_desc == 'c4s2' else 3}>"
     if conv.last_desc == "s2cw":  # csrc/conv_s2_cw.hip (register-weights stride-2 gathers: KS 4 = D's down-sampling convs, 3 = conv-transpose dgrad)
-        return f"conv_s2_cw_kernel<{4 if conv.spec.kind == 'c4s2' else 3}, {conv.last_rw_nch}, .., {TAG[dtype]}>"
+        return f"conv_s2_cw_kernel<{4 if conv.spec.kind == 'c4s2' else 3}, {conv.last_rw_nch}, ..>"   # (statistics / element type left open: pmc_traffic's prefix rule)
     if conv.last_desc == "rgb":  # csrc/conv_rgb.hip (the generator's output layer)
         return f"conv_rgb_kernel<{TAG[dtype]}>"
     if conv.last_desc == "ctcw":  # csrc/convt_cw.hip (conv-transpose forward, class-specialised waves)

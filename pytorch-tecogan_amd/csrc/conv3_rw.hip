@@ -370,6 +370,7 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const char* a_in, const c
 #pragma unroll
   for (int k = 0; k < G::KS; ++k) pre[k] = u32x4{0u, 0u, 0u, 0u};
   auto issue_pre = [&](const Tile& tl) {
+#ifdef TG_EXPERIMENTS   // (bit-exact and slower in the step; even unused it cost the default kernel 0.03 ms per step: profiles/r06_n_mask_code_ab.log)
     if (p.mask_mode == TG_MASK_RELU_BITS) {
       // the 1-bit form of a ReLU mask ([N][H][W][Cout / 8] bytes, written by the forward launch that produced the activation): the
       // lane's 8 channels are ONE byte - a sixteenth of the 16-bit rows' bytes through the CU's vector-memory pipe
@@ -380,7 +381,9 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const char* a_in, const c
         const int cy = min(tl.ty0 + (pl >> 4), p.H - 1), cx = min(tl.tx0 + (pl & 15), p.W - 1);
         pre[k][0] = src_n[(unsigned)((cy * p.W + cx) * p.Cout + ch0) / 8u];
       }
-    } else if (pre_src) {
+    } else
+#endif
+    if (pre_src) {
       const char* src_n = pre_src + (size_t)tl.n * p.H * p.W * p.Cout * 2;
 #pragma unroll
       for (int k = 0; k < G::KS; ++k) {
@@ -475,8 +478,11 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const char* a_in, const c
   //   0 forward: + bias, activation, no mask / residual      1 input-gradient under a ReLU mask (no bias / activation / residual)
   //   2 input-gradient + residual (no bias / activation / mask)      3 anything else (every option tested at run time)
   //   4 input-gradient under a 1-BIT ReLU mask (no bias / activation / residual; the entry point refuses other combinations)
-  const int emode = (p.mask_mode == TG_MASK_RELU_BITS) ? 4
-                    : (p.mask_mode == TG_MASK_NONE && !p.res) ? 0
+  const int emode =
+#ifdef TG_EXPERIMENTS
+                    (p.mask_mode == TG_MASK_RELU_BITS) ? 4 :
+#endif
+                    (p.mask_mode == TG_MASK_NONE && !p.res) ? 0
                     : (p.mask_mode == TG_MASK_RELU && !p.res && !p.bias && p.act == TG_ACT_NONE) ? 1
                     : (p.mask_mode == TG_MASK_NONE && p.res && !p.bias && p.act == TG_ACT_NONE) ? 2 : 3;
   // activation as max(v, slope * v): slope 1 = none, 0 = ReLU, 0.2 = LeakyReLU (mode 0: no branch on p.act)
@@ -537,10 +543,12 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const char* a_in, const c
           v[2 * e] = (int)((unsigned)w_ << 16) > 0 ? v[2 * e] : 0.f;
           v[2 * e + 1] = w_ > 0xffff ? v[2 * e + 1] : 0.f;
         }
+#ifdef TG_EXPERIMENTS
       } else if constexpr (M == 4) {
         const unsigned bm = mk[k][0];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (bm >> e) & 1u ? v[e] : 0.f;
+#endif
       } else if constexpr (M == 2) {
         float r[8];
         unpack8<T>(mk[k], r);
@@ -644,7 +652,9 @@ __global__ __launch_bounds__(512) void conv3_rw_kernel(const char* a_in, const c
       if (emode == 0) compute(st_prev, (i - 1) & 1, mk, std::integral_constant<int, 0>{});
       else if (emode == 1) compute(st_prev, (i - 1) & 1, mk, std::integral_constant<int, 1>{});
       else if (emode == 2) compute(st_prev, (i - 1) & 1, mk, std::integral_constant<int, 2>{});
+#ifdef TG_EXPERIMENTS
       else if (emode == 4) compute(st_prev, (i - 1) & 1, mk, std::integral_constant<int, 4>{});
+#endif
       else compute(st_prev, (i - 1) & 1, mk, std::integral_constant<int, 3>{});
     }
     st_prev = prev;
@@ -686,7 +696,7 @@ extern "C" int tg_conv3x3_rw(int dtype, const void* in, const void* w_packed, co
   if (act != TG_ACT_NONE && act != TG_ACT_RELU && act != TG_ACT_LRELU) return TG_E_UNSUPPORTED;
   if (mask_mode != TG_MASK_NONE && !mask) return TG_E_BADARG;
   if (mask_mode < TG_MASK_NONE || mask_mode > TG_MASK_RELU_BITS || mask_mode == TG_MASK_BNZ) return TG_E_BADARG;
-  if (mask_mode == TG_MASK_RELU_BITS && (res || bias || act != TG_ACT_NONE)) return TG_E_UNSUPPORTED;   // the plain masked input-gradient only
+  if (mask_mode == TG_MASK_RELU_BITS && (res || bias || act != TG_ACT_NONE || !kTgExperiments)) return TG_E_UNSUPPORTED;   // the plain masked input-gradient only, experiments build only
   if (stats && (stats_groups <= 0 || N % stats_groups || stats_mode < 1 || stats_mode > 2)) return TG_E_BADARG;
   if (stats && (stats_replicas < 1 || (stats_replicas & (stats_replicas - 1)))) return TG_E_BADARG;  // a power of two
   if (!tg_aligned16(in) || !tg_aligned16(w_packed) || !tg_aligned16(out) || (res && !tg_aligned16(res)) ||

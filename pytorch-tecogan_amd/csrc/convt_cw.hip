@@ -260,7 +260,11 @@ __global__ __launch_bounds__(512) void convt_cw_kernel(const char* a_in, const c
           }
         }
       };
-      const bool with_bits = p.bits != nullptr;
+#ifdef TG_EXPERIMENTS   // the 1-bit-mask form: bit-exact, and slower in the step (profiles/r06_k_mask_bits_ab.log); its mere presence costs
+      const bool with_bits = p.bits != nullptr;   // the default kernel 0.016 ms per step (r06_n_mask_code_ab.log): experiments build only
+#else
+      constexpr bool with_bits = false;
+#endif
       if (p.act == TG_ACT_RELU && with_bits) finish(std::true_type{}, std::true_type{});
       else if (p.act == TG_ACT_RELU) finish(std::true_type{}, std::false_type{});
       else finish(std::false_type{}, std::false_type{});
@@ -300,6 +304,7 @@ extern "C" int tg_convt_fwd_cw(int dtype, const void* in, const void* w_packed, 
                                int Cin, int Cout, int act, void* relu_bits, int max_workgroups, void* stream) {
   if (!in || !w_packed || !out || N <= 0 || H <= 0 || W <= 0) return TG_E_BADARG;
   if (relu_bits && act != TG_ACT_RELU) return TG_E_BADARG;
+  if (relu_bits && !kTgExperiments) return TG_E_UNSUPPORTED;   // (the 1-bit mask output is compiled into the experiments build only)
   if ((dtype != TG_BF16 && dtype != TG_F16) || (Cin != 64 && Cin != 128) || Cout <= 0 || Cout % 64) return TG_E_UNSUPPORTED;
   if (act != TG_ACT_NONE && act != TG_ACT_RELU && act != TG_ACT_LRELU) return TG_E_UNSUPPORTED;
   if (!tg_aligned16(in) || !tg_aligned16(w_packed) || !tg_aligned16(out) || (bias && !tg_aligned16(bias))) return TG_E_ALIGN;

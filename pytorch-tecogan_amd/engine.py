@@ -817,6 +817,8 @@ class GeneratorEngine:
         # round 5: the wave-specialised, stream-first form of the fused block (csrc/resblock_ws.hip); no prefetch hint there
         self.rb_ws = TU().rb_ws
         self.mask_bits = TU().mask_bits
+        if self.mask_bits:
+            tuning.need_experiments("mask_bits")
         self.rb_pair_ws = self.rb_ws and TU().rb_pair_ws
         if self.rb_pair_ws:
             tuning.need_experiments("rb_pair_ws")

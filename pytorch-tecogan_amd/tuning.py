@@ -102,10 +102,6 @@ KNOBS = OrderedDict((k.attr, k) for k in (
     # ---- batch norm
     _k("STATS_REPLICAS", "stats_replicas", "int", 4, "profiles/r02_k_mb_stats_replicas.log, r02_k_stats_replicas_ab.log",
        "replica blocks of the batch-norm accumulators (a power of two)"),
-    _k("MASK_BITS", "mask_bits", "flag", False, "profiles/r06_k_mask_bits_ab.log (G backward alone 1.262 -> 1.251 ms, chain alone 1.215 -> 1.236: step +0.02-0.03 ms)",
-       "conv_trans.4's forward also writes the 1-bit mask of its ReLU output and c6's input-gradient (the batched G backward's largest "
-       "launch) reads that instead of the 168-MB activation; bit-for-bit the same results - and slower: four more store instructions per "
-       "tile in the CHAIN cost more than the input-gradient gains"),
     _k("D_TAIL", "d_tail", "on", True, "profiles/r06_d_tail_ab.log",
        "the discriminator's tail (BN + LeakyReLU of block4, block5, fc, sigmoid [, the real half's loss seed]; and its backward down to "
        "block4's output gradient) as ONE single-workgroup launch per direction (d_tail.hip; 0: 5-6 + 6 separate launches)"),
@@ -124,6 +120,10 @@ KNOBS = OrderedDict((k.attr, k) for k in (
        "single-launch batch-norm backward for small tensors (tg_bn_bwd_fused)", True),
     _k("BN_BWD_COOP", "bn_bwd_coop", "flag", False, "profiles/r04_y_bn_bwd_coop_ab.log (step 3.77 -> 4.52 ms)",
        "batch-norm backward as ONE cooperative launch (sums, grid-wide wait, apply; tg_bn_bwd_coop)", True),
+    _k("MASK_BITS", "mask_bits", "flag", False, "profiles/r06_k_mask_bits_ab.log, r06_n_mask_code_ab.log (G backward alone 1.262 -> 1.251 ms, chain alone 1.215 -> 1.236: step +0.02-0.03 ms)",
+       "conv_trans.4's forward also writes the 1-bit mask of its ReLU output and c6's input-gradient (the batched G backward's largest "
+       "launch) reads that instead of the 168-MB activation; bit-for-bit the same results - and slower: four more store instructions per "
+       "tile in the CHAIN cost more than the input-gradient gains", True),
     _k("WGRAD_B128_PIXELS", "wgrad_b128_pixels", "int", 0, "profiles/r03_m_wgrad_b128.log (1.1-2.5x slower: spills)",
        "64 x 128 channel blocks in the work lists for layers with at least this many pixels (0: never)", True),
 ))

@@ -557,7 +557,7 @@ def test_tuning_defaults_equal_the_documented_optimum(monkeypatch):
     assert t.dtype == "bf16"
     # every rejected experiment is off, and is marked as needing the experiments build
     exp = [k for k in tuning.KNOBS.values() if k.experiment]
-    assert {k.attr for k in exp} == {"rb_pair", "rb_pair_ws", "bn_fuse", "bn_bwd_fused", "bn_bwd_coop", "wgrad_b128_pixels"}
+    assert {k.attr for k in exp} == {"rb_pair", "rb_pair_ws", "bn_fuse", "bn_bwd_fused", "bn_bwd_coop", "wgrad_b128_pixels", "mask_bits"}
     assert all(not getattr(t, k.attr) for k in exp)
     for k in tuning.KNOBS.values():
         assert k.evidence and k.doc, k.env

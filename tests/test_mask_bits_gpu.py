@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.experiments]   # built, bit-exact, slower in the step: experiments build only (profiles/r06_k_*)
 
 import pytorch_tecogan_amd  # noqa: E402,F401
 from pytorch_tecogan_amd import _lib as L  # noqa: E402

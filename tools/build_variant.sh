@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../pytorch-tecogan_amd/csrc"
 name=$1; stems=$2; shift 2
 out=../../_ab; mkdir -p $out/$name
 objs=""
-for f in conv_mfma wgrad_mfma wgrad_group warp elementwise fnet resblock resblock_ws convt_mfma convt_cw conv4s2_mfma conv4s2d_cw runtime conv3_rw conv3_cw vgg conv_rgb rgb_bwd; do
+for f in conv_mfma wgrad_mfma wgrad_group warp elementwise fnet resblock resblock_ws convt_mfma convt_cw conv4s2_mfma conv4s2d_cw conv_s2_cw d_tail runtime conv3_rw conv3_cw vgg conv_rgb rgb_bwd; do
   if [[ ",$stems," == *",$f,"* ]]; then
     per_file=""; [ $f = conv3_rw ] && per_file="-fno-slp-vectorize"   # (as csrc/build.sh)
     [ -z "${NO_PRELOAD:-}" ] && per_file="$per_file -mllvm -amdgpu-kernarg-preload-count=16"   # (as csrc/build.sh's FLAGS)
