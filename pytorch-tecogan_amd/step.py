@@ -157,7 +157,7 @@ class TecoGANStep:
         self.gen = torch.empty(B, T, 3, H, H, **f32)
         self.flow = torch.empty(B, T - 1, 2, H, H, **f32)
         self.tvel = torch.empty(B * self.tsize, H, H, 2, **f32)
-        self.target = self.out_gen = None   # the last call's fresh result tensors (_emit_target / _emit_gen)
+        self.target = self.out_gen = self.out_scalars = None   # the last call's fresh result tensors (_emit_target / _emit_gen / _emit_scalars)
         self.acc = torch.zeros(16, **f32)
         self.scalars = torch.zeros(64, **f32)
         # per-step host parameters (loss config, Adam bias corrections, lr) travel through ONE small async copy from a
@@ -429,6 +429,14 @@ class TecoGANStep:
         K.nhwc_to_nchw(self.D.act["in"][:tb], out, 27 * H * H, tb, 27, H, H)
         self.target = out
 
+    def _emit_scalars(self):
+        """the step's loss scalars for the Network tuple: a copy, so that the next call's graphs may overwrite the buffer - made on lane B
+        (whose loss_finalize wrote them), not behind the step on the caller's stream"""
+        out = torch.empty_like(self.scalars)
+        out.record_stream(self._caller)
+        out.copy_(self.scalars, non_blocking=True)
+        self.out_scalars = out
+
     def _emit_gen(self):
         """Network.gen_output of this call: a fresh copy of the step's frame buffer (which the next call's graphs overwrite)"""
         out = torch.empty_like(self.gen)
@@ -666,6 +674,7 @@ class TecoGANStep:
                 tm["B1"].record(sB)
             fn["update_d"]()
             self._emit_gen()   # (the frames are final since the tail event this lane waited for; 8 MB, beside lane A's update)
+            self._emit_scalars()
             ev["d"].record(sB)
         for w in works_g:
             if w is not None:
@@ -706,6 +715,7 @@ class TecoGANStep:
         fwd_bwd()
         self._emit_target()
         self._emit_gen()
+        self._emit_scalars()
         works = [self._allreduce(self.G.flat.g), self._allreduce(self.D.flat.g)]
         if self.F_train:
             works.append(self._allreduce(self.F.flat.g))

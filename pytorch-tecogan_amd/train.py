@@ -153,7 +153,7 @@ def TecoGAN(r_inputs, r_targets, discriminator_F, generator_F, args, Global_step
 def _network(st, args, global_step, counter1, counter2):
     """Network tuple of code/train.py:354-370 from the device scalars written by tg_loss_finalize (update_list, its EMA
     and tb are computed in that kernel; nothing here launches work besides one 192-byte copy, and nothing synchronises)."""
-    s = st.scalars.clone()
+    s = st.out_scalars   # (a per-call copy made on lane B: step._emit_scalars)
     names = []
     if args.D_LAYERLOSS:
         names += ["D_layer_%d_loss" % i for i in range(4)] + ["D_layer_loss_sum"]
