@@ -17,6 +17,11 @@
 // conflict-free under the usual piece swizzle at any base row (tools/lds_layout.py).  Reduction channels travel in PHASES of two
 // 32-channel chunks (50 / 46 KB): a 64-channel layer is one phase per tile, a 128-channel layer two, the next phase's patch in
 // flight during the current one's k-loop (two buffers).  LDS: 2 x 50 KB + 48 KB exchange.
+//
+// NWC (round 6, second form): a tile costs what its PATCH costs to take in - 50 KB per phase through the CU's ~25 B/clk, 2000 ticks for
+// ~1150 of matrix work - and with 128 output channels as two 64-channel workgroups the patch was taken in twice.  Where the registers
+// allow (KS^2 x Cin / 32 <= 36 k-steps: every layer but the 128 -> 128 4x4 one) ONE workgroup now makes all 128 channels of a tile:
+// NWC = 4 channel quarters x 2 reduction halves instead of 2 halves x 4 quarters - half the patch bytes per output, a 2-way exchange.
 #ifndef TG_ST_AUX
 #define TG_ST_AUX "sc1"   // results are written THROUGH the L2 (common.h, tg_store16; profiles/r05_u_write_through_ab.log)
 #endif
@@ -44,9 +49,12 @@ template <int KS> struct Geo {
   static constexpr int kChunkBytes = KB * 1024;
   static constexpr int kPhaseBytes = 2 * kChunkBytes;
   static constexpr int NS = 2 * NT;                      // k-steps of a phase: step s = (tap s / 2, chunk s % 2)
-  // wave group kg owns steps [first(kg), first(kg + 1)): 8 each (KS = 4); 5, 4, 4, 5 (KS = 3: groups kg and kg + 2 share a SIMD)
-  static constexpr int first(int kg) { return KS == 4 ? 8 * kg : (kg == 0 ? 0 : kg == 1 ? 5 : kg == 2 ? 9 : kg == 3 ? 13 : 18); }
-  static constexpr int kLds = 2 * kPhaseBytes + kXBytes + 1024;
+  // wave group kg of NKG owns steps [first(kg), first(kg + 1)).  NKG = 4: 8 each (KS = 4); 5, 4, 4, 5 (KS = 3: groups kg and kg + 2 share
+  // a SIMD).  NKG = 2: halves
+  template <int NKG> static constexpr int first(int kg) {
+    return NKG == 2 ? (NS / 2) * kg : KS == 4 ? 8 * kg : (kg == 0 ? 0 : kg == 1 ? 5 : kg == 2 ? 9 : kg == 3 ? 13 : 18);
+  }
+  static constexpr int kLds = 2 * kPhaseBytes + kXBytes + 2048;
 };
 
 template <typename T> __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return Mma16<T>::run(a, b, c); }
@@ -62,7 +70,7 @@ struct S2K {
 };
 
 // (arguments one by one: the first 16 dwords are preloaded into SGPRs with the wave - csrc/build.sh, -amdgpu-kernarg-preload-count)
-template <int KS, int NCH, bool STATS, typename T>
+template <int KS, int NCH, bool STATS, typename T, int NWC>
 __global__ __launch_bounds__(512) void conv_s2_cw_kernel(const char* a_in, const char* a_w, const char* a_zero, int a_IH, int a_IW, int a_OH,
                                                          int a_OW, int a_Cout, int a_tiles_x, int a_tiles_y, int a_ntiles, char* a_out,
                                                          const float* a_bias, float* a_stats, int a_N, int a_groups, int a_replicas) {
@@ -77,9 +85,11 @@ __global__ __launch_bounds__(512) void conv_s2_cw_kernel(const char* a_in, const
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int idx = lane & 15, g = lane >> 4;
-  const int wc = wid & 1;                                     // channel half: packed rows 32 wc .. + 31
-  const int kgr = wid >> 1;                                   // reduction quarter; the tile row this wave finishes
-  const int co_base = blockIdx.y * 64;
+  constexpr int NKG = 8 / NWC;                                // reduction groups: 4 (two channel halves) or 2 (four channel quarters)
+  constexpr int RPW = 4 / NKG;                                // tile rows a wave finishes: kg, kg + NKG, ...
+  const int wc = wid % NWC;                                   // channel group: packed rows 32 wc .. + 31 of the workgroup's 32 NWC
+  const int kgr = wid / NWC;                                  // reduction group
+  const int co_base = blockIdx.y * (32 * NWC);
   const int ntl = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   constexpr int pix_bytes = NCH * 64;
@@ -157,11 +167,12 @@ __global__ __launch_bounds__(512) void conv_s2_cw_kernel(const char* a_in, const
   // through an LDS accumulator -> ONE global atomic per channel and workgroup, issued by whichever wave arrives last (conv3_cw.hip)
   float s1[STATS ? 8 : 1], s2[STATS ? 8 : 1];
   int cur_grp = -1;
-  float* const red = reinterpret_cast<float*>(smem + kRed);   // [2][64] sums, [128] the ticket
+  constexpr int CW = 32 * NWC;                                // the workgroup's output channels
+  float* const red = reinterpret_cast<float*>(smem + kRed);   // [2][CW] sums, [2 CW] the ticket
   if constexpr (STATS) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-    if (tid < 132) red[tid] = 0.f;   // published by the first barrier
+    if (tid < 2 * CW + 4) red[tid] = 0.f;   // published by the first barrier
   }
   auto flush_stats = [&](int grp) {
     if constexpr (STATS) {
@@ -177,19 +188,22 @@ __global__ __launch_bounds__(512) void conv_s2_cw_kernel(const char* a_in, const
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           atomicAdd(&red[wc * 32 + 8 * g + e], s1[e]);
-          atomicAdd(&red[64 + wc * 32 + 8 * g + e], s2[e]);
+          atomicAdd(&red[CW + wc * 32 + 8 * g + e], s2[e]);
         }
       }
       unsigned ticket = 0;
-      if (lane == 0) ticket = atomicAdd(reinterpret_cast<unsigned*>(red + 128), 1u);
+      if (lane == 0) ticket = atomicAdd(reinterpret_cast<unsigned*>(red + 2 * CW), 1u);
       ticket = __builtin_amdgcn_readfirstlane(ticket);
       if ((ticket & 7u) == 7u) {   // the last of the eight waves (a wave's LDS operations are served in order)
         const size_t rep = (size_t)(blockIdx.x & (p.stats_replicas - 1)) * p.stats_groups * 2 * p.Cout;
-        float* dst = p.stats + rep + (size_t)grp * 2 * p.Cout + co_base + lane;
-        atomicAdd(dst, red[lane]);
-        red[lane] = 0.f;
-        atomicAdd(dst + p.Cout, red[64 + lane]);
-        red[64 + lane] = 0.f;
+#pragma unroll
+        for (int c = lane; c < CW; c += 64) {
+          float* dst = p.stats + rep + (size_t)grp * 2 * p.Cout + co_base + c;
+          atomicAdd(dst, red[c]);
+          red[c] = 0.f;
+          atomicAdd(dst + p.Cout, red[CW + c]);
+          red[CW + c] = 0.f;
+        }
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
@@ -198,8 +212,8 @@ __global__ __launch_bounds__(512) void conv_s2_cw_kernel(const char* a_in, const
 
   auto run = [&](auto KGT) {
     constexpr int KG = decltype(KGT)::value;
-    constexpr int S0 = GG::first(KG), CNT = GG::first(KG + 1) - S0;
-    constexpr int kDepth = (NCH == 4 && KS == 4) ? 2 : 3;     // fragment sets in flight
+    constexpr int S0 = GG::template first<NKG>(KG), CNT = GG::template first<NKG>(KG + 1) - S0;
+    constexpr int kDepth = (NPH * CNT >= 16) ? 2 : 3;         // fragment sets in flight (the weights take 8 VGPRs per k-step)
     // A-fragments of packed rows 32 wc + 16 a + idx for this wave's k-steps of every phase.  Packed image [slot][chunk][Cout rows][64 B]
     bf16x8 wfr[NPH][CNT][2];
     const char* const wl = p.w + ((size_t)co_base + wc * 32 + idx) * 64 + g * 16;
@@ -255,37 +269,20 @@ __global__ __launch_bounds__(512) void conv_s2_cw_kernel(const char* a_in, const
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         buf ^= 1;
       }
-      // ---- exchange: the three tile rows this wave does not finish, slot = the source group's rank among the other three
+      // ---- exchange: the tile rows this wave does not finish (it finishes rows KG, KG + NKG, ...), slot = the source group's rank among
+      //      the other groups.  Image: [channel group][tile row][source slot][2 x 1 KiB]
       {
         char* const xw = smem + kX + lane * 16;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          if (b == KG) continue;
-          const int slot = KG < b ? KG : KG - 1;
+          if (b % NKG == KG) continue;
+          const int owner = b % NKG, slot = KG < owner ? KG : KG - 1;
 #pragma unroll
           for (int a = 0; a < 2; ++a)
-            *reinterpret_cast<f32x4*>(xw + (((wc * 4 + b) * 3 + slot) * 2 + a) * 1024) = acc[a][b];
+            *reinterpret_cast<f32x4*>(xw + (((wc * 4 + b) * (NKG - 1) + slot) * 2 + a) * 1024) = acc[a][b];
         }
       }
       lds_barrier();
-      f32x4 tot[2];
-      {
-        const char* const xr = smem + kX + lane * 16;
-        f32x4 part[4][2];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (k == KG) continue;
-          const int slot = k < KG ? k : k - 1;
-#pragma unroll
-          for (int a = 0; a < 2; ++a) part[k][a] = *reinterpret_cast<const f32x4*>(xr + (((wc * 4 + KG) * 3 + slot) * 2 + a) * 1024);
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          part[KG][a] = acc[a][KG];
-          tot[a] = ((part[0][a] + part[1][a]) + part[2][a]) + part[3][a];   // group order: the same sum whichever wave finishes the row
-        }
-      }
-      // ---- epilogue: pixel (ty0 + KG, tx0 + idx), channels ch0 .. + 7
       if constexpr (STATS) {
         const int grp = mine.n / (p.N / p.stats_groups);
         if (grp != cur_grp) {
@@ -293,45 +290,74 @@ __global__ __launch_bounds__(512) void conv_s2_cw_kernel(const char* a_in, const
           cur_grp = grp;
         }
       }
-      const bool ok = (mine.tx0 + idx < p.OW) & (mine.ty0 + KG < p.OH);
-      float v[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = tot[0][e] + bias_r[e];
-        v[4 + e] = tot[1][e] + bias_r[4 + e];
-      }
-      if constexpr (STATS) {
-        if (ok) {
+      for (int j = 0; j < RPW; ++j) {
+        const int row = KG + NKG * j;
+        f32x4 tot[2];
+        {
+          const char* const xr = smem + kX + lane * 16;
+          f32x4 part[NKG][2];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            s1[e] += v[e];
-            s2[e] += v[e] * v[e];
+          for (int k = 0; k < NKG; ++k) {
+            if (k == KG) continue;
+            const int slot = k < KG ? k : k - 1;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) part[k][a] = *reinterpret_cast<const f32x4*>(xr + (((wc * 4 + row) * (NKG - 1) + slot) * 2 + a) * 1024);
+          }
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            part[KG][a] = acc[a][row];
+            tot[a] = part[0][a];   // group order: the same sum whichever wave finishes the row
+#pragma unroll
+            for (int k = 1; k < NKG; ++k) tot[a] += part[k][a];
           }
         }
-      }
-      u32x4 o;
+        // ---- epilogue: pixel (ty0 + row, tx0 + idx), channels ch0 .. + 7
+        const bool ok = (mine.tx0 + idx < p.OW) & (mine.ty0 + row < p.OH);
+        float v[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
-      char* const dst = p.out + ((((size_t)mine.n * p.OH + mine.ty0 + KG) * p.OW + mine.tx0 + idx) * p.Cout + ch0) * 2;
-      if (ok) tg_store16(dst, o);
+        for (int e = 0; e < 4; ++e) {
+          v[e] = tot[0][e] + bias_r[e];
+          v[4 + e] = tot[1][e] + bias_r[4 + e];
+        }
+        if constexpr (STATS) {
+          if (ok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              s1[e] += v[e];
+              s2[e] += v[e] * v[e];
+            }
+          }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack2<T>(v[2 * e], v[2 * e + 1]);
+        char* const dst = p.out + ((((size_t)mine.n * p.OH + mine.ty0 + row) * p.OW + mine.tx0 + idx) * p.Cout + ch0) * 2;
+        if (ok) tg_store16(dst, o);
+      }
     }
     if constexpr (STATS) {
       lds_barrier();   // (a flush in the last tile's epilogue and this one must not overlap: conv3_cw.hip)
       if (cur_grp >= 0) flush_stats(cur_grp);
     }
   };
-  switch (kgr) {
-    case 0: run(std::integral_constant<int, 0>{}); break;
-    case 1: run(std::integral_constant<int, 1>{}); break;
-    case 2: run(std::integral_constant<int, 2>{}); break;
-    default: run(std::integral_constant<int, 3>{}); break;
+  if constexpr (NKG == 2) {
+    if (kgr == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+  } else {
+    switch (kgr) {
+      case 0: run(std::integral_constant<int, 0>{}); break;
+      case 1: run(std::integral_constant<int, 1>{}); break;
+      case 2: run(std::integral_constant<int, 2>{}); break;
+      default: run(std::integral_constant<int, 3>{}); break;
+    }
   }
 }
 
-template <int KS, int NCH, bool STATS, typename T>
+template <int KS, int NCH, bool STATS, typename T, int NWC>
 int launch_s2cw(const S2K& k, dim3 grid, hipStream_t st) {
   constexpr int lds = Geo<KS>::kLds;
-  auto fn = conv_s2_cw_kernel<KS, NCH, STATS, T>;
+  auto fn = conv_s2_cw_kernel<KS, NCH, STATS, T, NWC>;
   static std::atomic<bool> attr_done{false};  // one-time function attribute (benign race: idempotent)
   if (!attr_done) {
     TG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -366,17 +392,29 @@ int go_s2cw(int dtype, const void* in, const void* w_packed, const float* bias, 
   const long long nt = (long long)k.tiles_x * k.tiles_y * N;
   if (nt > 0x3fffffffLL) return TG_E_UNSUPPORTED;
   k.ntiles = (int)nt;
-  // persistent grid: the cap's workgroups shared by the Cout/64 channel tiles, pixel tiles dealt evenly
-  const int co_tiles = Cout / 64;
+  // 128 output channels per workgroup (the patch taken in once for all of them) where the weights of a reduction HALF fit a wave's
+  // registers: KS^2 * Cin / 32 k-steps / 2 * 8 VGPRs <= 144; A/B hook TECOGAN_S2_NWC=2 forces the 64-channel form
+  static const int env_nwc = [] { const char* e = getenv("TECOGAN_S2_NWC"); return e ? atoi(e) : 0; }();
+  const bool wide = Cout % 128 == 0 && KS * KS * (Cin / 32) <= 36 && env_nwc != 2;
+  // persistent grid: the cap's workgroups shared by the channel tiles, pixel tiles dealt evenly
+  const int co_tiles = Cout / (wide ? 128 : 64);
   const int cap = max_workgroups > 0 ? max_workgroups : 256;
   const int per = cap / co_tiles > 0 ? cap / co_tiles : 1;
   const int rounds = (k.ntiles + per - 1) / per;
   const int gx = (k.ntiles + rounds - 1) / rounds;
   dim3 grid((unsigned)gx, (unsigned)co_tiles);
   hipStream_t st = (hipStream_t)stream;
-#define S2_GO(NCH, TAG) (stats ? launch_s2cw<KS, NCH, true, TAG>(k, grid, st) : launch_s2cw<KS, NCH, false, TAG>(k, grid, st))
-  if (dtype == TG_F16) return Cin == 64 ? S2_GO(2, F16) : S2_GO(4, F16);
-  return Cin == 64 ? S2_GO(2, BF16) : S2_GO(4, BF16);
+#define S2_GO(NCH, TAG, NWC) (stats ? launch_s2cw<KS, NCH, true, TAG, NWC>(k, grid, st) : launch_s2cw<KS, NCH, false, TAG, NWC>(k, grid, st))
+  if (wide) {
+    if constexpr (KS == 3) {
+      if (dtype == TG_F16) return Cin == 64 ? S2_GO(2, F16, 4) : S2_GO(4, F16, 4);
+      return Cin == 64 ? S2_GO(2, BF16, 4) : S2_GO(4, BF16, 4);
+    } else {   // (KS = 4: 64 reduction channels only - `wide` excludes 128)
+      return dtype == TG_F16 ? S2_GO(2, F16, 4) : S2_GO(2, BF16, 4);
+    }
+  }
+  if (dtype == TG_F16) return Cin == 64 ? S2_GO(2, F16, 2) : S2_GO(4, F16, 2);
+  return Cin == 64 ? S2_GO(2, BF16, 2) : S2_GO(4, BF16, 2);
 #undef S2_GO
 }
 

@@ -86,26 +86,43 @@ def test_k_step_ranges_partition_the_reduction_and_balance_the_simds():
 
 
 def test_exchange_slots():
-    used = {}
-    for wc in range(2):
-        for kg in range(4):                    # writer
-            for b in range(4):
-                if b == kg:
-                    continue
-                slot = kg if kg < b else kg - 1
-                for a in range(2):
-                    off = (((wc * 4 + b) * 3 + slot) * 2 + a) * 1024
-                    assert off not in used and off + 1024 <= 2 * 4 * 3 * 2048
-                    used[off] = (wc, b, kg, a)
-    for wc in range(2):
-        for kg in range(4):                    # reader: row kg, source k
-            for k in range(4):
-                if k == kg:
-                    continue
-                slot = k if k < kg else k - 1
-                for a in range(2):
-                    assert used[(((wc * 4 + kg) * 3 + slot) * 2 + a) * 1024] == (wc, kg, k, a)
-    assert len(used) == 2 * 4 * 3 * 2
+    """both forms: NWC = 2 channel halves x NKG = 4 reduction groups (a wave finishes tile row kg) and NWC = 4 quarters x NKG = 2 halves
+    (rows kg, kg + 2): every (channel group, row, source != owner) has its own 2 KiB inside the 48-KB image; writer and reader agree"""
+    for nwc in (2, 4):
+        nkg = 8 // nwc
+        used = {}
+        for wc in range(nwc):
+            for kg in range(nkg):                  # writer
+                for b in range(4):
+                    if b % nkg == kg:
+                        continue
+                    owner = b % nkg
+                    slot = kg if kg < owner else kg - 1
+                    for a in range(2):
+                        off = (((wc * 4 + b) * (nkg - 1) + slot) * 2 + a) * 1024
+                        assert off not in used and off + 1024 <= 2 * 4 * 3 * 2048
+                        used[off] = (wc, b, kg, a)
+        for wc in range(nwc):
+            for kg in range(nkg):                  # reader: rows kg, kg + nkg, ...; source k
+                for row in range(kg, 4, nkg):
+                    for k in range(nkg):
+                        if k == kg:
+                            continue
+                        slot = k if k < kg else k - 1
+                        for a in range(2):
+                            assert used[(((wc * 4 + row) * (nkg - 1) + slot) * 2 + a) * 1024] == (wc, row, k, a)
+        assert len(used) == nwc * 4 * (nkg - 1) * 2
+
+
+def test_wide_form_is_chosen_where_a_reduction_half_fits_the_registers():
+    """host rule of go_s2cw: 128 output channels per workgroup iff Cout % 128 == 0 and KS^2 * Cin / 32 <= 36 k-steps (a half = 18 steps
+    x 8 VGPRs = 144): every layer of the step but the 128 -> 128 4x4 one; the halves of the k-steps partition the reduction"""
+    wide = lambda ks, cin, cout: cout % 128 == 0 and ks * ks * (cin // 32) <= 36
+    assert wide(3, 128, 128) and wide(3, 64, 128) and wide(4, 64, 128)
+    assert not wide(4, 128, 128) and not wide(4, 64, 64) and not wide(3, 128, 64)
+    for ks in (3, 4):
+        ns = 2 * ks * ks
+        assert ns % 2 == 0 and [(ns // 2) * kg for kg in range(3)] == [0, ns // 2, ns]
 
 
 def _through_the_tables(x, wslots, ks, oh, ow):
