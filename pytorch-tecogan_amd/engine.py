@@ -861,7 +861,10 @@ class GeneratorEngine:
         if ent is None:
             if self.ws.frozen:
                 raise L.TecoganHipError("new output-layer backward shape after graph capture")
-            cap = TU().rgb_bwd_wgs   # 160 / 256 / 512 / 1024: 4.37 4.37 4.39 4.41 ms per step
+            # round 3: 160 / 256 / 512 / 1024 = 4.37 4.37 4.39 4.41 ms per step.  Round 6 (lane A is the long pole and the fake half runs
+            # beside this launch): 128 / 160 / 192 / 256 = 3.237 / 3.21-3.23 / 3.231 / 3.237 at config 2, 160 / 192 / 256 = 8.17 / 8.30 / 8.15 ms
+            # at the configs[3] shard (profiles/r06_u_knobs.log): 160 for the small step, 256 otherwise
+            cap = TU().rgb_bwd_wgs_for(x.shape[0] * x.shape[1] * x.shape[2])
             nwg = K.rgb_bwd_workgroups(x.shape[0], x.shape[1], x.shape[2], cap)
             slot = int(L.load().tg_conv3x3_rgb_bwd_slot_floats())
             slab = torch.empty(nwg * slot, dtype=torch.float32, device=x.device)

@@ -60,8 +60,10 @@ KNOBS = OrderedDict((k.attr, k) for k in (
     _k("RW_FWD_MIN", "rw_fwd_min", "int", 4096, "profiles/r04_x_rw_fwd_routing.log",
        "FORWARD 3x3 launches (Cin 64 / 128, any Cout multiple of 64) of at least this many pixels go to it too (0: off): "
        "config 2 3.92 -> 3.80 ms (16384) -> 3.79 (4096), config 4 9.7 -> 9.4-9.5 ms, config 5 2840 -> 2946 frames/s"),
-    _k("PAIR_RW_MIN", "pair_rw_min", "int", 16384, "profiles/r04_x_rw_fwd_routing.log",
-       "conv_trans.2's conv pair as two register-weights launches instead of the fused block launch from this many pixels (0: never): config 5 3126 -> 3208 frames/s, config 2 -0.02 ms"),
+    _k("PAIR_RW_MIN", "pair_rw_min", "int", 32768, "profiles/r04_x_rw_fwd_routing.log, r06_u_knobs.log",
+       "conv_trans.2's conv pair as two register-weights launches instead of the fused block launch from this many pixels (0: never): "
+       "config 5 3126 -> 3208 frames/s; round 6: 16384 -> 32768, i.e. config 2's chain (4 x 64 x 64 pixels) back on the ONE fused launch "
+       "(3.237 -> 3.22 ms: a launch less on the critical path of each of the ten passes), configs[3] / [4] unchanged"),
     _k("INFER_CHUNK", "infer_chunk", "int", 16, "profiles/r04_z_inference_chunks.log",
        "frames per hipGraph (and per staging copy) in RecurrentGenerator"),
     _k("INFER_WGS", "infer_wgs", "int", 256, "profiles/r04_x_rw_fwd_routing.log",
@@ -81,7 +83,8 @@ KNOBS = OrderedDict((k.attr, k) for k in (
        "dedicated stride-2 kernels (4x4 s2 forward / input-gradient, conv-transpose input-gradient)"),
     _k("RGB_OUT", "rgb_out", "on", True, "profiles/r02_i_bench_5p25ms.json", "output layer forward on conv_rgb.hip"),
     _k("RGB_BWD", "rgb_bwd", "on", True, "profiles/r03_o_rgb_bwd_ab.log", "output layer backward as one launch (rgb_bwd.hip)"),
-    _k("RGB_BWD_WGS", "rgb_bwd_wgs", "int", 256, "profiles/r03_o_rgb_bwd_ab.log", "its workgroups (160 / 256 / 512 / 1024 measured)"),
+    _k("RGB_BWD_WGS", "rgb_bwd_wgs", "int", 0, "profiles/r03_o_rgb_bwd_ab.log, r06_u_knobs.log",
+       "its workgroups (0: 160 up to 40 x 128 x 128 output pixels - the launch runs beside the fake half's 96 -, 256 beyond)"),
     _k("FUSED_RESBLOCK", "fused_resblock", "on", True, "profiles/r01_h_bench_6p1ms.json",
        "conv-relu-conv(+skip) of the trunk in one launch (resblock.hip)"),
     _k("RB_WS", "rb_ws", "on", True, "profiles/r05_a_resblock_ws_ab.log",
@@ -186,6 +189,12 @@ class Tuning:
         if self.persist_fwd_g:
             return self.persist_fwd_g
         return 160 if lr_pixels <= 4096 else 0
+
+    def rgb_bwd_wgs_for(self, hr_pixels):
+        """workgroups of the output layer's one-pass backward for a batch of `hr_pixels` = N * H * W output pixels"""
+        if self.rgb_bwd_wgs:
+            return self.rgb_bwd_wgs
+        return 160 if hr_pixels <= 40 * 128 * 128 else 256
 
     def cap_trunk_g_for(self, lr_pixels):
         """cap of the trunk's 32 input-gradient launches of the batched G backward (0: the generator's).  Round 4 found no effect

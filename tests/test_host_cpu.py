@@ -544,7 +544,7 @@ def test_tuning_defaults_equal_the_documented_optimum(monkeypatch):
     assert not t.explicit
     assert (t.cap("G"), t.cap("D"), t.cap(None), t.cap_g_for(4096), t.cap_dreal_for(4096), t.cap_dreal_for(8192)) == \
         (160, 96, 160, 144, 96, None)
-    assert (t.cap_g_for(8192), t.rw_fwd_min, t.pair_rw_min, t.infer_wgs, t.infer_chunk) == (160, 4096, 16384, 256, 16)
+    assert (t.cap_g_for(8192), t.rw_fwd_min, t.pair_rw_min, t.infer_wgs, t.infer_chunk) == (160, 4096, 32768, 256, 16)
     assert (t.cap_fwd_g_for(4096), t.cap_fwd_g_for(8192)) == (160, 0)
     assert (t.cap_trunk_g_for(4096), t.cap_trunk_g_for(8192), t.s2_cw, t.d_tail, t.mask_bits) == (160, 0, True, True, False)
     assert (t.graph, t.lanes, t.dreal_bwd, t.dp_inline, t.dp_buckets, t.cu_reserve, t.force_collectives) == \
@@ -553,7 +553,8 @@ def test_tuning_defaults_equal_the_documented_optimum(monkeypatch):
     assert (t.wgrad_list, t.wgrad_groups, t.defer_finalize, t.fold_items, t.pack_blocks, t.stats_replicas) == \
         (True, True, True, True, 48, 4)
     assert (t.fused_resblock, t.fused_resblock_bwd, t.subpix_ct, t.fast_c4s2, t.rgb_out, t.rgb_bwd, t.rgb_bwd_wgs, t.rb_prefetch, t.rb_ws) == \
-        (True, False, True, True, True, True, 256, False, True)
+        (True, False, True, True, True, True, 0, False, True)
+    assert (t.rgb_bwd_wgs_for(40 * 128 * 128), t.rgb_bwd_wgs_for(32 * 256 * 256)) == (160, 256)
     assert t.dtype == "bf16"
     # every rejected experiment is off, and is marked as needing the experiments build
     exp = [k for k in tuning.KNOBS.values() if k.experiment]
